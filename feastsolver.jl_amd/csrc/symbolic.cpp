@@ -1,0 +1,516 @@
+// Ordering (nested dissection by BFS level structures), elimination tree,
+// supernode detection, relaxed amalgamation and front/arena layout.
+// See symbolic.hpp for the role of this phase on the hot path.
+#include "symbolic.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace feasthip {
+namespace {
+
+struct Graph {
+    int n = 0;
+    std::vector<int64_t> xadj;
+    std::vector<int> adj;
+};
+
+Graph symmetrize(int n, const int64_t* colptr, const int64_t* rowidx) {
+    Graph g;
+    g.n = n;
+    std::vector<int64_t> cnt(n + 1, 0);
+    for (int j = 0; j < n; ++j)
+        for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) {
+            int i = (int)rowidx[t];
+            if (i != j) { cnt[i + 1]++; cnt[j + 1]++; }
+        }
+    for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
+    std::vector<int> tmp(cnt[n]);
+    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int j = 0; j < n; ++j)
+        for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) {
+            int i = (int)rowidx[t];
+            if (i != j) { tmp[pos[i]++] = j; tmp[pos[j]++] = i; }
+        }
+    g.xadj.assign(n + 1, 0);
+    g.adj.reserve(cnt[n]);
+    for (int j = 0; j < n; ++j) {
+        std::sort(tmp.begin() + cnt[j], tmp.begin() + cnt[j + 1]);
+        auto e = std::unique(tmp.begin() + cnt[j], tmp.begin() + cnt[j + 1]);
+        g.adj.insert(g.adj.end(), tmp.begin() + cnt[j], e);
+        g.xadj[j + 1] = (int64_t)g.adj.size();
+    }
+    return g;
+}
+
+Graph permute_graph(const Graph& g, const std::vector<int>& perm, const std::vector<int>& iperm) {
+    Graph h;
+    h.n = g.n;
+    h.xadj.assign(g.n + 1, 0);
+    h.adj.resize(g.adj.size());
+    for (int j = 0; j < g.n; ++j) h.xadj[j + 1] = h.xadj[j] + (g.xadj[perm[j] + 1] - g.xadj[perm[j]]);
+    for (int j = 0; j < g.n; ++j) {
+        int64_t o = h.xadj[j];
+        for (int64_t t = g.xadj[perm[j]]; t < g.xadj[perm[j] + 1]; ++t) h.adj[o++] = iperm[g.adj[t]];
+        std::sort(h.adj.begin() + h.xadj[j], h.adj.begin() + h.xadj[j + 1]);
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------------------
+// Nested dissection.  Separators are BFS level sets from pseudo-peripheral
+// vertices, trimmed to the vertices that actually touch both sides.
+// ---------------------------------------------------------------------------
+class NestedDissection {
+public:
+    NestedDissection(const Graph& g, int leaf) : g_(g), leaf_(leaf), part_(g.n, -1), vis_(g.n, -1), lvl_(g.n, 0), order_(g.n, -1) {}
+
+    std::vector<int> run() {
+        std::vector<int> all(g_.n);
+        std::iota(all.begin(), all.end(), 0);
+        dissect(all, 0);
+        return order_;
+    }
+
+private:
+    const Graph& g_;
+    int leaf_;
+    std::vector<int> part_, vis_, lvl_, order_;
+    int next_id_ = 0, stamp_ = 0;
+    std::vector<int> queue_, lptr_;
+
+    // BFS restricted to part_ == id.  Fills queue_ (visit order) and lptr_ (level offsets).
+    void bfs(int root, int id) {
+        ++stamp_;
+        queue_.clear();
+        lptr_.clear();
+        queue_.push_back(root);
+        vis_[root] = stamp_;
+        lvl_[root] = 0;
+        lptr_.push_back(0);
+        size_t head = 0;
+        int cur = 0;
+        while (head < queue_.size()) {
+            int v = queue_[head];
+            if (lvl_[v] != cur) { cur = lvl_[v]; lptr_.push_back((int)head); }
+            ++head;
+            for (int64_t t = g_.xadj[v]; t < g_.xadj[v + 1]; ++t) {
+                int w = g_.adj[t];
+                if (part_[w] == id && vis_[w] != stamp_) {
+                    vis_[w] = stamp_;
+                    lvl_[w] = lvl_[v] + 1;
+                    queue_.push_back(w);
+                }
+            }
+        }
+        lptr_.push_back((int)queue_.size());
+    }
+
+    struct Split {
+        std::vector<int> a, b, s;
+        double cost = 1e300;
+    };
+
+    // Evaluate the best level-set separator of the current BFS structure.
+    void candidate(int m, Split& best) {
+        int nl = (int)lptr_.size() - 1;
+        if (nl < 3) return;
+        int bj = -1;
+        double bcost = 1e300;
+        for (int j = 1; j < nl - 1; ++j) {
+            int below = lptr_[j], sz = lptr_[j + 1] - lptr_[j], above = m - below - sz;
+            int mn = std::min(below, above);
+            if (mn <= 0) continue;
+            double bal = (double)std::max(below, above) / (double)m;   // 0.5 ideal
+            double pen = bal > 0.70 ? 1.0 + 8.0 * (bal - 0.70) : 1.0;
+            double cost = sz * pen;
+            if (cost < bcost) { bcost = cost; bj = j; }
+        }
+        if (bj < 0 || bcost >= best.cost) return;
+        // build trimmed split: vertices of level bj with no neighbour in level bj+1 join side a
+        Split sp;
+        sp.cost = 0;
+        for (int k = 0; k < lptr_[bj]; ++k) sp.a.push_back(queue_[k]);
+        for (int k = lptr_[bj + 1]; k < m; ++k) sp.b.push_back(queue_[k]);
+        for (int k = lptr_[bj]; k < lptr_[bj + 1]; ++k) {
+            int v = queue_[k];
+            bool touches = false;
+            for (int64_t t = g_.xadj[v]; t < g_.xadj[v + 1] && !touches; ++t) {
+                int w = g_.adj[t];
+                if (vis_[w] == stamp_ && lvl_[w] == bj + 1) touches = true;
+            }
+            if (touches) sp.s.push_back(v); else sp.a.push_back(v);
+        }
+        double bal = (double)std::max(sp.a.size(), sp.b.size()) / (double)m;
+        sp.cost = sp.s.size() * (bal > 0.70 ? 1.0 + 8.0 * (bal - 0.70) : 1.0);
+        if (sp.cost < best.cost) best = std::move(sp);
+    }
+
+    void emit(const std::vector<int>& verts, int lo) {
+        for (size_t k = 0; k < verts.size(); ++k) order_[lo + k] = verts[k];
+    }
+
+    void dissect(std::vector<int>& verts, int lo) {
+        int m = (int)verts.size();
+        if (m <= leaf_) { emit(verts, lo); return; }
+        int id = next_id_++;
+        for (int v : verts) part_[v] = id;
+        bfs(verts[0], id);
+        if ((int)queue_.size() < m) {   // disconnected: order components independently
+            std::vector<int> comp(queue_), rest;
+            int st = stamp_;
+            for (int v : verts) if (vis_[v] != st) rest.push_back(v);
+            verts.clear(); verts.shrink_to_fit();
+            dissect(comp, lo);
+            dissect(rest, lo + (int)comp.size());
+            return;
+        }
+        Split best;
+        int height = (int)lptr_.size() - 1;
+        candidate(m, best);
+        for (int it = 0; it < 6; ++it) {
+            // min-degree vertex of the last level
+            int nl = (int)lptr_.size() - 1, r = -1;
+            int64_t bd = INT64_MAX;
+            for (int k = lptr_[nl - 1]; k < lptr_[nl]; ++k) {
+                int v = queue_[k];
+                int64_t d = g_.xadj[v + 1] - g_.xadj[v];
+                if (d < bd) { bd = d; r = v; }
+            }
+            bfs(r, id);
+            candidate(m, best);
+            int h2 = (int)lptr_.size() - 1;
+            if (h2 <= height) break;
+            height = h2;
+        }
+        if (best.s.empty() || best.a.empty() || best.b.empty()) { emit(verts, lo); return; }
+        verts.clear(); verts.shrink_to_fit();
+        int na = (int)best.a.size(), nb = (int)best.b.size();
+        emit(best.s, lo + na + nb);
+        std::vector<int> a(std::move(best.a)), b(std::move(best.b));
+        best.s.clear(); best.s.shrink_to_fit();
+        dissect(a, lo);
+        dissect(b, lo + na);
+    }
+};
+
+void finish_layout(Symbolic& S) {
+    int ns = S.nsuper;
+    S.depth.assign(ns, 0);
+    S.maxdepth = 0;
+    for (int s = ns - 1; s >= 0; --s) {
+        S.depth[s] = S.sn_parent[s] < 0 ? 0 : S.depth[S.sn_parent[s]] + 1;
+        S.maxdepth = std::max(S.maxdepth, S.depth[s]);
+    }
+    S.levels.assign(S.maxdepth + 1, {});
+    for (int s = 0; s < ns; ++s) S.levels[S.depth[s]].push_back(s);
+    S.lp_off.assign(ns, 0);
+    S.f12_off.assign(ns, 0);
+    S.cb_off.assign(ns, 0);
+    S.crow_off.assign(ns, 0);
+    S.cb_size[0] = S.cb_size[1] = 0;
+    S.crow_size[0] = S.crow_size[1] = 0;
+    int64_t off = 0;
+    S.nnz_l = S.nnz_u = 0;
+    S.flops_factor = 0;
+    S.max_p = S.max_front = 0;
+    for (int s = 0; s < ns; ++s) {
+        int64_t p = S.p(s), u = S.u(s);
+        S.lp_off[s] = off; off += (p + u) * p;
+        S.f12_off[s] = off; off += p * u;
+        S.nnz_l += p * (p + 1) / 2 + u * p;
+        S.nnz_u += p * (p - 1) / 2 + u * p;
+        double m = (double)(p + u);
+        for (int64_t k = 0; k < p; ++k) { double r = m - k - 1; S.flops_factor += 8.0 * (r * r) + 6.0 * r; }
+        S.max_p = std::max<int>(S.max_p, (int)p);
+        S.max_front = std::max<int>(S.max_front, (int)(p + u));
+    }
+    S.fact_size = off;
+    std::vector<int64_t> cbl(S.maxdepth + 1, 0), crl(S.maxdepth + 1, 0);
+    for (int s = 0; s < ns; ++s) {
+        int d = S.depth[s];
+        int64_t u = S.u(s);
+        S.cb_off[s] = cbl[d]; cbl[d] += u * u;
+        S.crow_off[s] = crl[d]; crl[d] += u;
+    }
+    for (int d = 0; d <= S.maxdepth; ++d) {
+        S.cb_size[d & 1] = std::max(S.cb_size[d & 1], cbl[d]);
+        S.crow_size[d & 1] = std::max(S.crow_size[d & 1], crl[d]);
+    }
+}
+
+}  // namespace
+
+void analyze_dense(int n, Symbolic& S) {
+    S = Symbolic();
+    S.n = n;
+    S.dense = true;
+    S.perm.resize(n);
+    std::iota(S.perm.begin(), S.perm.end(), 0);
+    S.iperm = S.perm;
+    S.nsuper = 1;
+    S.sn_start = {0, n};
+    S.sn_of.assign(n, 0);
+    S.sn_parent = {-1};
+    S.struct_ptr = {0, 0};
+    S.child_ptr = {0, 0};
+    finish_layout(S);
+}
+
+std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx, const SymbolicOptions& opt, Symbolic& S) {
+    S = Symbolic();
+    S.n = n;
+    if (n <= 0) return "empty matrix";
+    for (int j = 0; j < n; ++j) {
+        if (colptr[j + 1] < colptr[j]) return "column pointers not monotone";
+        for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t)
+            if (rowidx[t] < 0 || rowidx[t] >= n) return "row index out of range";
+    }
+    Graph g = symmetrize(n, colptr, rowidx);
+
+    // ---- 1. fill-reducing ordering --------------------------------------
+    std::vector<int> perm(n), iperm(n);
+    if (opt.ordering == 1) {
+        std::iota(perm.begin(), perm.end(), 0);
+    } else {
+        NestedDissection nd(g, std::max(1, opt.leaf_size));
+        perm = nd.run();
+    }
+    for (int k = 0; k < n; ++k) {
+        if (perm[k] < 0 || perm[k] >= n) return "internal: ordering incomplete";
+        iperm[perm[k]] = k;
+    }
+    Graph h = permute_graph(g, perm, iperm);
+
+    // ---- 2. elimination tree (Liu) + postorder ---------------------------
+    std::vector<int> parent(n, -1), anc(n, -1);
+    for (int j = 0; j < n; ++j)
+        for (int64_t t = h.xadj[j]; t < h.xadj[j + 1]; ++t) {
+            int i = h.adj[t];
+            if (i >= j) break;
+            int r = i;
+            while (anc[r] != -1 && anc[r] != j) { int nx = anc[r]; anc[r] = j; r = nx; }
+            if (anc[r] == -1) { anc[r] = j; parent[r] = j; }
+        }
+    {   // postorder (iterative DFS, children visited in increasing index)
+        std::vector<int> head(n, -1), next(n, -1), post;
+        post.reserve(n);
+        for (int j = n - 1; j >= 0; --j)
+            if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+        std::vector<int> stack;
+        for (int r = 0; r < n; ++r) {
+            if (parent[r] >= 0) continue;
+            stack.push_back(r);
+            while (!stack.empty()) {
+                int v = stack.back();
+                int c = head[v];
+                if (c >= 0) { head[v] = next[c]; stack.push_back(c); }
+                else { post.push_back(v); stack.pop_back(); }
+            }
+        }
+        std::vector<int> inv(n), perm2(n), parent2(n);
+        for (int k = 0; k < n; ++k) inv[post[k]] = k;
+        for (int k = 0; k < n; ++k) {
+            perm2[k] = perm[post[k]];
+            parent2[k] = parent[post[k]] < 0 ? -1 : inv[parent[post[k]]];
+        }
+        perm.swap(perm2);
+        parent.swap(parent2);
+        for (int k = 0; k < n; ++k) iperm[perm[k]] = k;
+        h = permute_graph(g, perm, iperm);
+    }
+
+    // ---- 3. column counts via row subtrees --------------------------------
+    std::vector<int> cc(n, 0), mark(n, -1), nchild(n, 0);
+    for (int i = 0; i < n; ++i) {
+        mark[i] = i;
+        for (int64_t t = h.xadj[i]; t < h.xadj[i + 1]; ++t) {
+            int k = h.adj[t];
+            if (k >= i) break;
+            int j = k;
+            while (mark[j] != i) { mark[j] = i; cc[j]++; j = parent[j]; }
+        }
+    }
+    for (int j = 0; j < n; ++j) if (parent[j] >= 0) nchild[parent[j]]++;
+
+    // ---- 4. fundamental supernodes ----------------------------------------
+    std::vector<int> fstart;   // first column of each fundamental supernode
+    for (int j = 0; j < n; ++j) {
+        bool join = j > 0 && parent[j - 1] == j && cc[j - 1] == cc[j] + 1 && nchild[j] == 1;
+        if (!join) fstart.push_back(j);
+    }
+    int nf = (int)fstart.size();
+    fstart.push_back(n);
+    std::vector<int> fof(n);
+    for (int s = 0; s < nf; ++s) for (int j = fstart[s]; j < fstart[s + 1]; ++j) fof[j] = s;
+    std::vector<int> fparent(nf, -1);
+    for (int s = 0; s < nf; ++s) {
+        int last = fstart[s + 1] - 1;
+        fparent[s] = parent[last] < 0 ? -1 : fof[parent[last]];
+    }
+
+    // ---- 5. relaxed amalgamation on the supernode tree --------------------
+    std::vector<int64_t> P(nf), U(nf);
+    std::vector<double> Z(nf, 0.0);
+    std::vector<char> dead(nf, 0);
+    std::vector<std::vector<int>> kids(nf), members(nf);
+    for (int s = 0; s < nf; ++s) {
+        P[s] = fstart[s + 1] - fstart[s];
+        U[s] = cc[fstart[s + 1] - 1];
+        members[s].push_back(s);
+    }
+    for (int s = 0; s < nf; ++s) if (fparent[s] >= 0) kids[fparent[s]].push_back(s);
+    for (int s = 0; s < nf; ++s) {   // children have smaller indices (postorder) and are final by now
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            // candidate with the fewest new zeros first
+            int bi = -1;
+            double bz = 1e300;
+            for (size_t q = 0; q < kids[s].size(); ++q) {
+                int c = kids[s][q];
+                double nz = (double)P[c] * (double)(P[s] + U[s] - U[c]);
+                if (nz < bz) { bz = nz; bi = (int)q; }
+            }
+            if (bi < 0) break;
+            int c = kids[s][bi];
+            int64_t pn = P[s] + P[c];
+            double zn = Z[s] + Z[c] + bz;
+            double tot = (double)pn * (pn + 1) / 2.0 + (double)pn * (double)U[s];
+            double zf = zn / tot;
+            bool ok = pn <= opt.relax_small || (pn <= opt.relax_mid && zf <= opt.zmid) || zf <= opt.zbig;
+            if (!ok) break;
+            // merge c into s
+            P[s] = pn;
+            Z[s] = zn;
+            dead[c] = 1;
+            kids[s].erase(kids[s].begin() + bi);
+            kids[s].insert(kids[s].end(), kids[c].begin(), kids[c].end());
+            members[s].insert(members[s].end(), members[c].begin(), members[c].end());
+            kids[c].clear(); members[c].clear();
+            changed = true;
+        }
+    }
+    // final numbering: DFS over the amalgamated tree, children first
+    {
+        std::vector<int> newpos;   // newpos[k] = old (postordered) column placed at k
+        newpos.reserve(n);
+        std::vector<int> sstart;
+        std::vector<std::pair<int, size_t>> stack;
+        for (int r = 0; r < nf; ++r) {
+            if (dead[r] || fparent[r] >= 0) continue;
+            // a live root: note fparent of merged nodes is irrelevant, kids[] holds the tree
+            stack.push_back({r, 0});
+            while (!stack.empty()) {
+                auto& top = stack.back();
+                int v = top.first;
+                if (top.second < kids[v].size()) { int c = kids[v][top.second++]; stack.push_back({c, 0}); }
+                else {
+                    std::vector<int> cols;
+                    for (int f : members[v]) for (int j = fstart[f]; j < fstart[f + 1]; ++j) cols.push_back(j);
+                    std::sort(cols.begin(), cols.end());
+                    sstart.push_back((int)newpos.size());
+                    newpos.insert(newpos.end(), cols.begin(), cols.end());
+                    stack.pop_back();
+                }
+            }
+        }
+        if ((int)newpos.size() != n) return "internal: amalgamation lost columns";
+        sstart.push_back(n);
+        std::vector<int> perm2(n);
+        for (int k = 0; k < n; ++k) perm2[k] = perm[newpos[k]];
+        perm.swap(perm2);
+        for (int k = 0; k < n; ++k) iperm[perm[k]] = k;
+        S.sn_start = sstart;
+        S.nsuper = (int)sstart.size() - 1;
+    }
+    h = permute_graph(g, perm, iperm);
+    S.perm = perm;
+    S.iperm = iperm;
+    int ns = S.nsuper;
+    S.sn_of.resize(n);
+    for (int s = 0; s < ns; ++s) for (int j = S.sn_start[s]; j < S.sn_start[s + 1]; ++j) S.sn_of[j] = s;
+
+    // ---- 6. supernode row structures, tree, relative indices ---------------
+    S.sn_parent.assign(ns, -1);
+    S.struct_ptr.assign(ns + 1, 0);
+    std::vector<std::vector<int>> ch(ns);
+    std::vector<int> stamp(n, -1), rows;
+    std::vector<std::vector<int>> st(ns);
+    for (int s = 0; s < ns; ++s) {
+        int last = S.sn_start[s + 1] - 1;
+        rows.clear();
+        for (int j = S.sn_start[s]; j <= last; ++j)
+            for (int64_t t = h.xadj[j]; t < h.xadj[j + 1]; ++t) {
+                int i = h.adj[t];
+                if (i > last && stamp[i] != s) { stamp[i] = s; rows.push_back(i); }
+            }
+        for (int c : ch[s])
+            for (int i : st[c])
+                if (i > last && stamp[i] != s) { stamp[i] = s; rows.push_back(i); }
+        std::sort(rows.begin(), rows.end());
+        st[s] = rows;
+        if (!rows.empty()) {
+            int ps = S.sn_of[rows[0]];
+            S.sn_parent[s] = ps;
+            ch[ps].push_back(s);
+        }
+        S.struct_ptr[s + 1] = S.struct_ptr[s] + (int64_t)rows.size();
+    }
+    S.struct_idx.resize(S.struct_ptr[ns]);
+    S.rel.resize(S.struct_ptr[ns]);
+    S.child_ptr.assign(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) {
+        std::copy(st[s].begin(), st[s].end(), S.struct_idx.begin() + S.struct_ptr[s]);
+        S.child_ptr[s + 1] = S.child_ptr[s] + (int64_t)ch[s].size();
+        S.child_idx.insert(S.child_idx.end(), ch[s].begin(), ch[s].end());
+    }
+    for (int c = 0; c < ns; ++c) {
+        int ps = S.sn_parent[c];
+        if (ps < 0) continue;
+        int c0 = S.sn_start[ps], pp = S.sn_start[ps + 1] - c0;
+        const std::vector<int>& pst = st[ps];
+        size_t q = 0;
+        for (size_t k = 0; k < st[c].size(); ++k) {
+            int i = st[c][k];
+            int r;
+            if (i < c0 + pp) r = i - c0;
+            else {
+                while (q < pst.size() && pst[q] < i) ++q;
+                if (q >= pst.size() || pst[q] != i) return "internal: child structure not contained in parent front";
+                r = pp + (int)q;
+            }
+            S.rel[S.struct_ptr[c] + k] = r;
+        }
+    }
+    finish_layout(S);
+    return "";
+}
+
+int64_t entry_dest(const Symbolic& S, int i_old, int j_old) {
+    int i = S.iperm[i_old], j = S.iperm[j_old];
+    int m = std::min(i, j);
+    int s = S.sn_of[m];
+    int c0 = S.sn_start[s];
+    int64_t p = S.p(s), u = S.u(s);
+    const int* st = S.struct_idx.data() + S.struct_ptr[s];
+    auto pos = [&](int r) -> int64_t {
+        const int* it = std::lower_bound(st, st + u, r);
+        if (it == st + u || *it != r) return -1;
+        return (int64_t)(it - st);
+    };
+    if (i >= j) {   // lower triangle incl. diagonal -> L panel
+        int64_t col = j - c0, row;
+        if (i < c0 + p) row = i - c0;
+        else { int64_t q = pos(i); if (q < 0) return -1; row = p + q; }
+        return S.lp_off[s] + row + col * (p + u);
+    }
+    int64_t row = i - c0;
+    if (j < c0 + p) return S.lp_off[s] + row + (int64_t)(j - c0) * (p + u);
+    int64_t q = pos(j);
+    if (q < 0) return -1;
+    return S.f12_off[s] + row + q * p;
+}
+
+}  // namespace feasthip
