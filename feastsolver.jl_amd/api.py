@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's solver interface (src/feast.jl,
+src/nlfeast.jl, src/utils.jl:173-179) on top of the C ABI.
+
+    feast(X, A, contour)            <->  feast!(X, A, contour; ...)       src/feast.jl:10-80
+    gen_feast(X, A, B, contour)     <->  gen_feast!(X, A, B, contour; ...) src/feast.jl:89-156
+    nlfeast(T, X, nodes, iter)      <->  nlfeast!(T, X, nodes, iter; ...)  src/nlfeast.jl:2-84
+    lu / ldiv / finalize            <->  factorizer / left_divider / finalize!
+
+X is overwritten in place (the `!` convention); return values are the reference's
+3-tuples.  Keyword names follow the reference (eps for the Julia epsilon).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+try:
+    import scipy.sparse as sp
+except Exception:  # pragma: no cover
+    sp = None
+
+from . import _lib
+from .contour import CircularContour, circular_contour_trapezoidal
+
+F64, C128, I64T = 0, 1, 2
+
+
+def _issparse(M):
+    return sp is not None and sp.issparse(M)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dense_arg(M):
+    """-> (array kept alive, type tag) column-major."""
+    M = np.asarray(M)
+    if M.dtype == np.complex128:
+        return np.asfortranarray(M), C128
+    if M.dtype == np.float64:
+        return np.asfortranarray(M), F64
+    if np.issubdtype(M.dtype, np.integer):
+        return np.asfortranarray(M.astype(np.int64)), I64T
+    if np.issubdtype(M.dtype, np.complexfloating):
+        return np.asfortranarray(M.astype(np.complex128)), C128
+    return np.asfortranarray(M.astype(np.float64)), F64
+
+
+def _csc_arg(M):
+    M = sp.csc_matrix(M)
+    M.sort_indices()
+    M.sum_duplicates()
+    if np.issubdtype(M.dtype, np.complexfloating):
+        vals, ty = np.ascontiguousarray(M.data, dtype=np.complex128), C128
+    else:
+        vals, ty = np.ascontiguousarray(M.data, dtype=np.float64), F64
+    return (np.ascontiguousarray(M.indptr, dtype=np.int64), np.ascontiguousarray(M.indices, dtype=np.int64), vals), ty
+
+
+class PolynomialNEP:
+    """T(z) = sum_j z^j M_j.  Callable like the reference's closures
+    (test/butterfly.jl:60-62, test/paper.jl:38-52) and understood by ``nlfeast``'s
+    device fast path."""
+
+    def __init__(self, coeffs):
+        self.coeffs = list(coeffs)
+
+    def __call__(self, z):
+        out = self.coeffs[0] * 1.0
+        zz = 1.0
+        for M in self.coeffs[1:]:
+            zz = zz * z
+            out = out + M * zz
+        return out
+
+
+class FeastHandle:
+    """Owns one feasthip_handle_t (one GPU).  Used by feast/gen_feast/nlfeast and by the
+    multi-GPU driver (distributed.py)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load_library()
+        h = C.c_void_p()
+        code = self.lib.feasthip_create(C.byref(h), int(device))
+        if code != 0:
+            msg = self.lib.feasthip_last_error(None)
+            raise _lib.FeastHipError(code, msg.decode() if msg else "")
+        self.h = h
+        self._keep = []
+        self.n = 0
+        self.m0 = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.feasthip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, code):
+        return _lib.check(self.lib, self.h, code)
+
+    # ---- problem -------------------------------------------------------------
+    def set_terms(self, mats, scales=None):
+        """mats[j] is M_j (dense ndarray, scipy sparse, or None for the identity)."""
+        nterms = len(mats)
+        n = None
+        for M in mats:
+            if M is not None:
+                if M.shape[0] != M.shape[1]:
+                    raise ValueError("Incorrect dimensions of A, must be square")
+                n = M.shape[0]
+        if n is None:
+            raise ValueError("at least one explicit matrix is required")
+        sc = np.ones(nterms, dtype=np.complex128) if scales is None else np.asarray(scales, dtype=np.complex128)
+        scd = np.ascontiguousarray(sc.view(np.float64))
+        types = (C.c_int * nterms)()
+        any_sparse = any(_issparse(M) for M in mats if M is not None)
+        keep = []
+        if any_sparse:
+            cps, rvs, vls = (C.c_void_p * nterms)(), (C.c_void_p * nterms)(), (C.c_void_p * nterms)()
+            for j, M in enumerate(mats):
+                if M is None:
+                    cps[j] = rvs[j] = vls[j] = None
+                    continue
+                (cp, rv, vl), ty = _csc_arg(M)
+                keep += [cp, rv, vl]
+                cps[j], rvs[j], vls[j], types[j] = cp.ctypes.data, rv.ctypes.data, vl.ctypes.data, ty
+            self._ck(self.lib.feasthip_set_csc(self.h, n, nterms, cps, rvs, vls, types,
+                                               scd.ctypes.data_as(C.POINTER(C.c_double)), 0))
+        else:
+            ptrs = (C.c_void_p * nterms)()
+            for j, M in enumerate(mats):
+                if M is None:
+                    ptrs[j] = None
+                    continue
+                arr, ty = _dense_arg(M)
+                keep.append(arr)
+                ptrs[j], types[j] = arr.ctypes.data, ty
+            self._ck(self.lib.feasthip_set_dense(self.h, n, nterms, ptrs, types,
+                                                 scd.ctypes.data_as(C.POINTER(C.c_double))))
+        self.n = n
+        self.nterms = nterms
+
+    def set_contour(self, contour):
+        nodes = np.ascontiguousarray(contour.nodes, dtype=np.complex128)
+        weights = np.ascontiguousarray(contour.weights, dtype=np.complex128)
+        kind, region = contour.region()
+        region = np.ascontiguousarray(region, dtype=np.float64)
+        self._ck(self.lib.feasthip_set_contour(self.h, len(nodes), _vp(nodes), _vp(weights), kind, _vp(region)))
+        self.K = len(nodes)
+
+    def set_node_shard(self, first, stride):
+        self._ck(self.lib.feasthip_set_node_shard(self.h, int(first), int(stride)))
+
+    def analyze(self):
+        self._ck(self.lib.feasthip_analyze(self.h))
+
+    def factorize(self):
+        return self._ck(self.lib.feasthip_factorize(self.h))
+
+    # ---- iteration -------------------------------------------------------------
+    def set_x(self, X):
+        X = np.asfortranarray(X, dtype=np.complex128)
+        if X.shape[0] != self.n:
+            raise ValueError("Incorrect dimensions of X, must match A")
+        self.m0 = X.shape[1]
+        self._ck(self.lib.feasthip_set_x(self.h, _vp(X), X.shape[0], X.shape[1]))
+
+    def get_block(self, which=0):
+        out = np.empty((self.n, self.m0), dtype=np.complex128, order="F")
+        self._ck(self.lib.feasthip_get_block(self.h, which, _vp(out)))
+        return out
+
+    def _outs(self):
+        return (np.zeros(self.m0, dtype=np.complex128), np.zeros(self.m0), np.zeros(self.m0, dtype=np.uint8))
+
+    def rr_step(self):
+        lam, res, ins = self._outs()
+        self._ck(self.lib.feasthip_rr_step(self.h, _vp(lam), _vp(res), _vp(ins)))
+        return lam, res, ins.astype(bool)
+
+    def contour_step(self, refactor=False):
+        return self._ck(self.lib.feasthip_contour_step(self.h, 1 if refactor else 0))
+
+    def nl_orthonormalize_x(self):
+        self._ck(self.lib.feasthip_nl_orthonormalize_x(self.h))
+
+    def nl_contour_step(self, first):
+        return self._ck(self.lib.feasthip_nl_contour_step(self.h, 1 if first else 0))
+
+    def nl_rr_step(self):
+        lam, res, ins = self._outs()
+        self._ck(self.lib.feasthip_nl_rr_step(self.h, _vp(lam), _vp(res), _vp(ins)))
+        return lam, res, ins.astype(bool)
+
+    def nl_finalize_x(self):
+        self._ck(self.lib.feasthip_nl_finalize_x(self.h))
+
+    def q_device(self):
+        p, n, ld, nb = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int()
+        self._ck(self.lib.feasthip_q_device(self.h, C.byref(p), C.byref(n), C.byref(ld), C.byref(nb)))
+        return p.value, n.value, ld.value, nb.value
+
+    def feast_run(self, X, iter, eps, store):
+        """feasthip_feast_run: whole `for nit=0:iter` loop in the library.  X (F-ordered
+        complex128) is overwritten."""
+        if X.shape[0] != self.n:
+            raise ValueError("Incorrect dimensions of X, must match A")
+        self.m0 = X.shape[1]
+        lam, res, ins = self._outs()
+        nit = C.c_int(0)
+        code = self._ck(self.lib.feasthip_feast_run(self.h, _vp(X), X.shape[0], X.shape[1], int(iter), float(eps),
+                                                    1 if store else 0, _vp(lam), _vp(res), _vp(ins), C.byref(nit)))
+        return lam, res, ins.astype(bool), nit.value, code
+
+    def nlfeast_run(self, X, iter, eps, spurious):
+        self.m0 = X.shape[1]
+        lam, res, ins = self._outs()
+        nit = C.c_int(0)
+        code = self._ck(self.lib.feasthip_nlfeast_run(self.h, _vp(X), X.shape[0], X.shape[1], int(iter), float(eps),
+                                                      float(spurious), _vp(lam), _vp(res), _vp(ins), C.byref(nit)))
+        return lam, res, ins.astype(bool), nit.value, code
+
+    def stats(self):
+        s = _lib.Stats()
+        self._ck(self.lib.feasthip_get_stats(self.h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in _lib.Stats._fields_}
+
+    def profile_solve(self):
+        out = np.zeros((8, 4))
+        self._ck(self.lib.feasthip_profile_solve(self.h, _vp(out)))
+        names = ["gather_rhs", "fwd_assemble", "diag_solve", "panel_apply", "accumulate"]
+        return {nm: dict(ms=out[i, 0], bytes=out[i, 1], flops=out[i, 2], launches=int(out[i, 3])) for i, nm in enumerate(names)}
+
+
+# ---------------------------------------------------------------------------
+def _inplace_target(X):
+    X_in = X
+    Xw = X if (isinstance(X, np.ndarray) and X.dtype == np.complex128 and X.flags.f_contiguous) else \
+        np.asfortranarray(np.asarray(X.toarray() if _issparse(X) else X), dtype=np.complex128)
+    return X_in, Xw
+
+
+def _writeback(X_in, Xw):
+    if X_in is not Xw and isinstance(X_in, np.ndarray) and np.issubdtype(X_in.dtype, np.complexfloating):
+        X_in[...] = Xw
+
+
+def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=False, store=False, eps=1e-12,
+              factorizer=None, left_divider=None, device=0, info=None):
+    """gen_feast!(X, A, B[, contour]; ...)  src/feast.jl:82-156.  B=None gives feast!.
+
+    ``factorizer``/``left_divider`` are accepted for signature parity; the built-in
+    GPU LU (the ``lu``/``ldiv`` of this module) is what runs.  ``info`` (a dict) receives
+    iteration count, library statistics and the static-pivot warning count."""
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Incorrect dimensions of A, must be square")
+    if X.shape[0] != A.shape[0]:
+        raise ValueError("Incorrect dimensions of X, must match A")
+    if contour is None:
+        contour = circular_contour_trapezoidal(c, r, nodes)
+    X_in, Xw = _inplace_target(X)
+    h = FeastHandle(device)
+    try:
+        h.set_terms([A, B], scales=[1.0, -1.0])          # T(z) = A - z B
+        h.set_contour(contour)
+        lam, res, ins, nit, warn = h.feast_run(Xw, iter, eps, store)
+        if debug:
+            print(f"converged in {nit} iteration" if ins.any() and res[ins].max() < eps else f"stopped after {nit} iterations")
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=nit, warn=warn, lam_all=lam.copy(), res_all=res.copy(), inside=ins.copy())
+    finally:
+        h.close()
+    _writeback(X_in, Xw)
+    if not ins.any():
+        print("no eigenvalues found in contour!")                # src/feast.jl:78
+    return lam[ins], Xw[:, ins], res[ins]
+
+
+def feast(X, A, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, eps=1e-12, debug=False, store=False,
+          mixed_prec=False, factorizer=None, left_divider=None, device=0, info=None):
+    """feast!(X, A[, contour]; ...)  src/feast.jl:3-80."""
+    if mixed_prec:
+        raise NotImplementedError("mixed_prec (ComplexF32 factor/solve, src/feast.jl:19-25) is a later-round row (SURVEY 8f)")
+    return gen_feast(X, A, None, contour, nodes=nodes, iter=iter, c=c, r=r, debug=debug, store=store, eps=eps,
+                     factorizer=factorizer, left_divider=left_divider, device=device, info=info)
+
+
+def nlfeast(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, store=True, spurious=1e-5,
+            factorizer=None, left_divider=None, device=0, info=None):
+    """nlfeast!(T, X, nodes, iter; ...)  src/nlfeast.jl:2-84.  Returns (lam, X, res) for ALL m0
+    pairs (unfiltered).  T must be a PolynomialNEP (device fast path)."""
+    if not isinstance(T, PolynomialNEP):
+        raise NotImplementedError("nlfeast on the GPU needs a PolynomialNEP; generic closures are a later-round row (SURVEY 8f)")
+    if not (isinstance(X, np.ndarray) and X.dtype == np.complex128):
+        raise TypeError("X must be an AbstractMatrix{ComplexF64}")       # src/nlfeast.jl:2
+    X_in, Xw = _inplace_target(X)
+    h = FeastHandle(device)
+    try:
+        h.set_terms(T.coeffs)
+        h.set_contour(circular_contour_trapezoidal(c, r, nodes))           # src/nlfeast.jl:8
+        lam, res, ins, nit, warn = h.nlfeast_run(Xw, iter, eps, spurious)
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=nit, warn=warn, inside=ins.copy())
+    finally:
+        h.close()
+    _writeback(X_in, Xw)
+    return lam, Xw, res
+
+
+# ---------------------------------------------------------------------------
+# factorizer / left_divider / finalize! seam  (src/utils.jl:173-179)
+# ---------------------------------------------------------------------------
+class HipLU:
+    """Factorization object returned by ``lu`` (the reference's `factorizer`)."""
+
+    def __init__(self, handle, n, lib):
+        self._h, self.n, self._lib = handle, n, lib
+
+    def __del__(self):
+        try:
+            finalize(self)
+        except Exception:
+            pass
+
+
+def lu(Cm, device=0):
+    """factorizer(C): GPU LU of the assembled shifted matrix; C is copied (src/feast.jl:29-36)."""
+    lib = _lib.load_library()
+    F = C.c_void_p()
+    if Cm.shape[0] != Cm.shape[1]:
+        raise ValueError("Incorrect dimensions of A, must be square")
+    n = Cm.shape[0]
+    if _issparse(Cm):
+        (cp, rv, vl), ty = _csc_arg(Cm)
+        code = lib.feasthip_lu_csc(int(device), n, _vp(cp), _vp(rv), _vp(vl), ty, 0, C.byref(F))
+    else:
+        arr = np.asfortranarray(Cm, dtype=np.complex128)
+        code = lib.feasthip_lu_dense(int(device), _vp(arr), n, C.byref(F))
+    if code < 0:
+        msg = lib.feasthip_last_error(None)
+        raise _lib.FeastHipError(code, msg.decode() if msg else "")
+    return HipLU(F, n, lib)
+
+
+def ldiv(Y, F, R):
+    """left_divider(Y, F, R): Y .= C^-1 R, R untouched (src/feast.jl:62)."""
+    Rw = np.asfortranarray(R, dtype=np.complex128)
+    Yw = Y if (Y.dtype == np.complex128 and Y.flags.f_contiguous) else np.empty(Rw.shape, dtype=np.complex128, order="F")
+    code = F._lib.feasthip_ldiv(F._h, _vp(Yw), Yw.shape[0], _vp(Rw), Rw.shape[0], Rw.shape[1])
+    if code < 0:
+        raise _lib.FeastHipError(code, "feasthip_ldiv failed")
+    if Yw is not Y:
+        Y[...] = Yw
+    return Y
+
+
+def finalize(F):
+    """finalize!(F): release the device memory of a factor object (src/utils.jl:173)."""
+    if getattr(F, "_h", None):
+        F._lib.feasthip_fact_free(F._h)
+        F._h = None

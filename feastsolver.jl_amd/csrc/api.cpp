@@ -1,0 +1,261 @@
+// extern "C" surface of libfeasthip.so (include/feasthip.h).  Nothing here
+// throws across the ABI: every entry point catches and maps to a status code.
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/feasthip.h"
+#include "engine.hpp"
+#include "smalleig.hpp"
+
+using namespace feasthip;
+
+struct feasthip_handle_s { Engine* e; };
+struct feasthip_fact_s { Engine* e; std::mutex mu; };
+
+static std::string g_create_error;
+static std::mutex g_mu;
+
+#define GUARD(h) if (!(h) || !(h)->e) return FEASTHIP_EARG; try {
+#define ENDGUARD(h) } catch (const std::bad_alloc&) { (h)->e->err = "host out of memory"; return FEASTHIP_EARG; } \
+                      catch (const std::exception& ex) { (h)->e->err = ex.what(); return FEASTHIP_EARG; } \
+                      catch (...) { (h)->e->err = "unknown C++ exception"; return FEASTHIP_EARG; }
+
+extern "C" {
+
+int feasthip_version(void) { return 100; }
+
+int feasthip_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < cnt; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strstr(p.gcnArchName, "gfx950")) ++ok;
+    }
+    return ok;
+}
+
+int feasthip_create(feasthip_handle_t* h, int device_id) {
+    if (!h) return FEASTHIP_EARG;
+    *h = nullptr;
+    try {
+        Engine* e = new Engine(device_id);
+        if (e->status) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            g_create_error = e->err;
+            int st = e->status;
+            delete e;
+            return st;
+        }
+        feasthip_handle_s* hs = new feasthip_handle_s;
+        hs->e = e;
+        *h = hs;
+        return 0;
+    } catch (...) { std::lock_guard<std::mutex> lk(g_mu); g_create_error = "exception in feasthip_create"; return FEASTHIP_EARG; }
+}
+
+int feasthip_destroy(feasthip_handle_t h) {
+    if (!h) return 0;
+    try { delete h->e; delete h; } catch (...) {}
+    return 0;
+}
+
+const char* feasthip_last_error(feasthip_handle_t h) {
+    if (!h || !h->e) return g_create_error.c_str();
+    return h->e->err.c_str();
+}
+
+int feasthip_set_stream(feasthip_handle_t h, void* s) { GUARD(h) return h->e->set_stream(s); ENDGUARD(h) }
+
+int feasthip_set_dense(feasthip_handle_t h, int64_t n, int nterms, const void* const* mats, const int* types, const double* scale) {
+    GUARD(h) return h->e->set_dense(n, nterms, mats, types, scale); ENDGUARD(h)
+}
+
+int feasthip_set_csc(feasthip_handle_t h, int64_t n, int nterms, const int64_t* const* colptr, const int64_t* const* rowval,
+                     const void* const* nzval, const int* types, const double* scale, int index_base) {
+    GUARD(h) return h->e->set_csc(n, nterms, colptr, rowval, nzval, types, scale, index_base); ENDGUARD(h)
+}
+
+int feasthip_set_contour(feasthip_handle_t h, int K, const double* nodes, const double* weights, int kind, const double* region) {
+    GUARD(h) return h->e->set_contour(K, nodes, weights, kind, region); ENDGUARD(h)
+}
+
+int feasthip_set_node_shard(feasthip_handle_t h, int first, int stride) { GUARD(h) return h->e->set_shard(first, stride); ENDGUARD(h) }
+int feasthip_analyze(feasthip_handle_t h) { GUARD(h) return h->e->analyze(); ENDGUARD(h) }
+int feasthip_factorize(feasthip_handle_t h) { GUARD(h) return h->e->factorize(); ENDGUARD(h) }
+int feasthip_set_x(feasthip_handle_t h, const void* X, int64_t n, int m0) { GUARD(h) return h->e->set_x(X, n, m0); ENDGUARD(h) }
+int feasthip_get_x(feasthip_handle_t h, void* X) { GUARD(h) return h->e->get_block(0, X); ENDGUARD(h) }
+int feasthip_get_block(feasthip_handle_t h, int which, void* out) { GUARD(h) return h->e->get_block(which, out); ENDGUARD(h) }
+int feasthip_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside) { GUARD(h) return h->e->rr_step(lambda, res, inside); ENDGUARD(h) }
+int feasthip_contour_step(feasthip_handle_t h, int refactor) { GUARD(h) return h->e->contour_step(refactor); ENDGUARD(h) }
+int feasthip_nl_contour_step(feasthip_handle_t h, int first) { GUARD(h) return h->e->nl_contour_step(first); ENDGUARD(h) }
+int feasthip_nl_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside) { GUARD(h) return h->e->nl_rr_step(lambda, res, inside); ENDGUARD(h) }
+int feasthip_nl_orthonormalize_x(feasthip_handle_t h) { GUARD(h) return h->e->nl_orthonormalize_x(); ENDGUARD(h) }
+int feasthip_nl_finalize_x(feasthip_handle_t h) { GUARD(h) return h->e->nl_finalize_x(); ENDGUARD(h) }
+int feasthip_q_device(feasthip_handle_t h, void** p, int64_t* n, int64_t* ldq, int* nb) { GUARD(h) return h->e->q_device(p, n, ldq, nb); ENDGUARD(h) }
+
+int feasthip_feast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps, int store, double* lambda,
+                       double* res, uint8_t* inside, int* nit) {
+    GUARD(h) return h->e->feast_run(X, n, m0, iter, eps, store, lambda, res, inside, nit); ENDGUARD(h)
+}
+
+int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps, double spurious,
+                         double* lambda, double* res, uint8_t* inside, int* nit) {
+    GUARD(h) return h->e->nlfeast_run(X, n, m0, iter, eps, spurious, lambda, res, inside, nit); ENDGUARD(h)
+}
+
+int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
+    GUARD(h)
+    if (!o) return FEASTHIP_EARG;
+    Engine* e = h->e;
+    std::memset(o, 0, sizeof(*o));
+    o->n = e->n; o->nsuper = e->S.nsuper; o->nnz_l = e->S.nnz_l; o->nnz_u = e->S.nnz_u; o->fact_elems = e->S.fact_size;
+    o->max_front = e->S.max_front; o->max_p = e->S.max_p; o->depth = e->S.maxdepth + 1;
+    o->flops_factor = e->S.flops_factor; o->analyze_seconds = e->analyze_seconds; o->factor_ms = e->factor_ms;
+    o->solve_ms = e->solve_ms; o->rr_ms = e->rr_ms;
+    o->solve_bytes = e->ldw ? e->solve_bytes() : 0; o->solve_flops = e->ldw ? e->solve_flops() : 0;
+    o->perturbed_pivots = e->perturbed; o->local_nodes = e->Kloc; o->m0 = e->m0; o->ldw = e->ldw; o->dense = e->dense ? 1 : 0;
+    return 0;
+    ENDGUARD(h)
+}
+
+int feasthip_profile_solve(feasthip_handle_t h, double* out /* 8 rows x 4: ms, bytes, flops, launches */) {
+    GUARD(h)
+    if (!out) return FEASTHIP_EARG;
+    ProfileRow rows[8];
+    int r = h->e->profile_solve(rows);
+    if (r) return r;
+    for (int i = 0; i < 8; ++i) { out[4 * i] = rows[i].ms; out[4 * i + 1] = rows[i].bytes; out[4 * i + 2] = rows[i].flops; out[4 * i + 3] = rows[i].launches; }
+    return 0;
+    ENDGUARD(h)
+}
+
+// ---- fine-grained seam -----------------------------------------------------
+static int make_fact(Engine* e, feasthip_fact_t* F) {
+    double node[2] = {0.0, 0.0}, w[2] = {1.0, 0.0}, reg[4] = {0, 0, 1, 0};
+    int r = e->set_contour(1, node, w, FEASTHIP_REGION_DISC, reg);
+    if (r == 0) r = e->analyze();
+    if (r == 0) r = e->factorize();
+    if (r < 0) { { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return r; }
+    feasthip_fact_s* f = new feasthip_fact_s;
+    f->e = e;
+    *F = f;
+    return r;
+}
+
+int feasthip_lu_dense(int device_id, const void* C, int64_t n, feasthip_fact_t* F) {
+    if (!C || !F || n <= 0) return FEASTHIP_EARG;
+    *F = nullptr;
+    try {
+        Engine* e = new Engine(device_id);
+        if (e->status) { int st = e->status; { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return st; }
+        const void* mats[1] = {C};
+        int types[1] = {FEASTHIP_C128};
+        int r = e->set_dense(n, 1, mats, types, nullptr);
+        if (r) { { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return r; }
+        return make_fact(e, F);
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
+int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64_t* rowval, const void* nzval, int type,
+                    int index_base, feasthip_fact_t* F) {
+    if (!colptr || !rowval || !nzval || !F || n <= 0) return FEASTHIP_EARG;
+    *F = nullptr;
+    try {
+        Engine* e = new Engine(device_id);
+        if (e->status) { int st = e->status; { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return st; }
+        const int64_t* cps[1] = {colptr};
+        const int64_t* rvs[1] = {rowval};
+        const void* vs[1] = {nzval};
+        int types[1] = {type};
+        int r = e->set_csc(n, 1, cps, rvs, vs, types, nullptr, index_base);
+        if (r) { { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return r; }
+        return make_fact(e, F);
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
+int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0) {
+    if (!F || !F->e) return FEASTHIP_EARG;
+    try {
+        std::lock_guard<std::mutex> lk(F->mu);
+        return F->e->ldiv(Y, ldy, R, ldr, m0);
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
+int feasthip_fact_free(feasthip_fact_t F) {
+    if (!F) return 0;
+    try { delete F->e; delete F; } catch (...) {}
+    return 0;
+}
+
+// ---- host-only helpers -----------------------------------------------------
+static int build_pattern(int64_t n, const int64_t* colptr, const int64_t* rowval, int base, std::vector<int64_t>& cp, std::vector<int64_t>& ri) {
+    if (n <= 0 || !colptr || !rowval) return FEASTHIP_EARG;
+    cp.resize(n + 1);
+    for (int64_t j = 0; j <= n; ++j) cp[j] = colptr[j] - base;
+    if (cp[0] != 0) return FEASTHIP_EARG;
+    ri.resize(cp[n]);
+    for (int64_t e = 0; e < cp[n]; ++e) ri[e] = rowval[e] - base;
+    return 0;
+}
+
+int feasthip_symbolic_probe(int64_t n, const int64_t* colptr, const int64_t* rowval, int index_base, int ordering,
+                            int64_t* stats, int32_t* perm_out, int32_t* sn_of_out, int32_t* unused) {
+    (void)unused;
+    try {
+        std::vector<int64_t> cp, ri;
+        int r = build_pattern(n, colptr, rowval, index_base, cp, ri);
+        if (r) return r;
+        Symbolic S;
+        SymbolicOptions opt;
+        opt.ordering = ordering;
+        std::string e = analyze_pattern((int)n, cp.data(), ri.data(), opt, S);
+        if (!e.empty()) { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e; return FEASTHIP_EARG; }
+        if (stats) {
+            stats[0] = S.nsuper; stats[1] = S.nnz_l; stats[2] = S.nnz_u; stats[3] = S.fact_size; stats[4] = S.max_front;
+            stats[5] = S.max_p; stats[6] = S.maxdepth + 1; stats[7] = (int64_t)S.flops_factor;
+        }
+        if (perm_out) for (int64_t i = 0; i < n; ++i) perm_out[i] = S.perm[i];
+        if (sn_of_out) for (int64_t i = 0; i < n; ++i) sn_of_out[i] = S.sn_of[i];
+        return 0;
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
+int feasthip_symbolic_contains(int64_t n, const int64_t* colptr, const int64_t* rowval, int index_base, int ordering,
+                               const int32_t* ii, const int32_t* jj, int64_t count) {
+    try {
+        std::vector<int64_t> cp, ri;
+        int r = build_pattern(n, colptr, rowval, index_base, cp, ri);
+        if (r) return r;
+        Symbolic S;
+        SymbolicOptions opt;
+        opt.ordering = ordering;
+        std::string e = analyze_pattern((int)n, cp.data(), ri.data(), opt, S);
+        if (!e.empty()) return FEASTHIP_EARG;
+        int64_t bad = 0;
+        for (int64_t t = 0; t < count; ++t) {
+            if (ii[t] < 0 || ii[t] >= n || jj[t] < 0 || jj[t] >= n) return FEASTHIP_EARG;
+            if (entry_dest(S, ii[t], jj[t]) < 0) ++bad;
+        }
+        return bad > 0x7fffffff ? 0x7fffffff : (int)bad;
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
+int feasthip_small_eig(int m, const double* A, const double* B, double* lambda, double* V) {
+    if (m <= 0 || !A || !lambda || !V) return FEASTHIP_EARG;
+    try {
+        std::vector<zc> a((size_t)m * m), b, lam(m), v((size_t)m * m);
+        std::memcpy(a.data(), A, sizeof(zc) * (size_t)m * m);
+        int info;
+        if (B) { b.resize((size_t)m * m); std::memcpy(b.data(), B, sizeof(zc) * (size_t)m * m); info = eig_generalized(m, a.data(), b.data(), lam.data(), v.data()); }
+        else info = eig_general(m, a.data(), lam.data(), v.data());
+        std::memcpy(lambda, lam.data(), sizeof(zc) * m);
+        std::memcpy(V, v.data(), sizeof(zc) * (size_t)m * m);
+        return info ? FEASTHIP_ENUM : 0;
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// Shared host/device definitions for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace feasthip {
+
+typedef double2 cz;                                             // complex128 (re, im)
+typedef double d4 __attribute__((ext_vector_type(4)));         // f64 MFMA accumulator fragment
+
+// One supernodal front.  Its L panel is (p+u) x p column-major (ld = p+u) and
+// holds L11\U11 in the top p rows and L21 below; U12 is p x u column-major.
+struct FrontD {
+    int c0, p, u, parent;
+    int64_t lp, f12, cb;      // element offsets: factor arena (lp, f12), CB arena of depth&1 (cb)
+    int64_t sptr;             // offset into struct_idx / rel
+    int64_t crow;             // row offset into the solve-contribution arena of depth&1
+    int64_t child_ptr;
+    int nchild, depth;
+};
+
+struct Tile { int f, a, b, c; };
+
+__host__ __device__ inline cz cz_make(double x, double y) { cz r; r.x = x; r.y = y; return r; }
+__host__ __device__ inline cz cz_mul(cz a, cz b) { return cz_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__host__ __device__ inline cz cz_add(cz a, cz b) { return cz_make(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline cz cz_sub(cz a, cz b) { return cz_make(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline cz cz_conj(cz a) { return cz_make(a.x, -a.y); }
+// a -= b*c
+__host__ __device__ inline void cz_msub(cz& a, cz b, cz c) {
+    a.x -= b.x * c.x - b.y * c.y;
+    a.y -= b.x * c.y + b.y * c.x;
+}
+__host__ __device__ inline void cz_madd(cz& a, cz b, cz c) {
+    a.x += b.x * c.x - b.y * c.y;
+    a.y += b.x * c.y + b.y * c.x;
+}
+__host__ __device__ inline cz cz_inv(cz a) {
+    // Smith's algorithm (overflow-safe reciprocal)
+    if (fabs(a.x) >= fabs(a.y)) {
+        double r = a.y / a.x, d = a.x + a.y * r;
+        return cz_make(1.0 / d, -r / d);
+    }
+    double r = a.x / a.y, d = a.x * r + a.y;
+    return cz_make(r / d, -1.0 / d);
+}
+__host__ __device__ inline double cz_abs1(cz a) { return fabs(a.x) + fabs(a.y); }
+
+}  // namespace feasthip

@@ -1,0 +1,962 @@
+// See engine.hpp.  Reference semantics: src/feast.jl:10-80, 89-156;
+// src/nlfeast.jl:2-84; src/utils.jl:69-77, 104-116, 151-179.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/feasthip.h"
+#include "smalleig.hpp"
+
+namespace feasthip {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+template <class T> void DevBuf<T>::release() { if (p) { (void)hipFree((void*)p); p = nullptr; n = 0; } }
+template <class T> bool DevBuf<T>::alloc(size_t count) {
+    if (count <= n && p) return true;
+    release();
+    if (count == 0) count = 1;
+    void* q = nullptr;
+    if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    p = (T*)q;
+    n = count;
+    return true;
+}
+template <class T> bool DevBuf<T>::upload(const T* h, size_t count, hipStream_t st) {
+    if (!alloc(count)) return false;
+    if (count == 0) return true;
+    if (hipMemcpyAsync((void*)p, h, count * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+    return hipStreamSynchronize(st) == hipSuccess;
+}
+template struct DevBuf<cz>;
+template struct DevBuf<int>;
+template struct DevBuf<int64_t>;
+template struct DevBuf<double>;
+template struct DevBuf<FrontD>;
+template struct DevBuf<Tile>;
+template struct DevBuf<const cz*>;
+
+static inline cz to_cz(zc v) { return cz_make(v.real(), v.imag()); }
+
+Engine::Engine(int device) : device_(device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { (void)hipGetLastError(); fail(FEASTHIP_ENOGPU, "no HIP device visible: feasthip has no CPU fallback"); return; }
+    if (device < 0 || device >= cnt) { fail(FEASTHIP_EARG, "device id out of range"); return; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(FEASTHIP_EHIP, "hipGetDeviceProperties failed"); return; }
+    if (std::strstr(prop.gcnArchName, "gfx950") == nullptr) { fail(FEASTHIP_ENOGPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"); return; }
+    if (hipSetDevice(device) != hipSuccess) { fail(FEASTHIP_EHIP, "hipSetDevice failed"); return; }
+    if (hipStreamCreate(&stream_) != hipSuccess) { fail(FEASTHIP_EHIP, "hipStreamCreate failed"); return; }
+    own_stream_ = true;
+    (void)hipEventCreate(&ev0_);
+    (void)hipEventCreate(&ev1_);
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Engine::hip_fail(hipError_t e, const char* what) {
+    (void)hipGetLastError();
+    return fail(FEASTHIP_EHIP, std::string("HIP error '") + hipGetErrorString(e) + "' in " + what);
+}
+
+int Engine::set_stream(void* s) {
+    if (own_stream_ && stream_) { (void)hipStreamSynchronize(stream_); (void)hipStreamDestroy(stream_); }
+    stream_ = (hipStream_t)s;
+    own_stream_ = false;
+    return 0;
+}
+
+static zc read_val(const void* p, int type, int64_t idx) {
+    switch (type) {
+        case FEASTHIP_F64: return zc(((const double*)p)[idx], 0.0);
+        case FEASTHIP_C128: return zc(((const double*)p)[2 * idx], ((const double*)p)[2 * idx + 1]);
+        default: return zc((double)((const int64_t*)p)[idx], 0.0);
+    }
+}
+
+int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const int* types, const double* scale) {
+    if (n_ <= 0 || n_ > 65536 || nterms_ < 1 || nterms_ > 16 || !mats) return fail(FEASTHIP_EARG, "set_dense: bad n or nterms");
+    HIPCHK(hipSetDevice(device_));
+    n = (int)n_; nterms = nterms_; dense = true;
+    analyzed_ = factored_ = have_x_ = false;
+    terms_.clear();
+    terms_.resize(nterms);
+    std::vector<zc> tmp;
+    for (int t = 0; t < nterms; ++t) {
+        SparseTerm& T = terms_[t];
+        T.scale = scale ? zc(scale[2 * t], scale[2 * t + 1]) : zc(1.0);
+        if (!mats[t]) { T.identity = true; T.maxabs = 1.0; continue; }
+        int ty = types ? types[t] : FEASTHIP_C128;
+        if (ty < 0 || ty > 2) return fail(FEASTHIP_EARG, "set_dense: bad element type");
+        size_t nn = (size_t)n * n;
+        tmp.resize(nn);
+        double mx = 0;
+        for (size_t e = 0; e < nn; ++e) { tmp[e] = read_val(mats[t], ty, (int64_t)e); mx = std::max(mx, std::abs(tmp[e])); }
+        T.maxabs = mx;
+        if (!T.d_dense.upload((const cz*)tmp.data(), nn, stream_)) return fail(FEASTHIP_EHIP, "set_dense: device allocation/upload failed");
+    }
+    return 0;
+}
+
+int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const int64_t* const* rowval,
+                    const void* const* nzval, const int* types, const double* scale, int base) {
+    if (n_ <= 0 || n_ > 0x7fffffff / 2 || nterms_ < 1 || nterms_ > 16 || !colptr || !rowval || !nzval)
+        return fail(FEASTHIP_EARG, "set_csc: bad n or nterms");
+    HIPCHK(hipSetDevice(device_));
+    n = (int)n_; nterms = nterms_; dense = false;
+    analyzed_ = factored_ = have_x_ = false;
+    terms_.clear();
+    terms_.resize(nterms);
+    for (int t = 0; t < nterms; ++t) {
+        SparseTerm& T = terms_[t];
+        T.scale = scale ? zc(scale[2 * t], scale[2 * t + 1]) : zc(1.0);
+        T.colptr.resize(n + 1);
+        if (!colptr[t]) {   // identity, stored as an explicit diagonal
+            T.identity = true;
+            T.rowval.resize(n);
+            T.val.assign(n, zc(1.0));
+            for (int j = 0; j <= n; ++j) T.colptr[j] = j;
+            for (int j = 0; j < n; ++j) T.rowval[j] = j;
+            T.maxabs = 1.0;
+            continue;
+        }
+        int ty = types ? types[t] : FEASTHIP_C128;
+        if (ty < 0 || ty > 2) return fail(FEASTHIP_EARG, "set_csc: bad element type");
+        for (int j = 0; j <= n; ++j) T.colptr[j] = colptr[t][j] - base;
+        int64_t nnz = T.colptr[n];
+        if (T.colptr[0] != 0 || nnz < 0) return fail(FEASTHIP_EARG, "set_csc: colptr[0] != index_base");
+        T.rowval.resize(nnz);
+        T.val.resize(nnz);
+        double mx = 0;
+        for (int j = 0; j < n; ++j) {
+            if (T.colptr[j + 1] < T.colptr[j]) return fail(FEASTHIP_EARG, "set_csc: colptr not monotone");
+            for (int64_t e = T.colptr[j]; e < T.colptr[j + 1]; ++e) {
+                int64_t r = rowval[t][e] - base;
+                if (r < 0 || r >= n) return fail(FEASTHIP_EDIM_A, "Incorrect dimensions of A, must be square");
+                T.rowval[e] = (int)r;
+                T.val[e] = read_val(nzval[t], ty, e);
+                mx = std::max(mx, std::abs(T.val[e]));
+            }
+        }
+        T.maxabs = mx;
+    }
+    return 0;
+}
+
+int Engine::set_contour(int K_, const double* nodes, const double* weights, int kind, const double* region) {
+    if (K_ <= 0 || !nodes || !weights) return fail(FEASTHIP_EARG, "set_contour: bad arguments");
+    K = K_;
+    nodes_.resize(K); weights_.resize(K);
+    for (int k = 0; k < K; ++k) { nodes_[k] = zc(nodes[2 * k], nodes[2 * k + 1]); weights_[k] = zc(weights[2 * k], weights[2 * k + 1]); }
+    region_kind_ = kind;
+    if (region) std::memcpy(region_, region, sizeof(region_));
+    factored_ = false;
+    return set_shard(shard_first_, shard_stride_);
+}
+
+int Engine::set_shard(int first, int stride) {
+    if (first < 0 || stride < 1) return fail(FEASTHIP_EARG, "set_node_shard: bad shard");
+    shard_first_ = first; shard_stride_ = stride;
+    local_.clear();
+    for (int k = first; k < K; k += stride) local_.push_back(k);
+    if ((int)local_.size() != Kloc) { factored_ = false; analyzed_ = false; have_x_ = false; }
+    factored_ = false;
+    Kloc = (int)local_.size();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+bool Engine::build_plans() {
+    std::vector<Tile> tiles;
+    std::vector<int> lists;
+    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    int nd = S.maxdepth + 1;
+    fplan_.assign(nd, FactorLevel());
+    splan_.assign(nd, SolveLevel());
+    std::vector<int> nchild(S.nsuper);
+    for (int s = 0; s < S.nsuper; ++s) nchild[s] = (int)(S.child_ptr[s + 1] - S.child_ptr[s]);
+    for (int d = 0; d < nd; ++d) {
+        const std::vector<int>& lv = S.levels[d];
+        FactorLevel& F = fplan_[d];
+        SolveLevel& V = splan_[d];
+        int pmax = 0;
+        for (int s : lv) pmax = std::max(pmax, S.p(s));
+        // extend-add / solve assembly
+        F.extend.off = (int64_t)tiles.size();
+        for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s) + S.u(s), 64); for (int a = 0; a < nt; ++a) for (int b = 0; b < nt; ++b) tiles.push_back({s, a, b, 0}); }
+        F.extend.count = (int)(tiles.size() - F.extend.off);
+        V.assemble.off = (int64_t)tiles.size();
+        for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s) + S.u(s), 64); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }
+        V.assemble.count = (int)(tiles.size() - V.assemble.off);
+        // factor steps
+        for (int k0 = 0; k0 < pmax; k0 += FACT_NB) {
+            FactorStep st;
+            st.k0 = k0;
+            st.panel.off = (int64_t)lists.size();
+            for (int s : lv) if (S.p(s) > k0) lists.push_back(s);
+            st.panel.count = (int)(lists.size() - st.panel.off);
+            st.swap.off = (int64_t)tiles.size();
+            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); int nt = cdiv(p - b + u, 256); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }
+            st.swap.count = (int)(tiles.size() - st.swap.off);
+            st.trsm.off = (int64_t)tiles.size();
+            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); int nc = (p - k0 - b) + u; int nt = cdiv(nc, 128); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }
+            st.trsm.count = (int)(tiles.size() - st.trsm.off);
+            st.gemm.off = (int64_t)tiles.size();
+            for (int s : lv) if (S.p(s) > k0) {
+                int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0), ld = p + u;
+                int M0 = ld - k0 - b, N0 = p - k0 - b;
+                if (M0 > 0 && N0 > 0) for (int a = 0; a < cdiv(M0, 64); ++a) for (int c = 0; c < cdiv(N0, 64); ++c) tiles.push_back({s, 0, a, c});
+                int M1 = p - k0 - b, N1 = u;
+                if (M1 > 0 && N1 > 0) for (int a = 0; a < cdiv(M1, 64); ++a) for (int c = 0; c < cdiv(N1, 64); ++c) tiles.push_back({s, 1, a, c});
+            }
+            st.gemm.count = (int)(tiles.size() - st.gemm.off);
+            F.steps.push_back(st);
+        }
+        F.cbgemm.off = (int64_t)tiles.size();
+        for (int s : lv) if (S.u(s) > 0) { int nt = cdiv(S.u(s), 64); for (int a = 0; a < nt; ++a) for (int c = 0; c < nt; ++c) tiles.push_back({s, 2, a, c}); }
+        F.cbgemm.count = (int)(tiles.size() - F.cbgemm.off);
+        F.fronts.off = (int64_t)lists.size();
+        for (int s : lv) lists.push_back(s);
+        F.fronts.count = (int)lv.size();
+        // solve steps
+        for (int k0 = 0; k0 < pmax; k0 += SOLVE_NB) {
+            SolveStep st;
+            st.k0 = k0;
+            st.diag.off = (int64_t)lists.size();
+            for (int s : lv) if (S.p(s) > k0) lists.push_back(s);
+            st.diag.count = (int)(lists.size() - st.diag.off);
+            st.fwd.off = (int64_t)tiles.size();
+            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), b = std::min(SOLVE_NB, p - k0); int rows = p + S.u(s) - k0 - b; for (int a = 0; a < cdiv(rows, 64); ++a) tiles.push_back({s, a, 0, 0}); }
+            st.fwd.count = (int)(tiles.size() - st.fwd.off);
+            st.bwd.off = (int64_t)tiles.size();
+            for (int s : lv) if (S.p(s) > k0 && k0 > 0) for (int a = 0; a < cdiv(k0, 64); ++a) tiles.push_back({s, a, 0, 0});
+            st.bwd.count = (int)(tiles.size() - st.bwd.off);
+            V.steps.push_back(st);
+        }
+        V.u12.off = (int64_t)tiles.size();
+        for (int s : lv) if (S.u(s) > 0) for (int a = 0; a < cdiv(S.p(s), 64); ++a) tiles.push_back({s, a, 0, 0});
+        V.u12.count = (int)(tiles.size() - V.u12.off);
+    }
+    if (tiles.empty()) tiles.push_back({0, 0, 0, 0});
+    if (lists.empty()) lists.push_back(0);
+    return d_tiles_.upload(tiles.data(), tiles.size(), stream_) && d_lists_.upload(lists.data(), lists.size(), stream_);
+}
+
+int Engine::analyze() {
+    if (n <= 0 || terms_.empty()) return fail(FEASTHIP_ESTATE, "analyze: no matrices set");
+    if (Kloc <= 0) return fail(FEASTHIP_ESTATE, "analyze: no contour nodes on this shard");
+    HIPCHK(hipSetDevice(device_));
+    auto t0 = std::chrono::steady_clock::now();
+    if (dense) {
+        analyze_dense(n, S);
+    } else {
+        std::vector<int64_t> cp(n + 1, 0), ri;
+        for (int j = 0; j < n; ++j) {
+            int64_t c = 1;
+            for (auto& T : terms_) c += T.colptr[j + 1] - T.colptr[j];
+            cp[j + 1] = cp[j] + c;
+        }
+        ri.resize(cp[n]);
+        for (int j = 0; j < n; ++j) {
+            int64_t o = cp[j];
+            ri[o++] = j;
+            for (auto& T : terms_) for (int64_t e = T.colptr[j]; e < T.colptr[j + 1]; ++e) ri[o++] = T.rowval[e];
+        }
+        SymbolicOptions opt;
+        std::string e = analyze_pattern(n, cp.data(), ri.data(), opt, S);
+        if (!e.empty()) return fail(FEASTHIP_EARG, "analyze: " + e);
+        // arena destinations + CSR copies for SpMM
+        for (auto& T : terms_) {
+            int64_t nnz = T.colptr[n];
+            std::vector<int64_t> dest(nnz);
+            for (int j = 0; j < n; ++j)
+                for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
+                    dest[e2] = entry_dest(S, T.rowval[e2], j);
+                    if (dest[e2] < 0) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
+                }
+            std::vector<int64_t> rp(n + 1, 0);
+            for (int64_t e2 = 0; e2 < nnz; ++e2) rp[T.rowval[e2] + 1]++;
+            for (int i = 0; i < n; ++i) rp[i + 1] += rp[i];
+            std::vector<int> col(nnz);
+            std::vector<zc> v(nnz);
+            std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
+            for (int j = 0; j < n; ++j)
+                for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; col[q] = j; v[q] = T.val[e2]; }
+            bool ok = T.d_dest.upload(dest.data(), nnz, stream_) && T.d_cscval.upload((const cz*)T.val.data(), nnz, stream_) &&
+                      T.d_rowptr.upload(rp.data(), n + 1, stream_) && T.d_col.upload(col.data(), nnz, stream_) &&
+                      T.d_val.upload((const cz*)v.data(), nnz, stream_);
+            if (!ok) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+        }
+    }
+    // device symbolic
+    std::vector<FrontD> fr(S.nsuper);
+    for (int s = 0; s < S.nsuper; ++s) {
+        FrontD& f = fr[s];
+        f.c0 = S.sn_start[s]; f.p = S.p(s); f.u = S.u(s); f.parent = S.sn_parent[s];
+        f.lp = S.lp_off[s]; f.f12 = S.f12_off[s]; f.cb = S.cb_off[s];
+        f.sptr = S.struct_ptr[s]; f.crow = S.crow_off[s];
+        f.child_ptr = S.child_ptr[s]; f.nchild = (int)(S.child_ptr[s + 1] - S.child_ptr[s]); f.depth = S.depth[s];
+    }
+    std::vector<int> c0row(n);
+    for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
+    std::vector<int> one(1, 0);
+    bool ok = d_fr_.upload(fr.data(), fr.size(), stream_) &&
+              d_struct_.upload(S.struct_idx.empty() ? one.data() : S.struct_idx.data(), std::max<size_t>(1, S.struct_idx.size()), stream_) &&
+              d_rel_.upload(S.rel.empty() ? one.data() : S.rel.data(), std::max<size_t>(1, S.rel.size()), stream_) &&
+              d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
+              d_perm_.upload(S.perm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_);
+    if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
+    dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
+    dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.n = n;
+    // numeric arenas
+    ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
+         d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
+         d_rowperm_.alloc((size_t)Kloc * n) && d_rowinv_.alloc((size_t)Kloc * n) && d_nperturb_.alloc(Kloc) &&
+         d_tiny_.alloc(Kloc) && d_coef_.alloc((size_t)Kloc * nterms);
+    if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
+    analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    analyzed_ = true;
+    factored_ = false;
+    return 0;
+}
+
+int Engine::factorize() {
+    if (!analyzed_) { int r = analyze(); if (r) return r; }
+    HIPCHK(hipSetDevice(device_));
+    // per-node polynomial coefficients scale_t * z_k^t and pivot thresholds
+    std::vector<zc> coef((size_t)Kloc * nterms);
+    std::vector<double> tiny(Kloc);
+    for (int kk = 0; kk < Kloc; ++kk) {
+        zc z = nodes_[local_[kk]], zp = 1.0;
+        double nrm = 0;
+        for (int t = 0; t < nterms; ++t) { coef[(size_t)kk * nterms + t] = terms_[t].scale * zp; nrm += std::abs(coef[(size_t)kk * nterms + t]) * terms_[t].maxabs; zp *= z; }
+        tiny[kk] = std::max(nrm * 2.2e-19, 1e-300);
+    }
+    HIPCHK(hipMemcpyAsync(d_coef_.p, coef.data(), coef.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(d_tiny_.p, tiny.data(), tiny.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemsetAsync(d_nperturb_.p, 0, Kloc * sizeof(int), stream_));
+    HIPCHK(hipStreamSynchronize(stream_));   // coef/tiny are stack-owned host buffers
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int64_t fs = S.fact_size;
+    if (dense) {
+        std::vector<const cz*> ptrs(nterms);
+        for (int t = 0; t < nterms; ++t) ptrs[t] = terms_[t].identity ? nullptr : terms_[t].d_dense.p;
+        if (!d_matptr_.upload(ptrs.data(), nterms, stream_)) return fail(FEASTHIP_EHIP, "factorize: upload failed");
+        launch_dense_assemble(stream_, d_fact_.p, fs, n, d_matptr_.p, nterms, d_coef_.p, Kloc);
+    } else {
+        HIPCHK(hipMemsetAsync(d_fact_.p, 0, (size_t)Kloc * fs * sizeof(cz), stream_));
+        for (int t = 0; t < nterms; ++t)
+            launch_scatter(stream_, d_fact_.p, fs, terms_[t].d_dest.p, terms_[t].d_cscval.p, terms_[t].colptr[n], d_coef_.p, nterms, t, Kloc);
+    }
+    const Tile* tl = d_tiles_.p;
+    const int* ls = d_lists_.p;
+    for (int d = S.maxdepth; d >= 0; --d) {
+        FactorLevel& F = fplan_[d];
+        int par = d & 1;
+        cz* cbp = d_cb_[par].p;
+        int64_t cbs = std::max<int64_t>(1, S.cb_size[par]);
+        if (S.cb_used[d] > 0)
+            HIPCHK(hipMemset2DAsync(cbp, (size_t)cbs * sizeof(cz), 0, (size_t)S.cb_used[d] * sizeof(cz), Kloc, stream_));
+        launch_extend_add(stream_, dsym_, tl + F.extend.off, F.extend.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
+                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc);
+        for (FactorStep& st : F.steps) {
+            launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc);
+            launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
+            launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
+            launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
+        }
+        launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
+        launch_rowperm(stream_, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
+    }
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    std::vector<int> np(Kloc);
+    HIPCHK(hipMemcpyAsync(np.data(), d_nperturb_.p, Kloc * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    factor_ms = ms;
+    perturbed = 0;
+    for (int v : np) perturbed += v;
+    factored_ = true;
+    return perturbed > 0 ? (int)std::min<int64_t>(perturbed, 0x7fffffff) : 0;
+}
+
+// ---------------------------------------------------------------------------
+int Engine::alloc_iteration_buffers() {
+    size_t blk = (size_t)n * ldw;
+    bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && d_Q_.alloc(2 * blk) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
+              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * blk) &&
+              d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * ldw) &&
+              d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * ldw) &&
+              d_e0_.alloc((size_t)Kloc * ldw) && d_e1_.alloc((size_t)Kloc * ldw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
+              d_lam_.alloc(ldw) && d_gram_scratch_.alloc(gram_scratch_elems(n, ldw)) && d_io_.alloc((size_t)n * std::max(1, m0)) &&
+              d_nrm_.alloc(ldw) && d_nrm_scratch_.alloc(colnorm_scratch_elems(n, ldw));
+    if (!ok) return fail(FEASTHIP_EHIP, "out of device memory for the iteration buffers");
+    return 0;
+}
+
+int Engine::set_x(const void* X, int64_t n_, int m0_) {
+    if (!X || m0_ <= 0) return fail(FEASTHIP_EARG, "set_x: bad arguments");
+    if (n_ != n) return fail(FEASTHIP_EDIM_X, "Incorrect dimensions of X, must match A");
+    if (m0_ > n) return fail(FEASTHIP_EARG, "set_x: m0 must not exceed n");
+    if (!analyzed_) { int r = analyze(); if (r) return r; }
+    HIPCHK(hipSetDevice(device_));
+    m0 = m0_;
+    ldw = ((m0 + 15) / 16) * 16;
+    int r = alloc_iteration_buffers();
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(d_io_.p, X, (size_t)n * m0 * sizeof(cz), hipMemcpyHostToDevice, stream_));
+    launch_cm_to_rm(stream_, n, m0, ldw, d_io_.p, n, d_X_.p);
+    HIPCHK(hipMemcpyAsync(d_Q_.p, d_X_.p, (size_t)n * ldw * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+    HIPCHK(hipMemsetAsync(d_R_.p, 0, (size_t)n * ldw * sizeof(cz), stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    lambda_.assign(m0, zc(0.0));
+    have_x_ = true;
+    return 0;
+}
+
+int Engine::get_block(int which, void* out) {
+    if (!have_x_ || !out) return fail(FEASTHIP_ESTATE, "get_block: no iteration state");
+    HIPCHK(hipSetDevice(device_));
+    const cz* src = which == 0 ? d_X_.p : which == 1 ? d_R_.p : which == 2 ? d_Q_.p : d_Q_.p + (size_t)n * ldw;
+    launch_rm_to_cm(stream_, n, m0, ldw, src, d_io_.p, n);
+    HIPCHK(hipMemcpyAsync(out, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return 0;
+}
+
+int Engine::q_device(void** p, int64_t* n_, int64_t* ldq, int* nblocks) {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "q_device: call set_x first");
+    if (p) *p = (void*)d_Q_.p;
+    if (n_) *n_ = n;
+    if (ldq) *ldq = ldw;
+    if (nblocks) *nblocks = 2;
+    return 0;
+}
+
+void Engine::apply_term(int t, const cz* V, cz* out, zc alpha, bool accumulate) {
+    SparseTerm& T = terms_[t];
+    zc a = alpha * T.scale;
+    if (dense) {
+        if (T.identity) launch_axpby(stream_, n, ldw, out, to_cz(a), V, accumulate ? 1 : 0);
+        else launch_dense_mv(stream_, n, T.d_dense.p, V, ldw, out, to_cz(a), accumulate ? 1 : 0);
+    } else {
+        launch_spmm_csr(stream_, n, T.d_rowptr.p, T.d_col.p, T.d_val.p, V, ldw, out, to_cz(a), accumulate ? 1 : 0);
+    }
+}
+
+int Engine::col_norms(const cz* V, std::vector<double>& out) {
+    launch_colnorm2(stream_, n, ldw, V, d_nrm_scratch_.p, d_nrm_.p);
+    out.resize(ldw);
+    HIPCHK(hipMemcpyAsync(out.data(), d_nrm_.p, ldw * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (double& v : out) v = std::sqrt(v);
+    return 0;
+}
+
+// Thin orthonormal basis of span(Q) (replaces `Q .= Matrix(qr(Q).Q)`, src/feast.jl:41,117).
+// Column-scaled CholeskyQR2: columns are normalised first (the FEAST filter scales column j by
+// rho(lambda_j), which is the dominant source of ill-conditioning), then two Cholesky passes on
+// the f64-MFMA Gram matrix.  Rtotal (optional) receives R with Q_in = Q_out * R.
+int Engine::orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
+    int m = m0;
+    std::vector<double> nr;
+    int r = col_norms(Q, nr);
+    if (r) return r;
+    std::vector<zc> sc(ldw, zc(0.0)), Rt((size_t)m * m, zc(0.0));
+    for (int j = 0; j < m; ++j) {
+        if (!(nr[j] > 0.0) || !std::isfinite(nr[j])) return fail(FEASTHIP_ENUM, "orthonormalize: zero or non-finite column in the subspace");
+        sc[j] = 1.0 / nr[j];
+        Rt[j + (size_t)j * m] = nr[j];
+    }
+    HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, n, ldw, Q, d_lam_.p);
+    HIPCHK(hipStreamSynchronize(stream_));
+    std::vector<zc> G((size_t)m * m), Rn((size_t)m * m), up((size_t)ldw * ldw);
+    cz* dG = d_small_.p;
+    cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
+    for (int pass = 0; pass < 2; ++pass) {
+        launch_gram(stream_, n, m, ldw, Q, Q, d_gram_scratch_.p, dG);
+        HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (G[i + (size_t)j * m] + std::conj(G[j + (size_t)i * m])); G[i + (size_t)j * m] = a; G[j + (size_t)i * m] = std::conj(a); }
+        std::vector<zc> Gc(G);
+        int info = cholesky_upper(m, Gc.data());
+        if (info) {   // shifted CholeskyQR for a numerically rank-deficient block
+            double tr = 0;
+            for (int j = 0; j < m; ++j) tr += G[j + (size_t)j * m].real();
+            double shift = 1e-13 * tr + 1e-300;
+            for (int tries = 0; tries < 6 && info; ++tries) {
+                Gc = G;
+                for (int j = 0; j < m; ++j) Gc[j + (size_t)j * m] += shift;
+                info = cholesky_upper(m, Gc.data());
+                shift *= 100.0;
+            }
+            if (info) return fail(FEASTHIP_ENUM, "orthonormalize: Gram matrix not positive definite");
+            if (pass == 1) pass = 0;   // one more clean-up pass after a shifted one
+        }
+        // Rt <- R * Rt
+        matmul(m, Gc.data(), Rt.data(), Rn.data());
+        Rt.swap(Rn);
+        trtri_upper(m, Gc.data());
+        HIPCHK(hipMemcpyAsync(dM, Gc.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        launch_ts_gemm(stream_, n, m, ldw, Q, dM, tmp);
+        HIPCHK(hipMemcpyAsync(Q, tmp, (size_t)n * ldw * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+    }
+    if (Rtotal) *Rtotal = Rt;
+    return 0;
+}
+
+void Engine::inside_test(const zc* lam, uint8_t* inside) const {
+    for (int j = 0; j < m0; ++j) {
+        if (region_kind_ == FEASTHIP_REGION_RECT)
+            inside[j] = (region_[0] < lam[j].real() && lam[j].real() < region_[2] && region_[1] < lam[j].imag() && lam[j].imag() < region_[3]) ? 1 : 0;
+        else
+            inside[j] = (std::abs(lam[j] - zc(region_[0], region_[1])) <= region_[2]) ? 1 : 0;
+    }
+}
+
+int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "rr_step: call set_x first");
+    if (nterms != 2) return fail(FEASTHIP_ESTATE, "rr_step: linear pencil (2 terms) required");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int m = m0;
+    int r = orthonormalize(d_Q_.p, d_T1_.p, nullptr);                     // src/feast.jl:41
+    if (r) return r;
+    cz* dA = d_small_.p;
+    cz* dB = d_small_.p + (size_t)ldw * ldw;
+    cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
+    std::vector<zc> Aq((size_t)m * m), Bq((size_t)m * m), lam(m), Xq((size_t)m * m);
+    apply_term(0, d_Q_.p, d_R_.p, 1.0, false);                            // R = A Q          :42
+    launch_gram(stream_, n, m, ldw, d_Q_.p, d_R_.p, d_gram_scratch_.p, dA);   // Aq = Q' R   :43
+    // B = -scale_1 * M_1
+    bool b_is_identity = terms_[1].identity && std::abs(terms_[1].scale + 1.0) == 0.0;
+    if (!b_is_identity) {
+        apply_term(1, d_Q_.p, d_T1_.p, -1.0, false);                      // R = B Q          :120
+        launch_gram(stream_, n, m, ldw, d_Q_.p, d_T1_.p, d_gram_scratch_.p, dB);   // Bq    :121
+        HIPCHK(hipMemcpyAsync(Bq.data(), dB, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    }
+    HIPCHK(hipMemcpyAsync(Aq.data(), dA, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    int info = b_is_identity ? eig_general(m, Aq.data(), lam.data(), Xq.data())     // :45
+                             : eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data());   // :122
+    if (info) return fail(FEASTHIP_ENUM, "rr_step: reduced eigenproblem failed to converge");
+    HIPCHK(hipMemcpyAsync(dM, Xq.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_ts_gemm(stream_, n, m, ldw, d_Q_.p, dM, d_X_.p);              // X = Q Xq         :48
+    // update_R!  src/utils.jl:111-116
+    std::vector<double> nr;
+    r = col_norms(d_X_.p, nr);
+    if (r) return r;
+    std::vector<zc> sc(ldw, zc(0.0)), lamp(ldw, zc(0.0));
+    for (int j = 0; j < m; ++j) { sc[j] = nr[j] > 0 ? 1.0 / nr[j] : 1.0; lamp[j] = lam[j]; }
+    HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, n, ldw, d_X_.p, d_lam_.p);
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipMemcpyAsync(d_lam_.p, lamp.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    apply_term(0, d_X_.p, d_T1_.p, 1.0, false);                          // A X
+    const cz* BX = d_X_.p;
+    if (!b_is_identity) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
+    launch_residual_combine(stream_, n, ldw, d_T1_.p, BX, d_lam_.p, d_R_.p);
+    r = col_norms(d_R_.p, nr);                                           // residuals! :166-171
+    if (r) return r;
+    lambda_ = lam;
+    for (int j = 0; j < m; ++j) { lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag(); res[j] = nr[j]; }
+    inside_test(lam.data(), inside);
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    rr_ms = ms;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+int Engine::solve_all(const cz* rhs) { return solve_all_impl(rhs, nullptr); }
+
+int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
+    if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
+    int64_t fs = S.fact_size, ws = (int64_t)n * ldw;
+    const Tile* tl = d_tiles_.p;
+    const int* ls = d_lists_.p;
+    hipEvent_t pa = nullptr, pb = nullptr;
+    if (prof) { HIPCHK(hipEventCreate(&pa)); HIPCHK(hipEventCreate(&pb)); }
+    auto begin = [&]() { if (prof) (void)hipEventRecord(pa, stream_); };
+    auto end = [&](int row, double bytes, double flops) {
+        if (!prof) return;
+        (void)hipEventRecord(pb, stream_);
+        (void)hipEventSynchronize(pb);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, pa, pb);
+        prof[row].ms += ms; prof[row].bytes += bytes; prof[row].flops += flops; prof[row].launches++;
+    };
+    double rowb = (double)ldw * 16.0;
+    begin();
+    launch_gather_rhs(stream_, dsym_, rhs, ldw, d_W_.p, ws, d_rowperm_.p, Kloc);
+    end(0, 2.0 * n * rowb * Kloc, 0);
+    // per-level byte/flop tallies for the profile rows
+    auto level_stats = [&](int d, int k0, int kind, double& bytes, double& flops) {
+        bytes = flops = 0;
+        for (int s : S.levels[d]) {
+            int p = S.p(s), u = S.u(s);
+            if (kind == 2) { if (u > 0) { bytes += ((double)p * u * 16 + (double)(u + 2.0 * p) * rowb) ; flops += 8.0 * p * u * ldw; } continue; }
+            if (p <= k0) continue;
+            int b = std::min(SOLVE_NB, p - k0);
+            double rows = kind == 0 ? (double)(p + u - k0 - b) : (double)k0;
+            if (rows <= 0) continue;
+            bytes += rows * b * 16 + (2.0 * rows + b) * rowb;
+            flops += 8.0 * rows * b * ldw;
+        }
+        bytes *= Kloc; flops *= Kloc;
+    };
+    auto diag_stats = [&](int d, int k0, double& bytes, double& flops) {
+        bytes = flops = 0;
+        for (int s : S.levels[d]) { int p = S.p(s); if (p <= k0) continue; int b = std::min(SOLVE_NB, p - k0); bytes += (double)b * b * 16 + 2.0 * b * rowb; flops += 4.0 * b * b * ldw; }
+        bytes *= Kloc; flops *= Kloc;
+    };
+    for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
+        SolveLevel& V = splan_[d];
+        int par = d & 1;
+        int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
+        if (S.crow_used[d] > 0)
+            HIPCHK(hipMemset2DAsync(d_crow_[par].p, (size_t)crs * sizeof(cz), 0, (size_t)S.crow_used[d] * ldw * sizeof(cz), Kloc, stream_));
+        begin();
+        launch_fwd_assemble(stream_, dsym_, tl + V.assemble.off, V.assemble.count, d_W_.p, ws, ldw, d_crow_[par].p, crs,
+                            d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc);
+        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 3.0 * rows * rowb * Kloc, 0); }
+        for (SolveStep& st : V.steps) {
+            double by, fl;
+            begin();
+            launch_diag_solve(stream_, dsym_, ls + st.diag.off, st.diag.count, st.k0, 0, d_fact_.p, fs, d_W_.p, ws, ldw, Kloc);
+            if (prof) { diag_stats(d, st.k0, by, fl); end(2, by, fl); }
+            begin();
+            launch_panel_apply(stream_, dsym_, tl + st.fwd.off, st.fwd.count, st.k0, 0, d_fact_.p, fs, d_W_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
+            if (prof && st.fwd.count) { level_stats(d, st.k0, 0, by, fl); end(3, by, fl); }
+        }
+    }
+    for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
+        SolveLevel& V = splan_[d];
+        double by, fl;
+        begin();
+        launch_panel_apply(stream_, dsym_, tl + V.u12.off, V.u12.count, 0, 2, d_fact_.p, fs, d_W_.p, ws, ldw, nullptr, 0, Kloc);
+        if (prof && V.u12.count) { level_stats(d, 0, 2, by, fl); end(3, by, fl); }
+        for (int si = (int)V.steps.size() - 1; si >= 0; --si) {
+            SolveStep& st = V.steps[si];
+            begin();
+            launch_diag_solve(stream_, dsym_, ls + st.diag.off, st.diag.count, st.k0, 1, d_fact_.p, fs, d_W_.p, ws, ldw, Kloc);
+            if (prof) { diag_stats(d, st.k0, by, fl); end(2, by, fl); }
+            begin();
+            launch_panel_apply(stream_, dsym_, tl + st.bwd.off, st.bwd.count, st.k0, 1, d_fact_.p, fs, d_W_.p, ws, ldw, nullptr, 0, Kloc);
+            if (prof && st.bwd.count) { level_stats(d, st.k0, 1, by, fl); end(3, by, fl); }
+        }
+    }
+    if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+double Engine::solve_bytes() const {
+    // factor entries streamed once per node and sweep pair + block-vector traffic
+    double rowb = (double)ldw * 16.0;
+    double per_node = (double)S.fact_size * 16.0 + (double)S.sum_u * 4.0 + (4.0 * n + 3.0 * (double)S.sum_u) * rowb;
+    return per_node * Kloc + 3.0 * n * rowb;
+}
+
+double Engine::solve_flops() const {
+    return ((double)(S.nnz_l + S.nnz_u) * 8.0 * ldw) * Kloc + 16.0 * n * (double)ldw * Kloc;
+}
+
+int Engine::contour_step(int refactor) {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "contour_step: call set_x and rr_step first");
+    HIPCHK(hipSetDevice(device_));
+    if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; }
+    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
+    for (int kk = 0; kk < Kloc; ++kk) {
+        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
+        for (int j = 0; j < m0; ++j) e0[(size_t)kk * ldw + j] = w / (z - lambda_[j]);      // src/feast.jl:60,69
+    }
+    HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int r = solve_all(d_R_.p);                                                                // :61-66
+    if (r) return r;
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_Q_.p, nullptr);   // :68-70
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    solve_ms = ms;
+    return 0;
+}
+
+int Engine::profile_solve(ProfileRow* rows) {
+    if (!have_x_ || !factored_) return fail(FEASTHIP_ESTATE, "profile_solve: needs a factorised problem and iteration state");
+    HIPCHK(hipSetDevice(device_));
+    for (int i = 0; i < 8; ++i) rows[i] = ProfileRow();
+    int r = solve_all_impl(d_R_.p, rows);
+    if (r) return r;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, stream_));
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
+    HIPCHK(hipEventRecord(b, stream_));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    rows[4].ms = ms; rows[4].launches = 1; rows[4].bytes = ((double)Kloc + 2.0) * n * ldw * 16.0;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// NLFEAST  (src/nlfeast.jl:2-84)
+// ---------------------------------------------------------------------------
+int Engine::nl_orthonormalize_x() {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "nl_orthonormalize_x: call set_x first");
+    HIPCHK(hipSetDevice(device_));
+    return orthonormalize(d_X_.p, d_T1_.p, nullptr);       // src/nlfeast.jl:12-13
+}
+
+int Engine::nl_contour_step(int first) {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "nl_contour_step: call set_x first");
+    HIPCHK(hipSetDevice(device_));
+    if (!factored_) { int r = factorize(); if (r < 0) return r; }
+    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0)), e1((size_t)Kloc * ldw, zc(0.0));
+    for (int kk = 0; kk < Kloc; ++kk) {
+        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
+        for (int j = 0; j < m0; ++j) {
+            zc e = first ? w : w / (z - lambda_[j]);           // src/nlfeast.jl:42 / :47
+            e0[(size_t)kk * ldw + j] = e;
+            e1[(size_t)kk * ldw + j] = e * z;                  // :58
+        }
+    }
+    HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(d_e1_.p, e1.data(), e1.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int r = solve_all(first ? d_X_.p : d_R_.p);               // :41 / :49
+    if (r) return r;
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, d_Q_.p,
+                      d_Q_.p + (size_t)n * ldw);
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    solve_ms = ms;
+    return 0;
+}
+
+static double frob_inner_sparse(const SparseTerm& A, const SparseTerm& B, int n, zc& out) {
+    zc acc = 0;
+    for (int j = 0; j < n; ++j) {
+        int64_t a = A.colptr[j], ae = A.colptr[j + 1], b = B.colptr[j], be = B.colptr[j + 1];
+        while (a < ae && b < be) {
+            if (A.rowval[a] < B.rowval[b]) ++a;
+            else if (A.rowval[a] > B.rowval[b]) ++b;
+            else { acc += std::conj(A.val[a]) * B.val[b]; ++a; ++b; }
+        }
+    }
+    out = acc;
+    return 0;
+}
+
+int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside) {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "nl_rr_step: call set_x first");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int m = m0;
+    cz* Q0 = d_Q_.p;
+    cz* Q1 = d_Q_.p + (size_t)n * ldw;
+    // beyn_svd_step!  src/utils.jl:69-77: thin SVD of Q0 through the orthonormal basis Qo (Q0 = Qo Rr)
+    std::vector<zc> Rr;
+    int r = orthonormalize(Q0, d_T1_.p, &Rr);
+    if (r) return r;
+    std::vector<zc> Ur((size_t)m * m), Vr((size_t)m * m), G1((size_t)m * m), A((size_t)m * m), T((size_t)m * m), lam(m), vec((size_t)m * m);
+    std::vector<double> sv(m);
+    jacobi_svd(m, Rr.data(), Ur.data(), sv.data(), Vr.data());          // Rr = Ur S Vr^H  => U = Qo Ur
+    cz* dG = d_small_.p;
+    cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
+    launch_gram(stream_, n, m, ldw, Q0, Q1, d_gram_scratch_.p, dG);     // Qo^H Q1
+    HIPCHK(hipMemcpyAsync(G1.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    // A = Ur^H G1 V S^-1      (mul!(A,S.U',Q1); mul!(B,A,S.V); mul!(A,B,Diagonal(1 ./ S.S)))
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { zc s = 0; for (int k = 0; k < m; ++k) s += std::conj(Ur[k + (size_t)i * m]) * G1[k + (size_t)j * m]; T[i + (size_t)j * m] = s; }
+    matmul(m, T.data(), Vr.data(), A.data());
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) A[i + (size_t)j * m] *= 1.0 / sv[j];
+    int info = eig_general(m, A.data(), lam.data(), vec.data());
+    if (info) return fail(FEASTHIP_ENUM, "nl_rr_step: reduced eigenproblem failed to converge");
+    matmul(m, Ur.data(), vec.data(), T.data());                           // X = U vecs = Qo (Ur vecs)
+    HIPCHK(hipMemcpyAsync(dM, T.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_ts_gemm(stream_, n, m, ldw, Q0, dM, d_X_.p);
+    // update_R!(X,R,lam,T)  src/utils.jl:104-109: normalise, R[:,i] = T(lam_i) x_i = sum_t lam_i^t M_t x_i
+    std::vector<double> nr;
+    r = col_norms(d_X_.p, nr);
+    if (r) return r;
+    std::vector<zc> sc(ldw, zc(0.0)), lamp(ldw, zc(0.0));
+    for (int j = 0; j < m; ++j) { sc[j] = nr[j] > 0 ? 1.0 / nr[j] : 1.0; lamp[j] = lam[j]; }
+    HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, n, ldw, d_X_.p, d_lam_.p);
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipMemcpyAsync(d_lam_.p, lamp.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    int64_t blk = (int64_t)n * ldw;
+    for (int t = 0; t < nterms; ++t) apply_term(t, d_X_.p, d_MX_.p + (size_t)t * blk, 1.0, false);
+    launch_poly_combine(stream_, n, ldw, d_MX_.p, blk, nterms, d_lam_.p, d_R_.p);
+    r = col_norms(d_R_.p, nr);
+    if (r) return r;
+    // residuals(R,lam,T): ||R_i|| / ||T(lam_i)||_F   src/utils.jl:151-157, Frobenius norm from the
+    // table <M_s, M_t>_F (computed once per problem)
+    if (frob_.empty()) {
+        frob_.assign(nterms, std::vector<double>(2 * nterms, 0.0));
+        for (int s = 0; s < nterms; ++s)
+            for (int t = 0; t < nterms; ++t) {
+                zc ip = 0;
+                if (dense) {
+                    // dense inner products: download once (n <= a few thousand on this path)
+                    std::vector<zc> a, b;
+                    auto fetch = [&](int q, std::vector<zc>& o) -> int {
+                        o.assign((size_t)n * n, zc(0.0));
+                        if (terms_[q].identity) { for (int i = 0; i < n; ++i) o[i + (size_t)i * n] = 1.0; return 0; }
+                        if (hipMemcpy(o.data(), terms_[q].d_dense.p, (size_t)n * n * sizeof(zc), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+                        return 0;
+                    };
+                    if (fetch(s, a) || fetch(t, b)) return fail(FEASTHIP_EHIP, "nl_rr_step: download failed");
+                    for (size_t e = 0; e < (size_t)n * n; ++e) ip += std::conj(a[e]) * b[e];
+                } else {
+                    frob_inner_sparse(terms_[s], terms_[t], n, ip);
+                }
+                ip *= std::conj(terms_[s].scale) * terms_[t].scale;
+                frob_[s][2 * t] = ip.real(); frob_[s][2 * t + 1] = ip.imag();
+            }
+    }
+    for (int j = 0; j < m; ++j) {
+        zc acc = 0, ls = 1.0;
+        for (int s = 0; s < nterms; ++s) {
+            zc lt = 1.0;
+            for (int t = 0; t < nterms; ++t) { acc += std::conj(ls) * lt * zc(frob_[s][2 * t], frob_[s][2 * t + 1]); lt *= lam[j]; }
+            ls *= lam[j];
+        }
+        double tn = std::sqrt(std::max(acc.real(), 0.0));
+        res[j] = nr[j] / tn;
+        lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag();
+    }
+    lambda_ = lam;
+    inside_test(lam.data(), inside);
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    rr_ms = ms;
+    return 0;
+}
+
+int Engine::nl_finalize_x() {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "nl_finalize_x: call set_x first");
+    HIPCHK(hipSetDevice(device_));
+    std::vector<double> nr;
+    int r = col_norms(d_X_.p, nr);
+    if (r) return r;
+    std::vector<zc> sc(ldw, zc(0.0));
+    for (int j = 0; j < m0; ++j) sc[j] = nr[j] > 0 ? 1.0 / nr[j] : 1.0;
+    HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, n, ldw, d_X_.p, d_lam_.p);
+    HIPCHK(hipStreamSynchronize(stream_));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// whole loops
+// ---------------------------------------------------------------------------
+int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int store, double* lambda, double* res,
+                      uint8_t* inside, int* nit_out) {
+    int r = set_x(X, n_, m0_);
+    if (r) return r;
+    int warn = 0;
+    if (store) { r = factorize(); if (r < 0) return r; warn = r; }                 // src/feast.jl:28-38
+    int nit = 0;
+    for (nit = 0; nit <= iter; ++nit) {                                             // :40
+        r = rr_step(lambda, res, inside);
+        if (r) return r;
+        bool any = false;
+        double mx = 0;
+        for (int j = 0; j < m0; ++j) if (inside[j]) { any = true; mx = std::max(mx, res[j]); }
+        if (any && mx < eps) break;                                                 // :53-56
+        if (nit < iter) { r = contour_step(store ? 0 : 1); if (r < 0) return r; if (r > 0) warn = r; }   // :57-72
+    }
+    if (nit_out) *nit_out = std::min(nit, iter);
+    r = get_block(0, X);
+    if (r) return r;
+    return warn;
+}
+
+int Engine::nlfeast_run(void* X, int64_t n_, int m0_, int iter, double eps, double spurious, double* lambda, double* res,
+                        uint8_t* inside, int* nit_out) {
+    int r = set_x(X, n_, m0_);
+    if (r) return r;
+    r = nl_orthonormalize_x();
+    if (r) return r;
+    int warn = factorize();                                                         // src/nlfeast.jl:17-28
+    if (warn < 0) return warn;
+    int nit = 0;
+    for (nit = 0; nit <= iter; ++nit) {
+        r = nl_contour_step(nit == 0);
+        if (r < 0) return r;
+        r = nl_rr_step(lambda, res, inside);
+        if (r) return r;
+        bool any = false, anys = false;
+        double mx = 0, mxs = 0;
+        for (int j = 0; j < m0; ++j) if (inside[j]) { any = true; mx = std::max(mx, res[j]); if (res[j] < spurious) { anys = true; mxs = std::max(mxs, res[j]); } }
+        if (any && mx < eps) break;                                                 // :73-76
+        if (nit > 1 && anys && mxs < eps) break;                                    // :77-79
+    }
+    if (nit_out) *nit_out = std::min(nit, iter);
+    r = nl_finalize_x();
+    if (r) return r;
+    r = get_block(0, X);
+    if (r) return r;
+    return warn;
+}
+
+int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
+    if (!Y || !R || m0_ <= 0 || ldy < n || ldr < n) return fail(FEASTHIP_EARG, "ldiv: bad arguments");
+    if (!factored_) return fail(FEASTHIP_ESTATE, "ldiv: not factorised");
+    HIPCHK(hipSetDevice(device_));
+    if (m0_ != m0 || !have_x_) {
+        m0 = m0_;
+        ldw = ((m0 + 15) / 16) * 16;
+        int r = alloc_iteration_buffers();
+        if (r) return r;
+        have_x_ = true;
+        lambda_.assign(m0, zc(0.0));
+    }
+    // stage R column by column when ldr != n
+    if (ldr == n) HIPCHK(hipMemcpyAsync(d_io_.p, R, (size_t)n * m0 * sizeof(cz), hipMemcpyHostToDevice, stream_));
+    else HIPCHK(hipMemcpy2DAsync(d_io_.p, (size_t)n * sizeof(cz), R, (size_t)ldr * sizeof(cz), (size_t)n * sizeof(cz), m0, hipMemcpyHostToDevice, stream_));
+    launch_cm_to_rm(stream_, n, m0, ldw, d_io_.p, n, d_R_.p);
+    int r = solve_all(d_R_.p);
+    if (r) return r;
+    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
+    for (int j = 0; j < ldw; ++j) e0[j] = 1.0;        // node 0 only
+    HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, 1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    launch_rm_to_cm(stream_, n, m0, ldw, d_T1_.p, d_io_.p, n);
+    if (ldy == n) HIPCHK(hipMemcpyAsync(Y, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
+    else HIPCHK(hipMemcpy2DAsync(Y, (size_t)ldy * sizeof(cz), d_io_.p, (size_t)n * sizeof(cz), (size_t)n * sizeof(cz), m0, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace feasthip

@@ -1,0 +1,146 @@
+// Host orchestration of the FEAST inner loop on one MI355X: problem storage,
+// launch plans built from the symbolic analysis, numeric factorisation of all
+// local contour nodes, block solves + moment accumulation, Rayleigh-Ritz step.
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "symbolic.hpp"
+
+namespace feasthip {
+
+typedef std::complex<double> zc;
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void release();
+    bool alloc(size_t count);          // false on failure
+    bool upload(const T* h, size_t count, hipStream_t st);
+};
+
+struct Launch {        // a slice of the tile / list buffers
+    int64_t off = 0;
+    int count = 0;
+};
+
+struct FactorStep { int k0; Launch panel, swap, trsm, gemm; };
+struct FactorLevel { Launch extend; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; };
+struct SolveStep { int k0; Launch diag, fwd, bwd; };
+struct SolveLevel { Launch assemble; std::vector<SolveStep> steps; Launch u12; };
+
+struct SparseTerm {
+    std::vector<int64_t> colptr;
+    std::vector<int> rowval;
+    std::vector<zc> val;
+    bool identity = false;
+    zc scale = 1.0;
+    double maxabs = 0;
+    // device
+    DevBuf<int64_t> d_rowptr;   // CSR (transpose of the CSC input) for SpMM
+    DevBuf<int> d_col;
+    DevBuf<cz> d_val;
+    DevBuf<int64_t> d_dest;     // arena destination of each CSC entry
+    DevBuf<cz> d_cscval;
+    DevBuf<cz> d_dense;         // dense column-major copy (dense path)
+};
+
+struct ProfileRow { double ms = 0, bytes = 0, flops = 0; int launches = 0; };
+
+class Engine {
+public:
+    explicit Engine(int device);
+    ~Engine();
+    std::string err;
+    int status = 0;
+
+    int set_stream(void* s);
+    int set_dense(int64_t n, int nterms, const void* const* mats, const int* types, const double* scale);
+    int set_csc(int64_t n, int nterms, const int64_t* const* colptr, const int64_t* const* rowval,
+                const void* const* nzval, const int* types, const double* scale, int index_base);
+    int set_contour(int K, const double* nodes, const double* weights, int kind, const double* region);
+    int set_shard(int first, int stride);
+    int analyze();
+    int factorize();
+    int set_x(const void* X, int64_t n, int m0);
+    int get_block(int which, void* out);
+    int rr_step(double* lambda, double* res, uint8_t* inside);
+    int contour_step(int refactor);
+    int nl_contour_step(int first);
+    int nl_rr_step(double* lambda, double* res, uint8_t* inside);
+    int nl_orthonormalize_x();
+    int nl_finalize_x();
+    int q_device(void** p, int64_t* n, int64_t* ldq, int* nblocks);
+    int feast_run(void* X, int64_t n, int m0, int iter, double eps, int store, double* lambda, double* res,
+                  uint8_t* inside, int* nit);
+    int nlfeast_run(void* X, int64_t n, int m0, int iter, double eps, double spurious, double* lambda, double* res,
+                    uint8_t* inside, int* nit);
+    // fine-grained seam: Y = T^-1 R for the single factorised matrix of this engine (node 0)
+    int ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
+    int profile_solve(ProfileRow* rows /*[8]*/);
+
+    // stats
+    double analyze_seconds = 0, factor_ms = 0, solve_ms = 0, rr_ms = 0;
+    int64_t perturbed = 0;
+    Symbolic S;
+    int n = 0, nterms = 0, K = 0, Kloc = 0, m0 = 0, ldw = 0;
+    bool dense = false;
+    double solve_bytes() const;
+    double solve_flops() const;
+
+private:
+    int device_;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = false;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    std::vector<SparseTerm> terms_;
+    std::vector<zc> nodes_, weights_;      // all K
+    std::vector<int> local_;               // indices of local nodes
+    int shard_first_ = 0, shard_stride_ = 1;
+    int region_kind_ = 0;
+    double region_[4] = {0, 0, 1, 0};
+    bool analyzed_ = false, factored_ = false, have_x_ = false;
+    std::vector<zc> lambda_;               // current Ritz values (m0)
+    std::vector<std::vector<double>> frob_;  // <M_s, M_t>_F table for the NLFEAST residual norm
+
+    // device symbolic
+    DevBuf<FrontD> d_fr_;
+    DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_c0row_;
+    DevBuf<Tile> d_tiles_;
+    DevBuf<int> d_lists_;
+    std::vector<FactorLevel> fplan_;
+    std::vector<SolveLevel> splan_;
+    DevSym dsym_;
+    // numeric
+    DevBuf<cz> d_fact_, d_cb_[2], d_coef_;
+    DevBuf<const cz*> d_matptr_;
+    DevBuf<int> d_piv_, d_rowperm_, d_rowinv_, d_nperturb_;
+    DevBuf<double> d_tiny_;
+    // iteration state (row-major n x ldw)
+    DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_crow_[2];
+    DevBuf<cz> d_e0_, d_e1_, d_small_, d_lam_, d_gram_scratch_, d_io_;
+    DevBuf<double> d_nrm_, d_nrm_scratch_;
+
+    int fail(int code, const std::string& msg) { err = msg; status = code; return code; }
+    int hip_fail(hipError_t e, const char* what);
+    bool build_plans();
+    int alloc_iteration_buffers();
+    void apply_term(int t, const cz* V, cz* out, zc alpha, bool accumulate);
+    int orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal);
+    int col_norms(const cz* V, std::vector<double>& out);
+    int solve_all(const cz* rhs);            // W_k = T(z_k)^-1 rhs for all local nodes
+    void inside_test(const zc* lam, uint8_t* inside) const;
+    int solve_all_impl(const cz* rhs, ProfileRow* prof);
+};
+
+}  // namespace feasthip

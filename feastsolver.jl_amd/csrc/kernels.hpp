@@ -1,0 +1,80 @@
+// Host-callable launchers of the gfx950 kernels (definitions in kernels_*.hip).
+#pragma once
+#include "dev_common.hpp"
+
+namespace feasthip {
+
+constexpr int FACT_NB = 32;     // panel width of the blocked front factorisation
+constexpr int SOLVE_NB = 64;    // diagonal block of the blocked triangular solves
+constexpr int LDS_COLS = 64;    // block-vector columns processed per workgroup pass
+
+struct DevSym {          // device copies of the symbolic structure
+    const FrontD* fr;
+    const int* struct_idx;
+    const int* rel;
+    const int* child_idx;
+    const int* perm;     // new -> old
+    const int* c0_of_row;  // first column of the supernode owning (new) row i
+    int n;
+};
+
+// ---- numeric factorisation ------------------------------------------------
+void launch_scatter(hipStream_t st, cz* fact, int64_t fs, const int64_t* dest, const cz* val, int64_t nnz,
+                    const cz* coef, int coef_stride, int term, int K);
+void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz* const* mats, int nterms,
+                           const cz* coef, int K);
+void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,
+                       cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K);
+void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
+                  int* piv, const double* tiny, int* nperturb, int K);
+void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                 const int* piv, int K);
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K);
+// kinds: 0 = L-panel trailing update, 1 = U12 trailing update, 2 = contribution block (K = p)
+void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                    cz* cb, int64_t cbs, int K);
+void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* piv, int* rowperm,
+                    int* rowinv, int K);
+
+// ---- block triangular solves ------------------------------------------------
+void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cz* W, int64_t ws,
+                       const int* rowperm, int K);
+void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
+                         cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
+                         const int* rowinv, int K);
+// mode 0: forward (unit lower), 1: backward (upper)
+void launch_diag_solve(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, int mode, const cz* fact,
+                       int64_t fs, cz* W, int64_t ws, int ldw, int K);
+// kinds: 0 = forward panel update (rows below block, into W or the contribution rows),
+//        1 = backward update of rows above the block, 2 = backward U12 * x_struct
+void launch_panel_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int kind, const cz* fact,
+                        int64_t fs, cz* W, int64_t ws, int ldw, cz* crow, int64_t crs, int K);
+// Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order
+void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int K,
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
+
+// ---- Rayleigh-Ritz block ------------------------------------------------------
+void launch_spmm_csr(hipStream_t st, int n, const int64_t* rowptr, const int* col, const cz* val, const cz* V, int ldw,
+                     cz* out, cz alpha, int accumulate);
+// out(row-major n x ldw) (+)= alpha * A(col-major n x n) * V
+void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate);
+// G(m x m, column-major, ld m) = V^H W  (row-major n x ldw blocks); scratch >= gram_scratch_elems()
+size_t gram_scratch_elems(int n, int m);
+void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G);
+// out = V * M  (M m x m column-major on device)
+void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* M, cz* out);
+// nrm2[j] = sum_i |V[i,j]|^2 ; scratch >= colnorm_scratch_elems()
+size_t colnorm_scratch_elems(int n, int ldw);
+void launch_colnorm2(hipStream_t st, int n, int ldw, const cz* V, double* scratch, double* nrm2);
+void launch_scale_cols(hipStream_t st, int n, int ldw, cz* V, const cz* s);
+// out = alpha*V (+ out)
+void launch_axpby(hipStream_t st, int n, int ldw, cz* out, cz alpha, const cz* V, int accumulate);
+// R = AX - BX .* lam[j]
+void launch_residual_combine(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* R);
+// R = sum_t MX[t] .* lam[j]^t   (polynomial NEP residual; MX blocks contiguous with stride blk)
+void launch_poly_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t blk, int nterms, const cz* lam, cz* R);
+// column-major (ld n) <-> row-major (ld ldw) conversion of n x m0 blocks, zero padding columns m0..ldw
+void launch_cm_to_rm(hipStream_t st, int n, int m0, int ldw, const cz* cm, int64_t ldcm, cz* rm);
+void launch_rm_to_cm(hipStream_t st, int n, int m0, int ldw, const cz* rm, cz* cm, int64_t ldcm);
+
+}  // namespace feasthip

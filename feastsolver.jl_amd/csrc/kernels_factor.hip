@@ -1,0 +1,401 @@
+// Batched multifrontal LU on gfx950: all fronts of one elimination-tree depth
+// and ALL contour nodes of this GPU are processed by each launch (the pattern
+// of T(z_k) is node-independent, only values differ).  This is the GPU side of
+// the reference's `factorizer` seam (src/feast.jl:28-38, 104-114,
+// src/nlfeast.jl:17-28; dense zgetrf / UMFPACK in the reference).
+#include "kernels.hpp"
+
+namespace feasthip {
+
+__device__ inline int lower_bound_dev(const int* a, int n, int v) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// complex accumulate D += A*B on the f64 matrix cores; per-lane operands
+// a = A[i = l&15][k = l>>4], b = B[k = l>>4][j = l&15]; D: reg r -> row (l>>4)+4r, col l&15.
+__device__ inline void cmfma(d4& cr, d4& ci, double ar, double ai, double br, double bi) {
+    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ci, 0, 0, 0);
+    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cr, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// assembly of T(z_k) = sum_t coef[k][t] * M_t into the fronts
+// ---------------------------------------------------------------------------
+__global__ void k_scatter(cz* fact, int64_t fs, const int64_t* __restrict__ dest, const cz* __restrict__ val, int64_t nnz,
+                          const cz* __restrict__ coef, int coef_stride, int term) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (e >= nnz) return;
+    int64_t d = dest[e];
+    if (d < 0) return;
+    cz c = coef[(int64_t)k * coef_stride + term];
+    cz* p = fact + (int64_t)k * fs + d;
+    cz v = *p;
+    cz_madd(v, c, val[e]);
+    *p = v;
+}
+
+void launch_scatter(hipStream_t st, cz* fact, int64_t fs, const int64_t* dest, const cz* val, int64_t nnz,
+                    const cz* coef, int coef_stride, int term, int K) {
+    if (nnz <= 0 || K <= 0) return;
+    dim3 g((unsigned)((nnz + 255) / 256), K);
+    hipLaunchKernelGGL(k_scatter, g, dim3(256), 0, st, fact, fs, dest, val, nnz, coef, coef_stride, term);
+}
+
+__global__ void k_dense_assemble(cz* fact, int64_t fs, int n, const cz* const* mats, int nterms, const cz* __restrict__ coef) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    int64_t nn = (int64_t)n * n;
+    if (e >= nn) return;
+    int i = (int)(e % n), j = (int)(e / n);
+    cz acc = cz_make(0, 0);
+    for (int t = 0; t < nterms; ++t) {
+        cz c = coef[k * nterms + t];
+        const cz* M = mats[t];
+        if (M) cz_madd(acc, c, M[e]);
+        else if (i == j) acc = cz_add(acc, c);
+    }
+    fact[(int64_t)k * fs + e] = acc;
+}
+
+void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz* const* mats, int nterms,
+                           const cz* coef, int K) {
+    int64_t nn = (int64_t)n * n;
+    dim3 g((unsigned)((nn + 255) / 256), K);
+    hipLaunchKernelGGL(k_dense_assemble, g, dim3(256), 0, st, fact, fs, n, mats, nterms, coef);
+}
+
+// ---------------------------------------------------------------------------
+// extend-add: parent front += children contribution blocks.  One workgroup owns
+// a 64 x 64 tile of the parent front and pulls from every child in a fixed
+// order, so the sum is deterministic and needs no atomics.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                                    const int* __restrict__ rel, const int* __restrict__ child_idx,
+                                                    cz* fact, int64_t fs, cz* cbp, int64_t cbsp, const cz* __restrict__ cbc,
+                                                    int64_t cbsc) {
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int p = f.p, u = f.u, ld = p + u;
+    int r0 = t.a * 64, q0 = t.b * 64;
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* F12 = fact + (int64_t)k * fs + f.f12;
+    cz* CB = cbp + (int64_t)k * cbsp + f.cb;
+    for (int ci = 0; ci < f.nchild; ++ci) {
+        FrontD g = fr[child_idx[f.child_ptr + ci]];
+        const int* rc = rel + g.sptr;
+        int uc = g.u;
+        int ia = lower_bound_dev(rc, uc, r0), ib = lower_bound_dev(rc, uc, r0 + 64);
+        int ja = lower_bound_dev(rc, uc, q0), jb = lower_bound_dev(rc, uc, q0 + 64);
+        int nr = ib - ia, nc = jb - ja;
+        if (nr > 0 && nc > 0) {
+            const cz* src = cbc + (int64_t)k * cbsc + g.cb;
+            for (int idx = threadIdx.x; idx < nr * nc; idx += 256) {
+                int i = ia + idx % nr, j = ja + idx / nr;
+                cz v = src[i + (int64_t)j * uc];
+                int r = rc[i], q = rc[j];
+                cz* d;
+                if (q < p) d = Lp + r + (int64_t)q * ld;
+                else if (r < p) d = F12 + r + (int64_t)(q - p) * p;
+                else d = CB + (r - p) + (int64_t)(q - p) * u;
+                cz o = *d;
+                o.x += v.x; o.y += v.y;
+                *d = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,
+                       cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_extend_add, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, fact, fs,
+                       cb_parent, cbs_parent, cb_child, cbs_child);
+}
+
+// ---------------------------------------------------------------------------
+// panel factorisation with partial pivoting restricted to the fully summed
+// rows [k0+j, p) of the front.  One workgroup per (front, node).
+// ---------------------------------------------------------------------------
+constexpr int PANEL_NT = 256;
+
+__global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
+                                                     cz* fact, int64_t fs, int* piv, int npiv,
+                                                     const double* __restrict__ tiny, int* nperturb) {
+    __shared__ double s_val[PANEL_NT / 64];
+    __shared__ int s_idx[PANEL_NT / 64];
+    __shared__ int s_piv;
+    __shared__ cz s_urow[FACT_NB];
+    FrontD f = fr[list[blockIdx.x]];
+    int k = blockIdx.y;
+    int p = f.p, ld = f.p + f.u;
+    int b = min(FACT_NB, p - k0);
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double tiny_k = tiny[k];
+    for (int j = 0; j < b; ++j) {
+        int kj = k0 + j;
+        cz* col = Lp + (int64_t)kj * ld;
+        double best = -1.0;
+        int bi = kj;
+        for (int r = k0 + tid; r < p; r += PANEL_NT) {
+            if (r < kj) continue;
+            double a = cz_abs1(col[r]);
+            if (a > best) { best = a; bi = r; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double ob = __shfl_xor(best, off);
+            int oi = __shfl_xor(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double bb = s_val[0];
+            int ii = s_idx[0];
+            for (int w = 1; w < PANEL_NT / 64; ++w)
+                if (s_val[w] > bb || (s_val[w] == bb && s_idx[w] < ii)) { bb = s_val[w]; ii = s_idx[w]; }
+            if (bb < 0) ii = kj;
+            s_piv = ii;
+            piv[(int64_t)k * npiv + f.c0 + kj] = ii;
+        }
+        __syncthreads();
+        int pr = s_piv;
+        if (pr != kj && tid < b) {
+            cz* c2 = Lp + (int64_t)(k0 + tid) * ld;
+            cz a = c2[kj], bb = c2[pr];
+            c2[kj] = bb; c2[pr] = a;
+        }
+        __syncthreads();
+        cz pv = col[kj];
+        double pa = cz_abs1(pv);
+        if (!(pa >= tiny_k)) {   // static pivot perturbation (also catches NaN)
+            pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+            if (tid == 0) { col[kj] = pv; atomicAdd(nperturb + k, 1); }
+        }
+        cz inv = cz_inv(pv);
+        if (tid > j && tid < b) s_urow[tid] = Lp[(int64_t)(k0 + tid) * ld + kj];
+        __syncthreads();
+        for (int r = k0 + tid; r < ld; r += PANEL_NT) {
+            if (r <= kj) continue;
+            cz l = cz_mul(col[r], inv);
+            col[r] = l;
+            for (int jj = j + 1; jj < b; ++jj) {
+                cz* d = Lp + (int64_t)(k0 + jj) * ld + r;
+                cz v = *d;
+                cz_msub(v, l, s_urow[jj]);
+                *d = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
+                  int* piv, const double* tiny, int* nperturb, int K) {
+    if (nlist <= 0) return;
+    hipLaunchKernelGGL(k_panel, dim3(nlist, K), dim3(PANEL_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
+}
+
+// ---------------------------------------------------------------------------
+// apply the panel's row interchanges to every other column of the front
+// ---------------------------------------------------------------------------
+__global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
+                       const int* __restrict__ piv, int npiv) {
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int p = f.p, u = f.u, ld = p + u;
+    int b = min(FACT_NB, p - k0);
+    int v = t.a * 256 + threadIdx.x;
+    int nv = (p - b) + u;
+    if (v >= nv) return;
+    cz* col;
+    if (v < k0) col = fact + (int64_t)k * fs + f.lp + (int64_t)v * ld;
+    else if (v < p - b) col = fact + (int64_t)k * fs + f.lp + (int64_t)(v + b) * ld;
+    else col = fact + (int64_t)k * fs + f.f12 + (int64_t)(v - (p - b)) * p;
+    const int* pv = piv + (int64_t)k * npiv + f.c0 + k0;
+    for (int j = 0; j < b; ++j) {
+        int pr = pv[j];
+        if (pr != k0 + j) { cz a = col[k0 + j], c = col[pr]; col[k0 + j] = c; col[pr] = a; }
+    }
+}
+
+void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                 const int* piv, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n);
+}
+
+// ---------------------------------------------------------------------------
+// U row block: columns right of the panel (inside the pivot block and U12)
+// get x <- L11^-1 x, one thread per column.
+// ---------------------------------------------------------------------------
+__global__ void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs) {
+    __shared__ cz s_l[FACT_NB * FACT_NB];
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int p = f.p, u = f.u, ld = p + u;
+    int b = min(FACT_NB, p - k0);
+    const cz* Lp = fact + (int64_t)k * fs + f.lp;
+    for (int idx = threadIdx.x; idx < b * b; idx += blockDim.x) {
+        int i = idx % b, kk = idx / b;
+        s_l[i + kk * FACT_NB] = Lp[(k0 + i) + (int64_t)(k0 + kk) * ld];
+    }
+    __syncthreads();
+    int v = t.a * 128 + threadIdx.x;
+    int nin = p - k0 - b;
+    if (v >= nin + u) return;
+    cz* x;
+    if (v < nin) x = fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0;
+    else x = fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
+    for (int i = 1; i < b; ++i) {
+        cz xi = x[i];
+        for (int kk = 0; kk < i; ++kk) cz_msub(xi, s_l[i + kk * FACT_NB], x[kk]);
+        x[i] = xi;
+    }
+}
+
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(128), 0, st, S.fr, tiles, k0, fact, fs);
+}
+
+// ---------------------------------------------------------------------------
+// grouped complex GEMM  C -= A * B  (all column-major) on v_mfma_f64_16x16x4_f64.
+// Workgroup tile 64 (m) x 64 (n); wave w owns rows [16w, 16w+16) and streams its
+// A rows straight from global memory (each A element is used once per n tile);
+// the K x 64 B tile is staged in LDS as [k][n] so every fragment read is a
+// conflict-free ds_read_b128.  The MFMA computes the transposed tile D[n][m] so
+// that C is written with 16 consecutive m per lane group (256 B segments).
+// ---------------------------------------------------------------------------
+constexpr int GEMM_KC = 32;
+
+__global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
+                                                  cz* fact, int64_t fs, cz* cb, int64_t cbs) {
+    __shared__ cz Bs[GEMM_KC][65];
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int p = f.p, u = f.u, ld = p + u;
+    int b = min(FACT_NB, p - k0);
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* F12 = fact + (int64_t)k * fs + f.f12;
+    const cz *A, *B;
+    cz* C;
+    int M, N, Kd;
+    int64_t lda, ldb, ldc;
+    if (t.a == 0) {
+        A = Lp + (k0 + b) + (int64_t)k0 * ld; lda = ld; M = ld - k0 - b; Kd = b;
+        B = Lp + k0 + (int64_t)(k0 + b) * ld; ldb = ld; N = p - k0 - b;
+        C = Lp + (k0 + b) + (int64_t)(k0 + b) * ld; ldc = ld;
+    } else if (t.a == 1) {
+        A = Lp + (k0 + b) + (int64_t)k0 * ld; lda = ld; M = p - k0 - b; Kd = b;
+        B = F12 + k0; ldb = p; N = u;
+        C = F12 + (k0 + b); ldc = p;
+    } else {
+        A = Lp + p; lda = ld; M = u; Kd = p;
+        B = F12; ldb = p; N = u;
+        C = cb + (int64_t)k * cbs + f.cb; ldc = u;
+    }
+    int m0 = t.b * 64, n0 = t.c * 64;
+    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    int mrow = m0 + wave * 16 + li;
+    bool mok = mrow < M;
+    d4 cr[4], ci[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+    for (int kc = 0; kc < Kd; kc += GEMM_KC) {
+        __syncthreads();
+        for (int idx = tid; idx < GEMM_KC * 64; idx += 256) {
+            int kk = idx % GEMM_KC, nn = idx / GEMM_KC;
+            int gk = kc + kk, gn = n0 + nn;
+            Bs[kk][nn] = (gk < Kd && gn < N) ? B[gk + (int64_t)gn * ldb] : cz_make(0, 0);
+        }
+        cz av[GEMM_KC / 4];
+#pragma unroll
+        for (int ks = 0; ks < GEMM_KC / 4; ++ks) {
+            int gk = kc + ks * 4 + lk;
+            av[ks] = (mok && gk < Kd) ? A[mrow + (int64_t)gk * lda] : cz_make(0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GEMM_KC / 4; ++ks) {
+            int kk = ks * 4 + lk;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                cz bv = Bs[kk][nt * 16 + li];
+                cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);
+            }
+        }
+    }
+    if (mok) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int gn = n0 + nt * 16 + lk + 4 * r;
+                if (gn < N) {
+                    cz* d = C + mrow + (int64_t)gn * ldc;
+                    cz v = *d;
+                    v.x -= cr[nt][r]; v.y -= ci[nt][r];
+                    *d = v;
+                }
+            }
+    }
+}
+
+void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                    cz* cb, int64_t cbs, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_gemm_nn, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, cb, cbs);
+}
+
+// ---------------------------------------------------------------------------
+// pivot sequence -> row permutation of the pivot block (and its inverse), so the
+// solves gather the right-hand side once instead of replaying p swaps.
+// rowperm[c0+i] = original local row that ended in position i.
+// ---------------------------------------------------------------------------
+constexpr int ROWPERM_LDS = 12288;
+
+__global__ void k_rowperm(const FrontD* __restrict__ fr, const int* __restrict__ list, const int* __restrict__ piv,
+                          int* rowperm, int* rowinv, int n) {
+    __shared__ int s_rp[ROWPERM_LDS];
+    FrontD f = fr[list[blockIdx.x]];
+    int k = blockIdx.y;
+    int p = f.p;
+    const int* pv = piv + (int64_t)k * n + f.c0;
+    int* rp = rowperm + (int64_t)k * n + f.c0;
+    int* ri = rowinv + (int64_t)k * n + f.c0;
+    if (p <= ROWPERM_LDS / 2) {
+        int* s_pv = s_rp + p;
+        for (int i = threadIdx.x; i < p; i += blockDim.x) { s_rp[i] = i; s_pv[i] = pv[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int j = 0; j < p; ++j) { int q = s_pv[j]; if (q != j) { int a = s_rp[j]; s_rp[j] = s_rp[q]; s_rp[q] = a; } }
+        __syncthreads();
+        for (int i = threadIdx.x; i < p; i += blockDim.x) { int o = s_rp[i]; rp[i] = o; ri[o] = i; }
+    } else {
+        for (int i = threadIdx.x; i < p; i += blockDim.x) rp[i] = i;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int j = 0; j < p; ++j) { int q = pv[j]; if (q != j) { int a = rp[j]; rp[j] = rp[q]; rp[q] = a; } }
+        __syncthreads();
+        for (int i = threadIdx.x; i < p; i += blockDim.x) ri[rp[i]] = i;
+    }
+}
+
+void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* piv, int* rowperm,
+                    int* rowinv, int K) {
+    if (nlist <= 0) return;
+    hipLaunchKernelGGL(k_rowperm, dim3(nlist, K), dim3(256), 0, st, S.fr, list, piv, rowperm, rowinv, S.n);
+}
+
+}  // namespace feasthip

@@ -1,0 +1,319 @@
+// Rayleigh-Ritz block of the FEAST iteration on the GPU (src/feast.jl:41-50,
+// 117-127; src/utils.jl:104-116, 151-171): products A*Q / B*Q, the tall-skinny
+// projection Q^H (A Q) on the f64 matrix cores, Ritz back-transform, residual
+// vectors and column norms.  Block vectors are row-major n x ldw complex128.
+#include "kernels.hpp"
+
+namespace feasthip {
+
+__device__ inline void cmfma3(d4& cr, d4& ci, double ar, double ai, double br, double bi) {
+    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ci, 0, 0, 0);
+    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cr, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
+}
+
+// CSR SpMM: one wave per matrix row, one lane per block-vector column; the CSR
+// (rowptr, col, val) arrays are read coalesced by the wave, the gathered V rows are
+// whole contiguous lines.
+__global__ void k_spmm_csr(int n, const int64_t* __restrict__ rowptr, const int* __restrict__ col,
+                           const cz* __restrict__ val, const cz* __restrict__ V, int ldw, cz* out, cz alpha, int accumulate) {
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    int64_t a = rowptr[i], b = rowptr[i + 1];
+    for (int j = lane; j < ldw; j += 64) {
+        cz acc = cz_make(0, 0);
+        for (int64_t t = a; t < b; ++t) cz_madd(acc, val[t], V[(int64_t)col[t] * ldw + j]);
+        cz r = cz_mul(alpha, acc);
+        if (accumulate) r = cz_add(r, out[(int64_t)i * ldw + j]);
+        out[(int64_t)i * ldw + j] = r;
+    }
+}
+
+void launch_spmm_csr(hipStream_t st, int n, const int64_t* rowptr, const int* col, const cz* val, const cz* V, int ldw,
+                     cz* out, cz alpha, int accumulate) {
+    hipLaunchKernelGGL(k_spmm_csr, dim3((n + 3) / 4), dim3(256), 0, st, n, rowptr, col, val, V, ldw, out, alpha, accumulate);
+}
+
+// Dense product out = alpha * A * V (+ out): same streaming structure as the solve's panel kernel.
+__global__ __launch_bounds__(256) void k_dense_mv(int n, const cz* __restrict__ A, const cz* __restrict__ V, int ldw,
+                                                   cz* out, cz alpha, int accumulate) {
+    __shared__ cz Vs[64][LDS_COLS];
+    int rbase = blockIdx.x * 64, cg = blockIdx.y * LDS_COLS;
+    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    int arow = rbase + wave * 16 + li;
+    bool aok = arow < n;
+    d4 cr[4], ci[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+    for (int kc = 0; kc < n; kc += 64) {
+        __syncthreads();
+        for (int r = wave; r < 64; r += 4) {
+            int gk = kc + r;
+            Vs[r][lane] = (gk < n && cg + lane < ldw) ? V[(int64_t)gk * ldw + cg + lane] : cz_make(0, 0);
+        }
+        cz av[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            int gk = kc + ks * 4 + lk;
+            av[ks] = (aok && gk < n) ? A[arow + (int64_t)gk * n] : cz_make(0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                cz bv = Vs[ks * 4 + lk][nt * 16 + li];
+                cmfma3(cr[nt], ci[nt], av[ks].x, av[ks].y, bv.x, bv.y);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int orow = rbase + wave * 16 + lk + 4 * r;
+        if (orow >= n) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int col = cg + nt * 16 + li;
+            if (col < ldw) {
+                cz v = cz_mul(alpha, cz_make(cr[nt][r], ci[nt][r]));
+                cz* d = out + (int64_t)orow * ldw + col;
+                if (accumulate) v = cz_add(v, *d);
+                *d = v;
+            }
+        }
+    }
+}
+
+void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate) {
+    hipLaunchKernelGGL(k_dense_mv, dim3((n + 63) / 64, (ldw + LDS_COLS - 1) / LDS_COLS), dim3(256), 0, st, n, A, V, ldw, out, alpha, accumulate);
+}
+
+// Tall-skinny projection G = V^H W on the f64 matrix cores.  Stage 1: each
+// workgroup reduces GRAM_ROWS rows; wave jobs are (16-row i tile) x (64-col j group),
+// operands are read straight from the row-major blocks (16 consecutive columns of a
+// row per lane group = 256 B segments).  Stage 2 sums the partials in a fixed order.
+constexpr int GRAM_ROWS = 1024;
+
+size_t gram_scratch_elems(int n, int m) {
+    size_t chunks = ((size_t)n + GRAM_ROWS - 1) / GRAM_ROWS;
+    size_t mp = (size_t)((m + 15) / 16) * 16;
+    return chunks * mp * mp;
+}
+
+__global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, const cz* __restrict__ V, const cz* __restrict__ W,
+                                                       cz* scratch) {
+    int chunk = blockIdx.x;
+    int r0 = chunk * GRAM_ROWS, r1 = min(n, r0 + GRAM_ROWS);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    int nit = mp / 16, njg = (mp + 63) / 64;
+    cz* out = scratch + (size_t)chunk * mp * mp;
+    for (int job = wave; job < nit * njg; job += 4) {
+        int it = job / njg, jg = job % njg;
+        d4 cr[4], ci[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+        for (int r = r0; r < r1; r += 4) {
+            int row = r + lk;
+            bool ok = row < r1;
+            cz a = ok ? V[(int64_t)row * ldw + it * 16 + li] : cz_make(0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                int col = jg * 64 + nt * 16 + li;
+                cz b = (ok && col < mp) ? W[(int64_t)row * ldw + col] : cz_make(0, 0);
+                cmfma3(cr[nt], ci[nt], a.x, -a.y, b.x, b.y);   // conj(V)
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int i = it * 16 + lk + 4 * r, j = jg * 64 + nt * 16 + li;
+                if (j < mp) out[i + (size_t)j * mp] = cz_make(cr[nt][r], ci[nt][r]);
+            }
+    }
+}
+
+__global__ void k_gram_reduce(int nchunks, int mp, int m, const cz* __restrict__ scratch, cz* G) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * m) return;
+    int i = e % m, j = e / m;
+    cz acc = cz_make(0, 0);
+    for (int c = 0; c < nchunks; ++c) acc = cz_add(acc, scratch[(size_t)c * mp * mp + i + (size_t)j * mp]);
+    G[i + (size_t)j * m] = acc;
+}
+
+void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G) {
+    int chunks = (n + GRAM_ROWS - 1) / GRAM_ROWS;
+    int mp = ((m + 15) / 16) * 16;    // ldw >= mp by construction
+    hipLaunchKernelGGL(k_gram_partial, dim3(chunks), dim3(256), 0, st, n, mp, ldw, V, W, scratch);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 255) / 256), dim3(256), 0, st, chunks, mp, m, scratch, G);
+}
+
+// out[r,:] = V[r,:] * M  (M m x m column-major).  One wave per row, lane = output column;
+// M is staged in LDS in slabs of TS_KC rows x 64 columns (blockIdx.y = column group).
+constexpr int TS_KC = 64;
+
+__global__ __launch_bounds__(256) void k_ts_gemm(int n, int m, int ldw, const cz* __restrict__ V, const cz* __restrict__ M, cz* out) {
+    __shared__ cz Ms[TS_KC * 64];               // [i][64]
+    __shared__ cz Vr[4 * TS_KC];                // 4 rows x TS_KC
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int cg = blockIdx.y * 64, col = cg + lane;
+    cz* vr = Vr + (size_t)wave * TS_KC;
+    for (int ic = 0; ic < m; ic += TS_KC) {
+        int kc = min(TS_KC, m - ic);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kc * 64; idx += 256) {
+            int i = idx >> 6, jl = idx & 63;
+            Ms[idx] = (cg + jl < m) ? M[(ic + i) + (size_t)(cg + jl) * m] : cz_make(0, 0);
+        }
+        __syncthreads();
+        for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+            for (int i = lane; i < kc; i += 64) vr[i] = V[(int64_t)row * ldw + ic + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (col < ldw) {
+                cz acc = (ic == 0) ? cz_make(0, 0) : out[(int64_t)row * ldw + col];
+                for (int i = 0; i < kc; ++i) cz_madd(acc, vr[i], Ms[(size_t)i * 64 + lane]);
+                out[(int64_t)row * ldw + col] = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* M, cz* out) {
+    int blocks = (n + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_ts_gemm, dim3(blocks, (ldw + 63) / 64), dim3(256), 0, st, n, m, ldw, V, M, out);
+}
+
+// column sums of |V|^2, two deterministic stages
+constexpr int CN_ROWS = 512;
+size_t colnorm_scratch_elems(int n, int ldw) { return ((size_t)n + CN_ROWS - 1) / CN_ROWS * (size_t)ldw; }
+
+__global__ __launch_bounds__(256) void k_colnorm_partial(int n, int ldw, const cz* __restrict__ V, double* scratch) {
+    __shared__ double red[4][64];
+    int r0 = blockIdx.x * CN_ROWS, r1 = min(n, r0 + CN_ROWS);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int cg = 0; cg < ldw; cg += 64) {
+        int col = cg + lane;
+        double s = 0;
+        if (col < ldw)
+            for (int r = r0 + wave; r < r1; r += 4) { cz v = V[(int64_t)r * ldw + col]; s += v.x * v.x + v.y * v.y; }
+        red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && col < ldw) scratch[(size_t)blockIdx.x * ldw + col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        __syncthreads();
+    }
+}
+
+__global__ void k_colnorm_reduce(int nchunks, int ldw, const double* __restrict__ scratch, double* nrm2) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldw) return;
+    double s = 0;
+    for (int c = 0; c < nchunks; ++c) s += scratch[(size_t)c * ldw + j];
+    nrm2[j] = s;
+}
+
+void launch_colnorm2(hipStream_t st, int n, int ldw, const cz* V, double* scratch, double* nrm2) {
+    int chunks = (n + CN_ROWS - 1) / CN_ROWS;
+    hipLaunchKernelGGL(k_colnorm_partial, dim3(chunks), dim3(256), 0, st, n, ldw, V, scratch);
+    hipLaunchKernelGGL(k_colnorm_reduce, dim3((ldw + 63) / 64), dim3(64), 0, st, chunks, ldw, scratch, nrm2);
+}
+
+__global__ void k_scale_cols(int64_t total, int ldw, cz* V, const cz* __restrict__ s) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    V[e] = cz_mul(V[e], s[e % ldw]);
+}
+
+void launch_scale_cols(hipStream_t st, int n, int ldw, cz* V, const cz* s) {
+    int64_t total = (int64_t)n * ldw;
+    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, ldw, V, s);
+}
+
+__global__ void k_axpby(int64_t total, cz* out, cz alpha, const cz* __restrict__ V, int accumulate) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    cz r = cz_mul(alpha, V[e]);
+    if (accumulate) r = cz_add(r, out[e]);
+    out[e] = r;
+}
+
+void launch_axpby(hipStream_t st, int n, int ldw, cz* out, cz alpha, const cz* V, int accumulate) {
+    int64_t total = (int64_t)n * ldw;
+    hipLaunchKernelGGL(k_axpby, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, out, alpha, V, accumulate);
+}
+
+__global__ void k_residual_combine(int64_t total, int ldw, const cz* __restrict__ AX, const cz* __restrict__ BX,
+                                   const cz* __restrict__ lam, cz* R) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    cz r = AX[e];
+    cz_msub(r, BX[e], lam[e % ldw]);
+    R[e] = r;
+}
+
+void launch_residual_combine(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* R) {
+    int64_t total = (int64_t)n * ldw;
+    hipLaunchKernelGGL(k_residual_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, ldw, AX, BX, lam, R);
+}
+
+__global__ void k_poly_combine(int64_t total, int ldw, const cz* __restrict__ MX, int64_t blk, int nterms,
+                               const cz* __restrict__ lam, cz* R) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    cz l = lam[e % ldw];
+    cz acc = MX[(int64_t)(nterms - 1) * blk + e];      // Horner in lambda
+    for (int t = nterms - 2; t >= 0; --t) acc = cz_add(cz_mul(acc, l), MX[(int64_t)t * blk + e]);
+    R[e] = acc;
+}
+
+void launch_poly_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t blk, int nterms, const cz* lam, cz* R) {
+    int64_t total = (int64_t)n * ldw;
+    hipLaunchKernelGGL(k_poly_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, ldw, MX, blk, nterms, lam, R);
+}
+
+__global__ void k_cm_to_rm(int n, int m0, int ldw, const cz* __restrict__ cm, int64_t ldcm, cz* rm) {
+    __shared__ cz tile[32][33];
+    int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty 0..7
+    for (int jj = ty; jj < 32; jj += 8) {
+        int i = i0 + tx, j = j0 + jj;
+        tile[jj][tx] = (i < n && j < m0) ? cm[i + (int64_t)j * ldcm] : cz_make(0, 0);
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 32; ii += 8) {
+        int i = i0 + ii, j = j0 + tx;
+        if (i < n && j < ldw) rm[(int64_t)i * ldw + j] = tile[tx][ii];
+    }
+}
+
+void launch_cm_to_rm(hipStream_t st, int n, int m0, int ldw, const cz* cm, int64_t ldcm, cz* rm) {
+    hipLaunchKernelGGL(k_cm_to_rm, dim3((n + 31) / 32, (ldw + 31) / 32), dim3(256), 0, st, n, m0, ldw, cm, ldcm, rm);
+}
+
+__global__ void k_rm_to_cm(int n, int m0, int ldw, const cz* __restrict__ rm, cz* cm, int64_t ldcm) {
+    __shared__ cz tile[32][33];
+    int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int ii = ty; ii < 32; ii += 8) {
+        int i = i0 + ii, j = j0 + tx;
+        tile[ii][tx] = (i < n && j < ldw) ? rm[(int64_t)i * ldw + j] : cz_make(0, 0);
+    }
+    __syncthreads();
+    for (int jj = ty; jj < 32; jj += 8) {
+        int i = i0 + tx, j = j0 + jj;
+        if (i < n && j < m0) cm[i + (int64_t)j * ldcm] = tile[tx][jj];
+    }
+}
+
+void launch_rm_to_cm(hipStream_t st, int n, int m0, int ldw, const cz* rm, cz* cm, int64_t ldcm) {
+    hipLaunchKernelGGL(k_rm_to_cm, dim3((n + 31) / 32, (m0 + 31) / 32), dim3(256), 0, st, n, m0, ldw, rm, cm, ldcm);
+}
+
+}  // namespace feasthip

@@ -1,0 +1,275 @@
+#include "smalleig.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace feasthip {
+namespace {
+inline double cabs1(zc z) { return std::fabs(z.real()) + std::fabs(z.imag()); }
+const double EPS = 2.220446049250313e-16;
+
+// Householder reduction to upper Hessenberg form, H = Z^H A Z.
+void hessenberg(int m, zc* H, zc* Z) {
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Z[i + (size_t)j * m] = (i == j) ? 1.0 : 0.0;
+    std::vector<zc> v(m);
+    for (int k = 0; k + 2 < m; ++k) {
+        double nrm = 0;
+        for (int i = k + 1; i < m; ++i) nrm += std::norm(H[i + (size_t)k * m]);
+        nrm = std::sqrt(nrm);
+        if (nrm == 0.0) continue;
+        zc x0 = H[k + 1 + (size_t)k * m];
+        zc ph = (std::abs(x0) == 0.0) ? zc(1.0) : x0 / std::abs(x0);
+        zc alpha = -ph * nrm;
+        double vn = 0;
+        for (int i = k + 1; i < m; ++i) { v[i] = H[i + (size_t)k * m]; if (i == k + 1) v[i] -= alpha; vn += std::norm(v[i]); }
+        vn = std::sqrt(vn);
+        if (vn == 0.0) continue;
+        for (int i = k + 1; i < m; ++i) v[i] /= vn;
+        // H <- (I - 2 v v^H) H
+        for (int j = k; j < m; ++j) {
+            zc s = 0;
+            for (int i = k + 1; i < m; ++i) s += std::conj(v[i]) * H[i + (size_t)j * m];
+            s *= 2.0;
+            for (int i = k + 1; i < m; ++i) H[i + (size_t)j * m] -= v[i] * s;
+        }
+        // H <- H (I - 2 v v^H),  Z <- Z (I - 2 v v^H)
+        for (int i = 0; i < m; ++i) {
+            zc s = 0, t = 0;
+            for (int j = k + 1; j < m; ++j) { s += H[i + (size_t)j * m] * v[j]; t += Z[i + (size_t)j * m] * v[j]; }
+            s *= 2.0; t *= 2.0;
+            for (int j = k + 1; j < m; ++j) { H[i + (size_t)j * m] -= s * std::conj(v[j]); Z[i + (size_t)j * m] -= t * std::conj(v[j]); }
+        }
+        H[k + 1 + (size_t)k * m] = alpha;
+        for (int i = k + 2; i < m; ++i) H[i + (size_t)k * m] = 0.0;
+    }
+}
+
+// Single-shift complex QR on an upper Hessenberg matrix; H becomes the Schur form T, Z the Schur vectors.
+int hqr_schur(int m, zc* H, zc* Z) {
+    int ihi = m - 1, its = 0, total = 0;
+    double hn = 0;
+    for (size_t i = 0; i < (size_t)m * m; ++i) hn = std::max(hn, cabs1(H[i]));
+    if (hn == 0.0) return 0;
+    while (ihi >= 0) {
+        int l = ihi;
+        for (; l > 0; --l) {
+            double sub = cabs1(H[l + (size_t)(l - 1) * m]);
+            double dd = cabs1(H[l - 1 + (size_t)(l - 1) * m]) + cabs1(H[l + (size_t)l * m]);
+            if (dd == 0.0) dd = hn;
+            if (sub <= EPS * dd) break;
+        }
+        if (l > 0) H[l + (size_t)(l - 1) * m] = 0.0;
+        if (l == ihi) { --ihi; its = 0; continue; }
+        if (++total > 60 * m + 200) return 2;
+        zc s;
+        if (its == 10 || its == 20) {
+            s = zc(std::fabs(H[ihi + (size_t)(ihi - 1) * m].real()) + (ihi >= 2 ? std::fabs(H[ihi - 1 + (size_t)(ihi - 2) * m].real()) : 0.0), 0.0) + H[ihi + (size_t)ihi * m];
+        } else {   // Wilkinson shift: eigenvalue of the trailing 2x2 closer to H[ihi][ihi]
+            zc a = H[ihi - 1 + (size_t)(ihi - 1) * m], b = H[ihi - 1 + (size_t)ihi * m];
+            zc c = H[ihi + (size_t)(ihi - 1) * m], d = H[ihi + (size_t)ihi * m];
+            zc tr2 = 0.5 * (a + d), det = a * d - b * c;
+            zc disc = std::sqrt(tr2 * tr2 - det);
+            zc e1 = tr2 + disc, e2 = tr2 - disc;
+            s = (std::abs(e1 - d) < std::abs(e2 - d)) ? e1 : e2;
+        }
+        ++its;
+        zc x = H[l + (size_t)l * m] - s, y = H[l + 1 + (size_t)l * m];
+        for (int k = l; k < ihi; ++k) {
+            // Givens G = [c sn; -conj(sn) c] with G [x;y] = [r;0]
+            double ax = std::abs(x), ay = std::abs(y), c;
+            zc sn;
+            if (ay == 0.0) { c = 1.0; sn = 0.0; }
+            else if (ax == 0.0) { c = 0.0; sn = std::conj(y) / ay; }
+            else { double nr = std::hypot(ax, ay); c = ax / nr; sn = (x / ax) * std::conj(y) / nr; }
+            int j0 = std::max(l, k - 1);
+            for (int j = j0; j < m; ++j) {
+                zc h0 = H[k + (size_t)j * m], h1 = H[k + 1 + (size_t)j * m];
+                H[k + (size_t)j * m] = c * h0 + sn * h1;
+                H[k + 1 + (size_t)j * m] = -std::conj(sn) * h0 + c * h1;
+            }
+            if (k > l) H[k + 1 + (size_t)(k - 1) * m] = 0.0;
+            int i1 = std::min(k + 2, ihi);
+            for (int i = 0; i <= i1; ++i) {
+                zc h0 = H[i + (size_t)k * m], h1 = H[i + (size_t)(k + 1) * m];
+                H[i + (size_t)k * m] = c * h0 + std::conj(sn) * h1;
+                H[i + (size_t)(k + 1) * m] = -sn * h0 + c * h1;
+            }
+            for (int i = 0; i < m; ++i) {
+                zc z0 = Z[i + (size_t)k * m], z1 = Z[i + (size_t)(k + 1) * m];
+                Z[i + (size_t)k * m] = c * z0 + std::conj(sn) * z1;
+                Z[i + (size_t)(k + 1) * m] = -sn * z0 + c * z1;
+            }
+            if (k + 1 < ihi) { x = H[k + 1 + (size_t)k * m]; y = H[k + 2 + (size_t)k * m]; }
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+void matmul(int m, const zc* A, const zc* B, zc* C) {
+    for (int j = 0; j < m; ++j) {
+        for (int i = 0; i < m; ++i) C[i + (size_t)j * m] = 0.0;
+        for (int k = 0; k < m; ++k) {
+            zc b = B[k + (size_t)j * m];
+            for (int i = 0; i < m; ++i) C[i + (size_t)j * m] += A[i + (size_t)k * m] * b;
+        }
+    }
+}
+
+int eig_general(int m, zc* A, zc* lam, zc* V) {
+    if (m <= 0) return 0;
+    std::vector<zc> Z((size_t)m * m);
+    hessenberg(m, A, Z.data());
+    int info = hqr_schur(m, A, Z.data());
+    if (info) return info;
+    double tn = 0;
+    for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) tn = std::max(tn, cabs1(A[i + (size_t)j * m]));
+    double small = std::max(EPS * tn, 1e-300);
+    std::vector<zc> x(m), w(m);
+    std::vector<zc> vals(m), vecs((size_t)m * m);
+    for (int k = 0; k < m; ++k) {
+        zc t = A[k + (size_t)k * m];
+        vals[k] = t;
+        std::fill(x.begin(), x.end(), zc(0.0));
+        x[k] = 1.0;
+        for (int j = k - 1; j >= 0; --j) {
+            zc s = 0;
+            for (int i = j + 1; i <= k; ++i) s += A[j + (size_t)i * m] * x[i];
+            zc d = A[j + (size_t)j * m] - t;
+            if (cabs1(d) < small) d = small;
+            x[j] = -s / d;
+            if (cabs1(x[j]) > 1e100) {   // rescale to avoid overflow
+                for (int i = j; i <= k; ++i) x[i] *= 1e-100;
+            }
+        }
+        double nr = 0;
+        for (int i = 0; i < m; ++i) {
+            zc s = 0;
+            for (int j = 0; j <= k; ++j) s += Z[i + (size_t)j * m] * x[j];
+            w[i] = s;
+            nr += std::norm(s);
+        }
+        nr = std::sqrt(nr);
+        for (int i = 0; i < m; ++i) vecs[i + (size_t)k * m] = w[i] / nr;
+    }
+    std::vector<int> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (vals[a].real() != vals[b].real()) return vals[a].real() < vals[b].real();
+        return vals[a].imag() < vals[b].imag();
+    });
+    for (int k = 0; k < m; ++k) {
+        lam[k] = vals[order[k]];
+        for (int i = 0; i < m; ++i) V[i + (size_t)k * m] = vecs[i + (size_t)order[k] * m];
+    }
+    return 0;
+}
+
+int eig_generalized(int m, zc* A, zc* B, zc* lam, zc* V) {
+    // C = B^-1 A by LU with partial pivoting on B applied to A
+    int info = 0;
+    for (int k = 0; k < m; ++k) {
+        int pr = k;
+        double best = cabs1(B[k + (size_t)k * m]);
+        for (int i = k + 1; i < m; ++i) { double a = cabs1(B[i + (size_t)k * m]); if (a > best) { best = a; pr = i; } }
+        if (best == 0.0) { info = 1; B[k + (size_t)k * m] = 1e-300; }
+        if (pr != k) {
+            for (int j = 0; j < m; ++j) { std::swap(B[k + (size_t)j * m], B[pr + (size_t)j * m]); std::swap(A[k + (size_t)j * m], A[pr + (size_t)j * m]); }
+        }
+        zc piv = B[k + (size_t)k * m];
+        for (int i = k + 1; i < m; ++i) {
+            zc l = B[i + (size_t)k * m] / piv;
+            if (l == zc(0.0)) continue;
+            for (int j = k + 1; j < m; ++j) B[i + (size_t)j * m] -= l * B[k + (size_t)j * m];
+            for (int j = 0; j < m; ++j) A[i + (size_t)j * m] -= l * A[k + (size_t)j * m];
+        }
+    }
+    for (int j = 0; j < m; ++j)
+        for (int i = m - 1; i >= 0; --i) {
+            zc s = A[i + (size_t)j * m];
+            for (int k = i + 1; k < m; ++k) s -= B[i + (size_t)k * m] * A[k + (size_t)j * m];
+            A[i + (size_t)j * m] = s / B[i + (size_t)i * m];
+        }
+    int e = eig_general(m, A, lam, V);
+    return e ? e : info;
+}
+
+int cholesky_upper(int m, zc* G) {
+    for (int j = 0; j < m; ++j) {
+        double d = G[j + (size_t)j * m].real();
+        for (int k = 0; k < j; ++k) d -= std::norm(G[k + (size_t)j * m]);
+        if (!(d > 0.0)) return j + 1;
+        d = std::sqrt(d);
+        G[j + (size_t)j * m] = d;
+        for (int i = j + 1; i < m; ++i) {
+            zc s = G[j + (size_t)i * m];
+            for (int k = 0; k < j; ++k) s -= std::conj(G[k + (size_t)j * m]) * G[k + (size_t)i * m];
+            G[j + (size_t)i * m] = s / d;
+        }
+        for (int i = j + 1; i < m; ++i) G[i + (size_t)j * m] = 0.0;
+    }
+    return 0;
+}
+
+void trtri_upper(int m, zc* R) {
+    for (int j = 0; j < m; ++j) {
+        R[j + (size_t)j * m] = 1.0 / R[j + (size_t)j * m];
+        for (int i = 0; i < j; ++i) {
+            zc s = 0;
+            for (int k = i; k < j; ++k) s += R[i + (size_t)k * m] * R[k + (size_t)j * m];
+            R[i + (size_t)j * m] = -s * R[j + (size_t)j * m];
+        }
+    }
+}
+
+int jacobi_svd(int m, zc* M, zc* U, double* s, zc* V) {
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) V[i + (size_t)j * m] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < m - 1; ++p)
+            for (int q = p + 1; q < m; ++q) {
+                double a = 0, b = 0;
+                zc g = 0;
+                for (int i = 0; i < m; ++i) {
+                    a += std::norm(M[i + (size_t)p * m]);
+                    b += std::norm(M[i + (size_t)q * m]);
+                    g += std::conj(M[i + (size_t)p * m]) * M[i + (size_t)q * m];
+                }
+                double ag = std::abs(g);
+                if (ag <= 1e-15 * std::sqrt(a * b) || ag == 0.0) continue;
+                off = std::max(off, ag / std::sqrt(a * b));
+                zc ph = g / ag;
+                double zeta = (b - a) / (2.0 * ag);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < m; ++i) {
+                    zc mp = M[i + (size_t)p * m], mq = M[i + (size_t)q * m];
+                    M[i + (size_t)p * m] = c * mp - sn * std::conj(ph) * mq;
+                    M[i + (size_t)q * m] = sn * ph * mp + c * mq;
+                    zc vp = V[i + (size_t)p * m], vq = V[i + (size_t)q * m];
+                    V[i + (size_t)p * m] = c * vp - sn * std::conj(ph) * vq;
+                    V[i + (size_t)q * m] = sn * ph * vp + c * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    std::vector<int> order(m);
+    std::vector<double> sv(m);
+    for (int j = 0; j < m; ++j) { double a = 0; for (int i = 0; i < m; ++i) a += std::norm(M[i + (size_t)j * m]); sv[j] = std::sqrt(a); }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sv[a] > sv[b]; });
+    std::vector<zc> Vt((size_t)m * m);
+    for (int k = 0; k < m; ++k) {
+        int j = order[k];
+        s[k] = sv[j];
+        for (int i = 0; i < m; ++i) {
+            U[i + (size_t)k * m] = sv[j] > 0 ? M[i + (size_t)j * m] / sv[j] : zc(i == k ? 1.0 : 0.0);
+            Vt[i + (size_t)k * m] = V[i + (size_t)j * m];
+        }
+    }
+    std::copy(Vt.begin(), Vt.end(), V);
+    return 0;
+}
+
+}  // namespace feasthip

@@ -4,6 +4,8 @@
 #include "symbolic.hpp"
 
 #include <algorithm>
+#include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -118,14 +120,21 @@ private:
         if (nl < 3) return;
         int bj = -1;
         double bcost = 1e300;
+        // only levels that leave both sides with at least 35% of the vertices; among them the smallest
         for (int j = 1; j < nl - 1; ++j) {
             int below = lptr_[j], sz = lptr_[j + 1] - lptr_[j], above = m - below - sz;
-            int mn = std::min(below, above);
-            if (mn <= 0) continue;
-            double bal = (double)std::max(below, above) / (double)m;   // 0.5 ideal
-            double pen = bal > 0.70 ? 1.0 + 8.0 * (bal - 0.70) : 1.0;
-            double cost = sz * pen;
+            if (std::min(below, above) < 0.35 * (m - sz)) continue;
+            double cost = sz + 1e-3 * std::abs(below - above);
             if (cost < bcost) { bcost = cost; bj = j; }
+        }
+        if (bj < 0) {   // no balanced level: take the one closest to the median
+            int bestd = INT32_MAX;
+            for (int j = 1; j < nl - 1; ++j) {
+                int below = lptr_[j], sz = lptr_[j + 1] - lptr_[j], above = m - below - sz;
+                if (below <= 0 || above <= 0) continue;
+                int d = std::abs(below - above);
+                if (d < bestd) { bestd = d; bj = j; bcost = sz * (1.0 + 4.0 * (double)d / m); }
+            }
         }
         if (bj < 0 || bcost >= best.cost) return;
         // build trimmed split: vertices of level bj with no neighbour in level bj+1 join side a
@@ -142,8 +151,7 @@ private:
             }
             if (touches) sp.s.push_back(v); else sp.a.push_back(v);
         }
-        double bal = (double)std::max(sp.a.size(), sp.b.size()) / (double)m;
-        sp.cost = sp.s.size() * (bal > 0.70 ? 1.0 + 8.0 * (bal - 0.70) : 1.0);
+        sp.cost = bcost;
         if (sp.cost < best.cost) best = std::move(sp);
     }
 
@@ -162,8 +170,9 @@ private:
             int st = stamp_;
             for (int v : verts) if (vis_[v] != st) rest.push_back(v);
             verts.clear(); verts.shrink_to_fit();
+            int ncomp = (int)comp.size();
             dissect(comp, lo);
-            dissect(rest, lo + (int)comp.size());
+            dissect(rest, lo + ncomp);
             return;
         }
         Split best;
@@ -234,6 +243,10 @@ void finish_layout(Symbolic& S) {
         S.cb_off[s] = cbl[d]; cbl[d] += u * u;
         S.crow_off[s] = crl[d]; crl[d] += u;
     }
+    S.cb_used = cbl;
+    S.crow_used = crl;
+    S.sum_u = 0;
+    for (int s = 0; s < ns; ++s) S.sum_u += S.u(s);
     for (int d = 0; d <= S.maxdepth; ++d) {
         S.cb_size[d & 1] = std::max(S.cb_size[d & 1], cbl[d]);
         S.crow_size[d & 1] = std::max(S.crow_size[d & 1], crl[d]);

@@ -32,6 +32,8 @@ struct Symbolic {
     int64_t cb_size[2] = {0, 0};
     std::vector<int64_t> crow_off;   // offset (in rows) of the u-row solve contribution in arena depth%2
     int64_t crow_size[2] = {0, 0};
+    std::vector<int64_t> cb_used, crow_used;   // per depth: elements / rows actually used in the arena
+    int64_t sum_u = 0;
     int maxdepth = 0;
     std::vector<std::vector<int>> levels;  // supernodes by depth
     // statistics

@@ -1,0 +1,173 @@
+/* feasthip.h -- C ABI of libfeasthip.so: the MI355X (gfx950) FEAST inner loop.
+ *
+ * Drop-in boundary for the hot path of spacedome/FEASTSolver.jl (reference @
+ * 2024-12-18).  File:line citations below are relative to the reference tree.
+ * All entry points are extern "C", take plain pointers and sizes, never throw
+ * and never abort; they return an int status:
+ *     0   success
+ *    <0   FEASTHIP_E* (argument / dimension / HIP failure); text via
+ *         feasthip_last_error().  Dimension errors correspond to the
+ *         reference's error("Incorrect dimensions of A, must be square") /
+ *         error("Incorrect dimensions of X, must match A") (src/feast.jl:13-17).
+ *    >0   number of pivots that had to be statically perturbed during the
+ *         numeric factorisation (the LAPACK "info > 0 => singular" convention,
+ *         maps to Julia's SingularException).
+ * The caller owns every host array; pointers need to stay valid only for the
+ * duration of the call (the library copies to the device and keeps no host
+ * pointer) -- the same contract as the reference's one ccall,
+ * src/lapack.jl:79-89.  Complex numbers are interleaved (re, im) doubles, i.e.
+ * Julia ComplexF64 / numpy complex128.  Dense matrices and block vectors are
+ * column-major with leading dimension n (Julia Matrix layout).
+ */
+#ifndef FEASTHIP_H
+#define FEASTHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct feasthip_handle_s* feasthip_handle_t;
+typedef struct feasthip_fact_s* feasthip_fact_t;
+
+enum {
+    FEASTHIP_OK = 0,
+    FEASTHIP_EARG = -1,      /* bad argument */
+    FEASTHIP_EDIM_A = -2,    /* "Incorrect dimensions of A, must be square"  src/feast.jl:13-14 */
+    FEASTHIP_EDIM_X = -3,    /* "Incorrect dimensions of X, must match A"    src/feast.jl:15-16 */
+    FEASTHIP_ESTATE = -4,    /* call order (e.g. solve before factorize) */
+    FEASTHIP_EHIP = -5,      /* HIP runtime failure */
+    FEASTHIP_ENOGPU = -6,    /* no gfx950 device: the product path has NO CPU fallback */
+    FEASTHIP_ENUM = -7       /* numerical breakdown (Cholesky of a Gram matrix, small eigensolver) */
+};
+
+/* element type tags for matrix values */
+enum { FEASTHIP_F64 = 0, FEASTHIP_C128 = 1, FEASTHIP_I64 = 2 };
+/* contour region kinds for the inside test (src/contour.jl:88-100) */
+enum { FEASTHIP_REGION_DISC = 0, FEASTHIP_REGION_RECT = 1 };
+
+/* ---- lifecycle --------------------------------------------------------- */
+int feasthip_version(void);
+/* number of visible gfx950 devices (0 when none); does not create a context */
+int feasthip_device_count(void);
+int feasthip_create(feasthip_handle_t* h, int device_id);
+int feasthip_destroy(feasthip_handle_t h);
+const char* feasthip_last_error(feasthip_handle_t h);   /* h may be NULL: last create() error */
+/* run all work of this handle on an existing hipStream_t (e.g. the caller's) */
+int feasthip_set_stream(feasthip_handle_t h, void* hip_stream);
+
+/* ---- problem definition -------------------------------------------------
+ * The pencil / NEP is a matrix polynomial T(z) = sum_j z^j M_j, j = 0..nterms-1.
+ *   feast!    (src/feast.jl:10-80):    T(z) = A - z I       -> M_0 = A, M_1 = -I
+ *   gen_feast!(src/feast.jl:89-156):   T(z) = A - z B       -> M_0 = A, M_1 = -B
+ *   nlfeast!  (src/nlfeast.jl:2-84):   T(z) closure; polynomial fast path
+ *                                       (test/butterfly.jl:60-62).
+ * A NULL matrix pointer means the identity.  `scale[j]` (2 doubles, re/im)
+ * multiplies M_j (pass -1 for the B term of a linear pencil).
+ */
+int feasthip_set_dense(feasthip_handle_t h, int64_t n, int nterms, const void* const* mats,
+                       const int* types, const double* scale);
+/* SparseMatrixCSC fields (colptr, rowval, nzval) passed zero-copy; index_base 1 for Julia. */
+int feasthip_set_csc(feasthip_handle_t h, int64_t n, int nterms, const int64_t* const* colptr,
+                     const int64_t* const* rowval, const void* const* nzval, const int* types,
+                     const double* scale, int index_base);
+
+/* contour.nodes / contour.weights (src/contour.jl:3-22): K complex pairs each.
+ * region parameters: DISC -> {c_re, c_im, r, 0}; RECT -> {bl_re, bl_im, tr_re, tr_im}. */
+int feasthip_set_contour(feasthip_handle_t h, int K, const double* nodes, const double* weights,
+                         int region_kind, const double* region);
+/* Multi-GPU sharding: this handle owns nodes k = first, first+stride, ... */
+int feasthip_set_node_shard(feasthip_handle_t h, int first, int stride);
+
+/* ---- factorizer seam: facts[k] = factorizer(T(z_k))  (src/feast.jl:28-38, 104-114;
+ *      src/nlfeast.jl:17-28).  analyze = ordering + symbolic (once per pattern),
+ *      factorize = numeric LU of every local node, batched over nodes on the GPU. */
+int feasthip_analyze(feasthip_handle_t h);
+int feasthip_factorize(feasthip_handle_t h);
+
+/* ---- iteration state -----------------------------------------------------
+ * X is n x m0 ComplexF64 column-major, in/out (the `!` convention). */
+int feasthip_set_x(feasthip_handle_t h, const void* X, int64_t n, int m0);
+int feasthip_get_x(feasthip_handle_t h, void* X);
+int feasthip_get_block(feasthip_handle_t h, int which /*0 X,1 R,2 Q,3 Q1*/, void* out);
+
+/* Rayleigh-Ritz half of one iteration (src/feast.jl:41-50 / 117-127):
+ * Q <- orth(Q); Aq = Q'AQ (, Bq = Q'BQ); reduced eigenproblem; X = Q Xq;
+ * update_R! (src/utils.jl:111-116); residuals! (:166-171).
+ * Outputs: lambda (m0 complex, sorted by (re,im)), res (m0), inside (m0 bytes). */
+int feasthip_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside);
+
+/* Contour half (src/feast.jl:57-72 / 134-148): Q = sum_k (X - T(z_k)^-1 R) diag(w_k/(z_k-lambda))
+ * over the local nodes.  refactor != 0 reproduces store=false (src/utils.jl:175-179). */
+int feasthip_contour_step(feasthip_handle_t h, int refactor);
+
+/* NLFEAST halves (src/nlfeast.jl:32-61 and :64-67, src/utils.jl:69-77,104-109,151-157). */
+int feasthip_nl_contour_step(feasthip_handle_t h, int first_iteration);
+int feasthip_nl_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside);
+int feasthip_nl_orthonormalize_x(feasthip_handle_t h);    /* src/nlfeast.jl:12-13 */
+int feasthip_nl_finalize_x(feasthip_handle_t h);          /* normalize!(X), src/nlfeast.jl:82 */
+
+/* Device pointer of the local partial moment(s) so the host can sum them across
+ * ranks (RCCL all-reduce through torch.distributed).  Layout: row-major
+ * n x ldq complex128, `nblocks` consecutive blocks (1 for FEAST, 2 for NLFEAST). */
+int feasthip_q_device(feasthip_handle_t h, void** dptr, int64_t* n, int64_t* ldq, int* nblocks);
+
+/* ---- whole loops (same semantics as the reference drivers) ----------------
+ * feasthip_feast_run   = feast!/gen_feast! `for nit=0:iter` loop, src/feast.jl:40-73.
+ * On return: lambda/res/inside for all m0 Ritz pairs (caller filters with
+ * inside, src/feast.jl:77-79), X overwritten, *nit = iterations used. */
+int feasthip_feast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps,
+                       int store, double* lambda, double* res, uint8_t* inside, int* nit);
+int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps,
+                         double spurious, double* lambda, double* res, uint8_t* inside, int* nit);
+
+/* ---- fine-grained seam: factorizer / left_divider / finalize!  (src/utils.jl:173-179).
+ * F = factorizer(C): C is copied, never aliased (src/feast.jl:29-36).
+ * left_divider(Y, F, R): Y = C^-1 R, R untouched (src/feast.jl:62).  Thread-safe
+ * across distinct factor objects (src/nlfeast.jl:19-26, 36-55). */
+int feasthip_lu_dense(int device_id, const void* C, int64_t n, feasthip_fact_t* F);
+int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64_t* rowval,
+                    const void* nzval, int type, int index_base, feasthip_fact_t* F);
+int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
+int feasthip_fact_free(feasthip_fact_t F);
+
+/* ---- statistics ------------------------------------------------------------ */
+typedef struct {
+    int64_t n, nsuper, nnz_l, nnz_u, fact_elems, max_front, max_p, depth;
+    double flops_factor;        /* real flops of one numeric factorisation        */
+    double analyze_seconds;     /* host ordering + symbolic                         */
+    double factor_ms;           /* last feasthip_factorize, all local nodes (HIP events) */
+    double solve_ms;            /* last contour step: block solves + accumulation   */
+    double rr_ms;               /* last Rayleigh-Ritz step                          */
+    double solve_bytes;         /* algorithmic bytes of one contour step */
+    double solve_flops;         /* real flops of one contour step                   */
+    int64_t perturbed_pivots;
+    int32_t local_nodes, m0, ldw, dense;
+} feasthip_stats_t;
+int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* out);
+/* One instrumented contour sweep: HIP-event time per kernel class.  out = 8 rows x
+ * {ms, algorithmic bytes, flops, launches}: 0 gather, 1 assemble, 2 diag solve,
+ * 3 panel apply (the dominant kernel), 4 accumulate. */
+int feasthip_profile_solve(feasthip_handle_t h, double* out);
+
+/* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------- */
+/* symbolic analysis of a pattern: stats[0..7] = nsuper, nnz_l, nnz_u, fact_elems,
+ * max_front, max_p, depth, flops(as int64).  perm_out (n ints, new->old) optional. */
+int feasthip_symbolic_probe(int64_t n, const int64_t* colptr, const int64_t* rowval, int index_base,
+                            int ordering, int64_t* stats, int32_t* perm_out,
+                            int32_t* sn_of_out, int32_t* front_rows_ptr_out /* unused: NULL */);
+/* structural check: returns 0 if every (i,j) of the pattern and of its LU fill (given as a
+ * dense n x n 0/1 byte mask, column-major, in ORIGINAL ordering after the caller applied
+ * perm) lies inside the predicted supernodal structure. */
+int feasthip_symbolic_contains(int64_t n, const int64_t* colptr, const int64_t* rowval, int index_base,
+                               int ordering, const int32_t* ii, const int32_t* jj, int64_t count);
+/* small dense complex eigensolver used for the reduced problem (replaces Julia's
+ * eigen!(Aq) / eigen!(Aq,Bq), src/feast.jl:45,122): m x m column-major; B may be NULL.
+ * Outputs sorted by (re, im), unit 2-norm vectors. */
+int feasthip_small_eig(int m, const double* A, const double* B, double* lambda, double* V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEASTHIP_H */

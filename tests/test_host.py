@@ -1,0 +1,164 @@
+"""Host-side logic and the C-ABI surface, no GPU needed: the library loads and exports
+every symbol of include/feasthip.h, the symbolic analysis predicts a superset of the true
+LU fill, the small dense eigensolver matches LAPACK, contours match the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(lib, pkg):
+    hdr = open(os.path.join(ROOT, "include", "feasthip.h")).read()
+    names = sorted(set(re.findall(r"\b(feasthip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    import importlib
+    _lib = importlib.import_module(pkg.__name__ + "._lib")
+    for nm in names:
+        assert hasattr(lib, nm), f"{nm} declared in feasthip.h but not exported"
+        assert nm in _lib.PROTOTYPES, f"{nm} has no ctypes prototype"
+
+
+def test_no_gpu_fails_loudly(lib, pkg):
+    if lib.feasthip_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.FeastHipError):
+        pkg.FeastHandle(0)
+    with pytest.raises(pkg.FeastHipError):
+        pkg.gen_feast(np.ones((4, 2), dtype=complex), np.eye(4), np.eye(4))
+    with pytest.raises(pkg.FeastHipError):
+        pkg.lu(np.eye(4, dtype=complex))
+
+
+def _probe(lib, A, ordering=0):
+    A = sp.csc_matrix(A)
+    n = A.shape[0]
+    cp = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    ri = np.ascontiguousarray(A.indices, dtype=np.int64)
+    stats = np.zeros(8, dtype=np.int64)
+    perm = np.zeros(n, dtype=np.int32)
+    snof = np.zeros(n, dtype=np.int32)
+    rc = lib.feasthip_symbolic_probe(n, cp.ctypes.data, ri.ctypes.data, 0, ordering, stats.ctypes.data, perm.ctypes.data,
+                                     snof.ctypes.data, None)
+    assert rc == 0
+    return stats, perm, snof, cp, ri
+
+
+def _lu_nopivot_fill(M):
+    """pattern of L+U of a dense matrix eliminated without pivoting"""
+    M = M.copy()
+    n = M.shape[0]
+    for k in range(n):
+        M[k + 1:, k] /= M[k, k]
+        M[k + 1:, k + 1:] -= np.outer(M[k + 1:, k], M[k, k + 1:])
+    return np.abs(M) > 1e-13
+
+
+@pytest.mark.parametrize("case", ["lap1d", "grid2d", "grid3d_19", "random", "arrow", "blockdiag"])
+def test_symbolic_structure_contains_fill(lib, wl, case):
+    rng = np.random.default_rng(7)
+    if case == "lap1d":
+        A = sp.diags([-np.ones(99), 2 * np.ones(100), -np.ones(99)], [-1, 0, 1], format="csc")
+    elif case == "grid2d":
+        g = 12
+        T = sp.diags([-np.ones(g - 1), 2 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
+        A = sp.csc_matrix(sp.kron(sp.identity(g), T) + sp.kron(T, sp.identity(g)))
+    elif case == "grid3d_19":
+        A = wl.laplacian_3d(6, 19)
+    elif case == "random":
+        A = sp.random(150, 150, density=0.02, random_state=3, format="csc") + sp.identity(150, format="csc")
+    elif case == "arrow":
+        A = sp.lil_matrix((60, 60)); A.setdiag(1.0); A[0, :] = 1.0; A[:, 0] = 1.0; A[30, :] = 1.0; A = sp.csc_matrix(A)
+    else:
+        A = sp.block_diag([sp.random(20, 20, density=0.3, random_state=k) + sp.identity(20) for k in range(4)], format="csc")
+    n = A.shape[0]
+    stats, perm, snof, cp, ri = _probe(lib, A)
+    assert sorted(perm.tolist()) == list(range(n))
+    # numeric no-pivot LU of the symmetrised, permuted, diagonally dominant pattern
+    P = (abs(A) + abs(A).T).toarray() > 0
+    M = np.where(P, rng.uniform(0.5, 1.5, (n, n)), 0.0)
+    M[np.arange(n), np.arange(n)] = n * 2.0
+    Mp = M[np.ix_(perm, perm)]
+    fill = _lu_nopivot_fill(Mp)
+    ii, jj = np.nonzero(fill)
+    oi, oj = perm[ii].astype(np.int32), perm[jj].astype(np.int32)   # back to original labels
+    bad = lib.feasthip_symbolic_contains(n, cp.ctypes.data, ri.ctypes.data, 0, 0, np.ascontiguousarray(oi).ctypes.data,
+                                         np.ascontiguousarray(oj).ctypes.data, len(oi))
+    assert bad == 0
+    # stored entries >= true fill, and not absurdly larger
+    assert stats[3] >= fill.sum() - n
+    assert stats[1] + stats[2] <= 6 * fill.sum() + 64 * n
+
+
+def test_symbolic_quality_3d(lib, wl):
+    A = wl.laplacian_3d(16, 7)
+    stats, perm, *_ = _probe(lib, A)
+    n = A.shape[0]
+    # natural (banded) ordering would give about n * g^2 = 1.05e6 per factor; ND must beat it clearly
+    assert stats[1] < 0.6 * n * 16 * 16
+    assert stats[6] < 40      # tree depth stays logarithmic
+
+
+def test_small_eig_matches_lapack(lib):
+    rng = np.random.default_rng(11)
+    for m in (1, 2, 5, 16, 33, 64):
+        A = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        B = np.eye(m) + 0.2 * (rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
+        for Bm in (None, B):
+            lam = np.zeros(m, dtype=np.complex128)
+            V = np.zeros((m, m), dtype=np.complex128, order="F")
+            Af = np.asfortranarray(A)
+            Bf = None if Bm is None else np.asfortranarray(Bm)
+            rc = lib.feasthip_small_eig(m, Af.ctypes.data, None if Bf is None else Bf.ctypes.data, lam.ctypes.data, V.ctypes.data)
+            assert rc == 0
+            ref = sla.eigvals(A) if Bm is None else sla.eigvals(A, Bm)
+            assert np.abs(np.sort_complex(lam) - np.sort_complex(ref)).max() < 1e-9 * max(1, np.abs(ref).max())
+            # sorted by (re, im) like Julia's eigen
+            assert all((lam[i].real, lam[i].imag) <= (lam[i + 1].real, lam[i + 1].imag) for i in range(m - 1))
+            Bx = V if Bm is None else Bm @ V
+            resid = np.linalg.norm(A @ V - Bx * lam[None, :], axis=0)
+            assert resid.max() < 1e-9 * np.linalg.norm(A)
+            assert np.allclose(np.linalg.norm(V, axis=0), 1.0)
+
+
+def test_small_eig_hermitian_and_defective(lib):
+    # Hermitian input: real eigenvalues; Jordan block: still converges
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((20, 20)) + 1j * rng.standard_normal((20, 20))
+    H = np.asfortranarray(G + G.conj().T)
+    lam = np.zeros(20, dtype=np.complex128); V = np.zeros((20, 20), dtype=np.complex128, order="F")
+    assert lib.feasthip_small_eig(20, H.ctypes.data, None, lam.ctypes.data, V.ctypes.data) == 0
+    assert np.abs(lam.imag).max() < 1e-10 and np.abs(np.sort(lam.real) - np.linalg.eigvalsh(H)).max() < 1e-10
+    J = np.asfortranarray(np.diag(np.full(6, 2.0 + 0j)) + np.diag(np.ones(5), 1))
+    lam = np.zeros(6, dtype=np.complex128); V = np.zeros((6, 6), dtype=np.complex128, order="F")
+    assert lib.feasthip_small_eig(6, J.ctypes.data, None, lam.ctypes.data, V.ctypes.data) == 0
+    assert np.abs(lam - 2.0).max() < 1e-6
+
+
+def test_contours_match_oracle(pkg, fo):
+    for N in (4, 8, 16, 32):
+        for name in ("circular_contour_trapezoidal", "circular_contour_gauss"):
+            a, b = getattr(pkg, name)(0.3 + 0.1j, 0.7, N), getattr(fo, name)(0.3 + 0.1j, 0.7, N)
+            assert np.abs(a.nodes - b.nodes).max() < 1e-15 and np.abs(a.weights - b.weights).max() < 1e-15
+        for name in ("rectangular_contour_trapezoidal", "rectangular_contour_gauss"):
+            a, b = getattr(pkg, name)(-0.1 - 0.2j, 0.5 + 0.3j, N), getattr(fo, name)(-0.1 - 0.2j, 0.5 + 0.3j, N)
+            assert np.abs(a.nodes - b.nodes).max() < 1e-15 and np.abs(a.weights - b.weights).max() < 1e-15
+    with pytest.raises(ValueError):
+        pkg.RectangularContour(1 + 1j, 0, [], [])
+    lam = np.array([0.1, 0.75, 0.3 + 0.69j, 2.0])
+    c = pkg.circular_contour_trapezoidal(0.05, 0.7, 8)
+    assert pkg.in_contour(lam, c).tolist() == fo.in_contour(lam, fo.circular_contour_trapezoidal(0.05, 0.7, 8)).tolist()
+
+
+def test_argument_validation_without_gpu(pkg):
+    with pytest.raises(ValueError, match="must be square"):
+        pkg.gen_feast(np.ones((4, 2), dtype=complex), np.ones((4, 3)), None)
+    with pytest.raises(ValueError, match="must match A"):
+        pkg.gen_feast(np.ones((5, 2), dtype=complex), np.eye(4), None)
+    with pytest.raises(NotImplementedError):
+        pkg.nlfeast(lambda z: np.eye(3), np.ones((3, 2), dtype=complex), 8, 2)

@@ -1,0 +1,97 @@
+"""Pins the CPU oracle (oracle/feast_oracle.py) against the reference's own known
+answers (test/runtests.jl) and against companion-linearisation spectra of the
+reference's data files (src/companion.jl).  CPU only."""
+import numpy as np
+import scipy.sparse as sp
+
+
+def c2n(pairs):
+    return np.array([complex(a, b) for a, b in pairs])
+
+
+def test_runtests_dense_standard(fo, wl):
+    # test/runtests.jl:16-20
+    A = np.diag(np.arange(1, 26))
+    e, v, res = fo.feast(wl.rand_x0(25, 5, 101), A, fo.circular_contour_trapezoidal(1.5, 2.0, 8), iter=10)
+    assert np.allclose(np.sort(e.real), [1, 2, 3])
+    assert np.sort(res)[:3].max() < 1e-12
+
+
+def test_runtests_dense_generalized(fo, wl):
+    # test/runtests.jl:21-23
+    A = np.diag(np.arange(1, 26)).astype(float)
+    e, v, res = fo.gen_feast(wl.rand_x0(25, 5, 102), A, np.eye(25), fo.circular_contour_trapezoidal(1.5, 2, 8), iter=100)
+    assert np.sort(res).max() < 1e-12
+    assert np.allclose(np.sort(e.real), [1, 2, 3])
+
+
+def test_runtests_sparse_contours(fo, wl, golden):
+    # test/runtests.jl:33-49
+    A = sp.diags([-np.ones(99), 2 * np.ones(100), -np.ones(99)], [-1, 0, 1], format="csc")
+    Cc, R = 0.05, 0.05
+    ana = np.array(golden["runtests_laplace1d_analytic"])
+    for k, con in enumerate([fo.circular_contour_trapezoidal(Cc, R, 8),
+                             fo.rectangular_contour_trapezoidal(0.0 - R * 1j, 2 * R + R * 1j, 8),
+                             fo.rectangular_contour_gauss(0.0 - R * 1j, 2 * R + R * 1j, 8)]):
+        e, v, res = fo.feast(wl.rand_x0(100, 20, 110 + k), A, con, eps=10e-15)
+        assert e.shape[0] == 10
+        assert res.max() < 10e-15
+        assert np.abs(np.sort(e.real) - ana).max() < 1e-13
+
+
+def test_contour_weights_integrate_resolvent(fo):
+    # sum_k w_k/(z_k - z) ~ 1 inside, ~ 0 outside (src/contour.jl:102-108 rational_func)
+    for con in [fo.circular_contour_trapezoidal(0.2, 1.0, 32), fo.circular_contour_gauss(0.2, 1.0, 32),
+                fo.rectangular_contour_trapezoidal(-1 - 1j, 1 + 1j, 64), fo.rectangular_contour_gauss(-1 - 1j, 1 + 1j, 64)]:
+        f = lambda z: np.sum(con.weights / (con.nodes - z))
+        assert abs(f(0.1 + 0.05j) - 1) < 1e-3
+        assert abs(f(5.0)) < 1e-3
+
+
+def test_butterfly_companion_and_nlfeast(fo, wl, golden):
+    w = wl.c4_butterfly()
+    cl, cx, cr = fo.companion(w["coeffs"])
+    ins = np.abs(cl - w["c"]) <= w["r"]
+    assert ins.sum() == 13
+    assert cr[ins].max() < 1e-10
+    lam, X, res = fo.nlfeast(fo.poly_T(w["coeffs"]), w["X0"].copy(), 16, 10, c=w["c"], r=w["r"], eps=w["eps"])
+    li = np.abs(lam - w["c"]) <= w["r"]
+    assert li.sum() == 13 and res[li].max() < 1e-10
+    d = [np.abs(cl[ins] - l).min() for l in lam[li]]
+    assert max(d) < 1e-11
+    g = c2n(golden["c4_butterfly"]["companion_inside"])
+    assert np.abs(np.sort_complex(cl[ins]) - g).max() < 1e-10
+
+
+def test_deficient_and_system5_counts(fo, wl, golden):
+    cl, _, _ = fo.companion(wl.deficient_quadratic_coeffs())
+    fin = np.isfinite(cl)
+    assert (np.abs(cl[fin]) <= 0.25).sum() == 4
+    assert len(golden["system5"]["companion_inside"]) == 50
+
+
+def test_golden_c3_small_reproduces(fo, wl, golden):
+    g = golden["c3_g8_s19_m16"]
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    hist = []
+    lam, X, res = fo.gen_feast(w["X0"].copy(), w["A"], w["B"], fo.circular_contour_trapezoidal(w["c"], w["r"], 16),
+                               iter=w["iter"], eps=w["eps"], store=True, history=hist)
+    assert len(lam) == len(g["lam"]) == w["n_inside"]
+    assert np.abs(np.sort_complex(lam) - np.sort_complex(c2n(g["lam"]))).max() < 1e-10
+    assert len(hist) == len(g["history"])
+
+
+def test_store_false_equals_store_true(fo, wl):
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    a = fo.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=3, eps=0.0, store=True)
+    b = fo.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=3, eps=0.0, store=False)
+    assert np.abs(np.sort_complex(a[0]) - np.sort_complex(b[0])).max() < 1e-10
+
+
+def test_dimension_errors(fo, wl):
+    import pytest
+    with pytest.raises(ValueError, match="must be square"):
+        fo.feast(wl.rand_x0(5, 2, 1), np.zeros((5, 4)), fo.circular_contour_trapezoidal(0, 1, 8))
+    with pytest.raises(ValueError, match="must match A"):
+        fo.feast(wl.rand_x0(6, 2, 1), np.eye(5), fo.circular_contour_trapezoidal(0, 1, 8))
