@@ -52,6 +52,7 @@ PROTOTYPES = {
     "feasthip_nl_orthonormalize_x": (I, [VP]),
     "feasthip_nl_finalize_x": (I, [VP]),
     "feasthip_q_device": (I, [VP, PVP, C.POINTER(I64), C.POINTER(I64), C.POINTER(I)]),
+    "feasthip_set_q_buffer": (I, [VP, VP, C.c_size_t]),
     "feasthip_feast_run": (I, [VP, VP, I64, I, I, D, I, VP, VP, VP, C.POINTER(I)]),
     "feasthip_nlfeast_run": (I, [VP, VP, I64, I, I, D, D, VP, VP, VP, C.POINTER(I)]),
     "feasthip_lu_dense": (I, [I, VP, I64, PVP]),

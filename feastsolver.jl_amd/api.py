@@ -208,6 +208,9 @@ class FeastHandle:
         self._ck(self.lib.feasthip_q_device(self.h, C.byref(p), C.byref(n), C.byref(ld), C.byref(nb)))
         return p.value, n.value, ld.value, nb.value
 
+    def set_q_buffer(self, dptr, nbytes):
+        self._ck(self.lib.feasthip_set_q_buffer(self.h, C.c_void_p(dptr), nbytes))
+
     def feast_run(self, X, iter, eps, store):
         """feasthip_feast_run: whole `for nit=0:iter` loop in the library.  X (F-ordered
         complex128) is overwritten."""

@@ -84,6 +84,7 @@ int feasthip_set_contour(feasthip_handle_t h, int K, const double* nodes, const 
 }
 
 int feasthip_set_node_shard(feasthip_handle_t h, int first, int stride) { GUARD(h) return h->e->set_shard(first, stride); ENDGUARD(h) }
+int feasthip_set_q_buffer(feasthip_handle_t h, void* dptr, size_t bytes) { GUARD(h) return h->e->set_q_buffer(dptr, bytes); ENDGUARD(h) }
 int feasthip_analyze(feasthip_handle_t h) { GUARD(h) return h->e->analyze(); ENDGUARD(h) }
 int feasthip_factorize(feasthip_handle_t h) { GUARD(h) return h->e->factorize(); ENDGUARD(h) }
 int feasthip_set_x(feasthip_handle_t h, const void* X, int64_t n, int m0) { GUARD(h) return h->e->set_x(X, n, m0); ENDGUARD(h) }

@@ -152,6 +152,13 @@ int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const
     return 0;
 }
 
+int Engine::set_q_buffer(void* dptr, size_t bytes) {
+    q_ext_ = (cz*)dptr;
+    q_ext_bytes_ = dptr ? bytes : 0;
+    have_x_ = false;
+    return 0;
+}
+
 int Engine::set_contour(int K_, const double* nodes, const double* weights, int kind, const double* region) {
     if (K_ <= 0 || !nodes || !weights) return fail(FEASTHIP_EARG, "set_contour: bad arguments");
     K = K_;
@@ -394,7 +401,7 @@ int Engine::factorize() {
 // ---------------------------------------------------------------------------
 int Engine::alloc_iteration_buffers() {
     size_t blk = (size_t)n * ldw;
-    bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && d_Q_.alloc(2 * blk) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
+    bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && (q_ext_ ? (q_ext_bytes_ >= 2 * blk * sizeof(cz)) : d_Q_.alloc(2 * blk)) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
               d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * blk) &&
               d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * ldw) &&
               d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * ldw) &&
@@ -417,7 +424,7 @@ int Engine::set_x(const void* X, int64_t n_, int m0_) {
     if (r) return r;
     HIPCHK(hipMemcpyAsync(d_io_.p, X, (size_t)n * m0 * sizeof(cz), hipMemcpyHostToDevice, stream_));
     launch_cm_to_rm(stream_, n, m0, ldw, d_io_.p, n, d_X_.p);
-    HIPCHK(hipMemcpyAsync(d_Q_.p, d_X_.p, (size_t)n * ldw * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(Qp(), d_X_.p, (size_t)n * ldw * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
     HIPCHK(hipMemsetAsync(d_R_.p, 0, (size_t)n * ldw * sizeof(cz), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     lambda_.assign(m0, zc(0.0));
@@ -428,7 +435,7 @@ int Engine::set_x(const void* X, int64_t n_, int m0_) {
 int Engine::get_block(int which, void* out) {
     if (!have_x_ || !out) return fail(FEASTHIP_ESTATE, "get_block: no iteration state");
     HIPCHK(hipSetDevice(device_));
-    const cz* src = which == 0 ? d_X_.p : which == 1 ? d_R_.p : which == 2 ? d_Q_.p : d_Q_.p + (size_t)n * ldw;
+    const cz* src = which == 0 ? d_X_.p : which == 1 ? d_R_.p : which == 2 ? Qp() : Qp() + (size_t)n * ldw;
     launch_rm_to_cm(stream_, n, m0, ldw, src, d_io_.p, n);
     HIPCHK(hipMemcpyAsync(out, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -437,7 +444,7 @@ int Engine::get_block(int which, void* out) {
 
 int Engine::q_device(void** p, int64_t* n_, int64_t* ldq, int* nblocks) {
     if (!have_x_) return fail(FEASTHIP_ESTATE, "q_device: call set_x first");
-    if (p) *p = (void*)d_Q_.p;
+    if (p) *p = (void*)Qp();
     if (n_) *n_ = n;
     if (ldq) *ldq = ldw;
     if (nblocks) *nblocks = 2;
@@ -533,19 +540,19 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     int m = m0;
-    int r = orthonormalize(d_Q_.p, d_T1_.p, nullptr);                     // src/feast.jl:41
+    int r = orthonormalize(Qp(), d_T1_.p, nullptr);                     // src/feast.jl:41
     if (r) return r;
     cz* dA = d_small_.p;
     cz* dB = d_small_.p + (size_t)ldw * ldw;
     cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
     std::vector<zc> Aq((size_t)m * m), Bq((size_t)m * m), lam(m), Xq((size_t)m * m);
-    apply_term(0, d_Q_.p, d_R_.p, 1.0, false);                            // R = A Q          :42
-    launch_gram(stream_, n, m, ldw, d_Q_.p, d_R_.p, d_gram_scratch_.p, dA);   // Aq = Q' R   :43
+    apply_term(0, Qp(), d_R_.p, 1.0, false);                            // R = A Q          :42
+    launch_gram(stream_, n, m, ldw, Qp(), d_R_.p, d_gram_scratch_.p, dA);   // Aq = Q' R   :43
     // B = -scale_1 * M_1
     bool b_is_identity = terms_[1].identity && std::abs(terms_[1].scale + 1.0) == 0.0;
     if (!b_is_identity) {
-        apply_term(1, d_Q_.p, d_T1_.p, -1.0, false);                      // R = B Q          :120
-        launch_gram(stream_, n, m, ldw, d_Q_.p, d_T1_.p, d_gram_scratch_.p, dB);   // Bq    :121
+        apply_term(1, Qp(), d_T1_.p, -1.0, false);                      // R = B Q          :120
+        launch_gram(stream_, n, m, ldw, Qp(), d_T1_.p, d_gram_scratch_.p, dB);   // Bq    :121
         HIPCHK(hipMemcpyAsync(Bq.data(), dB, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
     }
     HIPCHK(hipMemcpyAsync(Aq.data(), dA, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
@@ -554,7 +561,7 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
                              : eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data());   // :122
     if (info) return fail(FEASTHIP_ENUM, "rr_step: reduced eigenproblem failed to converge");
     HIPCHK(hipMemcpyAsync(dM, Xq.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_ts_gemm(stream_, n, m, ldw, d_Q_.p, dM, d_X_.p);              // X = Q Xq         :48
+    launch_ts_gemm(stream_, n, m, ldw, Qp(), dM, d_X_.p);              // X = Q Xq         :48
     // update_R!  src/utils.jl:111-116
     std::vector<double> nr;
     r = col_norms(d_X_.p, nr);
@@ -691,7 +698,7 @@ int Engine::contour_step(int refactor) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_Q_.p, nullptr);   // :68-70
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);   // :68-70
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
@@ -748,8 +755,8 @@ int Engine::nl_contour_step(int first) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(first ? d_X_.p : d_R_.p);               // :41 / :49
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, d_Q_.p,
-                      d_Q_.p + (size_t)n * ldw);
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, Qp(),
+                      Qp() + (size_t)n * ldw);
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
@@ -778,8 +785,8 @@ int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside) {
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     int m = m0;
-    cz* Q0 = d_Q_.p;
-    cz* Q1 = d_Q_.p + (size_t)n * ldw;
+    cz* Q0 = Qp();
+    cz* Q1 = Qp() + (size_t)n * ldw;
     // beyn_svd_step!  src/utils.jl:69-77: thin SVD of Q0 through the orthonormal basis Qo (Q0 = Qo Rr)
     std::vector<zc> Rr;
     int r = orthonormalize(Q0, d_T1_.p, &Rr);

@@ -70,6 +70,7 @@ public:
                 const void* const* nzval, const int* types, const double* scale, int index_base);
     int set_contour(int K, const double* nodes, const double* weights, int kind, const double* region);
     int set_shard(int first, int stride);
+    int set_q_buffer(void* dptr, size_t bytes);
     int analyze();
     int factorize();
     int set_x(const void* X, int64_t n, int m0);
@@ -131,6 +132,9 @@ private:
     DevBuf<cz> d_e0_, d_e1_, d_small_, d_lam_, d_gram_scratch_, d_io_;
     DevBuf<double> d_nrm_, d_nrm_scratch_;
 
+    cz* q_ext_ = nullptr;
+    size_t q_ext_bytes_ = 0;
+    cz* Qp() const { return q_ext_ ? q_ext_ : d_Q_.p; }
     int fail(int code, const std::string& msg) { err = msg; status = code; return code; }
     int hip_fail(hipError_t e, const char* what);
     bool build_plans();

@@ -112,6 +112,10 @@ int feasthip_nl_finalize_x(feasthip_handle_t h);          /* normalize!(X), src/
  * ranks (RCCL all-reduce through torch.distributed).  Layout: row-major
  * n x ldq complex128, `nblocks` consecutive blocks (1 for FEAST, 2 for NLFEAST). */
 int feasthip_q_device(feasthip_handle_t h, void** dptr, int64_t* n, int64_t* ldq, int* nblocks);
+/* Alternatively the caller supplies the moment buffer (e.g. a torch tensor's data_ptr, so the
+ * collective runs on memory its framework owns): >= 2 * n * ldq * 16 bytes with
+ * ldq = 16*ceil(m0/16).  Call before feasthip_set_x; NULL restores the internal buffer. */
+int feasthip_set_q_buffer(feasthip_handle_t h, void* dptr, size_t bytes);
 
 /* ---- whole loops (same semantics as the reference drivers) ----------------
  * feasthip_feast_run   = feast!/gen_feast! `for nit=0:iter` loop, src/feast.jl:40-73.

@@ -114,6 +114,9 @@ def main():
     ins = np.abs(cl + 1.55) <= 0.05
     out["system5"] = dict(companion_inside=cplx(np.sort_complex(cl[ins])))
 
+    # C5 (ii): system5 companion pencil 2000 x 2000, 32 nodes, m0 = 128
+    out["c5_system5_companion"] = run_linear(wl.c5_system5_companion(128))
+
     json.dump(out, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
     print({k: (len(v["lam"]) if isinstance(v, dict) and "lam" in v else "-") for k, v in out.items()})
 

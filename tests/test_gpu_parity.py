@@ -1,0 +1,285 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI.  Run on the MI355X
+box:  python -m pytest tests -m gpu.   Tolerances (fp64): eigenvalues |dlam| <= 1e-10
+max(1,|lam|) against the oracle; residuals below the test's eps and within 1e3 x of the
+oracle's; iteration counts within +-1."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+pytestmark = pytest.mark.gpu
+
+
+def c2n(pairs):
+    return np.array([complex(a, b) for a, b in pairs])
+
+
+def match_sets(a, b):
+    """max over a of the distance to the nearest element of b (order-insensitive, like approx_in in runtests.jl)"""
+    a, b = np.asarray(a), np.asarray(b)
+    return max(np.abs(b - x).min() for x in a) if len(a) else 0.0
+
+
+# ---------------------------------------------------------------------------------------
+# factorizer / left_divider seam
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m0", [(1, 1), (5, 3), (33, 16), (64, 64), (100, 20), (257, 64), (300, 100), (700, 37)])
+def test_seam_dense_lu_ldiv(gpu, pkg, n, m0):
+    rng = np.random.default_rng(n * 1000 + m0)
+    Cm = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))      # needs real pivoting
+    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
+    R0 = R.copy()
+    F = pkg.lu(Cm)
+    Y = np.zeros((n, m0), dtype=np.complex128, order="F")
+    pkg.ldiv(Y, F, R)
+    pkg.finalize(F)
+    assert np.array_equal(R, R0)                                              # R untouched (src/feast.jl:62)
+    ref = np.linalg.solve(Cm, R)
+    assert np.abs(Y - ref).max() <= 1e-9 * np.abs(ref).max() * max(1.0, np.linalg.cond(Cm) * 1e-3)
+    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y)
+
+
+@pytest.mark.parametrize("case", ["lap1d", "grid2d", "grid3d_7", "grid3d_19", "random_unsym", "block"])
+@pytest.mark.parametrize("m0", [1, 20, 64])
+def test_seam_sparse_lu_ldiv(gpu, pkg, wl, case, m0):
+    rng = np.random.default_rng(42)
+    if case == "lap1d":
+        A = sp.diags([-np.ones(99), 2 * np.ones(100), -np.ones(99)], [-1, 0, 1], format="csc")
+    elif case == "grid2d":
+        g = 20
+        T = sp.diags([-np.ones(g - 1), 2 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
+        A = sp.csc_matrix(sp.kron(sp.identity(g), T) + sp.kron(T, sp.identity(g)))
+    elif case == "grid3d_7":
+        A = wl.laplacian_3d(10, 7)
+    elif case == "grid3d_19":
+        A = wl.laplacian_3d(9, 19)
+    elif case == "random_unsym":
+        A = sp.random(400, 400, density=0.01, random_state=5, format="csc") * 1.0 + sp.identity(400, format="csc") * 0.3
+    else:
+        A = sp.block_diag([sp.random(30, 30, density=0.2, random_state=k) + sp.identity(30) for k in range(5)], format="csc")
+    n = A.shape[0]
+    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.3 + 0.4j) * sp.identity(n))
+    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
+    F = pkg.lu(Cm)
+    Y = np.zeros((n, m0), dtype=np.complex128, order="F")
+    pkg.ldiv(Y, F, R)
+    pkg.finalize(F)
+    ref = spla.splu(Cm).solve(np.ascontiguousarray(R))
+    assert np.abs(Y - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * spla.norm(Cm) * np.linalg.norm(Y) + 1e-13 * np.linalg.norm(R)
+
+
+def test_seam_used_inside_oracle_loop(gpu, pkg, fo, wl):
+    """The reference's own loop (oracle restatement) with factorizer=lu / left_divider=ldiv replaced
+    by the GPU seam gives the same eigenpairs -- the drop-in at the fine-grained boundary."""
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    facts = []
+
+    def factorizer(Cm):
+        F = pkg.lu(Cm)
+        facts.append(F)
+        return F
+
+    lam_g, _, res_g = fo.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True,
+                                   factorizer=factorizer, left_divider=pkg.ldiv)
+    for F in facts:
+        pkg.finalize(F)
+    lam_o, _, res_o = fo.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True)
+    assert len(lam_g) == len(lam_o) == w["n_inside"]
+    assert match_sets(lam_g, lam_o) < 1e-10
+    assert res_g.max() < w["eps"]
+
+
+# ---------------------------------------------------------------------------------------
+# the reference's own tests (test/runtests.jl), replayed on the HIP path
+# ---------------------------------------------------------------------------------------
+def test_runtests_dense_standard(gpu, pkg, wl):
+    A = np.diag(np.arange(1, 26))                      # Int matrix, as in runtests.jl:16
+    e, v, res = pkg.feast(wl.rand_x0(25, 5, 11), A, nodes=8, iter=10, c=1.5, r=2.0)
+    assert match_sets([1, 2, 3], e.real) < 1e-10       # approx_in(1:3, real.(e))
+    assert np.sort(res)[:3].max() < 1e-12
+
+
+def test_runtests_dense_generalized(gpu, pkg, wl):
+    A = np.diag(np.arange(1, 26))
+    e, v, res = pkg.gen_feast(wl.rand_x0(25, 5, 12), A, sp.diags(np.ones(25)), nodes=8, iter=100, c=1.5, r=2)
+    assert np.sort(res).max() < 1e-12
+    assert match_sets([1, 2, 3], e.real) < 1e-10
+
+
+@pytest.mark.parametrize("kind", ["circular", "rect_trap", "rect_gauss"])
+def test_runtests_sparse_contours(gpu, pkg, wl, golden, kind):
+    A = sp.diags([-np.ones(99), 2 * np.ones(100), -np.ones(99)], [-1, 0, 1], format="csc")
+    Cc, R = complex(0.05, 0.0), 0.05
+    con = {"circular": pkg.circular_contour_trapezoidal(Cc, R, 8),
+           "rect_trap": pkg.rectangular_contour_trapezoidal(0.0 - R * 1j, 2 * R + R * 1j, 8),
+           "rect_gauss": pkg.rectangular_contour_gauss(0.0 - R * 1j, 2 * R + R * 1j, 8)}[kind]
+    X = wl.rand_x0(100, 20, 21)
+    e, v, res = pkg.feast(X, A, con, eps=10e-15)
+    assert e.shape[0] == 10
+    assert res.max() < 10e-15
+    assert np.abs(np.sort(e.real) - np.array(golden["runtests_laplace1d_analytic"])).max() < 1e-13
+    # returned vectors are eigenvectors, X was updated in place
+    assert np.linalg.norm(A @ v - v * e[None, :], axis=0).max() < 1e-13
+    assert np.allclose(np.linalg.norm(X, axis=0), 1.0)
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE configs at oracle sizes against committed golden vectors
+# ---------------------------------------------------------------------------------------
+def _check_linear(pkg, w, g, store=True, tol_lam=1e-10):
+    info = {}
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
+    X = w["X0"].copy()
+    lam, V, res = pkg.gen_feast(X, w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=store, info=info)
+    glam = c2n(g["lam"])
+    assert len(lam) == len(glam) == w["n_inside"]
+    scale = np.maximum(1.0, np.abs(glam).max())
+    assert match_sets(lam, glam) < tol_lam * scale and match_sets(glam, lam) < tol_lam * scale
+    assert res.max() < w["eps"]
+    assert abs(info["nit"] - g["history"][-1][0]) <= 1
+    assert info["warn"] == 0
+    # true residual of the returned pairs, computed on the host
+    A, B = w["A"], w["B"]
+    BV = V if B is None else B @ V
+    r_true = np.linalg.norm(A @ V - BV * lam[None, :], axis=0)
+    assert r_true.max() < 10 * w["eps"] + 1e-12
+    return info
+
+
+def test_c1_dense_hermitian_n512(gpu, pkg, wl, golden):
+    _check_linear(pkg, wl.c1_dense_hermitian(512, 16), golden["c1_n512"])
+
+
+def test_c1_store_false(gpu, pkg, wl, golden):
+    _check_linear(pkg, wl.c1_dense_hermitian(512, 16), golden["c1_n512"], store=False)
+
+
+def test_c2_dense_generalized_n512(gpu, pkg, wl, golden):
+    g = golden["c2_n512"]
+    _check_linear(pkg, wl.c2_dense_generalized(512, 64, radius=g["radius"], n_inside=32), g, tol_lam=1e-9)
+
+
+def test_c3_sparse_g12(gpu, pkg, wl, golden):
+    info = _check_linear(pkg, wl.c3_sparse_generalized(12, 19, 64), golden["c3_g12_s19"])
+    assert info["dense"] == 0 and info["nsuper"] > 1
+
+
+def test_c3_sparse_g8_m16(gpu, pkg, wl, golden):
+    _check_linear(pkg, wl.c3_sparse_generalized(8, 19, 16), golden["c3_g8_s19_m16"])
+
+
+def test_c5_literal_companion_m30(gpu, pkg, fo, wl, golden):
+    C1, C2 = fo.companion_pencil(wl.deficient_quadratic_coeffs())     # oracle used only to build the input pencil
+    X = wl.rand_x0(30, 30, 5002)
+    lam, V, res = pkg.gen_feast(X, C1, C2, nodes=32, iter=20, c=0j, r=0.25, eps=1e-10)
+    glam = c2n(golden["deficient_quadratic"]["companion_inside"])
+    assert len(lam) == 4 and match_sets(lam, glam) < 1e-8
+
+
+def test_c4_butterfly_nlfeast(gpu, pkg, wl, golden):
+    w = wl.c4_butterfly()
+    T = pkg.PolynomialNEP(w["coeffs"])
+    X = w["X0"].copy()
+    info = {}
+    lam, Xo, res = pkg.nlfeast(T, X, 16, 10, c=w["c"], r=w["r"], eps=w["eps"], spurious=w["spurious"], info=info)
+    assert lam.shape == (32,) and Xo.shape == (64, 32)                  # all m0 pairs, unfiltered
+    ins = np.abs(lam - w["c"]) <= w["r"]
+    comp = c2n(golden["c4_butterfly"]["companion_inside"])
+    assert ins.sum() == 13
+    assert match_sets(lam[ins], comp) < 1e-10 and match_sets(comp, lam[ins]) < 1e-10
+    assert res[ins].max() < 1e-10
+    assert abs(info["nit"] - golden["c4_butterfly"]["history"][-1][0]) <= 1
+    assert np.allclose(np.linalg.norm(Xo, axis=0), 1.0)
+    # relative residual definition (src/utils.jl:151-157)
+    for j in np.nonzero(ins)[0]:
+        Tl = T(lam[j])
+        assert abs(np.linalg.norm(Tl @ Xo[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
+
+
+def test_c5_system5_companion_m128(gpu, pkg, wl, golden):
+    """C5 (ii): system5 quadratic, companion pencil 2000 x 2000, 32 nodes, m0 = 128."""
+    g = golden["c5_system5_companion"]
+    _check_linear(pkg, wl.c5_system5_companion(128), g, tol_lam=1e-9)
+    comp = c2n(golden["system5"]["companion_inside"])
+    assert match_sets(c2n(g["lam"]), comp) < 1e-9
+
+
+def test_butterfly_sparse_terms_nlfeast(gpu, pkg, wl, golden):
+    """same NEP through feasthip_set_csc (5 sparse terms): exercises the sparse polynomial path"""
+    w = wl.c4_butterfly()
+    T = pkg.PolynomialNEP([sp.csc_matrix(M) for M in w["coeffs"]])
+    lam, Xo, res = pkg.nlfeast(T, w["X0"].copy(), 16, 10, c=w["c"], r=w["r"], eps=w["eps"])
+    ins = np.abs(lam - w["c"]) <= w["r"]
+    comp = c2n(golden["c4_butterfly"]["companion_inside"])
+    assert ins.sum() == 13 and match_sets(lam[ins], comp) < 1e-10 and res[ins].max() < 1e-10
+
+
+def test_system5_nlfeast_first_moments(gpu, pkg, fo, wl):
+    """nlfeast! does not converge on system5 with one moment pair (the reference uses
+    nlfeast_moments! there, test/polynomial.jl:20); compare the contour moments instead:
+    after nit = 0 the oracle's Q0, Q1 and ours span the same spaces."""
+    coeffs = wl.system5_coeffs(sparse=True)
+    X0 = wl.rand_x0(1000, 40, 77)
+    h = pkg.FeastHandle(0)
+    h.set_terms(coeffs)
+    h.set_contour(pkg.circular_contour_trapezoidal(-1.55 + 0j, 0.05, 16))
+    h.set_x(X0)
+    h.nl_orthonormalize_x()
+    Xq = h.get_block(0)
+    assert np.abs(Xq.conj().T @ Xq - np.eye(40)).max() < 1e-13
+    h.factorize()
+    h.nl_contour_step(True)
+    Q0, Q1 = h.get_block(2), h.get_block(3)
+    h.close()
+    T = fo.poly_T(coeffs)
+    zs = pkg.circular_contour_trapezoidal(-1.55 + 0j, 0.05, 16)
+    R0 = np.zeros_like(Q0); R1 = np.zeros_like(Q1)
+    for z, wgt in zip(zs.nodes, zs.weights):
+        Y = fo.lu(T(z)).solve(Xq) * wgt
+        R0 += Y; R1 += Y * z
+    assert np.abs(Q0 - R0).max() < 1e-9 * np.abs(R0).max()
+    assert np.abs(Q1 - R1).max() < 1e-9 * np.abs(R1).max()
+
+
+# ---------------------------------------------------------------------------------------
+# properties at sizes the oracle cannot reach quickly
+# ---------------------------------------------------------------------------------------
+def test_large_sparse_solve_residual(gpu, pkg, wl):
+    A = wl.laplacian_3d(24, 19)
+    n = A.shape[0]
+    rng = np.random.default_rng(1)
+    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.17 + 0.17j) * sp.diags(rng.uniform(0.5, 1.5, n)))
+    R = np.asfortranarray(rng.standard_normal((n, 64)) + 1j * rng.standard_normal((n, 64)))
+    F = pkg.lu(Cm)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    # linearity: solve(2R) == 2 solve(R)
+    Y2 = np.zeros_like(R)
+    pkg.ldiv(Y2, F, np.asfortranarray(2 * R))
+    pkg.finalize(F)
+    assert np.linalg.norm(Cm @ Y - R) <= 1e-12 * spla.norm(Cm) * np.linalg.norm(Y)
+    assert np.abs(Y2 - 2 * Y).max() <= 1e-12 * np.abs(Y).max()
+
+
+def test_c3_g24_converges_with_right_count(gpu, pkg, wl):
+    w = wl.c3_sparse_generalized(24, 19, 64)
+    info = {}
+    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10,
+                                store=True, info=info)
+    assert len(lam) == w["n_inside"]
+    assert res.max() < 1e-10
+    r_true = np.linalg.norm(w["A"] @ V - (w["B"] @ V) * lam[None, :], axis=0)
+    assert r_true.max() < 1e-9
+    assert np.abs(lam.imag).max() < 1e-10      # Hermitian-definite pencil
+
+
+def test_error_codes(gpu, pkg, wl):
+    with pytest.raises(ValueError, match="must be square"):
+        pkg.feast(wl.rand_x0(5, 2, 1), np.zeros((5, 4)))
+    with pytest.raises(ValueError, match="must match A"):
+        pkg.feast(wl.rand_x0(6, 2, 1), np.eye(5))
+    # empty contour is not an error: empty arrays + message (src/feast.jl:78-79)
+    e, v, res = pkg.feast(wl.rand_x0(25, 5, 3), np.diag(np.arange(1.0, 26)), nodes=8, iter=2, c=100.5, r=0.1)
+    assert e.shape == (0,) and v.shape == (25, 0) and res.shape == (0,)
