@@ -1,0 +1,77 @@
+"""Multi-GPU driver: contour nodes sharded over ranks, one RCCL sum of Q per iteration.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank g owns
+the nodes {k : k mod G = g} including their factorisations -- the memory-heavy
+state is what gets sharded; A, B, X, R are replicated.  After the all-reduce every rank
+runs the small Rayleigh-Ritz step redundantly, so no broadcast is needed.  The reference has
+no distributed path (Distributed/SharedArrays are imported but unused,
+src/FEASTSolver.jl:10-11); its node loop (src/feast.jl:59-71) is what is sharded here.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_nodes(K, world_size, rank):
+    """Indices of the contour nodes owned by `rank` (round robin, matches feasthip_set_node_shard)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    return list(range(rank, K, world_size))
+
+
+def allreduce_moment(q, group=None):
+    """Sum the partial moment(s) Q over all ranks in place.  `q` is a torch tensor (device
+    memory for nccl/RCCL, host memory for gloo); a no-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(q, op=dist.ReduceOp.SUM, group=group)
+    return q
+
+
+def gen_feast_distributed(X, A, B, contour, *, iter=10, eps=1e-12, store=True, device=None, group=None, info=None):
+    """gen_feast! (src/feast.jl:89-156) with the node loop sharded over the ranks of `group`.
+    Every rank passes the same X, A, B, contour and receives the same result.  B=None: feast!."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+    from .contour import in_contour
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if device is None:
+        device = torch.cuda.current_device()
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Incorrect dimensions of A, must be square")
+    if X.shape[0] != A.shape[0]:
+        raise ValueError("Incorrect dimensions of X, must match A")
+    n, m0 = X.shape
+    ldw = ((m0 + 15) // 16) * 16
+    h = api.FeastHandle(device)
+    try:
+        h.set_terms([A, B], scales=[1.0, -1.0])
+        h.set_contour(contour)
+        h.set_node_shard(rank, world)
+        q = torch.zeros(2 * n * ldw * 2, dtype=torch.float64, device=f"cuda:{device}")
+        h.set_q_buffer(q.data_ptr(), q.numel() * 8)
+        if store:
+            h.factorize()
+        h.set_x(np.asfortranarray(X, dtype=np.complex128))
+        nit = 0
+        for nit in range(iter + 1):                                   # src/feast.jl:40
+            lam, res, ins = h.rr_step()
+            if ins.any() and res[ins].max() < eps:                    # :53
+                break
+            if nit < iter:                                            # :57
+                h.contour_step(refactor=not store)
+                torch.cuda.synchronize()
+                allreduce_moment(q[: n * ldw * 2], group)
+                torch.cuda.synchronize()
+        Xo = h.get_block(0)
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=nit, rank=rank, world=world)
+    finally:
+        h.close()
+    if isinstance(X, np.ndarray) and np.issubdtype(X.dtype, np.complexfloating):
+        X[...] = Xo
+    inside = in_contour(lam, contour)
+    return lam[inside], Xo[:, inside], res[inside]
