@@ -234,24 +234,68 @@ bool Engine::build_plans() {
         F.fronts.off = (int64_t)lists.size();
         for (int s : lv) lists.push_back(s);
         F.fronts.count = (int)lv.size();
-        // solve steps
-        for (int k0 = 0; k0 < pmax; k0 += SOLVE_NB) {
-            SolveStep st;
-            st.k0 = k0;
-            st.diag.off = (int64_t)lists.size();
-            for (int s : lv) if (S.p(s) > k0) lists.push_back(s);
-            st.diag.count = (int)(lists.size() - st.diag.off);
-            st.fwd.off = (int64_t)tiles.size();
-            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), b = std::min(SOLVE_NB, p - k0); int rows = p + S.u(s) - k0 - b; for (int a = 0; a < cdiv(rows, 64); ++a) tiles.push_back({s, a, 0, 0}); }
-            st.fwd.count = (int)(tiles.size() - st.fwd.off);
-            st.bwd.off = (int64_t)tiles.size();
-            for (int s : lv) if (S.p(s) > k0 && k0 > 0) for (int a = 0; a < cdiv(k0, 64); ++a) tiles.push_back({s, a, 0, 0});
-            st.bwd.count = (int)(tiles.size() - st.bwd.off);
-            V.steps.push_back(st);
+        // solve-ready finalisation (block inverses + panel scaling)
+        F.binv.off = (int64_t)tiles.size();
+        for (int s : lv) for (int t = 0; t < cdiv(S.p(s), SOLVE_NB); ++t) tiles.push_back({s, t, 0, 0});
+        F.binv.count = (int)(tiles.size() - F.binv.off);
+        F.scale.off = (int64_t)tiles.size();
+        for (int s : lv) for (int t = 0; t < cdiv(S.p(s), SOLVE_NB); ++t) {
+            int p = S.p(s), ld = p + S.u(s), k0 = t * SOLVE_NB, b = std::min(SOLVE_NB, p - k0);
+            for (int a = 0; a < cdiv(k0, 64); ++a) tiles.push_back({s, t, a, 0});
+            for (int a = 0; a < cdiv(ld - k0 - b, 64); ++a) tiles.push_back({s, t, a, 1});
         }
-        V.u12.off = (int64_t)tiles.size();
-        for (int s : lv) if (S.u(s) > 0) for (int a = 0; a < cdiv(S.p(s), 64); ++a) tiles.push_back({s, a, 0, 0});
-        V.u12.count = (int)(tiles.size() - V.u12.off);
+        F.scale.count = (int)(tiles.size() - F.scale.off);
+        // block substitution launches (kernels.hpp: launch_apply)
+        double rowb = 1.0;   // bytes are scaled by 16*ldw at run time: count block-vector ROWS here
+        (void)rowb;
+        int nsteps = cdiv(pmax, SOLVE_NB);
+        for (int c = 0; c + 1 < nsteps; ++c) {
+            Launch L;
+            L.off = (int64_t)tiles.size();
+            for (int s : lv) {
+                int p = S.p(s), k0 = c * SOLVE_NB;
+                if (p <= k0 + SOLVE_NB) continue;
+                int rows = p - k0 - SOLVE_NB;
+                for (int a = 0; a < cdiv(rows, 64); ++a) tiles.push_back({s, 0, a, c});
+                L.bytes += (double)rows * SOLVE_NB * 16.0; L.flops += (double)rows * SOLVE_NB;
+            }
+            L.count = (int)(tiles.size() - L.off);
+            V.f1.push_back(L);
+        }
+        V.f2.off = (int64_t)tiles.size();
+        for (int s : lv) {
+            int p = S.p(s), u = S.u(s);
+            for (int a = 0; a < cdiv(u, 64); ++a) tiles.push_back({s, 1, a, 0});
+            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t) tiles.push_back({s, 2, t, 0});
+            V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, SOLVE_NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, SOLVE_NB);
+        }
+        V.f2.count = (int)(tiles.size() - V.f2.off);
+        V.b1.off = (int64_t)tiles.size();
+        for (int s : lv) if (S.u(s) > 0) {
+            for (int a = 0; a < cdiv(S.p(s), 64); ++a) tiles.push_back({s, 3, a, 0});
+            V.b1.bytes += (double)S.u(s) * S.p(s) * 16.0; V.b1.flops += (double)S.u(s) * S.p(s);
+        }
+        V.b1.count = (int)(tiles.size() - V.b1.off);
+        V.b2.assign(nsteps, Launch());
+        for (int c = 1; c < nsteps; ++c) {
+            Launch& L = V.b2[c];
+            L.off = (int64_t)tiles.size();
+            for (int s : lv) {
+                int p = S.p(s), k0 = c * SOLVE_NB;
+                if (p <= k0) continue;
+                int b = std::min(SOLVE_NB, p - k0);
+                for (int a = 0; a < cdiv(k0, 64); ++a) tiles.push_back({s, 4, a, c});
+                L.bytes += (double)k0 * b * 16.0; L.flops += (double)k0 * b;
+            }
+            L.count = (int)(tiles.size() - L.off);
+        }
+        V.b3.off = (int64_t)tiles.size();
+        for (int s : lv) {
+            int p = S.p(s);
+            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t) tiles.push_back({s, 5, t, 0});
+            V.b3.bytes += 0.5 * p * std::min(p, SOLVE_NB) * 16.0; V.b3.flops += 0.5 * p * std::min(p, SOLVE_NB);
+        }
+        V.b3.count = (int)(tiles.size() - V.b3.off);
     }
     if (tiles.empty()) tiles.push_back({0, 0, 0, 0});
     if (lists.empty()) lists.push_back(0);
@@ -383,6 +427,8 @@ int Engine::factorize() {
         }
         launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
         launch_rowperm(stream_, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
+        launch_block_inverse(stream_, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
+        launch_scale_panels(stream_, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
     }
     HIPCHK(hipEventRecord(ev1_, stream_));
     std::vector<int> np(Kloc);
@@ -402,7 +448,7 @@ int Engine::factorize() {
 int Engine::alloc_iteration_buffers() {
     size_t blk = (size_t)n * ldw;
     bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && (q_ext_ ? (q_ext_bytes_ >= 2 * blk * sizeof(cz)) : d_Q_.alloc(2 * blk)) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
-              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * blk) &&
+              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * blk) && d_Y_.alloc((size_t)Kloc * blk) &&
               d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * ldw) &&
               d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * ldw) &&
               d_e0_.alloc((size_t)Kloc * ldw) && d_e1_.alloc((size_t)Kloc * ldw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
@@ -612,26 +658,9 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
     begin();
     launch_gather_rhs(stream_, dsym_, rhs, ldw, d_W_.p, ws, d_rowperm_.p, Kloc);
     end(0, 2.0 * n * rowb * Kloc, 0);
-    // per-level byte/flop tallies for the profile rows
-    auto level_stats = [&](int d, int k0, int kind, double& bytes, double& flops) {
-        bytes = flops = 0;
-        for (int s : S.levels[d]) {
-            int p = S.p(s), u = S.u(s);
-            if (kind == 2) { if (u > 0) { bytes += ((double)p * u * 16 + (double)(u + 2.0 * p) * rowb) ; flops += 8.0 * p * u * ldw; } continue; }
-            if (p <= k0) continue;
-            int b = std::min(SOLVE_NB, p - k0);
-            double rows = kind == 0 ? (double)(p + u - k0 - b) : (double)k0;
-            if (rows <= 0) continue;
-            bytes += rows * b * 16 + (2.0 * rows + b) * rowb;
-            flops += 8.0 * rows * b * ldw;
-        }
-        bytes *= Kloc; flops *= Kloc;
-    };
-    auto diag_stats = [&](int d, int k0, double& bytes, double& flops) {
-        bytes = flops = 0;
-        for (int s : S.levels[d]) { int p = S.p(s); if (p <= k0) continue; int b = std::min(SOLVE_NB, p - k0); bytes += (double)b * b * 16 + 2.0 * b * rowb; flops += 4.0 * b * b * ldw; }
-        bytes *= Kloc; flops *= Kloc;
-    };
+    // Launch::bytes counts factor bytes, Launch::flops complex multiply-adds per block-vector column (one node)
+    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes + vec_rows * rowb) * Kloc; };
+    auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * Kloc; };
     for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
         SolveLevel& V = splan_[d];
         int par = d & 1;
@@ -642,31 +671,33 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         launch_fwd_assemble(stream_, dsym_, tl + V.assemble.off, V.assemble.count, d_W_.p, ws, ldw, d_crow_[par].p, crs,
                             d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc);
         if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 3.0 * rows * rowb * Kloc, 0); }
-        for (SolveStep& st : V.steps) {
-            double by, fl;
+        double lvl_rows = 0;
+        for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
+        for (Launch& L : V.f1) {
             begin();
-            launch_diag_solve(stream_, dsym_, ls + st.diag.off, st.diag.count, st.k0, 0, d_fact_.p, fs, d_W_.p, ws, ldw, Kloc);
-            if (prof) { diag_stats(d, st.k0, by, fl); end(2, by, fl); }
-            begin();
-            launch_panel_apply(stream_, dsym_, tl + st.fwd.off, st.fwd.count, st.k0, 0, d_fact_.p, fs, d_W_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
-            if (prof && st.fwd.count) { level_stats(d, st.k0, 0, by, fl); end(3, by, fl); }
+            launch_apply(stream_, dsym_, tl + L.off, L.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
+            if (L.count) end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L));
         }
+        begin();
+        launch_apply(stream_, dsym_, tl + V.f2.off, V.f2.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
+        if (V.f2.count) end(3, stat_bytes(V.f2, 2.0 * lvl_rows), stat_flops(V.f2));
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
         SolveLevel& V = splan_[d];
-        double by, fl;
+        double lvl_p = 0, lvl_u = 0;
+        for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
-        launch_panel_apply(stream_, dsym_, tl + V.u12.off, V.u12.count, 0, 2, d_fact_.p, fs, d_W_.p, ws, ldw, nullptr, 0, Kloc);
-        if (prof && V.u12.count) { level_stats(d, 0, 2, by, fl); end(3, by, fl); }
-        for (int si = (int)V.steps.size() - 1; si >= 0; --si) {
-            SolveStep& st = V.steps[si];
+        launch_apply(stream_, dsym_, tl + V.b1.off, V.b1.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc, true);
+        if (V.b1.count) end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1));
+        for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
+            Launch& L = V.b2[c];
             begin();
-            launch_diag_solve(stream_, dsym_, ls + st.diag.off, st.diag.count, st.k0, 1, d_fact_.p, fs, d_W_.p, ws, ldw, Kloc);
-            if (prof) { diag_stats(d, st.k0, by, fl); end(2, by, fl); }
-            begin();
-            launch_panel_apply(stream_, dsym_, tl + st.bwd.off, st.bwd.count, st.k0, 1, d_fact_.p, fs, d_W_.p, ws, ldw, nullptr, 0, Kloc);
-            if (prof && st.bwd.count) { level_stats(d, st.k0, 1, by, fl); end(3, by, fl); }
+            launch_apply(stream_, dsym_, tl + L.off, L.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc);
+            if (L.count) end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L));
         }
+        begin();
+        launch_apply(stream_, dsym_, tl + V.b3.off, V.b3.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc);
+        if (V.b3.count) end(3, stat_bytes(V.b3, 2.0 * lvl_p), stat_flops(V.b3));
     }
     if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }
     HIPCHK(hipGetLastError());
@@ -698,7 +729,7 @@ int Engine::contour_step(int refactor) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);   // :68-70
+    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);   // :68-70
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
@@ -717,7 +748,7 @@ int Engine::profile_solve(ProfileRow* rows) {
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     HIPCHK(hipEventRecord(a, stream_));
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
+    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
     HIPCHK(hipEventRecord(b, stream_));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0;
@@ -755,7 +786,7 @@ int Engine::nl_contour_step(int first) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(first ? d_X_.p : d_R_.p);               // :41 / :49
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, Qp(),
+    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, Qp(),
                       Qp() + (size_t)n * ldw);
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
@@ -957,7 +988,7 @@ int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
     std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
     for (int j = 0; j < ldw; ++j) e0[j] = 1.0;        // node 0 only
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, 1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, 1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
     launch_rm_to_cm(stream_, n, m0, ldw, d_T1_.p, d_io_.p, n);
     if (ldy == n) HIPCHK(hipMemcpyAsync(Y, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
     else HIPCHK(hipMemcpy2DAsync(Y, (size_t)ldy * sizeof(cz), d_io_.p, (size_t)n * sizeof(cz), (size_t)n * sizeof(cz), m0, hipMemcpyDeviceToHost, stream_));

@@ -32,12 +32,12 @@ struct DevBuf {
 struct Launch {        // a slice of the tile / list buffers
     int64_t off = 0;
     int count = 0;
+    double bytes = 0, flops = 0;   // algorithmic bytes / real flops of this launch for ONE contour node
 };
 
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm; };
-struct FactorLevel { Launch extend; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; };
-struct SolveStep { int k0; Launch diag, fwd, bwd; };
-struct SolveLevel { Launch assemble; std::vector<SolveStep> steps; Launch u12; };
+struct FactorLevel { Launch extend; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, scale; };
+struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; };
 
 struct SparseTerm {
     std::vector<int64_t> colptr;
@@ -128,7 +128,7 @@ private:
     DevBuf<int> d_piv_, d_rowperm_, d_rowinv_, d_nperturb_;
     DevBuf<double> d_tiny_;
     // iteration state (row-major n x ldw)
-    DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_crow_[2];
+    DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_Y_, d_crow_[2];
     DevBuf<cz> d_e0_, d_e1_, d_small_, d_lam_, d_gram_scratch_, d_io_;
     DevBuf<double> d_nrm_, d_nrm_scratch_;
 

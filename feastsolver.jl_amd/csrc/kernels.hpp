@@ -33,6 +33,9 @@ void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntile
 // kinds: 0 = L-panel trailing update, 1 = U12 trailing update, 2 = contribution block (K = p)
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                     cz* cb, int64_t cbs, int K);
+// solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled
+void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
+void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* piv, int* rowperm,
                     int* rowinv, int K);
 
@@ -42,13 +45,17 @@ void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, 
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
                          const int* rowinv, int K);
-// mode 0: forward (unit lower), 1: backward (upper)
-void launch_diag_solve(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, int mode, const cz* fact,
-                       int64_t fs, cz* W, int64_t ws, int ldw, int K);
-// kinds: 0 = forward panel update (rows below block, into W or the contribution rows),
-//        1 = backward update of rows above the block, 2 = backward U12 * x_struct
-void launch_panel_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int kind, const cz* fact,
-                        int64_t fs, cz* W, int64_t ws, int ldw, cz* crow, int64_t crs, int K);
+// Block substitution on the solve-ready factors: every tile is out (-)= A * V on the f64 matrix cores.
+// Tile.a = kind, Tile.b = row tile (or diagonal block), Tile.c = step block index:
+//   0 F1  forward, rows of the pivot block below diagonal block c:   W_r -= P_rc W_c
+//   1 F2a forward, contribution rows:                                  C_I -= P21 W_J          (K = p)
+//   2 F2b forward, diagonal block b:                                   Y_b  = inv(L_bb) W_b
+//   3 B1  backward, pivot rows:                                        Y_J -= U12 Y[struct]    (K = u, gathered)
+//   4 B2  backward, rows above diagonal block c:                       Y_r -= PU_rc Y_c
+//   5 B3  backward, diagonal block b (in place):                       Y_b  = inv(U_bb) Y_b
+void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
+                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false);
+// (gather = true for launches made only of kind-3 tiles: V rows are gathered through struct_idx)
 // Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);

@@ -359,6 +359,120 @@ void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntil
 }
 
 // ---------------------------------------------------------------------------
+// Solve-ready form.  After a front is factorised, every SOLVE_NB diagonal block of
+// its pivot block is replaced by the explicit inverses inv(L_tt) (unit lower, stored
+// strictly below the diagonal) and inv(U_tt) (upper incl. diagonal), and every
+// off-diagonal block of block column t is scaled:  below the diagonal block
+// P = L[:,t] inv(L_tt) (this includes L21), above it PU = U[:,t] inv(U_tt).
+// The block substitutions then contain no triangular solves at all:
+//   forward  w_r -= P_rt w_t,  y_t = inv(L_tt) w_t      backward  t_r -= PU_rt t_t,  x_t = inv(U_tt) t_t
+// (inverse-based blocked TRSM as in MAGMA), i.e. only GEMM-shaped work for the matrix cores.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_block_inverse(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                                       cz* fact, int64_t fs) {
+    __shared__ cz T[SOLVE_NB][SOLVE_NB + 1];
+    __shared__ cz O[SOLVE_NB][SOLVE_NB + 1];
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int ld = f.p + f.u, k0 = t.a * SOLVE_NB;
+    int b = min(SOLVE_NB, f.p - k0);
+    cz* D = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;
+    for (int idx = threadIdx.x; idx < b * b; idx += 128) { int i = idx % b, j = idx / b; T[i][j] = D[i + (int64_t)j * ld]; }
+    __syncthreads();
+    int j = threadIdx.x & 63;
+    if (j < b) {
+        if (threadIdx.x < 64) {          // column j of inv(L): solve L x = e_j, x_i = 0 for i < j, x_j = 1
+            for (int i = j + 1; i < b; ++i) {
+                cz s = T[i][j];                                  // l_ij * x_j
+                for (int q = j + 1; q < i; ++q) cz_madd(s, T[i][q], O[q][j]);
+                O[i][j] = cz_make(-s.x, -s.y);
+            }
+        } else {                          // column j of inv(U): solve U x = e_j, x_i = 0 for i > j
+            cz dj = cz_inv(T[j][j]);
+            O[j][j] = dj;
+            for (int i = j - 1; i >= 0; --i) {
+                cz s = cz_make(0, 0);
+                for (int q = i + 1; q <= j; ++q) cz_madd(s, T[i][q], O[q][j]);
+                cz di = cz_inv(T[i][i]);
+                cz v = cz_mul(s, di);
+                O[i][j] = cz_make(-v.x, -v.y);
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < b * b; idx += 128) { int i = idx % b, jj = idx / b; D[i + (int64_t)jj * ld] = O[i][jj]; }
+}
+
+void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_block_inverse, dim3(ntiles, K), dim3(128), 0, st, S.fr, tiles, fact, fs);
+}
+
+// rows of block column t (tile.a) outside the diagonal block: 64-row tile (tile.b) of the rows above
+// (tile.c = 0: row <- row * inv(U_tt)) or below (tile.c = 1: row <- row * inv(L_tt)) the diagonal block.
+// In place: every wave reads its 16 rows completely before it writes them.  f64 MFMA, same
+// transposed-tile layout as k_gemm_nn.
+__global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                                      cz* fact, int64_t fs) {
+    __shared__ cz Bs[SOLVE_NB][65];      // Bs[k][n] = Inv[k][n]
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int ld = f.p + f.u, k0 = t.a * SOLVE_NB;
+    int b = min(SOLVE_NB, f.p - k0);
+    bool below = t.c != 0;
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    for (int idx = threadIdx.x; idx < SOLVE_NB * SOLVE_NB; idx += 256) {
+        int i = idx % SOLVE_NB, j = idx / SOLVE_NB;
+        cz v = cz_make(0, 0);
+        if (i < b && j < b) {
+            if (below) { if (i > j) v = Lp[(k0 + i) + (int64_t)(k0 + j) * ld]; else if (i == j) v = cz_make(1, 0); }
+            else if (i <= j) v = Lp[(k0 + i) + (int64_t)(k0 + j) * ld];
+        }
+        Bs[i][j] = v;
+    }
+    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    int rbase = below ? k0 + b + t.b * 64 : t.b * 64;
+    int rend = below ? ld : k0;
+    int mrow = rbase + wave * 16 + li;
+    bool mok = mrow < rend;
+    cz av[SOLVE_NB / 4];
+#pragma unroll
+    for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
+        int kk = ks * 4 + lk;
+        av[ks] = (mok && kk < b) ? Lp[mrow + (int64_t)(k0 + kk) * ld] : cz_make(0, 0);
+    }
+    __syncthreads();
+    d4 cr[4], ci[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+    for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
+        int kk = ks * 4 + lk;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            cz bv = Bs[kk][nt * 16 + li];
+            cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);     // D[n][m] = sum_k Inv[k][n] A[m][k]
+        }
+    }
+    if (mok) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int gn = nt * 16 + lk + 4 * r;
+                if (gn < b) Lp[mrow + (int64_t)(k0 + gn) * ld] = cz_make(cr[nt][r], ci[nt][r]);
+            }
+    }
+}
+
+void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_scale_panels, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, fact, fs);
+}
+
+// ---------------------------------------------------------------------------
 // pivot sequence -> row permutation of the pivot block (and its inverse), so the
 // solves gather the right-hand side once instead of replaying p swaps.
 // rowperm[c0+i] = original local row that ended in position i.

@@ -81,149 +81,153 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
                        crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n);
 }
 
-// Triangular solve with one SOLVE_NB x SOLVE_NB diagonal block (forward: unit lower,
-// backward: upper), all right-hand sides.  One workgroup per (front, node); lanes
-// are right-hand-side columns, the four waves split the rows of each elimination step.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_diag_solve(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
-                                                     const cz* __restrict__ fact, int64_t fs, cz* W, int64_t ws, int ldw) {
-    __shared__ cz Ts[SOLVE_NB * SOLVE_NB];
-    __shared__ cz Ws[SOLVE_NB][LDS_COLS];
-    __shared__ cz Dinv[SOLVE_NB];
-    FrontD f = fr[list[blockIdx.x]];
-    int k = blockIdx.y;
-    int p = f.p, ld = f.p + f.u;
-    int b = min(SOLVE_NB, p - k0);
-    const cz* Lp = fact + (int64_t)k * fs + f.lp;
-    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int idx = tid; idx < b * b; idx += 256) {
-        int i = idx % b, kk = idx / b;
-        Ts[i + kk * SOLVE_NB] = Lp[(k0 + i) + (int64_t)(k0 + kk) * ld];
-    }
-    __syncthreads();
-    if (MODE == 1 && tid < b) Dinv[tid] = cz_inv(Ts[tid + tid * SOLVE_NB]);
-    cz* Wb = W + (int64_t)k * ws + (int64_t)(f.c0 + k0) * ldw;
-    for (int cg = 0; cg < ldw; cg += LDS_COLS) {
-        int col = cg + lane;
-        bool cok = col < ldw;
-        __syncthreads();
-        for (int r = wave; r < b; r += 4) Ws[r][lane] = cok ? Wb[(int64_t)r * ldw + col] : cz_make(0, 0);
-        if (MODE == 0) {
-            for (int i = 0; i < b; ++i) {
-                __syncthreads();
-                cz wi = Ws[i][lane];
-                for (int r = i + 1 + wave; r < b; r += 4) { cz v = Ws[r][lane]; cz_msub(v, Ts[r + i * SOLVE_NB], wi); Ws[r][lane] = v; }
-            }
-            __syncthreads();
-            for (int r = wave; r < b; r += 4) if (cok) Wb[(int64_t)r * ldw + col] = Ws[r][lane];
-        } else {
-            for (int i = b - 1; i >= 0; --i) {
-                __syncthreads();
-                cz xi = cz_mul(Ws[i][lane], Dinv[i]);
-                if ((i & 3) == wave && cok) Wb[(int64_t)i * ldw + col] = xi;
-                for (int r = wave; r < i; r += 4) { cz v = Ws[r][lane]; cz_msub(v, Ts[r + i * SOLVE_NB], xi); Ws[r][lane] = v; }
-            }
-        }
-    }
-}
-
-void launch_diag_solve(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, int mode, const cz* fact,
-                       int64_t fs, cz* W, int64_t ws, int ldw, int K) {
-    if (nlist <= 0) return;
-    if (mode == 0) hipLaunchKernelGGL(k_diag_solve<0>, dim3(nlist, K), dim3(256), 0, st, S.fr, list, k0, fact, fs, W, ws, ldw);
-    else hipLaunchKernelGGL(k_diag_solve<1>, dim3(nlist, K), dim3(256), 0, st, S.fr, list, k0, fact, fs, W, ws, ldw);
-}
-
 // ---------------------------------------------------------------------------
-// THE hot kernel: out[rows] -= A[rows x Kd] * V[Kd x 64 cols], A a column-major
-// slab of a factor panel streamed once from HBM, V rows of the block vector
-// staged in LDS, f64 MFMA.  Workgroup = 64 output rows x 64 columns, wave w owns
-// rows [16w, 16w+16): its A fragment is one 16-byte load per lane per k-step
-// (16 consecutive rows = 256 B segments), V fragments are conflict-free
-// ds_read_b128, and D's layout (row = (l>>4)+4r, col = l&15) writes 16 consecutive
-// columns of one block-vector row per lane group.
-//   KIND 0  forward: rows below diagonal block k0 of the L panel; rows < p update W,
-//           rows >= p the front's contribution rows.      V = y block (contiguous)
-//   KIND 1  backward: rows above block k0 (U11 column block).   V = x block
-//   KIND 2  backward: W[J] -= U12 * x[struct]                    V = gathered rows
+// THE hot kernel.  Every step of the block substitution on the solve-ready factors
+// (kernels_factor.hip: k_block_inverse / k_scale_panels) is  out (-)= A * V  with
+// A a column-major slab of a factor panel, streamed from HBM exactly once per sweep,
+// and V up to 64 columns of block-vector rows staged in LDS.  Workgroup = 64 output
+// rows x 64 columns, wave w owns rows [16w, 16w+16): its A fragment is one 16-byte
+// load per lane per k-step (16 consecutive rows = 256 B segments) that goes straight
+// into v_mfma_f64_16x16x4_f64; V fragments are conflict-free ds_read_b128; D's layout
+// (row = (l>>4)+4r, col = l&15) writes 16 consecutive columns of one block-vector row
+// per lane group.  The K loop is software pipelined: the next chunk's A and V loads are
+// in flight while the current chunk runs on the matrix cores.
+// Tile kinds: see kernels.hpp (launch_apply).
 // ---------------------------------------------------------------------------
-constexpr int APPLY_KC = 64;
+constexpr int APPLY_KC = 32;
 
-template <int KIND>
-__global__ __launch_bounds__(256) void k_panel_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
-                                                      const int* __restrict__ struct_idx, const cz* __restrict__ fact,
-                                                      int64_t fs, cz* W, int64_t ws, int ldw, cz* crow, int64_t crs) {
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                               const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
+                                               cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs) {
     __shared__ cz Vs[APPLY_KC][LDS_COLS];
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y, cg = blockIdx.z * LDS_COLS;
     FrontD f = fr[t.f];
+    int kind = t.a;
     int p = f.p, u = f.u, ld = p + u;
     const cz* Lp = fact + (int64_t)k * fs + f.lp;
-    cz* Wk = W + (int64_t)k * ws;
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    int b = min(SOLVE_NB, p - k0);
+    // ---- tile geometry ------------------------------------------------------
     const cz* A;
     int64_t lda;
-    int rbase, rend, Kd;
-    if (KIND == 0) { rbase = k0 + b + t.a * 64; rend = ld; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; }
-    else if (KIND == 1) { rbase = t.a * 64; rend = k0; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; }
-    else { rbase = t.a * 64; rend = p; A = fact + (int64_t)k * fs + f.f12; lda = p; Kd = u; }
-    int arow = rbase + wave * 16 + li;      // row of A this lane feeds to the MFMA
-    bool aok = arow < rend;
-    d4 cr[4], ci[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+    int rbase, rend, Kd, k0 = 0, mask = 0;     // mask 1: unit lower (F2b), 2: upper incl. diagonal (B3)
+    const cz* Vsrc;                            // block vector the V rows come from
+    int vrow0 = 0;                             // first V row (contiguous kinds)
+    if (kind == 0) { k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = k0 + b + t.b * 64; rend = p; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = W; vrow0 = f.c0 + k0; }
+    else if (kind == 1) { rbase = p + t.b * 64; rend = ld; A = Lp; lda = ld; Kd = p; Vsrc = W; vrow0 = f.c0; }
+    else if (kind == 2) { k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = k0; rend = k0 + b; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = W; vrow0 = f.c0 + k0; mask = 1; }
+    else if (kind == 3) { rbase = t.b * 64; rend = p; A = fact + (int64_t)k * fs + f.f12; lda = p; Kd = u; Vsrc = Y; }
+    else if (kind == 4) { k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = t.b * 64; rend = k0; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = Y; vrow0 = f.c0 + k0; }
+    else { k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = k0; rend = k0 + b; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = Y; vrow0 = f.c0 + k0; mask = 2; }
+    const cz* Vk = Vsrc + (int64_t)k * ws;
     const int* sidx = struct_idx + f.sptr;
-    for (int kc = 0; kc < Kd; kc += APPLY_KC) {
-        __syncthreads();
-        for (int r = wave; r < APPLY_KC; r += 4) {
-            int gk = kc + r;
-            cz v = cz_make(0, 0);
-            if (gk < Kd && cg + lane < ldw) {
-                int64_t vrow = (KIND == 2) ? (int64_t)sidx[gk] : (int64_t)(f.c0 + k0 + gk);
-                v = Wk[vrow * ldw + cg + lane];
-            }
-            Vs[r][lane] = v;
+    int arow = rbase + wave * 16 + li;         // row of A this lane feeds to the MFMA
+    bool aok = arow < rend;
+    int adiag = arow - k0;                     // column (relative to k0) of this row's diagonal element
+    bool cok = cg + lane < ldw;
+
+    cz av[APPLY_KC / 4], an[APPLY_KC / 4], vn[APPLY_KC / 4];
+    // Loads are unconditional (addresses clamped into the slab) and masked with selects afterwards, so
+    // the compiler emits straight-line global_load_dwordx4 that all stay in flight together.
+    const int arow_c = min(arow, rend - 1);
+    const int vcol_c = min(cg + lane, ldw - 1);
+    const int lo_keep = (mask == 2) ? adiag : 0;                 // keep gk in [lo_keep, hi_keep)
+    const int hi_keep = (mask == 1) ? adiag : 0x7fffffff;
+    const int unit_at = (mask == 1 && aok) ? adiag : -1;
+    auto load_chunk = [&](int kc) {
+        int vidx[APPLY_KC / 4];
+#pragma unroll
+        for (int q = 0; q < APPLY_KC / 4; ++q) {
+            int gk = min(kc + wave + 4 * q, Kd - 1);
+            vidx[q] = GATHER ? sidx[gk] : vrow0 + gk;
         }
-        cz av[APPLY_KC / 4];
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
             int gk = kc + ks * 4 + lk;
-            av[ks] = (aok && gk < Kd) ? A[arow + (int64_t)gk * lda] : cz_make(0, 0);
+            cz v = A[arow_c + (int64_t)min(gk, Kd - 1) * lda];
+            bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
+            v.x = keep ? v.x : (gk == unit_at ? 1.0 : 0.0);
+            v.y = keep ? v.y : 0.0;
+            an[ks] = v;
         }
+#pragma unroll
+        for (int q = 0; q < APPLY_KC / 4; ++q) {
+            int gk = kc + wave + 4 * q;
+            cz v = Vk[(int64_t)vidx[q] * ldw + vcol_c];
+            bool keep = gk < Kd && cok;
+            v.x = keep ? v.x : 0.0;
+            v.y = keep ? v.y : 0.0;
+            vn[q] = v;
+        }
+    };
+    d4 cr[4], ci[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+    load_chunk(0);
+    for (int kc = 0; kc < Kd; kc += APPLY_KC) {
+        __syncthreads();                       // previous chunk's fragment reads are done
+#pragma unroll
+        for (int q = 0; q < APPLY_KC / 4; ++q) Vs[wave + 4 * q][lane] = vn[q];
+#pragma unroll
+        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = an[ks];
         __syncthreads();
+        if (kc + APPLY_KC < Kd) load_chunk(kc + APPLY_KC);
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
             int kk = ks * 4 + lk;
+            cz bv[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                cz bv = Vs[kk][nt * 16 + li];
-                cmfma2(cr[nt], ci[nt], av[ks].x, av[ks].y, bv.x, bv.y);
-            }
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = Vs[kk][nt * 16 + li];
+            double ar = av[ks].x, ai = av[ks].y, nai = -av[ks].y;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[nt].x, cr[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[nt].y, ci[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bv[nt].y, cr[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[nt].x, ci[nt], 0, 0, 0);
         }
     }
+    // ---- epilogue: all 16 read-modify-write loads are issued together (clamped addresses), then stored
+    bool overwrite = (kind == 2 || kind == 5);
+    cz* Ok = ((kind == 0) ? W : Y) + (int64_t)k * ws;
+    cz* dptr[4];
+    bool rok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int orow = rbase + wave * 16 + lk + 4 * r;
-        if (orow >= rend) continue;
-        cz* d;
-        if (KIND == 0 && orow >= p) d = crow + (int64_t)k * crs + (f.crow + orow - p) * (int64_t)ldw;
-        else d = Wk + (int64_t)(f.c0 + orow) * ldw;
+        rok[r] = orow < rend;
+        int oc = min(orow, rend - 1);
+        dptr[r] = (kind == 1) ? crow + (int64_t)k * crs + (f.crow + oc - p) * (int64_t)ldw
+                              : Ok + (int64_t)(f.c0 + oc) * ldw;
+    }
+    cz old[4][4];
+    if (!overwrite) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) old[r][nt] = dptr[r][min(cg + nt * 16 + li, ldw - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             int col = cg + nt * 16 + li;
-            if (col < ldw) { cz v = d[col]; v.x -= cr[nt][r]; v.y -= ci[nt][r]; d[col] = v; }
+            cz v;
+            if (overwrite) v = cz_make(cr[nt][r], ci[nt][r]);
+            else v = cz_make(old[r][nt].x - cr[nt][r], old[r][nt].y - ci[nt][r]);
+            if (rok[r] && col < ldw) dptr[r][col] = v;
         }
-    }
 }
 
-void launch_panel_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int kind, const cz* fact,
-                        int64_t fs, cz* W, int64_t ws, int ldw, cz* crow, int64_t crs, int K) {
+void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
+                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather) {
     if (ntiles <= 0) return;
     dim3 g(ntiles, K, (ldw + LDS_COLS - 1) / LDS_COLS);
-    if (kind == 0) hipLaunchKernelGGL(k_panel_apply<0>, g, dim3(256), 0, st, S.fr, tiles, k0, S.struct_idx, fact, fs, W, ws, ldw, crow, crs);
-    else if (kind == 1) hipLaunchKernelGGL(k_panel_apply<1>, g, dim3(256), 0, st, S.fr, tiles, k0, S.struct_idx, fact, fs, W, ws, ldw, crow, crs);
-    else hipLaunchKernelGGL(k_panel_apply<2>, g, dim3(256), 0, st, S.fr, tiles, k0, S.struct_idx, fact, fs, W, ws, ldw, crow, crs);
+    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs);
+    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs);
 }
 
 // Q0[old,:] = sum_k T_k[i,:] .* e0[k,:]  (and Q1 with e1), T_k = mode ? X[old,:] - W_k[i,:] : W_k[i,:].
