@@ -665,12 +665,10 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         SolveLevel& V = splan_[d];
         int par = d & 1;
         int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
-        if (S.crow_used[d] > 0)
-            HIPCHK(hipMemset2DAsync(d_crow_[par].p, (size_t)crs * sizeof(cz), 0, (size_t)S.crow_used[d] * ldw * sizeof(cz), Kloc, stream_));
         begin();
         launch_fwd_assemble(stream_, dsym_, tl + V.assemble.off, V.assemble.count, d_W_.p, ws, ldw, d_crow_[par].p, crs,
-                            d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc);
-        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 3.0 * rows * rowb * Kloc, 0); }
+                            d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc, 0);
+        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * Kloc, 0); }
         double lvl_rows = 0;
         for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
         for (Launch& L : V.f1) {
@@ -681,6 +679,10 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         begin();
         launch_apply(stream_, dsym_, tl + V.f2.off, V.f2.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
         if (V.f2.count) end(3, stat_bytes(V.f2, 2.0 * lvl_rows), stat_flops(V.f2));
+        begin();
+        launch_fwd_assemble(stream_, dsym_, tl + V.assemble.off, V.assemble.count, d_W_.p, ws, ldw, d_crow_[par].p, crs,
+                            d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc, 1);
+        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * Kloc, 0); }
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
         SolveLevel& V = splan_[d];

@@ -44,11 +44,11 @@ void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, 
                        const int* rowperm, int K);
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
-                         const int* rowinv, int K);
+                         const int* rowinv, int K, int phase);
 // Block substitution on the solve-ready factors: every tile is out (-)= A * V on the f64 matrix cores.
 // Tile.a = kind, Tile.b = row tile (or diagonal block), Tile.c = step block index:
 //   0 F1  forward, rows of the pivot block below diagonal block c:   W_r -= P_rc W_c
-//   1 F2a forward, contribution rows:                                  C_I -= P21 W_J          (K = p)
+//   1 F2a forward, contribution rows:                                  C_I  = -P21 W_J         (K = p)
 //   2 F2b forward, diagonal block b:                                   Y_b  = inv(L_bb) W_b
 //   3 B1  backward, pivot rows:                                        Y_J -= U12 Y[struct]    (K = u, gathered)
 //   4 B2  backward, rows above diagonal block c:                       Y_r -= PU_rc Y_c

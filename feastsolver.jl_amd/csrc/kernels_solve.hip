@@ -51,11 +51,14 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
                                                       const int* __restrict__ rel, const int* __restrict__ child_idx,
                                                       cz* W, int64_t ws, int ldw, cz* crp, int64_t crsp,
                                                       const cz* __restrict__ crc, int64_t crsc,
-                                                      const int* __restrict__ rowinv, int n) {
+                                                      const int* __restrict__ rowinv, int n, int phase) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
     int p = f.p, r0 = t.a * 64;
+    // phase 0: destinations inside the pivot block (before the front is solved);
+    // phase 1: destinations among the contribution rows (after F2a has written them)
+    if (phase == 0 ? (r0 >= p) : (r0 + 64 <= p)) return;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int ci = 0; ci < f.nchild; ++ci) {
         FrontD g = fr[child_idx[f.child_ptr + ci]];
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
         int ia = lower_bound_dev2(rc, g.u, r0), ib = lower_bound_dev2(rc, g.u, r0 + 64);
         for (int i = ia + wave; i < ib; i += 4) {
             int dst = rc[i];
+            if ((dst < p) != (phase == 0)) continue;
             const cz* s = crc + (int64_t)k * crsc + (g.crow + i) * (int64_t)ldw;
             cz* d;
             if (dst < p) d = W + (int64_t)k * ws + (int64_t)(f.c0 + rowinv[(int64_t)k * n + f.c0 + dst]) * ldw;
@@ -75,10 +79,10 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
 
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
-                         const int* rowinv, int K) {
+                         const int* rowinv, int K, int phase) {
     if (ntiles <= 0) return;
     hipLaunchKernelGGL(k_fwd_assemble, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, W, ws, ldw,
-                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n);
+                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase);
 }
 
 // ---------------------------------------------------------------------------
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
         }
     }
     // ---- epilogue: all 16 read-modify-write loads are issued together (clamped addresses), then stored
-    bool overwrite = (kind == 2 || kind == 5);
+    bool overwrite = (kind == 1 || kind == 2 || kind == 5);     // kind 1 writes C_I = -P21 W_J (children are added afterwards)
+    double sgn = (kind == 1) ? -1.0 : 1.0;
     cz* Ok = ((kind == 0) ? W : Y) + (int64_t)k * ws;
     cz* dptr[4];
     bool rok[4];
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
         for (int nt = 0; nt < 4; ++nt) {
             int col = cg + nt * 16 + li;
             cz v;
-            if (overwrite) v = cz_make(cr[nt][r], ci[nt][r]);
+            if (overwrite) v = cz_make(sgn * cr[nt][r], sgn * ci[nt][r]);
             else v = cz_make(old[r][nt].x - cr[nt][r], old[r][nt].y - ci[nt][r]);
             if (rok[r] && col < ldw) dptr[r][col] = v;
         }

@@ -1,0 +1,110 @@
+# FEASTHip.jl -- the binding a FEASTSolver.jl maintainer would add to call libfeasthip.so.
+# NOT executed in this repository's CI: there is no Julia runtime in the build container
+# or on the GPU box (SURVEY section 0).  It mirrors, call for call, the ctypes binding in
+# feastsolver.jl_amd/api.py, which IS tested.  Style follows the reference's only ccall,
+# src/lapack.jl:79-89 (caller-allocated outputs, status code checked after the call).
+module FEASTHip
+
+using LinearAlgebra, SparseArrays
+import LinearAlgebra: ldiv!
+
+const lib = get(ENV, "FEASTHIP_LIB", "libfeasthip.so")
+const F64, C128, I64 = Cint(0), Cint(1), Cint(2)
+
+struct FeastHipError <: Exception
+    code::Int
+    msg::String
+end
+
+function check(h::Ptr{Cvoid}, code::Integer)
+    code >= 0 && return code
+    msg = unsafe_string(ccall((:feasthip_last_error, lib), Cstring, (Ptr{Cvoid},), h))
+    code == -2 && error("Incorrect dimensions of A, must be square")     # src/feast.jl:13-14
+    code == -3 && error("Incorrect dimensions of X, must match A")       # src/feast.jl:15-16
+    throw(FeastHipError(code, msg))
+end
+
+# ---- fine-grained seam: factorizer / left_divider / finalize!  (src/utils.jl:173-179) ----
+mutable struct HipLU <: Factorization{ComplexF64}
+    handle::Ptr{Cvoid}
+    n::Int
+end
+
+"factorizer(C): drop-in for `lu` in feast!(...; factorizer=hiplu)   src/feast.jl:29-36"
+function hiplu(C::Matrix{ComplexF64}; device::Integer=0)
+    F = Ref{Ptr{Cvoid}}(C_NULL)
+    n = size(C, 1)
+    code = GC.@preserve C ccall((:feasthip_lu_dense, lib), Cint, (Cint, Ptr{ComplexF64}, Int64, Ref{Ptr{Cvoid}}),
+                               device, C, n, F)
+    code < 0 && check(C_NULL, code)
+    HipLU(F[], n)
+end
+
+function hiplu(C::SparseMatrixCSC{ComplexF64,Int64}; device::Integer=0)
+    F = Ref{Ptr{Cvoid}}(C_NULL)
+    n = size(C, 1)
+    code = GC.@preserve C ccall((:feasthip_lu_csc, lib), Cint,
+        (Cint, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{ComplexF64}, Cint, Cint, Ref{Ptr{Cvoid}}),
+        device, n, C.colptr, C.rowval, C.nzval, C128, 1, F)      # index_base = 1: fields passed zero-copy
+    code < 0 && check(C_NULL, code)
+    HipLU(F[], n)
+end
+
+"left_divider(Y, F, R): Y .= C \\ R, R untouched   src/feast.jl:62"
+function ldiv!(Y::Matrix{ComplexF64}, F::HipLU, R::Matrix{ComplexF64})
+    code = GC.@preserve Y R ccall((:feasthip_ldiv, lib), Cint,
+        (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Ptr{ComplexF64}, Int64, Cint),
+        F.handle, Y, stride(Y, 2), R, stride(R, 2), size(R, 2))
+    code < 0 && throw(FeastHipError(code, "feasthip_ldiv"))
+    Y
+end
+
+"finalize!(F): overload of src/utils.jl:173 releasing the device memory"
+function finalize!(F::HipLU)
+    F.handle == C_NULL || ccall((:feasthip_fact_free, lib), Cint, (Ptr{Cvoid},), F.handle)
+    F.handle = C_NULL
+    nothing
+end
+
+# ---- coarse seam: the whole loop of gen_feast! (src/feast.jl:89-156) in one call -------------
+eltag(::Type{Float64}) = F64
+eltag(::Type{ComplexF64}) = C128
+eltag(::Type{Int64}) = I64
+
+function gen_feast!(X::Matrix{ComplexF64}, A::SparseMatrixCSC{TA,Int64}, B::SparseMatrixCSC{TB,Int64}, contour;
+                    iter::Integer=10, debug=false, store=false, ϵ=1e-12, device::Integer=0) where {TA,TB}
+    N, m₀ = size(X)
+    size(A, 1) != size(A, 2) && error("Incorrect dimensions of A, must be square")
+    size(A, 1) != N && error("Incorrect dimensions of X, must match A")
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(C_NULL, ccall((:feasthip_create, lib), Cint, (Ref{Ptr{Cvoid}}, Cint), h, device))
+    Λ, res, inside, nit = zeros(ComplexF64, m₀), zeros(m₀), zeros(UInt8, m₀), Ref{Cint}(0)
+    try
+        colptr = [pointer(A.colptr), pointer(B.colptr)]
+        rowval = [pointer(A.rowval), pointer(B.rowval)]
+        nzval = [Ptr{Cvoid}(pointer(A.nzval)), Ptr{Cvoid}(pointer(B.nzval))]
+        types = Cint[eltag(TA), eltag(TB)]
+        scale = ComplexF64[1.0, -1.0]                     # T(z) = A - z B
+        GC.@preserve A B X begin
+            check(h[], ccall((:feasthip_set_csc, lib), Cint,
+                (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Cvoid}}, Ptr{Cint}, Ptr{ComplexF64}, Cint),
+                h[], N, 2, colptr, rowval, nzval, types, scale, 1))
+            nodes, weights = ComplexF64.(contour.nodes), ComplexF64.(contour.weights)
+            kind, region = contour isa CircularContour ? (Cint(0), Float64[real(contour.c), imag(contour.c), contour.r, 0.0]) :
+                (Cint(1), Float64[real(contour.bottom_left), imag(contour.bottom_left), real(contour.top_right), imag(contour.top_right)])
+            check(h[], ccall((:feasthip_set_contour, lib), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{ComplexF64}, Ptr{ComplexF64}, Cint, Ptr{Float64}),
+                h[], length(nodes), nodes, weights, kind, region))
+            check(h[], ccall((:feasthip_feast_run, lib), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Cint, Float64, Cint, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}),
+                h[], X, N, m₀, iter, ϵ, store ? 1 : 0, Λ, res, inside, nit))
+        end
+    finally
+        ccall((:feasthip_destroy, lib), Cint, (Ptr{Cvoid},), h[])
+    end
+    in_c = inside .!= 0
+    any(in_c) || println("no eigenvalues found in contour!")           # src/feast.jl:78
+    Λ[in_c], X[:, in_c], res[in_c]
+end
+
+end # module
