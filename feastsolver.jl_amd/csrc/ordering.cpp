@@ -1,0 +1,305 @@
+// Multilevel vertex-separator search used by the nested-dissection ordering
+// (symbolic.cpp).  Standard scheme: heavy-edge-matching coarsening, greedy graph
+// growing on the coarsest graph, Fiduccia-Mattheyses edge-cut refinement while
+// uncoarsening, then a minimum vertex cover (Hopcroft-Karp + Koenig) of the cut
+// edges turns the edge separator into a vertex separator.  Minimising the edge cut
+// finds the axis-aligned planes of stencil graphs that BFS level sets (graph-metric
+// balls) miss; the fill of the top fronts, and with it the factor bytes every FEAST
+// iteration streams, drops accordingly.
+#include "ordering.hpp"
+
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <queue>
+
+namespace feasthip {
+namespace {
+
+struct XorShift {
+    uint64_t s;
+    explicit XorShift(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+    uint32_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
+};
+
+// one coarsening step; returns false if the graph hardly shrinks
+bool coarsen(const WGraph& g, WGraph& c, std::vector<int>& cmap, XorShift& rng) {
+    int n = g.n;
+    std::vector<int> match(n, -1), order(n);
+    std::iota(order.begin(), order.end(), 0);
+    for (int i = n - 1; i > 0; --i) std::swap(order[i], order[rng.next() % (i + 1)]);
+    int nc = 0;
+    cmap.assign(n, -1);
+    for (int v : order) {
+        if (match[v] >= 0) continue;
+        int best = -1, bw = -1;
+        for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
+            int w = g.adj[t];
+            if (match[w] < 0 && w != v && g.ewgt[t] > bw) { bw = g.ewgt[t]; best = w; }
+        }
+        if (best >= 0) { match[v] = best; match[best] = v; cmap[v] = cmap[best] = nc++; }
+        else { match[v] = v; cmap[v] = nc++; }
+    }
+    if (nc > 0.92 * n) return false;
+    c.n = nc;
+    c.vwgt.assign(nc, 0);
+    c.xadj.assign(nc + 1, 0);
+    c.adj.clear(); c.ewgt.clear();
+    std::vector<int> pos(nc, -1);
+    std::vector<std::pair<int, int>> members(nc, {-1, -1});
+    for (int v = 0; v < n; ++v) { auto& m = members[cmap[v]]; if (m.first < 0) m.first = v; else m.second = v; }
+    for (int cv = 0; cv < nc; ++cv) {
+        int start = (int)c.adj.size();
+        for (int v : {members[cv].first, members[cv].second}) {
+            if (v < 0) continue;
+            c.vwgt[cv] += g.vwgt[v];
+            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
+                int cw = cmap[g.adj[t]];
+                if (cw == cv) continue;
+                if (pos[cw] >= start) c.ewgt[pos[cw]] += g.ewgt[t];
+                else { pos[cw] = (int)c.adj.size(); c.adj.push_back(cw); c.ewgt.push_back(g.ewgt[t]); }
+            }
+        }
+        c.xadj[cv + 1] = (int)c.adj.size();
+    }
+    return true;
+}
+
+struct FM {
+    const WGraph& g;
+    std::vector<int>& part;
+    std::vector<int> id, ed;
+    int64_t w[2] = {0, 0}, total = 0, cut = 0;
+    FM(const WGraph& g_, std::vector<int>& p) : g(g_), part(p), id(g_.n), ed(g_.n) { recompute(); }
+    void recompute() {
+        w[0] = w[1] = 0; cut = 0;
+        for (int v = 0; v < g.n; ++v) {
+            w[part[v]] += g.vwgt[v];
+            int i = 0, e = 0;
+            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) (part[g.adj[t]] == part[v] ? i : e) += g.ewgt[t];
+            id[v] = i; ed[v] = e; cut += e;
+        }
+        cut /= 2;
+        total = w[0] + w[1];
+    }
+    // one FM pass with hill climbing and rollback; returns true if the cut (or balance) improved
+    bool pass(double maxfrac) {
+        int n = g.n;
+        int64_t maxw = (int64_t)(maxfrac * total) + 1;
+        typedef std::pair<int, int> PI;   // (gain, vertex)
+        std::priority_queue<PI> heap[2];
+        std::vector<char> locked(n, 0);
+        for (int v = 0; v < n; ++v) if (ed[v] > 0 || g.xadj[v + 1] == g.xadj[v]) heap[part[v]].push({ed[v] - id[v], v});
+        std::vector<int> moved;
+        int64_t bestcut = cut, curcut = cut;
+        int64_t bestimb = std::max(w[0], w[1]);
+        int bestidx = 0;
+        int limit = std::max(60, std::min(n / 20, 800));
+        while (true) {
+            int from;
+            if (w[0] > maxw) from = 0;
+            else if (w[1] > maxw) from = 1;
+            else {
+                // pop stale entries to see the true tops
+                for (int s = 0; s < 2; ++s)
+                    while (!heap[s].empty()) {
+                        PI t = heap[s].top();
+                        if (locked[t.second] || part[t.second] != s || t.first != ed[t.second] - id[t.second]) heap[s].pop(); else break;
+                    }
+                if (heap[0].empty() && heap[1].empty()) break;
+                if (heap[0].empty()) from = 1;
+                else if (heap[1].empty()) from = 0;
+                else from = heap[0].top().first >= heap[1].top().first ? 0 : 1;
+            }
+            int v = -1;
+            while (!heap[from].empty()) {
+                PI t = heap[from].top(); heap[from].pop();
+                if (locked[t.second] || part[t.second] != from || t.first != ed[t.second] - id[t.second]) continue;
+                if (w[from ^ 1] + g.vwgt[t.second] > maxw && w[from] <= maxw) continue;   // would break balance
+                v = t.second; break;
+            }
+            if (v < 0) { if (w[from] > maxw) break; else { if (heap[from ^ 1].empty()) break; else { std::priority_queue<PI>().swap(heap[from]); continue; } } }
+            // move v
+            int gain = ed[v] - id[v];
+            curcut -= gain;
+            part[v] = from ^ 1;
+            w[from] -= g.vwgt[v]; w[from ^ 1] += g.vwgt[v];
+            std::swap(id[v], ed[v]);
+            locked[v] = 1;
+            moved.push_back(v);
+            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
+                int u = g.adj[t], e = g.ewgt[t];
+                if (part[u] == part[v]) { id[u] += e; ed[u] -= e; } else { id[u] -= e; ed[u] += e; }
+                if (!locked[u]) heap[part[u]].push({ed[u] - id[u], u});
+            }
+            int64_t imb = std::max(w[0], w[1]);
+            bool better;
+            if (bestimb > maxw) better = imb < bestimb;                       // still repairing the balance
+            else better = imb <= maxw && (curcut < bestcut || (curcut == bestcut && imb < bestimb));
+            if (better) { bestcut = curcut; bestimb = imb; bestidx = (int)moved.size(); }
+            else if ((int)moved.size() - bestidx > limit) break;
+        }
+        // rollback
+        for (int i = (int)moved.size() - 1; i >= bestidx; --i) {
+            int v = moved[i];
+            int from = part[v];
+            part[v] = from ^ 1;
+            w[from] -= g.vwgt[v]; w[from ^ 1] += g.vwgt[v];
+            std::swap(id[v], ed[v]);
+            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
+                int u = g.adj[t], e = g.ewgt[t];
+                if (part[u] == part[v]) { id[u] += e; ed[u] -= e; } else { id[u] -= e; ed[u] += e; }
+            }
+        }
+        cut = bestcut;
+        return bestidx > 0;
+    }
+};
+
+void initial_partition(const WGraph& g, std::vector<int>& part, XorShift& rng) {
+    int n = g.n;
+    int64_t total = 0;
+    for (int v = 0; v < n; ++v) total += g.vwgt[v];
+    std::vector<int> best;
+    int64_t bestcut = INT64_MAX;
+    std::vector<int> p(n), q;
+    for (int trial = 0; trial < 10; ++trial) {
+        std::fill(p.begin(), p.end(), 1);
+        int64_t w0 = 0;
+        std::vector<char> seen(n, 0);
+        q.clear();
+        int seed = rng.next() % n;
+        q.push_back(seed); seen[seed] = 1;
+        size_t head = 0;
+        while (w0 * 2 < total) {
+            if (head == q.size()) {   // disconnected: restart from an unseen vertex
+                int s = -1;
+                for (int v = 0; v < n; ++v) if (!seen[v]) { s = v; break; }
+                if (s < 0) break;
+                q.push_back(s); seen[s] = 1;
+            }
+            int v = q[head++];
+            p[v] = 0; w0 += g.vwgt[v];
+            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) { int u = g.adj[t]; if (!seen[u]) { seen[u] = 1; q.push_back(u); } }
+        }
+        FM fm(g, p);
+        for (int it = 0; it < 6; ++it) if (!fm.pass(0.55)) break;
+        if (std::max(fm.w[0], fm.w[1]) <= 0.6 * total + 1 && fm.cut < bestcut) { bestcut = fm.cut; best = p; }
+    }
+    if (best.empty()) best = p;
+    part = best;
+}
+
+// maximum bipartite matching (Hopcroft-Karp) on the cut edges, then Koenig's construction
+void vertex_cover(const WGraph& g, const std::vector<int>& part, std::vector<char>& in_sep) {
+    int n = g.n;
+    std::vector<int> lid(n, -1), rid(n, -1), L, R;
+    for (int v = 0; v < n; ++v) {
+        bool b = false;
+        for (int t = g.xadj[v]; t < g.xadj[v + 1] && !b; ++t) b = part[g.adj[t]] != part[v];
+        if (!b) continue;
+        if (part[v] == 0) { lid[v] = (int)L.size(); L.push_back(v); } else { rid[v] = (int)R.size(); R.push_back(v); }
+    }
+    int nl = (int)L.size(), nr = (int)R.size();
+    std::vector<int> ml(nl, -1), mr(nr, -1), dist(nl), it(nl);
+    auto bfs = [&]() {
+        std::queue<int> q;
+        bool found = false;
+        for (int i = 0; i < nl; ++i) { if (ml[i] < 0) { dist[i] = 0; q.push(i); } else dist[i] = -1; }
+        while (!q.empty()) {
+            int i = q.front(); q.pop();
+            int v = L[i];
+            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
+                int j = rid[g.adj[t]];
+                if (j < 0) continue;
+                int i2 = mr[j];
+                if (i2 < 0) found = true;
+                else if (dist[i2] < 0) { dist[i2] = dist[i] + 1; q.push(i2); }
+            }
+        }
+        return found;
+    };
+    // iterative DFS along the layered graph
+    auto dfs = [&](int root) {
+        std::vector<std::pair<int, int>> st;   // (left vertex, chosen right)
+        st.push_back({root, -1});
+        while (!st.empty()) {
+            int i = st.back().first;
+            int v = L[i];
+            bool advanced = false;
+            while (it[i] < g.xadj[v + 1] - g.xadj[v]) {
+                int t = g.xadj[v] + it[i]++;
+                int j = rid[g.adj[t]];
+                if (j < 0) continue;
+                int i2 = mr[j];
+                if (i2 < 0) {   // augment along the stack
+                    st.back().second = j;
+                    for (auto& pr : st) { ml[pr.first] = pr.second; mr[pr.second] = pr.first; }
+                    return true;
+                }
+                if (dist[i2] == dist[i] + 1) { st.back().second = j; st.push_back({i2, -1}); advanced = true; break; }
+            }
+            if (!advanced) { dist[i] = -1; st.pop_back(); }
+        }
+        return false;
+    };
+    while (bfs()) {
+        std::fill(it.begin(), it.end(), 0);
+        for (int i = 0; i < nl; ++i) if (ml[i] < 0) dfs(i);
+    }
+    // Koenig: Z = reachable from unmatched L by alternating paths; cover = (L \ Z) u (R n Z)
+    std::vector<char> zl(nl, 0), zr(nr, 0);
+    std::queue<int> q;
+    for (int i = 0; i < nl; ++i) if (ml[i] < 0) { zl[i] = 1; q.push(i); }
+    while (!q.empty()) {
+        int i = q.front(); q.pop();
+        int v = L[i];
+        for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
+            int j = rid[g.adj[t]];
+            if (j < 0 || zr[j] || ml[i] == j) continue;
+            zr[j] = 1;
+            int i2 = mr[j];
+            if (i2 >= 0 && !zl[i2]) { zl[i2] = 1; q.push(i2); }
+        }
+    }
+    in_sep.assign(n, 0);
+    for (int i = 0; i < nl; ++i) if (!zl[i]) in_sep[L[i]] = 1;
+    for (int j = 0; j < nr; ++j) if (zr[j]) in_sep[R[j]] = 1;
+}
+
+}  // namespace
+
+bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t seed) {
+    int n = g0.n;
+    if (n < 8) return false;
+    XorShift rng(seed + (uint64_t)n);
+    std::vector<WGraph> levels;
+    std::vector<std::vector<int>> cmaps;
+    levels.push_back(g0);
+    while (levels.back().n > 160 && levels.size() < 40) {
+        WGraph c;
+        std::vector<int> cmap;
+        if (!coarsen(levels.back(), c, cmap, rng)) break;
+        levels.push_back(std::move(c));
+        cmaps.push_back(std::move(cmap));
+    }
+    std::vector<int> part;
+    initial_partition(levels.back(), part, rng);
+    for (int l = (int)levels.size() - 1; l >= 0; --l) {
+        if (l < (int)levels.size() - 1) {
+            std::vector<int> fine(levels[l].n);
+            for (int v = 0; v < levels[l].n; ++v) fine[v] = part[cmaps[l][v]];
+            part.swap(fine);
+        }
+        FM fm(levels[l], part);
+        for (int it = 0; it < 8; ++it) if (!fm.pass(0.54)) break;
+    }
+    std::vector<char> in_sep;
+    vertex_cover(g0, part, in_sep);
+    label.resize(n);
+    int64_t c[3] = {0, 0, 0};
+    for (int v = 0; v < n; ++v) { label[v] = in_sep[v] ? 2 : part[v]; c[label[v]]++; }
+    return c[0] > 0 && c[1] > 0 && c[2] > 0;
+}
+
+}  // namespace feasthip

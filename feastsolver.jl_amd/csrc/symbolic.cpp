@@ -2,6 +2,7 @@
 // supernode detection, relaxed amalgamation and front/arena layout.
 // See symbolic.hpp for the role of this phase on the hot path.
 #include "symbolic.hpp"
+#include "ordering.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -66,7 +67,7 @@ Graph permute_graph(const Graph& g, const std::vector<int>& perm, const std::vec
 // ---------------------------------------------------------------------------
 class NestedDissection {
 public:
-    NestedDissection(const Graph& g, int leaf) : g_(g), leaf_(leaf), part_(g.n, -1), vis_(g.n, -1), lvl_(g.n, 0), order_(g.n, -1) {}
+    NestedDissection(const Graph& g, int leaf) : g_(g), leaf_(leaf), part_(g.n, -1), vis_(g.n, -1), lvl_(g.n, 0), order_(g.n, -1), loc_(g.n, -1) {}
 
     std::vector<int> run() {
         std::vector<int> all(g_.n);
@@ -80,7 +81,40 @@ private:
     int leaf_;
     std::vector<int> part_, vis_, lvl_, order_;
     int next_id_ = 0, stamp_ = 0;
-    std::vector<int> queue_, lptr_;
+    std::vector<int> queue_, lptr_, loc_;
+
+    struct Split {
+        std::vector<int> a, b, s;
+        double cost = 1e300;
+    };
+
+    // multilevel (edge-cut minimising) separator of the induced subgraph; replaces `best` if smaller
+    void multilevel_candidate(const std::vector<int>& verts, int id, Split& best) {
+        int m = (int)verts.size();
+        WGraph w;
+        w.n = m;
+        w.xadj.assign(m + 1, 0);
+        w.vwgt.assign(m, 1);
+        for (int i = 0; i < m; ++i) loc_[verts[i]] = i;
+        for (int i = 0; i < m; ++i) {
+            int v = verts[i];
+            for (int64_t t = g_.xadj[v]; t < g_.xadj[v + 1]; ++t) if (part_[g_.adj[t]] == id) w.adj.push_back(loc_[g_.adj[t]]);
+            w.xadj[i + 1] = (int)w.adj.size();
+        }
+        w.ewgt.assign(w.adj.size(), 1);
+        std::vector<int> label;
+        int trials = m >= 20000 ? 3 : m >= 2000 ? 2 : 1;     // the top separators dominate the fill: try harder there
+        for (int tr = 0; tr < trials; ++tr) {
+            if (!multilevel_separator(w, label, (uint64_t)id * 7919u + 17u + 104729u * tr)) continue;
+            Split sp;
+            for (int i = 0; i < m; ++i) (label[i] == 0 ? sp.a : label[i] == 1 ? sp.b : sp.s).push_back(verts[i]);
+            if (sp.a.empty() || sp.b.empty() || sp.s.empty()) continue;
+            double bal = (double)std::max(sp.a.size(), sp.b.size()) / (double)(m - (int)sp.s.size());
+            if (bal > 0.68) continue;
+            sp.cost = (double)sp.s.size();
+            if (sp.cost < best.cost) best = std::move(sp);
+        }
+    }
 
     // BFS restricted to part_ == id.  Fills queue_ (visit order) and lptr_ (level offsets).
     void bfs(int root, int id) {
@@ -108,11 +142,6 @@ private:
         }
         lptr_.push_back((int)queue_.size());
     }
-
-    struct Split {
-        std::vector<int> a, b, s;
-        double cost = 1e300;
-    };
 
     // Evaluate the best level-set separator of the current BFS structure.
     void candidate(int m, Split& best) {
@@ -193,6 +222,7 @@ private:
             if (h2 <= height) break;
             height = h2;
         }
+        if (m >= 64) multilevel_candidate(verts, id, best);
         if (best.s.empty() || best.a.empty() || best.b.empty()) { emit(verts, lo); return; }
         verts.clear(); verts.shrink_to_fit();
         int na = (int)best.a.size(), nb = (int)best.b.size();
