@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/feasthip.h"
@@ -323,6 +324,11 @@ int Engine::analyze() {
             for (auto& T : terms_) for (int64_t e = T.colptr[j]; e < T.colptr[j + 1]; ++e) ri[o++] = T.rowval[e];
         }
         SymbolicOptions opt;
+        if (const char* v = getenv("FEASTHIP_RELAX_SMALL")) opt.relax_small = atoi(v);      // tuning knobs
+        if (const char* v = getenv("FEASTHIP_RELAX_MID")) opt.relax_mid = atoi(v);
+        if (const char* v = getenv("FEASTHIP_ZMID")) opt.zmid = atof(v);
+        if (const char* v = getenv("FEASTHIP_ZBIG")) opt.zbig = atof(v);
+        if (const char* v = getenv("FEASTHIP_LEAF")) opt.leaf_size = atoi(v);
         std::string e = analyze_pattern(n, cp.data(), ri.data(), opt, S);
         if (!e.empty()) return fail(FEASTHIP_EARG, "analyze: " + e);
         // arena destinations + CSR copies for SpMM

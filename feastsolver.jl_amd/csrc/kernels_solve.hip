@@ -100,6 +100,129 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // ---------------------------------------------------------------------------
 constexpr int APPLY_KC = 32;
 
+struct ApplyGeom {
+    const cz* A;         // factor slab, column-major
+    int64_t lda;
+    int rbase, rend, Kd, k0, mask;          // mask 1: unit lower (F2b), 2: upper incl. diagonal (B3)
+    const cz* Vk;        // block vector the V rows come from (this node)
+    const int* sidx;     // struct_idx of the front (gather kinds)
+    int vrow0;           // first V row (contiguous kinds)
+    cz* out;             // output rows base: row r of the tile is out + r * ldw   (r relative to orow0)
+    int orow_shift;      // output row index = orow + orow_shift
+    int mode;            // 0: out -= acc, 1: out = acc, 2: out = -acc
+};
+
+// NS = number of 16-row slabs of this tile that carry data (1, 2 or 4).  The 4 waves are arranged
+// as NS slabs x 4/NS column parts, so a tile with <= 16 (<= 32) rows still keeps every matrix core
+// busy with useful columns instead of multiplying zero rows.
+template <bool GATHER, int NS>
+__device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[LDS_COLS], int cg, int ldw) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
+    const bool wave_active = g.rbase + slab * 16 < g.rend;          // wave-uniform
+    const int arow = g.rbase + slab * 16 + li;
+    const bool aok = arow < g.rend;
+    const int adiag = arow - g.k0;
+    const bool cok = cg + lane < ldw;
+    const int Kd = g.Kd;
+    // Loads are unconditional (addresses clamped into the slab) and masked with selects afterwards, so
+    // the compiler emits straight-line global_load_dwordx4 that all stay in flight together.
+    const int arow_c = min(arow, g.rend - 1);
+    const int vcol_c = min(cg + lane, ldw - 1);
+    const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
+    const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
+    const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
+    cz av[APPLY_KC / 4], an[APPLY_KC / 4], vn[APPLY_KC / 4];
+    auto load_chunk = [&](int kc) {
+        int vidx[APPLY_KC / 4];
+#pragma unroll
+        for (int q = 0; q < APPLY_KC / 4; ++q) {
+            int gk = min(kc + wave + 4 * q, Kd - 1);
+            vidx[q] = GATHER ? g.sidx[gk] : g.vrow0 + gk;
+        }
+#pragma unroll
+        for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
+            int gk = kc + ks * 4 + lk;
+            cz v = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];
+            bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
+            v.x = keep ? v.x : (gk == unit_at ? 1.0 : 0.0);
+            v.y = keep ? v.y : 0.0;
+            an[ks] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < APPLY_KC / 4; ++q) {
+            int gk = kc + wave + 4 * q;
+            cz v = g.Vk[(int64_t)vidx[q] * ldw + vcol_c];
+            bool keep = gk < Kd && cok;
+            v.x = keep ? v.x : 0.0;
+            v.y = keep ? v.y : 0.0;
+            vn[q] = v;
+        }
+    };
+    d4 cr[NS], ci[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { cr[q] = (d4){0, 0, 0, 0}; ci[q] = (d4){0, 0, 0, 0}; }
+    load_chunk(0);
+    for (int kc = 0; kc < Kd; kc += APPLY_KC) {
+        __syncthreads();                       // previous chunk's fragment reads are done
+#pragma unroll
+        for (int q = 0; q < APPLY_KC / 4; ++q) Vs[wave + 4 * q][lane] = vn[q];
+#pragma unroll
+        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = an[ks];
+        __syncthreads();
+        if (kc + APPLY_KC < Kd) load_chunk(kc + APPLY_KC);
+        const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;           // k-steps that carry data (uniform)
+        if (wave_active) {
+#pragma unroll
+            for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
+                if (ks < nks) {
+                    const int kk = ks * 4 + lk;
+                    cz bv[NS];
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) bv[q] = Vs[kk][(ct0 + q) * 16 + li];
+                    const double ar = av[ks].x, ai = av[ks].y, nai = -av[ks].y;
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q].x, cr[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q].y, ci[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bv[q].y, cr[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[q].x, ci[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: all read-modify-write loads are issued together (clamped addresses), then stored
+    if (!wave_active) return;
+    cz* dptr[4];
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int orow = g.rbase + slab * 16 + lk + 4 * r;
+        rok[r] = orow < g.rend;
+        dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
+    }
+    cz old[4][NS];
+    if (g.mode == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][min(cg + (ct0 + q) * 16 + li, ldw - 1)];
+    }
+    const double sgn = (g.mode == 2) ? -1.0 : 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            int col = cg + (ct0 + q) * 16 + li;
+            cz v;
+            if (g.mode != 0) v = cz_make(sgn * cr[q][r], sgn * ci[q][r]);
+            else v = cz_make(old[r][q].x - cr[q][r], old[r][q].y - ci[q][r]);
+            if (rok[r] && col < ldw) dptr[r][col] = v;
+        }
+}
+
 template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
@@ -111,120 +234,22 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     int kind = t.a;
     int p = f.p, u = f.u, ld = p + u;
     const cz* Lp = fact + (int64_t)k * fs + f.lp;
-    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    // ---- tile geometry ------------------------------------------------------
-    const cz* A;
-    int64_t lda;
-    int rbase, rend, Kd, k0 = 0, mask = 0;     // mask 1: unit lower (F2b), 2: upper incl. diagonal (B3)
-    const cz* Vsrc;                            // block vector the V rows come from
-    int vrow0 = 0;                             // first V row (contiguous kinds)
-    if (kind == 0) { k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = k0 + b + t.b * 64; rend = p; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = W; vrow0 = f.c0 + k0; }
-    else if (kind == 1) { rbase = p + t.b * 64; rend = ld; A = Lp; lda = ld; Kd = p; Vsrc = W; vrow0 = f.c0; }
-    else if (kind == 2) { k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = k0; rend = k0 + b; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = W; vrow0 = f.c0 + k0; mask = 1; }
-    else if (kind == 3) { rbase = t.b * 64; rend = p; A = fact + (int64_t)k * fs + f.f12; lda = p; Kd = u; Vsrc = Y; }
-    else if (kind == 4) { k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = t.b * 64; rend = k0; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = Y; vrow0 = f.c0 + k0; }
-    else { k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - k0); rbase = k0; rend = k0 + b; A = Lp + (int64_t)k0 * ld; lda = ld; Kd = b; Vsrc = Y; vrow0 = f.c0 + k0; mask = 2; }
-    const cz* Vk = Vsrc + (int64_t)k * ws;
-    const int* sidx = struct_idx + f.sptr;
-    int arow = rbase + wave * 16 + li;         // row of A this lane feeds to the MFMA
-    bool aok = arow < rend;
-    int adiag = arow - k0;                     // column (relative to k0) of this row's diagonal element
-    bool cok = cg + lane < ldw;
-
-    cz av[APPLY_KC / 4], an[APPLY_KC / 4], vn[APPLY_KC / 4];
-    // Loads are unconditional (addresses clamped into the slab) and masked with selects afterwards, so
-    // the compiler emits straight-line global_load_dwordx4 that all stay in flight together.
-    const int arow_c = min(arow, rend - 1);
-    const int vcol_c = min(cg + lane, ldw - 1);
-    const int lo_keep = (mask == 2) ? adiag : 0;                 // keep gk in [lo_keep, hi_keep)
-    const int hi_keep = (mask == 1) ? adiag : 0x7fffffff;
-    const int unit_at = (mask == 1 && aok) ? adiag : -1;
-    auto load_chunk = [&](int kc) {
-        int vidx[APPLY_KC / 4];
-#pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) {
-            int gk = min(kc + wave + 4 * q, Kd - 1);
-            vidx[q] = GATHER ? sidx[gk] : vrow0 + gk;
-        }
-#pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
-            int gk = kc + ks * 4 + lk;
-            cz v = A[arow_c + (int64_t)min(gk, Kd - 1) * lda];
-            bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
-            v.x = keep ? v.x : (gk == unit_at ? 1.0 : 0.0);
-            v.y = keep ? v.y : 0.0;
-            an[ks] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) {
-            int gk = kc + wave + 4 * q;
-            cz v = Vk[(int64_t)vidx[q] * ldw + vcol_c];
-            bool keep = gk < Kd && cok;
-            v.x = keep ? v.x : 0.0;
-            v.y = keep ? v.y : 0.0;
-            vn[q] = v;
-        }
-    };
-    d4 cr[4], ci[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
-    load_chunk(0);
-    for (int kc = 0; kc < Kd; kc += APPLY_KC) {
-        __syncthreads();                       // previous chunk's fragment reads are done
-#pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) Vs[wave + 4 * q][lane] = vn[q];
-#pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = an[ks];
-        __syncthreads();
-        if (kc + APPLY_KC < Kd) load_chunk(kc + APPLY_KC);
-#pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
-            int kk = ks * 4 + lk;
-            cz bv[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bv[nt] = Vs[kk][nt * 16 + li];
-            double ar = av[ks].x, ai = av[ks].y, nai = -av[ks].y;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[nt].x, cr[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[nt].y, ci[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bv[nt].y, cr[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[nt].x, ci[nt], 0, 0, 0);
-        }
-    }
-    // ---- epilogue: all 16 read-modify-write loads are issued together (clamped addresses), then stored
-    bool overwrite = (kind == 1 || kind == 2 || kind == 5);     // kind 1 writes C_I = -P21 W_J (children are added afterwards)
-    double sgn = (kind == 1) ? -1.0 : 1.0;
-    cz* Ok = ((kind == 0) ? W : Y) + (int64_t)k * ws;
-    cz* dptr[4];
-    bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int orow = rbase + wave * 16 + lk + 4 * r;
-        rok[r] = orow < rend;
-        int oc = min(orow, rend - 1);
-        dptr[r] = (kind == 1) ? crow + (int64_t)k * crs + (f.crow + oc - p) * (int64_t)ldw
-                              : Ok + (int64_t)(f.c0 + oc) * ldw;
-    }
-    cz old[4][4];
-    if (!overwrite) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) old[r][nt] = dptr[r][min(cg + nt * 16 + li, ldw - 1)];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            int col = cg + nt * 16 + li;
-            cz v;
-            if (overwrite) v = cz_make(sgn * cr[nt][r], sgn * ci[nt][r]);
-            else v = cz_make(old[r][nt].x - cr[nt][r], old[r][nt].y - ci[nt][r]);
-            if (rok[r] && col < ldw) dptr[r][col] = v;
-        }
+    cz* Wk = W + (int64_t)k * ws;
+    cz* Yk = Y + (int64_t)k * ws;
+    ApplyGeom g;
+    g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0;
+    g.sidx = struct_idx + f.sptr;
+    g.out = Yk; g.orow_shift = f.c0;
+    if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * 64; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
+    else if (kind == 1) { g.rbase = p + t.b * 64; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2; }
+    else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
+    else if (kind == 3) { g.rbase = t.b * 64; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Yk; }
+    else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * 64; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
+    else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; }
+    int trows = min(64, g.rend - g.rbase);
+    if (trows <= 16) apply_body<GATHER, 1>(g, Vs, cg, ldw);
+    else if (trows <= 32) apply_body<GATHER, 2>(g, Vs, cg, ldw);
+    else apply_body<GATHER, 4>(g, Vs, cg, ldw);
 }
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
