@@ -61,6 +61,7 @@ PROTOTYPES = {
     "feasthip_fact_free": (I, [VP]),
     "feasthip_get_stats": (I, [VP, C.POINTER(Stats)]),
     "feasthip_profile_solve": (I, [VP, VP]),
+    "feasthip_profile_detail": (I, [VP, VP, I]),
     "feasthip_symbolic_probe": (I, [I64, VP, VP, I, I, VP, VP, VP, VP]),
     "feasthip_symbolic_contains": (I, [I64, VP, VP, I, I, VP, VP, I64]),
     "feasthip_small_eig": (I, [I, VP, VP, VP, VP]),

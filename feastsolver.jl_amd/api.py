@@ -239,6 +239,9 @@ class FeastHandle:
     def profile_solve(self):
         out = np.zeros((8, 4))
         self._ck(self.lib.feasthip_profile_solve(self.h, _vp(out)))
+        det = np.zeros((4096, 5))
+        nd = self.lib.feasthip_profile_detail(self.h, _vp(det), 4096)
+        self.last_profile_detail = det[:max(0, min(nd, 4096))]
         names = ["gather_rhs", "fwd_assemble", "diag_solve", "panel_apply", "accumulate"]
         return {nm: dict(ms=out[i, 0], bytes=out[i, 1], flops=out[i, 2], launches=int(out[i, 3])) for i, nm in enumerate(names)}
 

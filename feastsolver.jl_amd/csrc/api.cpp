@@ -134,6 +134,14 @@ int feasthip_profile_solve(feasthip_handle_t h, double* out /* 8 rows x 4: ms, b
     ENDGUARD(h)
 }
 
+int feasthip_profile_detail(feasthip_handle_t h, double* out, int cap) {
+    GUARD(h)
+    int n = (int)(h->e->prof_detail.size() / 5);
+    if (out) for (int i = 0; i < n && i < cap; ++i) for (int j = 0; j < 5; ++j) out[5 * i + j] = h->e->prof_detail[5 * i + j];
+    return n;
+    ENDGUARD(h)
+}
+
 // ---- fine-grained seam -----------------------------------------------------
 static int make_fact(Engine* e, feasthip_fact_t* F) {
     double node[2] = {0.0, 0.0}, w[2] = {1.0, 0.0}, reg[4] = {0, 0, 1, 0};
@@ -250,9 +258,17 @@ int feasthip_small_eig(int m, const double* A, const double* B, double* lambda, 
     try {
         std::vector<zc> a((size_t)m * m), b, lam(m), v((size_t)m * m);
         std::memcpy(a.data(), A, sizeof(zc) * (size_t)m * m);
-        int info;
-        if (B) { b.resize((size_t)m * m); std::memcpy(b.data(), B, sizeof(zc) * (size_t)m * m); info = eig_generalized(m, a.data(), b.data(), lam.data(), v.data()); }
-        else info = eig_general(m, a.data(), lam.data(), v.data());
+        int info = 1;
+        if (B) { b.resize((size_t)m * m); std::memcpy(b.data(), B, sizeof(zc) * (size_t)m * m); }
+        bool herm = hermitian_defect(m, a.data()) <= 1e-13 && (!B || hermitian_defect(m, b.data()) <= 1e-13);
+        if (herm) {   // same dispatch as Engine::rr_step
+            std::vector<zc> a2(a), b2(b);
+            info = eig_hermitian(m, a2.data(), B ? b2.data() : nullptr, lam.data(), v.data());
+        }
+        if (info) {
+            if (B) info = eig_generalized(m, a.data(), b.data(), lam.data(), v.data());
+            else info = eig_general(m, a.data(), lam.data(), v.data());
+        }
         std::memcpy(lambda, lam.data(), sizeof(zc) * m);
         std::memcpy(V, v.data(), sizeof(zc) * (size_t)m * m);
         return info ? FEASTHIP_ENUM : 0;

@@ -246,34 +246,43 @@ bool Engine::build_plans() {
             for (int a = 0; a < cdiv(ld - k0 - b, 64); ++a) tiles.push_back({s, t, a, 1});
         }
         F.scale.count = (int)(tiles.size() - F.scale.off);
-        // block substitution launches (kernels.hpp: launch_apply)
+        // block substitution launches (kernels.hpp: launch_apply).  Tile height (64/32/16 rows) is chosen per
+        // launch so that even the top of the tree (few fronts, long K) spreads over the whole chip.
+        auto pick_slabs = [&](auto&& rows_of) {     // rows_of(callback(rows)) enumerates the row extents of the launch
+            int64_t wgs = 0;
+            rows_of([&](int rows) { wgs += cdiv(rows, 64); });
+            return (wgs * Kloc >= 1024) ? 4 : 2;
+        };
         double rowb = 1.0;   // bytes are scaled by 16*ldw at run time: count block-vector ROWS here
         (void)rowb;
         int nsteps = cdiv(pmax, SOLVE_NB);
         for (int c = 0; c + 1 < nsteps; ++c) {
             Launch L;
             L.off = (int64_t)tiles.size();
+            int sl = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.p(s) > c * SOLVE_NB + SOLVE_NB) cb(S.p(s) - c * SOLVE_NB - SOLVE_NB); });
             for (int s : lv) {
                 int p = S.p(s), k0 = c * SOLVE_NB;
                 if (p <= k0 + SOLVE_NB) continue;
                 int rows = p - k0 - SOLVE_NB;
-                for (int a = 0; a < cdiv(rows, 64); ++a) tiles.push_back({s, 0, a, c});
+                for (int a = 0; a < cdiv(rows, 16 * sl); ++a) tiles.push_back({s, 0 | (sl << 8), a, c});
                 L.bytes += (double)rows * SOLVE_NB * 16.0; L.flops += (double)rows * SOLVE_NB;
             }
             L.count = (int)(tiles.size() - L.off);
             V.f1.push_back(L);
         }
         V.f2.off = (int64_t)tiles.size();
+        int sl2 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.u(s)); });
         for (int s : lv) {
             int p = S.p(s), u = S.u(s);
-            for (int a = 0; a < cdiv(u, 64); ++a) tiles.push_back({s, 1, a, 0});
+            for (int a = 0; a < cdiv(u, 16 * sl2); ++a) tiles.push_back({s, 1 | (sl2 << 8), a, 0});
             for (int t = 0; t < cdiv(p, SOLVE_NB); ++t) tiles.push_back({s, 2, t, 0});
             V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, SOLVE_NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, SOLVE_NB);
         }
         V.f2.count = (int)(tiles.size() - V.f2.off);
         V.b1.off = (int64_t)tiles.size();
+        int sl3 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
         for (int s : lv) if (S.u(s) > 0) {
-            for (int a = 0; a < cdiv(S.p(s), 64); ++a) tiles.push_back({s, 3, a, 0});
+            for (int a = 0; a < cdiv(S.p(s), 16 * sl3); ++a) tiles.push_back({s, 3 | (sl3 << 8), a, 0});
             V.b1.bytes += (double)S.u(s) * S.p(s) * 16.0; V.b1.flops += (double)S.u(s) * S.p(s);
         }
         V.b1.count = (int)(tiles.size() - V.b1.off);
@@ -281,11 +290,12 @@ bool Engine::build_plans() {
         for (int c = 1; c < nsteps; ++c) {
             Launch& L = V.b2[c];
             L.off = (int64_t)tiles.size();
+            int sl = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.p(s) > c * SOLVE_NB) cb(c * SOLVE_NB); });
             for (int s : lv) {
                 int p = S.p(s), k0 = c * SOLVE_NB;
                 if (p <= k0) continue;
                 int b = std::min(SOLVE_NB, p - k0);
-                for (int a = 0; a < cdiv(k0, 64); ++a) tiles.push_back({s, 4, a, c});
+                for (int a = 0; a < cdiv(k0, 16 * sl); ++a) tiles.push_back({s, 4 | (sl << 8), a, c});
                 L.bytes += (double)k0 * b * 16.0; L.flops += (double)k0 * b;
             }
             L.count = (int)(tiles.size() - L.off);
@@ -609,8 +619,16 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     }
     HIPCHK(hipMemcpyAsync(Aq.data(), dA, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
-    int info = b_is_identity ? eig_general(m, Aq.data(), lam.data(), Xq.data())     // :45
-                             : eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data());   // :122
+    // Julia's eigen! takes the Hermitian(-definite) LAPACK path for exactly Hermitian input; here the projected
+    // matrices are Hermitian up to rounding whenever A, B are, and the same path is taken below 1e-13.
+    int info = 1;
+    bool herm = hermitian_defect(m, Aq.data()) <= 1e-13 && (b_is_identity || hermitian_defect(m, Bq.data()) <= 1e-13);
+    if (herm) {
+        std::vector<zc> a2(Aq), b2(Bq);
+        info = eig_hermitian(m, a2.data(), b_is_identity ? nullptr : b2.data(), lam.data(), Xq.data());
+    }
+    if (info) info = b_is_identity ? eig_general(m, Aq.data(), lam.data(), Xq.data())     // :45
+                                   : eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data());   // :122
     if (info) return fail(FEASTHIP_ENUM, "rr_step: reduced eigenproblem failed to converge");
     HIPCHK(hipMemcpyAsync(dM, Xq.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
     launch_ts_gemm(stream_, n, m, ldw, Qp(), dM, d_X_.p);              // X = Q Xq         :48
@@ -651,6 +669,8 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
     const int* ls = d_lists_.p;
     hipEvent_t pa = nullptr, pb = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&pa)); HIPCHK(hipEventCreate(&pb)); }
+    if (prof) prof_detail.clear();
+    int cur_tiles = 0;
     auto begin = [&]() { if (prof) (void)hipEventRecord(pa, stream_); };
     auto end = [&](int row, double bytes, double flops) {
         if (!prof) return;
@@ -659,6 +679,7 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, pa, pb);
         prof[row].ms += ms; prof[row].bytes += bytes; prof[row].flops += flops; prof[row].launches++;
+        prof_detail.insert(prof_detail.end(), {(double)row, (double)ms, bytes, flops, (double)cur_tiles});
     };
     double rowb = (double)ldw * 16.0;
     begin();
@@ -680,11 +701,11 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         for (Launch& L : V.f1) {
             begin();
             launch_apply(stream_, dsym_, tl + L.off, L.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
-            if (L.count) end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L));
+            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
         }
         begin();
         launch_apply(stream_, dsym_, tl + V.f2.off, V.f2.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
-        if (V.f2.count) end(3, stat_bytes(V.f2, 2.0 * lvl_rows), stat_flops(V.f2));
+        if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows), stat_flops(V.f2)); }
         begin();
         launch_fwd_assemble(stream_, dsym_, tl + V.assemble.off, V.assemble.count, d_W_.p, ws, ldw, d_crow_[par].p, crs,
                             d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc, 1);
@@ -696,16 +717,16 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
         launch_apply(stream_, dsym_, tl + V.b1.off, V.b1.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc, true);
-        if (V.b1.count) end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1));
+        if (V.b1.count) { cur_tiles = -V.b1.count; end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1)); }
         for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
             Launch& L = V.b2[c];
             begin();
             launch_apply(stream_, dsym_, tl + L.off, L.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc);
-            if (L.count) end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L));
+            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
         }
         begin();
         launch_apply(stream_, dsym_, tl + V.b3.off, V.b3.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc);
-        if (V.b3.count) end(3, stat_bytes(V.b3, 2.0 * lvl_p), stat_flops(V.b3));
+        if (V.b3.count) { cur_tiles = V.b3.count; end(3, stat_bytes(V.b3, 2.0 * lvl_p), stat_flops(V.b3)); }
     }
     if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }
     HIPCHK(hipGetLastError());

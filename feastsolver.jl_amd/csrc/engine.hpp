@@ -89,6 +89,7 @@ public:
     // fine-grained seam: Y = T^-1 R for the single factorised matrix of this engine (node 0)
     int ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
     int profile_solve(ProfileRow* rows /*[8]*/);
+    std::vector<double> prof_detail;   // per launch: class, ms, bytes, flops, tiles (filled by profile_solve)
 
     // stats
     double analyze_seconds = 0, factor_ms = 0, solve_ms = 0, rr_ms = 0;

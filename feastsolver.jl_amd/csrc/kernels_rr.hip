@@ -93,7 +93,7 @@ void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, c
 // workgroup reduces GRAM_ROWS rows; wave jobs are (16-row i tile) x (64-col j group),
 // operands are read straight from the row-major blocks (16 consecutive columns of a
 // row per lane group = 256 B segments).  Stage 2 sums the partials in a fixed order.
-constexpr int GRAM_ROWS = 1024;
+constexpr int GRAM_ROWS = 256;
 
 size_t gram_scratch_elems(int n, int m) {
     size_t chunks = ((size_t)n + GRAM_ROWS - 1) / GRAM_ROWS;
@@ -192,7 +192,7 @@ void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz
 }
 
 // column sums of |V|^2, two deterministic stages
-constexpr int CN_ROWS = 512;
+constexpr int CN_ROWS = 1024;
 size_t colnorm_scratch_elems(int n, int ldw) { return ((size_t)n + CN_ROWS - 1) / CN_ROWS * (size_t)ldw; }
 
 __global__ __launch_bounds__(256) void k_colnorm_partial(int n, int ldw, const cz* __restrict__ V, double* scratch) {

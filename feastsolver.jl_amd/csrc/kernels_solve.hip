@@ -143,21 +143,24 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[LDS_COLS
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
             int gk = kc + ks * 4 + lk;
-            cz v = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];
-            bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
-            v.x = keep ? v.x : (gk == unit_at ? 1.0 : 0.0);
-            v.y = keep ? v.y : 0.0;
-            an[ks] = v;
+            an[ks] = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];      // raw; masked when consumed
         }
 #pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) {
-            int gk = kc + wave + 4 * q;
-            cz v = g.Vk[(int64_t)vidx[q] * ldw + vcol_c];
-            bool keep = gk < Kd && cok;
-            v.x = keep ? v.x : 0.0;
-            v.y = keep ? v.y : 0.0;
-            vn[q] = v;
-        }
+        for (int q = 0; q < APPLY_KC / 4; ++q) vn[q] = g.Vk[(int64_t)vidx[q] * ldw + vcol_c];
+    };
+    // masks are applied when a chunk is consumed, so nothing waits on the loads while the previous
+    // chunk is still on the matrix cores
+    auto mask_a = [&](cz v, int gk) {
+        bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
+        v.x = keep ? v.x : (gk == unit_at ? 1.0 : 0.0);
+        v.y = keep ? v.y : 0.0;
+        return v;
+    };
+    auto mask_v = [&](cz v, int gk) {
+        bool keep = gk < Kd && cok;
+        v.x = keep ? v.x : 0.0;
+        v.y = keep ? v.y : 0.0;
+        return v;
     };
     d4 cr[NS], ci[NS];
 #pragma unroll
@@ -166,9 +169,9 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[LDS_COLS
     for (int kc = 0; kc < Kd; kc += APPLY_KC) {
         __syncthreads();                       // previous chunk's fragment reads are done
 #pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) Vs[wave + 4 * q][lane] = vn[q];
+        for (int q = 0; q < APPLY_KC / 4; ++q) Vs[wave + 4 * q][lane] = mask_v(vn[q], kc + wave + 4 * q);
 #pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = an[ks];
+        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
         __syncthreads();
         if (kc + APPLY_KC < Kd) load_chunk(kc + APPLY_KC);
         const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;           // k-steps that carry data (uniform)
@@ -231,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y, cg = blockIdx.z * LDS_COLS;
     FrontD f = fr[t.f];
-    int kind = t.a;
+    int kind = t.a & 0xff;
+    int th = (t.a >> 8) ? 16 * (t.a >> 8) : 64;       // tile height in rows (16, 32 or 64), chosen per launch by the host
     int p = f.p, u = f.u, ld = p + u;
     const cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* Wk = W + (int64_t)k * ws;
@@ -240,13 +244,13 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0;
     g.sidx = struct_idx + f.sptr;
     g.out = Yk; g.orow_shift = f.c0;
-    if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * 64; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
-    else if (kind == 1) { g.rbase = p + t.b * 64; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2; }
+    if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
+    else if (kind == 1) { g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2; }
     else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
-    else if (kind == 3) { g.rbase = t.b * 64; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Yk; }
-    else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * 64; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
+    else if (kind == 3) { g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Yk; }
+    else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
     else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; }
-    int trows = min(64, g.rend - g.rbase);
+    int trows = min(th, g.rend - g.rbase);
     if (trows <= 16) apply_body<GATHER, 1>(g, Vs, cg, ldw);
     else if (trows <= 32) apply_body<GATHER, 2>(g, Vs, cg, ldw);
     else apply_body<GATHER, 4>(g, Vs, cg, ldw);

@@ -110,6 +110,14 @@ int main() {
         double fv = (double)blocks * 256 * iters * 8 * 8 * 2.0;
         printf("f64 valu  waves/CU %2d: %.2f ms  %.1f TFLOP/s\n", wpc, ms, fv / ms / 1e9);
     }
+    {   // sustained f64 MFMA rate (DVFS): ~0.5 s of back-to-back launches
+        int blocks = ncu * 4, iters = 16384;
+        for (int rep = 0; rep < 4; ++rep) {
+            float ms = time_ms([&] { mfma_f64_rate<<<blocks, 256>>>(out, iters); }, 20);
+            double fl = (double)blocks * 4 * iters * 4 * 2048.0;
+            printf("f64 mfma sustained rep %d: %.2f ms/launch  %.1f TFLOP/s\n", rep, ms, fl / ms / 1e9);
+        }
+    }
     size_t n = (size_t)1 << 27;  // 2 GiB of double2
     double2 *in, *o2; CK(hipMalloc(&in, n * 16)); CK(hipMalloc(&o2, n * 16));
     CK(hipMemset(in, 1, n * 16)); CK(hipMemset(o2, 0, n * 16));

@@ -195,6 +195,142 @@ int eig_generalized(int m, zc* A, zc* B, zc* lam, zc* V) {
     return e ? e : info;
 }
 
+double hermitian_defect(int m, const zc* M) {
+    double mx = 0, df = 0;
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i <= j; ++i) {
+            mx = std::max(mx, std::abs(M[i + (size_t)j * m]));
+            df = std::max(df, std::abs(M[i + (size_t)j * m] - std::conj(M[j + (size_t)i * m])));
+        }
+    return mx > 0 ? df / mx : 0.0;
+}
+
+int eig_hermitian(int m, zc* A, zc* B, zc* lam, zc* V) {
+    if (m <= 0) return 0;
+    std::vector<zc> R;
+    if (B) {   // C = R^-H A R^-1 with B = R^H R
+        R.assign(B, B + (size_t)m * m);
+        for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (R[i + (size_t)j * m] + std::conj(R[j + (size_t)i * m])); R[i + (size_t)j * m] = a; }
+        if (cholesky_upper(m, R.data())) return 1;
+        // A <- R^-H A : solve R^H X = A column by column (forward substitution, R^H lower)
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) {
+                zc s = A[i + (size_t)j * m];
+                for (int k = 0; k < i; ++k) s -= std::conj(R[k + (size_t)i * m]) * A[k + (size_t)j * m];
+                A[i + (size_t)j * m] = s / std::conj(R[i + (size_t)i * m]);
+            }
+        // A <- A R^-1 : solve X R = A row by row
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) {
+                zc s = A[i + (size_t)j * m];
+                for (int k = 0; k < j; ++k) s -= A[i + (size_t)k * m] * R[k + (size_t)j * m];
+                A[i + (size_t)j * m] = s / R[j + (size_t)j * m];
+            }
+    }
+    // symmetrise
+    for (int j = 0; j < m; ++j) { A[j + (size_t)j * m] = A[j + (size_t)j * m].real(); for (int i = 0; i < j; ++i) { zc a = 0.5 * (A[i + (size_t)j * m] + std::conj(A[j + (size_t)i * m])); A[i + (size_t)j * m] = a; A[j + (size_t)i * m] = std::conj(a); } }
+    // Householder tridiagonalisation, Q accumulated
+    std::vector<zc> Q((size_t)m * m, zc(0.0)), v(m), w(m);
+    for (int i = 0; i < m; ++i) Q[i + (size_t)i * m] = 1.0;
+    for (int k = 0; k + 2 < m; ++k) {
+        double nrm = 0;
+        for (int i = k + 1; i < m; ++i) nrm += std::norm(A[i + (size_t)k * m]);
+        nrm = std::sqrt(nrm);
+        if (nrm == 0.0) continue;
+        zc x0 = A[k + 1 + (size_t)k * m];
+        zc ph = std::abs(x0) == 0.0 ? zc(1.0) : x0 / std::abs(x0);
+        zc alpha = -ph * nrm;
+        double vn = 0;
+        for (int i = k + 1; i < m; ++i) { v[i] = A[i + (size_t)k * m]; if (i == k + 1) v[i] -= alpha; vn += std::norm(v[i]); }
+        vn = std::sqrt(vn);
+        if (vn == 0.0) continue;
+        for (int i = k + 1; i < m; ++i) v[i] /= vn;
+        // A <- H A H on the trailing block, H = I - 2 v v^H :  w = A v, K = v^H w, A -= 2 v w^H + 2 w v^H - 4 K v v^H
+        for (int i = k + 1; i < m; ++i) { zc s = 0; const zc* col = A + (size_t)i * m; for (int j = k + 1; j < m; ++j) s += std::conj(col[j]) * v[j]; w[i] = s; }   // A Hermitian: row i = conj(column i)
+        zc K = 0;
+        for (int i = k + 1; i < m; ++i) K += std::conj(v[i]) * w[i];
+        for (int i = k + 1; i < m; ++i) w[i] = 2.0 * (w[i] - K * v[i]);
+        for (int j = k + 1; j < m; ++j) for (int i = k + 1; i < m; ++i) A[i + (size_t)j * m] -= v[i] * std::conj(w[j]) + w[i] * std::conj(v[j]);
+        A[k + 1 + (size_t)k * m] = alpha; A[k + (size_t)(k + 1) * m] = std::conj(alpha);
+        for (int i = k + 2; i < m; ++i) { A[i + (size_t)k * m] = 0.0; A[k + (size_t)i * m] = 0.0; }
+        // Q <- Q H
+        std::fill(w.begin(), w.end(), zc(0.0));
+        for (int j = k + 1; j < m; ++j) { const zc* col = Q.data() + (size_t)j * m; zc vj = v[j]; for (int i = 0; i < m; ++i) w[i] += col[i] * vj; }
+        for (int j = k + 1; j < m; ++j) { zc* col = Q.data() + (size_t)j * m; zc cv = 2.0 * std::conj(v[j]); for (int i = 0; i < m; ++i) col[i] -= w[i] * cv; }
+    }
+    // real tridiagonal: T = D^H A D, D = diag(phases)
+    std::vector<double> d(m), e(m, 0.0);
+    std::vector<zc> phs(m, zc(1.0));
+    for (int i = 0; i < m; ++i) d[i] = A[i + (size_t)i * m].real();
+    for (int i = 0; i + 1 < m; ++i) {
+        zc c = A[i + 1 + (size_t)i * m];
+        double a = std::abs(c);
+        e[i + 1] = a;                                    // tql2 convention: e[i] couples i-1 and i
+        phs[i + 1] = a > 0 ? phs[i] * c / a : phs[i];
+    }
+    // implicit QL with accumulation (EISPACK tql2)
+    std::vector<double> Z((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i) Z[i + (size_t)i * m] = 1.0;
+    for (int i = 1; i < m; ++i) e[i - 1] = e[i];
+    e[m - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    for (int l = 0; l < m; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int mm = l;
+        while (mm < m) { if (std::fabs(e[mm]) <= EPS * tst1) break; ++mm; }
+        if (mm > l) {
+            int iter = 0;
+            do {
+                if (++iter > 60) return 1;
+                double g = d[l], p = (d[l + 1] - g) / (2.0 * e[l]), r = std::hypot(p, 1.0);
+                d[l] = e[l] / (p + (p < 0 ? -r : r));
+                d[l + 1] = e[l] * (p + (p < 0 ? -r : r));
+                double dl1 = d[l + 1], h = g - d[l];
+                for (int i = l + 2; i < m; ++i) d[i] -= h;
+                f += h;
+                p = d[mm];
+                double c = 1.0, c2 = c, c3 = c, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+                for (int i = mm - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i]; h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r; s = e[i] / r; c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int kk = 0; kk < m; ++kk) {
+                        double hh = Z[kk + (size_t)(i + 1) * m];
+                        Z[kk + (size_t)(i + 1) * m] = s * Z[kk + (size_t)i * m] + c * hh;
+                        Z[kk + (size_t)i * m] = c * Z[kk + (size_t)i * m] - s * hh;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > EPS * tst1);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    // vectors: X = Q D Z, then back-transform with R^-1, normalise, sort ascending
+    std::vector<int> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
+    std::vector<zc> x(m), y(m);
+    for (int kk = 0; kk < m; ++kk) {
+        int j = order[kk];
+        for (int i = 0; i < m; ++i) y[i] = phs[i] * Z[i + (size_t)j * m];
+        std::fill(x.begin(), x.end(), zc(0.0));
+        for (int q = 0; q < m; ++q) { const zc* col = Q.data() + (size_t)q * m; zc yq = y[q]; for (int i = 0; i < m; ++i) x[i] += col[i] * yq; }
+        if (B) for (int i = m - 1; i >= 0; --i) { zc s = x[i]; for (int q = i + 1; q < m; ++q) s -= R[i + (size_t)q * m] * x[q]; x[i] = s / R[i + (size_t)i * m]; }
+        double nr = 0;
+        for (int i = 0; i < m; ++i) nr += std::norm(x[i]);
+        nr = std::sqrt(nr);
+        lam[kk] = d[j];
+        for (int i = 0; i < m; ++i) V[i + (size_t)kk * m] = x[i] / nr;
+    }
+    return 0;
+}
+
 int cholesky_upper(int m, zc* G) {
     for (int j = 0; j < m; ++j) {
         double d = G[j + (size_t)j * m].real();

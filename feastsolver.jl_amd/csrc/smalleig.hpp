@@ -14,6 +14,12 @@ typedef std::complex<double> zc;
 int eig_general(int m, zc* A, zc* lam, zc* V);
 // Generalised problem A x = lam B x via B^-1 A (B destroyed).  0 on success, 1 if B singular.
 int eig_generalized(int m, zc* A, zc* B, zc* lam, zc* V);
+// Hermitian(-definite) fast path: A Hermitian, B Hermitian positive definite (or NULL).  Householder
+// tridiagonalisation + implicit QL.  Same outputs as eig_generalized (lam real, sorted ascending, unit
+// 2-norm vectors).  Returns 0, or 1 if B is not positive definite / QL did not converge.
+int eig_hermitian(int m, zc* A, zc* B, zc* lam, zc* V);
+// max |M - M^H| / max |M|
+double hermitian_defect(int m, const zc* M);
 // Upper Cholesky factor: G = R^H R, R overwrites the upper triangle of G (lower zeroed).
 // Returns 0 or the 1-based index of the first non-positive pivot.
 int cholesky_upper(int m, zc* G);

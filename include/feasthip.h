@@ -154,6 +154,8 @@ int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* out);
  * {ms, algorithmic bytes, flops, launches}: 0 gather, 1 assemble, 2 diag solve,
  * 3 panel apply (the dominant kernel), 4 accumulate. */
 int feasthip_profile_solve(feasthip_handle_t h, double* out);
+/* per-launch rows of the last feasthip_profile_solve: {class, ms, bytes, flops, tiles}; returns the row count */
+int feasthip_profile_detail(feasthip_handle_t h, double* out, int cap);
 
 /* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------- */
 /* symbolic analysis of a pattern: stats[0..7] = nsuper, nnz_l, nnz_u, fact_elems,
