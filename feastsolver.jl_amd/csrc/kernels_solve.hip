@@ -116,65 +116,62 @@ struct ApplyGeom {
 // as NS slabs x 4/NS column parts, so a tile with <= 16 (<= 32) rows still keeps every matrix core
 // busy with useful columns instead of multiplying zero rows.
 template <bool GATHER, int NS>
-__device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[LDS_COLS], int cg, int ldw) {
+__device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC][LDS_COLS], int cg, int ldw) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
     const bool wave_active = g.rbase + slab * 16 < g.rend;          // wave-uniform
     const int arow = g.rbase + slab * 16 + li;
     const bool aok = arow < g.rend;
     const int adiag = arow - g.k0;
-    const bool cok = cg + lane < ldw;
     const int Kd = g.Kd;
-    // Loads are unconditional (addresses clamped into the slab) and masked with selects afterwards, so
-    // the compiler emits straight-line global_load_dwordx4 that all stay in flight together.
+    // Loads are unconditional (addresses clamped into the slab); A is masked with selects when it is
+    // consumed, V needs no mask at all: k-steps beyond Kd are multiplied by the zeros of A and columns
+    // beyond ldw are never stored.
     const int arow_c = min(arow, g.rend - 1);
     const int vcol_c = min(cg + lane, ldw - 1);
     const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
     const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
     const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
-    cz av[APPLY_KC / 4], an[APPLY_KC / 4], vn[APPLY_KC / 4];
-    auto load_chunk = [&](int kc) {
-        int vidx[APPLY_KC / 4];
-#pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) {
-            int gk = min(kc + wave + 4 * q, Kd - 1);
-            vidx[q] = GATHER ? g.sidx[gk] : g.vrow0 + gk;
-        }
+    cz av[APPLY_KC / 4], an[APPLY_KC / 4];
+    // A: one 16-byte load per lane per k-step, straight to registers.  V: LDS-DMA, one
+    // global_load_lds_dwordx4 per block-vector row (64 lanes x 16 B = the 1 KiB LDS row), no VGPR staging.
+    auto load_chunk = [&](int kc, int buf) {
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
             int gk = kc + ks * 4 + lk;
-            an[ks] = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];      // raw; masked when consumed
+            an[ks] = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];
         }
 #pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) vn[q] = g.Vk[(int64_t)vidx[q] * ldw + vcol_c];
+        for (int q = 0; q < APPLY_KC / 4; ++q) {
+            int r = wave + 4 * q;
+            int gk = min(kc + r, Kd - 1);
+            int vrow = GATHER ? g.sidx[gk] : g.vrow0 + gk;
+            const cz* src = g.Vk + (int64_t)vrow * ldw + vcol_c;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)&Vs[buf][r][0], 16, 0, 0);
+        }
     };
-    // masks are applied when a chunk is consumed, so nothing waits on the loads while the previous
-    // chunk is still on the matrix cores
     auto mask_a = [&](cz v, int gk) {
         bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
         v.x = keep ? v.x : (gk == unit_at ? 1.0 : 0.0);
         v.y = keep ? v.y : 0.0;
         return v;
     };
-    auto mask_v = [&](cz v, int gk) {
-        bool keep = gk < Kd && cok;
-        v.x = keep ? v.x : 0.0;
-        v.y = keep ? v.y : 0.0;
-        return v;
-    };
-    d4 cr[NS], ci[NS];
+    // 3M complex product: T1 = ar*br, T2 = ai*bi, T3 = (ar+ai)*(br+bi);  re = T1 - T2, im = T3 - T1 - T2
+    // -> 3 instead of 4 v_mfma_f64_16x16x4_f64 per k-step and column tile (the kernel is matrix-core bound).
+    d4 t1[NS], t2[NS], t3[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { cr[q] = (d4){0, 0, 0, 0}; ci[q] = (d4){0, 0, 0, 0}; }
-    load_chunk(0);
-    for (int kc = 0; kc < Kd; kc += APPLY_KC) {
-        __syncthreads();                       // previous chunk's fragment reads are done
-#pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) Vs[wave + 4 * q][lane] = mask_v(vn[q], kc + wave + 4 * q);
+    for (int q = 0; q < NS; ++q) { t1[q] = (d4){0, 0, 0, 0}; t2[q] = (d4){0, 0, 0, 0}; t3[q] = (d4){0, 0, 0, 0}; }
+    load_chunk(0, 0);
+    int it = 0;
+    for (int kc = 0; kc < Kd; kc += APPLY_KC, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's A registers and V rows have landed
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
-        __syncthreads();
-        if (kc + APPLY_KC < Kd) load_chunk(kc + APPLY_KC);
-        const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;           // k-steps that carry data (uniform)
+        __syncthreads();                                      // everyone's rows landed; buffer buf^1 is free again
+        if (kc + APPLY_KC < Kd) load_chunk(kc + APPLY_KC, buf ^ 1);
+        const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;    // k-steps that carry data (uniform)
         if (wave_active) {
 #pragma unroll
             for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
@@ -182,20 +179,22 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[LDS_COLS
                     const int kk = ks * 4 + lk;
                     cz bv[NS];
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) bv[q] = Vs[kk][(ct0 + q) * 16 + li];
-                    const double ar = av[ks].x, ai = av[ks].y, nai = -av[ks].y;
+                    for (int q = 0; q < NS; ++q) bv[q] = Vs[buf][kk][(ct0 + q) * 16 + li];
+                    const double ar = av[ks].x, ai = av[ks].y, as = av[ks].x + av[ks].y;
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q].x, cr[q], 0, 0, 0);
+                    for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q].x, t1[q], 0, 0, 0);
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q].y, ci[q], 0, 0, 0);
+                    for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[q].y, t2[q], 0, 0, 0);
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bv[q].y, cr[q], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[q].x, ci[q], 0, 0, 0);
+                    for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv[q].x + bv[q].y, t3[q], 0, 0, 0);
                 }
             }
         }
     }
+    d4 cr[NS], ci[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { cr[q] = t1[q] - t2[q]; ci[q] = t3[q] - t1[q] - t2[q]; }
+    const bool cok_unused = true; (void)cok_unused;
     // ---- epilogue: all read-modify-write loads are issued together (clamped addresses), then stored
     if (!wave_active) return;
     cz* dptr[4];
@@ -230,7 +229,7 @@ template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
                                                cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs) {
-    __shared__ cz Vs[APPLY_KC][LDS_COLS];
+    __shared__ cz Vs[2][APPLY_KC][LDS_COLS];      // double buffered, filled by LDS-DMA
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y, cg = blockIdx.z * LDS_COLS;
     FrontD f = fr[t.f];
