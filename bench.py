@@ -165,6 +165,10 @@ def main():
 
     if rank == 0:
         pa = prof["panel_apply"]
+        traffic = None          # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/)
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.grid == 46 and args.stencil == 19 and world == 1:
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         dom_gbs = pa["bytes"] / (pa["ms"] * 1e-3) / 1e9
         dom_tf = pa["flops"] / (pa["ms"] * 1e-3) / 1e12
         out = {
@@ -179,9 +183,9 @@ def main():
                 "nnz_L": st["nnz_l"], "nnz_U": st["nnz_u"], "supernodes": st["nsuper"], "max_front": st["max_front"],
             },
             "roofline": {
-                "kernel": "k_panel_apply (supernodal block forward/back substitution)",
+                "kernel": "k_apply (supernodal block forward/back substitution, all kinds)",
                 "bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic, "algorithmic_bytes_per_launch": pa["bytes"] / max(1, pa["launches"]),
                 "launches_per_step": pa["launches"], "avg_launch_ms": pa["ms"] / max(1, pa["launches"]),
                 "f64_mfma": {"achieved": dom_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom_tf / F64_MFMA_PEAK_TF,
                              "note": "m0=64 complex f64 is 32 flop/B: the f64 matrix cores bind before HBM (ceiling 2.46 TB/s of factor bytes)"},

@@ -297,8 +297,9 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
     std::vector<char> in_sep;
     vertex_cover(g0, part, in_sep);
     label.resize(n);
+    for (int v = 0; v < n; ++v) label[v] = in_sep[v] ? 2 : part[v];
     int64_t c[3] = {0, 0, 0};
-    for (int v = 0; v < n; ++v) { label[v] = in_sep[v] ? 2 : part[v]; c[label[v]]++; }
+    for (int v = 0; v < n; ++v) c[label[v]]++;
     return c[0] > 0 && c[1] > 0 && c[2] > 0;
 }
 
