@@ -329,8 +329,9 @@ def nlfeast(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, store=Tr
 class HipLU:
     """Factorization object returned by ``lu`` (the reference's `factorizer`)."""
 
-    def __init__(self, handle, n, lib):
+    def __init__(self, handle, n, lib, info=0):
         self._h, self.n, self._lib = handle, n, lib
+        self.info = info          # > 0: number of statically perturbed pivots (LAPACK info convention)
 
     def __del__(self):
         try:
@@ -355,7 +356,7 @@ def lu(Cm, device=0):
     if code < 0:
         msg = lib.feasthip_last_error(None)
         raise _lib.FeastHipError(code, msg.decode() if msg else "")
-    return HipLU(F, n, lib)
+    return HipLU(F, n, lib, code)
 
 
 def ldiv(Y, F, R):

@@ -275,6 +275,69 @@ def test_c3_g24_converges_with_right_count(gpu, pkg, wl):
     assert np.abs(lam.imag).max() < 1e-10      # Hermitian-definite pencil
 
 
+@pytest.mark.parametrize("m0", [100, 128])
+def test_wide_blocks_sparse(gpu, pkg, wl, m0):
+    """m0 > 64: two 64-column groups per tile"""
+    A = wl.laplacian_3d(10, 19)
+    n = A.shape[0]
+    rng = np.random.default_rng(m0)
+    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.4 + 0.3j) * sp.identity(n))
+    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
+    F = pkg.lu(Cm)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    pkg.finalize(F)
+    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * spla.norm(Cm) * np.linalg.norm(Y)
+
+
+def test_sparse_store_false_and_handle_reuse(gpu, pkg, fo, wl, golden):
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    g = golden["c3_g8_s19_m16"]
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=False)
+    assert len(lam) == w["n_inside"] and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
+    # one handle, two runs with different starting blocks: same eigenvalues
+    h = pkg.FeastHandle(0)
+    h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+    h.set_contour(con)
+    outs = []
+    for seed in (1, 2):
+        X = wl.rand_x0(512, 16, seed)
+        lam2, res2, ins, nit, warn = h.feast_run(X, w["iter"], w["eps"], True)
+        outs.append(np.sort_complex(lam2[ins]))
+        assert res2[ins].max() < w["eps"] and warn == 0
+    h.close()
+    assert np.abs(outs[0] - outs[1]).max() < 1e-10
+
+
+def test_dense_nonhermitian_small_vs_oracle(gpu, pkg, fo, wl):
+    """general (non-Hermitian) reduced eigenproblem path, compared with the oracle run on the fly"""
+    w = wl.c2_dense_generalized(200, 24, seeds=(11, 12, 13), n_inside=10)
+    con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    lam_o, _, res_o = fo.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=20, eps=1e-10, store=True)
+    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10, store=True)
+    assert len(lam) == len(lam_o) == 10
+    assert match_sets(lam, lam_o) < 1e-9 and res.max() < 1e-10
+
+
+def test_zero_diagonal_is_never_silently_wrong(gpu, pkg):
+    """Saddle-point matrix with a structurally zero diagonal block.  Pivoting is restricted to the pivot
+    block of each front (UMFPACK pivots globally): the solve must either be accurate or the factorisation
+    must report perturbed pivots through the LAPACK-style positive status."""
+    rng = np.random.default_rng(3)
+    nA, nB = 40, 12
+    A = sp.random(nA, nA, density=0.2, random_state=1) + 4 * sp.identity(nA)
+    B = sp.random(nB, nA, density=0.3, random_state=2)
+    K = sp.bmat([[A + A.T, B.T], [B, None]], format="csc").astype(np.complex128)
+    R = np.asfortranarray(rng.standard_normal((nA + nB, 5)) + 0j)
+    F = pkg.lu(K)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    accurate = np.linalg.norm(K @ Y - R) <= 1e-9 * spla.norm(K) * np.linalg.norm(Y)
+    assert accurate or F.info > 0
+    pkg.finalize(F)
+
+
 def test_error_codes(gpu, pkg, wl):
     with pytest.raises(ValueError, match="must be square"):
         pkg.feast(wl.rand_x0(5, 2, 1), np.zeros((5, 4)))
