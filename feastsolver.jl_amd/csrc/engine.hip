@@ -54,11 +54,25 @@ Engine::Engine(int device) : device_(device) {
     own_stream_ = true;
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
+    int nst = 2;
+    if (const char* v = getenv("FEASTHIP_STREAMS")) nst = std::max(1, std::min(8, atoi(v)));
+    if (nst > 1) {
+        (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
+        for (int i = 0; i < nst; ++i) {
+            hipStream_t s2 = nullptr; hipEvent_t e2 = nullptr;
+            if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) break;
+            (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+            aux_streams_.push_back(s2); ev_join_.push_back(e2);
+        }
+    }
 }
 
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    for (hipStream_t s2 : aux_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
+    for (hipEvent_t e2 : ev_join_) (void)hipEventDestroy(e2);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -662,19 +676,22 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
 // ---------------------------------------------------------------------------
 int Engine::solve_all(const cz* rhs) { return solve_all_impl(rhs, nullptr); }
 
-int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
-    if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
+int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof) {
     int64_t fs = S.fact_size, ws = (int64_t)n * ldw;
+    cz* Fp = d_fact_.p + (int64_t)kb * fs;
+    cz* Wp = d_W_.p + (int64_t)kb * ws;
+    cz* Yp = d_Y_.p + (int64_t)kb * ws;
+    const int* rperm = d_rowperm_.p + (int64_t)kb * n;
+    const int* rinv = d_rowinv_.p + (int64_t)kb * n;
     const Tile* tl = d_tiles_.p;
-    const int* ls = d_lists_.p;
     hipEvent_t pa = nullptr, pb = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&pa)); HIPCHK(hipEventCreate(&pb)); }
     if (prof) prof_detail.clear();
     int cur_tiles = 0;
-    auto begin = [&]() { if (prof) (void)hipEventRecord(pa, stream_); };
+    auto begin = [&]() { if (prof) (void)hipEventRecord(pa, st); };
     auto end = [&](int row, double bytes, double flops) {
         if (!prof) return;
-        (void)hipEventRecord(pb, stream_);
+        (void)hipEventRecord(pb, st);
         (void)hipEventSynchronize(pb);
         float ms = 0;
         (void)hipEventElapsedTime(&ms, pa, pb);
@@ -683,53 +700,73 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
     };
     double rowb = (double)ldw * 16.0;
     begin();
-    launch_gather_rhs(stream_, dsym_, rhs, ldw, d_W_.p, ws, d_rowperm_.p, Kloc);
-    end(0, 2.0 * n * rowb * Kloc, 0);
+    launch_gather_rhs(st, dsym_, rhs, ldw, Wp, ws, rperm, kc);
+    end(0, 2.0 * n * rowb * kc, 0);
     // Launch::bytes counts factor bytes, Launch::flops complex multiply-adds per block-vector column (one node)
-    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes + vec_rows * rowb) * Kloc; };
-    auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * Kloc; };
+    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes + vec_rows * rowb) * kc; };
+    auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * kc; };
     for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
         SolveLevel& V = splan_[d];
         int par = d & 1;
         int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
         begin();
-        launch_fwd_assemble(stream_, dsym_, tl + V.assemble.off, V.assemble.count, d_W_.p, ws, ldw, d_crow_[par].p, crs,
-                            d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc, 0);
-        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * Kloc, 0); }
+        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs,
+                            (d_crow_[par ^ 1].p + (int64_t)kb * crsc), crsc, rinv, kc, 0);
+        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * kc, 0); }
         double lvl_rows = 0;
         for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
         for (Launch& L : V.f1) {
             begin();
-            launch_apply(stream_, dsym_, tl + L.off, L.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs, kc);
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
         }
         begin();
-        launch_apply(stream_, dsym_, tl + V.f2.off, V.f2.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, d_crow_[par].p, crs, Kloc);
+        launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs, kc);
         if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows), stat_flops(V.f2)); }
         begin();
-        launch_fwd_assemble(stream_, dsym_, tl + V.assemble.off, V.assemble.count, d_W_.p, ws, ldw, d_crow_[par].p, crs,
-                            d_crow_[par ^ 1].p, crsc, d_rowinv_.p, Kloc, 1);
-        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * Kloc, 0); }
+        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs,
+                            (d_crow_[par ^ 1].p + (int64_t)kb * crsc), crsc, rinv, kc, 1);
+        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * kc, 0); }
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
         SolveLevel& V = splan_[d];
         double lvl_p = 0, lvl_u = 0;
         for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
-        launch_apply(stream_, dsym_, tl + V.b1.off, V.b1.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc, true);
+        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true);
         if (V.b1.count) { cur_tiles = -V.b1.count; end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1)); }
         for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
             Launch& L = V.b2[c];
             begin();
-            launch_apply(stream_, dsym_, tl + L.off, L.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
         }
         begin();
-        launch_apply(stream_, dsym_, tl + V.b3.off, V.b3.count, d_fact_.p, fs, d_W_.p, d_Y_.p, ws, ldw, nullptr, 0, Kloc);
+        launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
         if (V.b3.count) { cur_tiles = V.b3.count; end(3, stat_bytes(V.b3, 2.0 * lvl_p), stat_flops(V.b3)); }
     }
     if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
+    if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
+    int ns = std::min<int>((int)aux_streams_.size(), Kloc);
+    if (prof || ns <= 1) return solve_range(stream_, 0, Kloc, rhs, prof);
+    // The nodes are independent: split them over a few streams so that the tails and the latency-bound small
+    // launches of one group overlap with the large launches of another.
+    HIPCHK(hipEventRecord(ev_fork_, stream_));
+    int per = (Kloc + ns - 1) / ns;
+    for (int g = 0; g < ns; ++g) {
+        int kb = g * per, kc = std::min(per, Kloc - kb);
+        if (kc <= 0) break;
+        HIPCHK(hipStreamWaitEvent(aux_streams_[g], ev_fork_, 0));
+        int r = solve_range(aux_streams_[g], kb, kc, rhs, nullptr);
+        if (r) return r;
+        HIPCHK(hipEventRecord(ev_join_[g], aux_streams_[g]));
+        HIPCHK(hipStreamWaitEvent(stream_, ev_join_[g], 0));
+    }
     return 0;
 }
 

@@ -146,6 +146,10 @@ private:
     int solve_all(const cz* rhs);            // W_k = T(z_k)^-1 rhs for all local nodes
     void inside_test(const zc* lam, uint8_t* inside) const;
     int solve_all_impl(const cz* rhs, ProfileRow* prof);
+    int solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof);
+    std::vector<hipStream_t> aux_streams_;
+    std::vector<hipEvent_t> ev_join_;
+    hipEvent_t ev_fork_ = nullptr;
 };
 
 }  // namespace feasthip
