@@ -8,7 +8,9 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 namespace feasthip {
 namespace {
@@ -79,9 +81,9 @@ public:
 private:
     const Graph& g_;
     int leaf_;
-    std::vector<int> part_, vis_, lvl_, order_;
-    int next_id_ = 0, stamp_ = 0;
-    std::vector<int> queue_, lptr_, loc_;
+    std::vector<int> part_, vis_, lvl_, order_, loc_;
+    std::atomic<int> next_id_{0}, stamp_{0};          // sub-problems run on disjoint vertex sets, possibly in parallel
+    struct Bfs { std::vector<int> queue, lptr; int stamp = 0; };
 
     struct Split {
         std::vector<int> a, b, s;
@@ -89,7 +91,7 @@ private:
     };
 
     // multilevel (edge-cut minimising) separator of the induced subgraph; replaces `best` if smaller
-    void multilevel_candidate(const std::vector<int>& verts, int id, Split& best) {
+    void multilevel_candidate(const std::vector<int>& verts, int id, uint64_t seed, Split& best) {
         int m = (int)verts.size();
         WGraph w;
         w.n = m;
@@ -103,9 +105,9 @@ private:
         }
         w.ewgt.assign(w.adj.size(), 1);
         std::vector<int> label;
-        int trials = m >= 20000 ? 3 : m >= 2000 ? 2 : 1;     // the top separators dominate the fill: try harder there
+        int trials = m >= 20000 ? 2 : 1;     // the top separators dominate the fill: try harder there
         for (int tr = 0; tr < trials; ++tr) {
-            if (!multilevel_separator(w, label, (uint64_t)id * 7919u + 17u + 104729u * tr)) continue;
+            if (!multilevel_separator(w, label, seed * 7919u + 17u + 104729u * tr)) continue;
             Split sp;
             for (int i = 0; i < m; ++i) (label[i] == 0 ? sp.a : label[i] == 1 ? sp.b : sp.s).push_back(verts[i]);
             if (sp.a.empty() || sp.b.empty() || sp.s.empty()) continue;
@@ -117,8 +119,10 @@ private:
     }
 
     // BFS restricted to part_ == id.  Fills queue_ (visit order) and lptr_ (level offsets).
-    void bfs(int root, int id) {
-        ++stamp_;
+    void bfs(int root, int id, Bfs& B) {
+        std::vector<int>& queue_ = B.queue;
+        std::vector<int>& lptr_ = B.lptr;
+        const int stamp_ = B.stamp = ++this->stamp_;
         queue_.clear();
         lptr_.clear();
         queue_.push_back(root);
@@ -144,7 +148,10 @@ private:
     }
 
     // Evaluate the best level-set separator of the current BFS structure.
-    void candidate(int m, Split& best) {
+    void candidate(int m, Split& best, const Bfs& B) {
+        const std::vector<int>& queue_ = B.queue;
+        const std::vector<int>& lptr_ = B.lptr;
+        const int stamp_ = B.stamp;
         int nl = (int)lptr_.size() - 1;
         if (nl < 3) return;
         int bj = -1;
@@ -188,25 +195,28 @@ private:
         for (size_t k = 0; k < verts.size(); ++k) order_[lo + k] = verts[k];
     }
 
-    void dissect(std::vector<int>& verts, int lo) {
+    void dissect(std::vector<int>& verts, int lo, int depth = 0) {
         int m = (int)verts.size();
         if (m <= leaf_) { emit(verts, lo); return; }
         int id = next_id_++;
         for (int v : verts) part_[v] = id;
-        bfs(verts[0], id);
+        Bfs B;
+        std::vector<int>& queue_ = B.queue;
+        std::vector<int>& lptr_ = B.lptr;
+        bfs(verts[0], id, B);
         if ((int)queue_.size() < m) {   // disconnected: order components independently
             std::vector<int> comp(queue_), rest;
-            int st = stamp_;
+            int st = B.stamp;
             for (int v : verts) if (vis_[v] != st) rest.push_back(v);
             verts.clear(); verts.shrink_to_fit();
             int ncomp = (int)comp.size();
-            dissect(comp, lo);
-            dissect(rest, lo + ncomp);
+            dissect(comp, lo, depth);
+            dissect(rest, lo + ncomp, depth);
             return;
         }
         Split best;
         int height = (int)lptr_.size() - 1;
-        candidate(m, best);
+        candidate(m, best, B);
         for (int it = 0; it < 6; ++it) {
             // min-degree vertex of the last level
             int nl = (int)lptr_.size() - 1, r = -1;
@@ -216,21 +226,27 @@ private:
                 int64_t d = g_.xadj[v + 1] - g_.xadj[v];
                 if (d < bd) { bd = d; r = v; }
             }
-            bfs(r, id);
-            candidate(m, best);
+            bfs(r, id, B);
+            candidate(m, best, B);
             int h2 = (int)lptr_.size() - 1;
             if (h2 <= height) break;
             height = h2;
         }
-        if (m >= 64) multilevel_candidate(verts, id, best);
+        if (m >= 64) multilevel_candidate(verts, id, (uint64_t)lo * 2654435761ull + (uint64_t)m, best);   // seed independent of thread timing
         if (best.s.empty() || best.a.empty() || best.b.empty()) { emit(verts, lo); return; }
         verts.clear(); verts.shrink_to_fit();
         int na = (int)best.a.size(), nb = (int)best.b.size();
         emit(best.s, lo + na + nb);
         std::vector<int> a(std::move(best.a)), b(std::move(best.b));
         best.s.clear(); best.s.shrink_to_fit();
-        dissect(a, lo);
-        dissect(b, lo + na);
+        if (depth < 4 && std::min(na, nb) >= 2000) {     // the two halves are independent: up to 16 host threads
+            std::thread th([&]() { dissect(a, lo, depth + 1); });
+            dissect(b, lo + na, depth + 1);
+            th.join();
+        } else {
+            dissect(a, lo, depth + 1);
+            dissect(b, lo + na, depth + 1);
+        }
     }
 };
 
