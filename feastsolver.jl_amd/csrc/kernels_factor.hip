@@ -309,47 +309,68 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int mrow = m0 + wave * 16 + li;
     bool mok = mrow < M;
+    int mrow_c = min(mrow, M - 1);
     d4 cr[4], ci[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+    // loads are unconditional (clamped addresses) and masked with selects, so they all stay in flight
     for (int kc = 0; kc < Kd; kc += GEMM_KC) {
-        __syncthreads();
-        for (int idx = tid; idx < GEMM_KC * 64; idx += 256) {
+        cz bvals[GEMM_KC * 64 / 256];
+#pragma unroll
+        for (int q = 0; q < GEMM_KC * 64 / 256; ++q) {
+            int idx = tid + 256 * q;
             int kk = idx % GEMM_KC, nn = idx / GEMM_KC;
-            int gk = kc + kk, gn = n0 + nn;
-            Bs[kk][nn] = (gk < Kd && gn < N) ? B[gk + (int64_t)gn * ldb] : cz_make(0, 0);
+            bvals[q] = B[min(kc + kk, Kd - 1) + (int64_t)min(n0 + nn, N - 1) * ldb];
         }
         cz av[GEMM_KC / 4];
 #pragma unroll
+        for (int ks = 0; ks < GEMM_KC / 4; ++ks) av[ks] = A[mrow_c + (int64_t)min(kc + ks * 4 + lk, Kd - 1) * lda];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < GEMM_KC * 64 / 256; ++q) {
+            int idx = tid + 256 * q;
+            int kk = idx % GEMM_KC, nn = idx / GEMM_KC;
+            bool keep = (kc + kk < Kd) && (n0 + nn < N);
+            Bs[kk][nn] = keep ? bvals[q] : cz_make(0, 0);
+        }
+#pragma unroll
         for (int ks = 0; ks < GEMM_KC / 4; ++ks) {
-            int gk = kc + ks * 4 + lk;
-            av[ks] = (mok && gk < Kd) ? A[mrow + (int64_t)gk * lda] : cz_make(0, 0);
+            bool keep = mok && (kc + ks * 4 + lk < Kd);
+            av[ks].x = keep ? av[ks].x : 0.0;
+            av[ks].y = keep ? av[ks].y : 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < GEMM_KC / 4; ++ks) {
             int kk = ks * 4 + lk;
+            cz bv[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                cz bv = Bs[kk][nt * 16 + li];
-                cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);
-            }
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = Bs[kk][nt * 16 + li];
+            double ar = av[ks].x, ai = av[ks].y, nai = -av[ks].y;
+            // D[n][m] += B^T[n][k] A^T[k][m]   (MFMA "A" operand = B tile from LDS, "B" operand = A slab)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].x, ar, cr[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].x, ai, ci[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].y, nai, cr[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].y, ar, ci[nt], 0, 0, 0);
         }
     }
-    if (mok) {
+    // epilogue: all 16 read-modify-write loads issued together, then stored
+    cz old[4][4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int gn = n0 + nt * 16 + lk + 4 * r;
-                if (gn < N) {
-                    cz* d = C + mrow + (int64_t)gn * ldc;
-                    cz v = *d;
-                    v.x -= cr[nt][r]; v.y -= ci[nt][r];
-                    *d = v;
-                }
-            }
-    }
+        for (int r = 0; r < 4; ++r) old[nt][r] = C[mrow_c + (int64_t)min(n0 + nt * 16 + lk + 4 * r, N - 1) * ldc];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int gn = n0 + nt * 16 + lk + 4 * r;
+            if (mok && gn < N) C[mrow + (int64_t)gn * ldc] = cz_make(old[nt][r].x - cr[nt][r], old[nt][r].y - ci[nt][r]);
+        }
 }
 
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
