@@ -162,15 +162,16 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
     d4 t1[NS], t2[NS], t3[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) { t1[q] = (d4){0, 0, 0, 0}; t2[q] = (d4){0, 0, 0, 0}; t3[q] = (d4){0, 0, 0, 0}; }
-    load_chunk(0, 0);
-    int it = 0;
-    for (int kc = 0; kc < Kd; kc += APPLY_KC, ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's A registers and V rows have landed
+    // output rows of this lane (D layout: row (l>>4)+4r, columns ct0*16 + li + 16 q)
+    cz* dptr[4];
+    bool rok[4];
 #pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
-        __syncthreads();                                      // everyone's rows landed; buffer buf^1 is free again
-        if (kc + APPLY_KC < Kd) load_chunk(kc + APPLY_KC, buf ^ 1);
+    for (int r = 0; r < 4; ++r) {
+        int orow = g.rbase + slab * 16 + lk + 4 * r;
+        rok[r] = orow < g.rend;
+        dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
+    }
+    auto mfma_chunk = [&](int kc, int buf) {
         const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;    // k-steps that carry data (uniform)
         if (wave_active) {
 #pragma unroll
@@ -190,28 +191,40 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
                 }
             }
         }
+    };
+    load_chunk(0, 0);
+    int it = 0, kc = 0;
+    for (; kc + APPLY_KC < Kd; kc += APPLY_KC, ++it) {       // all chunks but the last: prefetch the next one
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's A registers and V rows have landed
+#pragma unroll
+        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
+        __syncthreads();                                      // everyone's rows landed; buffer buf^1 is free again
+        load_chunk(kc + APPLY_KC, buf ^ 1);
+        mfma_chunk(kc, buf);
+    }
+    // last chunk: instead of a prefetch, issue the read-modify-write loads of the epilogue so that their
+    // latency overlaps with the last block of MFMAs (the prefetch registers are free by now)
+    cz old[4][NS];
+    {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
+        __syncthreads();
+        if (g.mode == 0 && wave_active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][min(cg + (ct0 + q) * 16 + li, ldw - 1)];
+        }
+        mfma_chunk(kc, buf);
     }
     d4 cr[NS], ci[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) { cr[q] = t1[q] - t2[q]; ci[q] = t3[q] - t1[q] - t2[q]; }
-    const bool cok_unused = true; (void)cok_unused;
-    // ---- epilogue: all read-modify-write loads are issued together (clamped addresses), then stored
+    // ---- epilogue (the read-modify-write loads were issued before the last MFMA block)
     if (!wave_active) return;
-    cz* dptr[4];
-    bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int orow = g.rbase + slab * 16 + lk + 4 * r;
-        rok[r] = orow < g.rend;
-        dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
-    }
-    cz old[4][NS];
-    if (g.mode == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][min(cg + (ct0 + q) * 16 + li, ldw - 1)];
-    }
     const double sgn = (g.mode == 2) ? -1.0 : 1.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
