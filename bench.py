@@ -104,9 +104,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch  # first: libfeasthip.so then shares torch's HIP runtime (same SONAME)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FEASTHIP_FORCE_DIST") == "1"    # the flag rehearses the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
@@ -125,7 +127,7 @@ def main():
     h.set_node_shard(rank, world)
     ldw = ((args.m0 + 15) // 16) * 16
     qbuf = None
-    if world > 1:
+    if use_dist:
         qbuf = torch.zeros(2 * n * ldw * 2, dtype=torch.float64, device=f"cuda:{local_rank}")
         h.set_q_buffer(qbuf.data_ptr(), qbuf.numel() * 8)
     t0 = time.perf_counter()
@@ -138,7 +140,7 @@ def main():
     def step():
         lam, res, ins = h.rr_step()
         h.contour_step()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(qbuf[: n * ldw * 2])
             torch.cuda.synchronize()
         return lam, res, ins
@@ -146,16 +148,16 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lam, res, ins = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -203,7 +205,7 @@ def main():
             h.close()
             out["cpu_baseline"] = cpu_baseline(pkg, wl, graft.load_oracle(), args)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

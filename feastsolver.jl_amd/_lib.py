@@ -78,6 +78,14 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch (if it is going to be used in this process: bench.py, distributed.py) bundles its own
+    # libamdhip64.so with the same SONAME as /opt/rocm's.  Whichever is loaded first wins, and torch does not
+    # find its GPUs on top of a foreign runtime -- so let torch load first when it is installed.
+    if os.environ.get("FEASTHIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = library_path()
     if not os.path.exists(path):
         raise FeastHipError(-6, f"{path} not found: build it with `make -C feastsolver.jl_amd/csrc` "

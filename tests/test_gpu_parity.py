@@ -338,6 +338,30 @@ def test_zero_diagonal_is_never_silently_wrong(gpu, pkg):
     pkg.finalize(F)
 
 
+def test_distributed_driver_rccl_world1(gpu, pkg, wl, golden):
+    """distributed.py end to end on the GPU with backend nccl (= RCCL) and one rank: node sharding,
+    external moment buffer (torch tensor), all-reduce between the two halves of each iteration."""
+    import importlib, os
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    dm = importlib.import_module(graft.PKG_NAME + ".distributed")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29541"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        w = wl.c3_sparse_generalized(8, 19, 16)
+        g = golden["c3_g8_s19_m16"]
+        con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+        info = {}
+        lam, V, res = dm.gen_feast_distributed(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, device=0, info=info)
+    finally:
+        dist.destroy_process_group()
+    assert len(lam) == w["n_inside"] and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
+    assert abs(info["nit"] - g["history"][-1][0]) <= 1
+
+
 def test_error_codes(gpu, pkg, wl):
     with pytest.raises(ValueError, match="must be square"):
         pkg.feast(wl.rand_x0(5, 2, 1), np.zeros((5, 4)))
