@@ -644,22 +644,31 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     if (info) info = b_is_identity ? eig_general(m, Aq.data(), lam.data(), Xq.data())     // :45
                                    : eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data());   // :122
     if (info) return fail(FEASTHIP_ENUM, "rr_step: reduced eigenproblem failed to converge");
+    // update_R! normalises the columns of X = Q Xq (src/utils.jl:113); Q is orthonormal, so ||X_j|| = ||Xq_j||
+    // and the normalisation is applied to the m x m Xq on the host (no extra pass over the n x m block)
+    for (int j = 0; j < m; ++j) {
+        double nq = 0;
+        for (int i = 0; i < m; ++i) nq += std::norm(Xq[i + (size_t)j * m]);
+        nq = std::sqrt(nq);
+        if (nq > 0) for (int i = 0; i < m; ++i) Xq[i + (size_t)j * m] /= nq;
+    }
+    std::vector<zc> lamp(ldw, zc(0.0));
+    for (int j = 0; j < m; ++j) lamp[j] = lam[j];
     HIPCHK(hipMemcpyAsync(dM, Xq.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_ts_gemm(stream_, n, m, ldw, Qp(), dM, d_X_.p);              // X = Q Xq         :48
-    // update_R!  src/utils.jl:111-116
-    std::vector<double> nr;
-    r = col_norms(d_X_.p, nr);
-    if (r) return r;
-    std::vector<zc> sc(ldw, zc(0.0)), lamp(ldw, zc(0.0));
-    for (int j = 0; j < m; ++j) { sc[j] = nr[j] > 0 ? 1.0 / nr[j] : 1.0; lamp[j] = lam[j]; }
-    HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_scale_cols(stream_, n, ldw, d_X_.p, d_lam_.p);
-    HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipMemcpyAsync(d_lam_.p, lamp.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    apply_term(0, d_X_.p, d_T1_.p, 1.0, false);                          // A X
+    launch_ts_gemm(stream_, n, m, ldw, Qp(), dM, d_X_.p);              // X = Q Xq         :48
+    std::vector<double> nr;
     const cz* BX = d_X_.p;
-    if (!b_is_identity) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
-    launch_residual_combine(stream_, n, ldw, d_T1_.p, BX, d_lam_.p, d_R_.p);
+    if (dense) {
+        // A X = (A Q) Xq, B X = (B Q) Xq: reuse the products of the projection instead of two more n x n passes
+        launch_ts_gemm(stream_, n, m, ldw, d_R_.p, dM, d_T2_.p);                       // A X
+        if (!b_is_identity) { launch_ts_gemm(stream_, n, m, ldw, d_T1_.p, dM, d_MX_.p); BX = d_MX_.p; }
+        launch_residual_combine(stream_, n, ldw, d_T2_.p, BX, d_lam_.p, d_R_.p);
+    } else {
+        apply_term(0, d_X_.p, d_T1_.p, 1.0, false);                      // A X
+        if (!b_is_identity) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
+        launch_residual_combine(stream_, n, ldw, d_T1_.p, BX, d_lam_.p, d_R_.p);
+    }
     r = col_norms(d_R_.p, nr);                                           // residuals! :166-171
     if (r) return r;
     lambda_ = lam;
