@@ -124,6 +124,7 @@ void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 // rows [k0+j, p) of the front.  One workgroup per (front, node).
 // ---------------------------------------------------------------------------
 constexpr int PANEL_NT = 256;
+constexpr int PANEL_SB = 8;      // sub-panel width: columns right of the sub-panel are touched once per 8 pivots
 
 __global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
                                                      cz* fact, int64_t fs, int* piv, int npiv,
@@ -132,6 +133,8 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ f
     __shared__ int s_idx[PANEL_NT / 64];
     __shared__ int s_piv;
     __shared__ cz s_urow[FACT_NB];
+    __shared__ cz s_u[PANEL_SB][FACT_NB];
+    __shared__ cz s_l[PANEL_SB][PANEL_SB];
     FrontD f = fr[list[blockIdx.x]];
     int k = blockIdx.y;
     int p = f.p, ld = f.p + f.u;
@@ -139,57 +142,93 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ f
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double tiny_k = tiny[k];
-    for (int j = 0; j < b; ++j) {
-        int kj = k0 + j;
-        cz* col = Lp + (int64_t)kj * ld;
-        double best = -1.0;
-        int bi = kj;
-        for (int r = k0 + tid; r < p; r += PANEL_NT) {
-            if (r < kj) continue;
-            double a = cz_abs1(col[r]);
-            if (a > best) { best = a; bi = r; }
+    for (int sb0 = 0; sb0 < b; sb0 += PANEL_SB) {
+        int sbe = min(b, sb0 + PANEL_SB);
+        for (int j = sb0; j < sbe; ++j) {
+            int kj = k0 + j;
+            cz* col = Lp + (int64_t)kj * ld;
+            double best = -1.0;
+            int bi = kj;
+            for (int r = k0 + tid; r < p; r += PANEL_NT) {
+                if (r < kj) continue;
+                double a = cz_abs1(col[r]);
+                if (a > best) { best = a; bi = r; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                double ob = __shfl_xor(best, off);
+                int oi = __shfl_xor(bi, off);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                double bb = s_val[0];
+                int ii = s_idx[0];
+                for (int w = 1; w < PANEL_NT / 64; ++w)
+                    if (s_val[w] > bb || (s_val[w] == bb && s_idx[w] < ii)) { bb = s_val[w]; ii = s_idx[w]; }
+                if (bb < 0) ii = kj;
+                s_piv = ii;
+                piv[(int64_t)k * npiv + f.c0 + kj] = ii;
+            }
+            __syncthreads();
+            int pr = s_piv;
+            if (pr != kj && tid < b) {      // interchange across the whole panel
+                cz* c2 = Lp + (int64_t)(k0 + tid) * ld;
+                cz a = c2[kj], bb = c2[pr];
+                c2[kj] = bb; c2[pr] = a;
+            }
+            __syncthreads();
+            cz pv = col[kj];
+            double pa = cz_abs1(pv);
+            if (!(pa >= tiny_k)) {   // static pivot perturbation (also catches NaN)
+                pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+                if (tid == 0) { col[kj] = pv; atomicAdd(nperturb + k, 1); }
+            }
+            cz inv = cz_inv(pv);
+            if (tid > j && tid < sbe) s_urow[tid] = Lp[(int64_t)(k0 + tid) * ld + kj];
+            __syncthreads();
+            for (int r = k0 + tid; r < ld; r += PANEL_NT) {     // scale + rank-1 update inside the sub-panel only
+                if (r <= kj) continue;
+                cz l = cz_mul(col[r], inv);
+                col[r] = l;
+                for (int jj = j + 1; jj < sbe; ++jj) {
+                    cz* d = Lp + (int64_t)(k0 + jj) * ld + r;
+                    cz v = *d;
+                    cz_msub(v, l, s_urow[jj]);
+                    *d = v;
+                }
+            }
+            __syncthreads();
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            double ob = __shfl_xor(best, off);
-            int oi = __shfl_xor(bi, off);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+        int nt = b - sbe;                 // trailing panel columns
+        if (nt <= 0) continue;
+        int sw = sbe - sb0;
+        // (a) U rows of the trailing columns: forward substitution with the unit-lower sw x sw block
+        for (int idx = tid; idx < sw * sw; idx += PANEL_NT) { int i = idx % sw, q = idx / sw; s_l[i][q] = Lp[(int64_t)(k0 + sb0 + q) * ld + k0 + sb0 + i]; }
         __syncthreads();
-        if (tid == 0) {
-            double bb = s_val[0];
-            int ii = s_idx[0];
-            for (int w = 1; w < PANEL_NT / 64; ++w)
-                if (s_val[w] > bb || (s_val[w] == bb && s_idx[w] < ii)) { bb = s_val[w]; ii = s_idx[w]; }
-            if (bb < 0) ii = kj;
-            s_piv = ii;
-            piv[(int64_t)k * npiv + f.c0 + kj] = ii;
+        if (tid < nt) {
+            cz* c2 = Lp + (int64_t)(k0 + sbe + tid) * ld + k0 + sb0;
+            cz x[PANEL_SB];
+#pragma unroll
+            for (int i = 0; i < PANEL_SB; ++i) x[i] = i < sw ? c2[i] : cz_make(0, 0);
+#pragma unroll
+            for (int i = 1; i < PANEL_SB; ++i)
+#pragma unroll
+                for (int q = 0; q < i; ++q) if (i < sw) cz_msub(x[i], s_l[i][q], x[q]);
+#pragma unroll
+            for (int i = 0; i < PANEL_SB; ++i) if (i < sw) { c2[i] = x[i]; s_u[i][tid] = x[i]; }
         }
         __syncthreads();
-        int pr = s_piv;
-        if (pr != kj && tid < b) {
-            cz* c2 = Lp + (int64_t)(k0 + tid) * ld;
-            cz a = c2[kj], bb = c2[pr];
-            c2[kj] = bb; c2[pr] = a;
-        }
-        __syncthreads();
-        cz pv = col[kj];
-        double pa = cz_abs1(pv);
-        if (!(pa >= tiny_k)) {   // static pivot perturbation (also catches NaN)
-            pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
-            if (tid == 0) { col[kj] = pv; atomicAdd(nperturb + k, 1); }
-        }
-        cz inv = cz_inv(pv);
-        if (tid > j && tid < b) s_urow[tid] = Lp[(int64_t)(k0 + tid) * ld + kj];
-        __syncthreads();
-        for (int r = k0 + tid; r < ld; r += PANEL_NT) {
-            if (r <= kj) continue;
-            cz l = cz_mul(col[r], inv);
-            col[r] = l;
-            for (int jj = j + 1; jj < b; ++jj) {
-                cz* d = Lp + (int64_t)(k0 + jj) * ld + r;
+        // (b) rows below the sub-panel: one pass over the trailing columns with a rank-sw update
+        for (int r = k0 + sbe + tid; r < ld; r += PANEL_NT) {
+            cz l[PANEL_SB];
+#pragma unroll
+            for (int q = 0; q < PANEL_SB; ++q) l[q] = q < sw ? Lp[(int64_t)(k0 + sb0 + q) * ld + r] : cz_make(0, 0);
+            for (int jj = 0; jj < nt; ++jj) {
+                cz* d = Lp + (int64_t)(k0 + sbe + jj) * ld + r;
                 cz v = *d;
-                cz_msub(v, l, s_urow[jj]);
+#pragma unroll
+                for (int q = 0; q < PANEL_SB; ++q) cz_msub(v, l[q], s_u[q][jj]);
                 *d = v;
             }
         }
