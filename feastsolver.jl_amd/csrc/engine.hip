@@ -445,10 +445,8 @@ int Engine::factorize() {
         int par = d & 1;
         cz* cbp = d_cb_[par].p;
         int64_t cbs = std::max<int64_t>(1, S.cb_size[par]);
-        if (S.cb_used[d] > 0)
-            HIPCHK(hipMemset2DAsync(cbp, (size_t)cbs * sizeof(cz), 0, (size_t)S.cb_used[d] * sizeof(cz), Kloc, stream_));
         launch_extend_add(stream_, dsym_, tl + F.extend.off, F.extend.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
-                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc);
+                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 0);
         for (FactorStep& st : F.steps) {
             launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc);
             launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
@@ -456,6 +454,8 @@ int Engine::factorize() {
             launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
         }
         launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
+        launch_extend_add(stream_, dsym_, tl + F.extend.off, F.extend.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
+                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
         launch_rowperm(stream_, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
         launch_block_inverse(stream_, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(stream_, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);

@@ -77,12 +77,15 @@ void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz
 __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                     const int* __restrict__ rel, const int* __restrict__ child_idx,
                                                     cz* fact, int64_t fs, cz* cbp, int64_t cbsp, const cz* __restrict__ cbc,
-                                                    int64_t cbsc) {
+                                                    int64_t cbsc, int phase) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
     int r0 = t.a * 64, q0 = t.b * 64;
+    // phase 0 (before the front is factorised): targets in the L / U12 panels;
+    // phase 1 (after the Schur complement has been WRITTEN, CB = -L21 U12): targets in the contribution block
+    if (phase == 0 ? (r0 >= p && q0 >= p) : (r0 + 64 <= p || q0 + 64 <= p)) return;
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* F12 = fact + (int64_t)k * fs + f.f12;
     cz* CB = cbp + (int64_t)k * cbsp + f.cb;
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ f
                 int i = ia + idx % nr, j = ja + idx / nr;
                 cz v = src[i + (int64_t)j * uc];
                 int r = rc[i], q = rc[j];
+                if ((r >= p && q >= p) != (phase == 1)) continue;
                 cz* d;
                 if (q < p) d = Lp + r + (int64_t)q * ld;
                 else if (r < p) d = F12 + r + (int64_t)(q - p) * p;
@@ -113,10 +117,10 @@ __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ f
 }
 
 void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,
-                       cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K) {
+                       cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K, int phase) {
     if (ntiles <= 0) return;
     hipLaunchKernelGGL(k_extend_add, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, fact, fs,
-                       cb_parent, cbs_parent, cb_child, cbs_child);
+                       cb_parent, cbs_parent, cb_child, cbs_child, phase);
 }
 
 // ---------------------------------------------------------------------------
@@ -397,12 +401,14 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
             for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].y, ar, ci[nt], 0, 0, 0);
         }
     }
-    // epilogue: all 16 read-modify-write loads issued together, then stored
+    // epilogue: all 16 read-modify-write loads issued together, then stored.  The contribution block
+    // (kind 2) is written, not updated: CB = -L21 U12, the children's blocks are added afterwards.
     cz old[4][4];
+    const bool rmw = (t.a != 2);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) old[nt][r] = C[mrow_c + (int64_t)min(n0 + nt * 16 + lk + 4 * r, N - 1) * ldc];
+        for (int r = 0; r < 4; ++r) old[nt][r] = rmw ? C[mrow_c + (int64_t)min(n0 + nt * 16 + lk + 4 * r, N - 1) * ldc] : cz_make(0, 0);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
