@@ -280,8 +280,9 @@ void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles,
 // U row block: columns right of the panel (inside the pivot block and U12)
 // get x <- L11^-1 x, one thread per column.
 // ---------------------------------------------------------------------------
-__global__ void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs) {
+__global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs) {
     __shared__ cz s_l[FACT_NB * FACT_NB];
+    __shared__ cz s_x[128][FACT_NB + 1];          // the slab of 128 columns x b rows, staged with coalesced accesses
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -292,17 +293,29 @@ __global__ void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__
         int i = idx % b, kk = idx / b;
         s_l[i + kk * FACT_NB] = Lp[(k0 + i) + (int64_t)(k0 + kk) * ld];
     }
+    int nin = p - k0 - b, ncol = nin + u;
+    int v0 = t.a * 128;
+    auto colptr = [&](int v) -> cz* {
+        return (v < nin) ? fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0
+                         : fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
+    };
+    for (int idx = threadIdx.x; idx < 128 * b; idx += 128) {     // b consecutive threads read one column's b rows
+        int i = idx % b, c = idx / b;
+        if (v0 + c < ncol) s_x[c][i] = colptr(v0 + c)[i];
+    }
     __syncthreads();
-    int v = t.a * 128 + threadIdx.x;
-    int nin = p - k0 - b;
-    if (v >= nin + u) return;
-    cz* x;
-    if (v < nin) x = fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0;
-    else x = fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
-    for (int i = 1; i < b; ++i) {
-        cz xi = x[i];
-        for (int kk = 0; kk < i; ++kk) cz_msub(xi, s_l[i + kk * FACT_NB], x[kk]);
-        x[i] = xi;
+    int c = threadIdx.x;
+    if (v0 + c < ncol) {
+        for (int i = 1; i < b; ++i) {
+            cz xi = s_x[c][i];
+            for (int kk = 0; kk < i; ++kk) cz_msub(xi, s_l[i + kk * FACT_NB], s_x[c][kk]);
+            s_x[c][i] = xi;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 128 * b; idx += 128) {
+        int i = idx % b, cc = idx / b;
+        if (v0 + cc < ncol) colptr(v0 + cc)[i] = s_x[cc][i];
     }
 }
 
