@@ -170,7 +170,9 @@ def main():
         traffic = None          # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/)
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath) and args.grid == 46 and args.stencil == 19 and world == 1:
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+            # the PMC run uses two streams (twice the launches of the single-stream profiling sweep): normalise per step
+            per_step = json.load(open(tpath)).get("traffic_bytes_per_contour_step")
+            traffic = per_step / max(1, pa["launches"]) if per_step else None
         dom_gbs = pa["bytes"] / (pa["ms"] * 1e-3) / 1e9
         dom_tf = pa["flops"] / (pa["ms"] * 1e-3) / 1e12
         out = {
