@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -588,9 +589,10 @@ int Engine::orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
             if (info) return fail(FEASTHIP_ENUM, "orthonormalize: Gram matrix not positive definite");
             if (pass == 1) pass = 0;   // one more clean-up pass after a shifted one
         }
-        // Rt <- R * Rt
-        matmul(m, Gc.data(), Rt.data(), Rn.data());
-        Rt.swap(Rn);
+        if (Rtotal) {   // Rt <- R * Rt (only the Beyn step needs the accumulated factor)
+            matmul(m, Gc.data(), Rt.data(), Rn.data());
+            Rt.swap(Rn);
+        }
         trtri_upper(m, Gc.data());
         HIPCHK(hipMemcpyAsync(dM, Gc.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
         launch_ts_gemm(stream_, n, m, ldw, Q, dM, tmp);
@@ -635,6 +637,7 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     HIPCHK(hipStreamSynchronize(stream_));
     // Julia's eigen! takes the Hermitian(-definite) LAPACK path for exactly Hermitian input; here the projected
     // matrices are Hermitian up to rounding whenever A, B are, and the same path is taken below 1e-13.
+    auto th0 = std::chrono::steady_clock::now();
     int info = 1;
     bool herm = hermitian_defect(m, Aq.data()) <= 1e-13 && (b_is_identity || hermitian_defect(m, Bq.data()) <= 1e-13);
     if (herm) {
@@ -644,6 +647,9 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     if (info) info = b_is_identity ? eig_general(m, Aq.data(), lam.data(), Xq.data())     // :45
                                    : eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data());   // :122
     if (info) return fail(FEASTHIP_ENUM, "rr_step: reduced eigenproblem failed to converge");
+    if (getenv("FEASTHIP_RR_TRACE"))
+        fprintf(stderr, "[feasthip] reduced eigenproblem (m=%d, %s): %.3f ms host\n", m, herm ? "hermitian" : "general",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
     // update_R! normalises the columns of X = Q Xq (src/utils.jl:113); Q is orthonormal, so ||X_j|| = ||Xq_j||
     // and the normalisation is applied to the m x m Xq on the host (no extra pass over the n x m block)
     for (int j = 0; j < m; ++j) {

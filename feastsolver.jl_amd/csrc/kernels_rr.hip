@@ -93,7 +93,7 @@ void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, c
 // workgroup reduces GRAM_ROWS rows; wave jobs are (16-row i tile) x (64-col j group),
 // operands are read straight from the row-major blocks (16 consecutive columns of a
 // row per lane group = 256 B segments).  Stage 2 sums the partials in a fixed order.
-constexpr int GRAM_ROWS = 256;
+constexpr int GRAM_ROWS = 512;
 
 size_t gram_scratch_elems(int n, int m) {
     size_t chunks = ((size_t)n + GRAM_ROWS - 1) / GRAM_ROWS;
