@@ -250,10 +250,13 @@ bool Engine::build_plans() {
         F.fronts.off = (int64_t)lists.size();
         for (int s : lv) lists.push_back(s);
         F.fronts.count = (int)lv.size();
-        // solve-ready finalisation (block inverses + panel scaling)
+        // solve-ready finalisation (block inverses, coupling into super blocks, panel scaling)
         F.binv.off = (int64_t)tiles.size();
-        for (int s : lv) for (int t = 0; t < cdiv(S.p(s), SOLVE_NB); ++t) tiles.push_back({s, t, 0, 0});
+        for (int s : lv) for (int t = 0; t < cdiv(S.p(s), INV_NB); ++t) tiles.push_back({s, t, 0, 0});
         F.binv.count = (int)(tiles.size() - F.binv.off);
+        F.couple.off = (int64_t)tiles.size();
+        for (int s : lv) for (int t = 0; t < cdiv(S.p(s), SOLVE_NB); ++t) if (S.p(s) - t * SOLVE_NB > INV_NB) tiles.push_back({s, t, 0, 0});
+        F.couple.count = (int)(tiles.size() - F.couple.off);
         F.scale.off = (int64_t)tiles.size();
         for (int s : lv) for (int t = 0; t < cdiv(S.p(s), SOLVE_NB); ++t) {
             int p = S.p(s), ld = p + S.u(s), k0 = t * SOLVE_NB, b = std::min(SOLVE_NB, p - k0);
@@ -290,7 +293,8 @@ bool Engine::build_plans() {
         for (int s : lv) {
             int p = S.p(s), u = S.u(s);
             for (int a = 0; a < cdiv(u, 16 * sl2); ++a) tiles.push_back({s, 1 | (sl2 << 8), a, 0});
-            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t) tiles.push_back({s, 2, t, 0});
+            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t)
+                for (int rt = 0; rt < cdiv(std::min(SOLVE_NB, p - t * SOLVE_NB), 64); ++rt) tiles.push_back({s, 2, t, rt});
             V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, SOLVE_NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, SOLVE_NB);
         }
         V.f2.count = (int)(tiles.size() - V.f2.off);
@@ -318,7 +322,8 @@ bool Engine::build_plans() {
         V.b3.off = (int64_t)tiles.size();
         for (int s : lv) {
             int p = S.p(s);
-            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t) tiles.push_back({s, 5, t, 0});
+            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t)
+                for (int rt = 0; rt < cdiv(std::min(SOLVE_NB, p - t * SOLVE_NB), 64); ++rt) tiles.push_back({s, 5, t, rt});
             V.b3.bytes += 0.5 * p * std::min(p, SOLVE_NB) * 16.0; V.b3.flops += 0.5 * p * std::min(p, SOLVE_NB);
         }
         V.b3.count = (int)(tiles.size() - V.b3.off);
@@ -459,6 +464,7 @@ int Engine::factorize() {
                           std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
         launch_rowperm(stream_, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
         launch_block_inverse(stream_, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
+        launch_couple_inverse(stream_, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(stream_, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
     }
     HIPCHK(hipEventRecord(ev1_, stream_));
@@ -810,7 +816,7 @@ int Engine::contour_step(int refactor) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);   // :68-70
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);   // :68-70
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
@@ -829,7 +835,7 @@ int Engine::profile_solve(ProfileRow* rows) {
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     HIPCHK(hipEventRecord(a, stream_));
-    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
     HIPCHK(hipEventRecord(b, stream_));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0;
@@ -867,7 +873,7 @@ int Engine::nl_contour_step(int first) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(first ? d_X_.p : d_R_.p);               // :41 / :49
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, Qp(),
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, Qp(),
                       Qp() + (size_t)n * ldw);
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
@@ -1069,7 +1075,7 @@ int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
     std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
     for (int j = 0; j < ldw; ++j) e0[j] = 1.0;        // node 0 only
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_accumulate(stream_, dsym_, d_X_.p, d_Y_.p, (int64_t)n * ldw, ldw, 1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, 1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
     launch_rm_to_cm(stream_, n, m0, ldw, d_T1_.p, d_io_.p, n);
     if (ldy == n) HIPCHK(hipMemcpyAsync(Y, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
     else HIPCHK(hipMemcpy2DAsync(Y, (size_t)ldy * sizeof(cz), d_io_.p, (size_t)n * sizeof(cz), (size_t)n * sizeof(cz), m0, hipMemcpyDeviceToHost, stream_));

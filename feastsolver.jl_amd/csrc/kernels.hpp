@@ -5,7 +5,8 @@
 namespace feasthip {
 
 constexpr int FACT_NB = 32;     // panel width of the blocked front factorisation
-constexpr int SOLVE_NB = 64;    // diagonal block of the blocked triangular solves
+constexpr int SOLVE_NB = 128;   // diagonal (super)block of the inverse-based block substitution
+constexpr int INV_NB = 64;      // size of the directly inverted triangular blocks (two are coupled into a super block)
 constexpr int LDS_COLS = 64;    // block-vector columns processed per workgroup pass
 
 struct DevSym {          // device copies of the symbolic structure
@@ -35,6 +36,7 @@ void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntil
                     cz* cb, int64_t cbs, int K);
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled
 void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
+void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* piv, int* rowperm,
                     int* rowinv, int K);
@@ -49,10 +51,10 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // Tile.a = kind, Tile.b = row tile (or diagonal block), Tile.c = step block index:
 //   0 F1  forward, rows of the pivot block below diagonal block c:   W_r -= P_rc W_c
 //   1 F2a forward, contribution rows:                                  C_I  = -P21 W_J         (K = p)
-//   2 F2b forward, diagonal block b:                                   Y_b  = inv(L_bb) W_b
-//   3 B1  backward, pivot rows:                                        Y_J -= U12 Y[struct]    (K = u, gathered)
+//   2 F2b forward, diagonal super block b, row tile c:                 Y_b  = inv(L_bb) W_b
+//   3 B1  backward, pivot rows:                                        Y_J -= U12 W[struct]    (K = u, gathered; final x lives in W)
 //   4 B2  backward, rows above diagonal block c:                       Y_r -= PU_rc Y_c
-//   5 B3  backward, diagonal block b (in place):                       Y_b  = inv(U_bb) Y_b
+//   5 B3  backward, diagonal super block b, row tile c:                W_b  = inv(U_bb) Y_b
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false);
 // (gather = true for launches made only of kind-3 tiles: V rows are gathered through struct_idx)

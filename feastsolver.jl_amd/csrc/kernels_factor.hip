@@ -449,13 +449,13 @@ void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntil
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void k_block_inverse(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                        cz* fact, int64_t fs) {
-    __shared__ cz T[SOLVE_NB][SOLVE_NB + 1];
-    __shared__ cz O[SOLVE_NB][SOLVE_NB + 1];
+    __shared__ cz T[INV_NB][INV_NB + 1];
+    __shared__ cz O[INV_NB][INV_NB + 1];
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
-    int ld = f.p + f.u, k0 = t.a * SOLVE_NB;
-    int b = min(SOLVE_NB, f.p - k0);
+    int ld = f.p + f.u, k0 = t.a * INV_NB;
+    int b = min(INV_NB, f.p - k0);
     cz* D = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;
     for (int idx = threadIdx.x; idx < b * b; idx += 128) { int i = idx % b, j = idx / b; T[i][j] = D[i + (int64_t)j * ld]; }
     __syncthreads();
@@ -488,13 +488,71 @@ void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, in
     hipLaunchKernelGGL(k_block_inverse, dim3(ntiles, K), dim3(128), 0, st, S.fr, tiles, fact, fs);
 }
 
-// rows of block column t (tile.a) outside the diagonal block: 64-row tile (tile.b) of the rows above
-// (tile.c = 0: row <- row * inv(U_tt)) or below (tile.c = 1: row <- row * inv(L_tt)) the diagonal block.
-// In place: every wave reads its 16 rows completely before it writes them.  f64 MFMA, same
-// transposed-tile layout as k_gemm_nn.
+// Couple two inverted INV_NB blocks of a SOLVE_NB super block:  inv([L1 0; C L2]) = [I1 0; -I2 C I1  I2] and
+// inv([U1 D; 0 U2]) = [J1  -J1 D J2; 0 J2], in place.  One workgroup per (front, super block, node).
+__global__ __launch_bounds__(256) void k_couple_inverse(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                                        cz* fact, int64_t fs) {
+    __shared__ cz M0[INV_NB][INV_NB + 1];
+    __shared__ cz M1[INV_NB][INV_NB + 1];
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int ld = f.p + f.u, k0 = t.a * SOLVE_NB;
+    int b2 = min(INV_NB, f.p - k0 - INV_NB);        // size of the second block (the tile exists only if b2 > 0)
+    cz* D0 = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;      // super block origin
+    auto at = [&](int i, int j) -> cz& { return D0[i + (int64_t)j * ld]; };
+    int tid = threadIdx.x;
+    // ---- lower: C (rows 64.., cols 0..63) <- -I2 (C I1)
+    for (int idx = tid; idx < b2 * INV_NB; idx += 256) { int i = idx % b2, j = idx / b2; M0[i][j] = at(INV_NB + i, j); }
+    __syncthreads();
+    for (int idx = tid; idx < b2 * INV_NB; idx += 256) {
+        int i = idx % b2, j = idx / b2;
+        cz s = M0[i][j];                                   // I1[j][j] = 1
+        for (int q = j + 1; q < INV_NB; ++q) cz_madd(s, M0[i][q], at(q, j));
+        M1[i][j] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < b2 * INV_NB; idx += 256) {
+        int i = idx % b2, j = idx / b2;
+        cz s = M1[i][j];                                   // I2[i][i] = 1
+        for (int q = 0; q < i; ++q) cz_madd(s, at(INV_NB + i, INV_NB + q), M1[q][j]);
+        M0[i][j] = cz_make(-s.x, -s.y);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < b2 * INV_NB; idx += 256) { int i = idx % b2, j = idx / b2; at(INV_NB + i, j) = M0[i][j]; }
+    __syncthreads();
+    // ---- upper: D (rows 0..63, cols 64..) <- -J1 (D J2)
+    for (int idx = tid; idx < INV_NB * b2; idx += 256) { int i = idx % INV_NB, j = idx / INV_NB; M0[i][j] = at(i, INV_NB + j); }
+    __syncthreads();
+    for (int idx = tid; idx < INV_NB * b2; idx += 256) {
+        int i = idx % INV_NB, j = idx / INV_NB;
+        cz s = cz_make(0, 0);
+        for (int q = 0; q <= j; ++q) cz_madd(s, M0[i][q], at(INV_NB + q, INV_NB + j));
+        M1[i][j] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < INV_NB * b2; idx += 256) {
+        int i = idx % INV_NB, j = idx / INV_NB;
+        cz s = cz_make(0, 0);
+        for (int q = i; q < INV_NB; ++q) cz_madd(s, at(i, q), M1[q][j]);
+        M0[i][j] = cz_make(-s.x, -s.y);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < INV_NB * b2; idx += 256) { int i = idx % INV_NB, j = idx / INV_NB; at(i, INV_NB + j) = M0[i][j]; }
+}
+
+void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_couple_inverse, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, fact, fs);
+}
+
+// Rows of super-block column T (tile.a) outside the diagonal super block: 64-row tile (tile.b) of the rows
+// above (tile.c = 0: row <- row * inv(U_TT)) or below (tile.c = 1: row <- row * inv(L_TT)).  In place: the
+// two 64-column halves are produced in an order that never overwrites an input that is still needed, and every
+// wave reads its 16 rows completely before it writes them.  f64 MFMA, transposed-tile layout of k_gemm_nn.
 __global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                       cz* fact, int64_t fs) {
-    __shared__ cz Bs[SOLVE_NB][65];      // Bs[k][n] = Inv[k][n]
+    __shared__ cz Bs[SOLVE_NB][65];      // Bs[k][n] = Inv[kfirst + k][ncol0 + n]
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -502,47 +560,65 @@ __global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__
     int b = min(SOLVE_NB, f.p - k0);
     bool below = t.c != 0;
     cz* Lp = fact + (int64_t)k * fs + f.lp;
-    for (int idx = threadIdx.x; idx < SOLVE_NB * SOLVE_NB; idx += 256) {
-        int i = idx % SOLVE_NB, j = idx / SOLVE_NB;
-        cz v = cz_make(0, 0);
-        if (i < b && j < b) {
-            if (below) { if (i > j) v = Lp[(k0 + i) + (int64_t)(k0 + j) * ld]; else if (i == j) v = cz_make(1, 0); }
-            else if (i <= j) v = Lp[(k0 + i) + (int64_t)(k0 + j) * ld];
-        }
-        Bs[i][j] = v;
-    }
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int rbase = below ? k0 + b + t.b * 64 : t.b * 64;
     int rend = below ? ld : k0;
     int mrow = rbase + wave * 16 + li;
     bool mok = mrow < rend;
-    cz av[SOLVE_NB / 4];
-#pragma unroll
-    for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
-        int kk = ks * 4 + lk;
-        av[ks] = (mok && kk < b) ? Lp[mrow + (int64_t)(k0 + kk) * ld] : cz_make(0, 0);
-    }
-    __syncthreads();
-    d4 cr[4], ci[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
-#pragma unroll
-    for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
-        int kk = ks * 4 + lk;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            cz bv = Bs[kk][nt * 16 + li];
-            cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);     // D[n][m] = sum_k Inv[k][n] A[m][k]
-        }
-    }
-    if (mok) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int gn = nt * 16 + lk + 4 * r;
-                if (gn < b) Lp[mrow + (int64_t)(k0 + gn) * ld] = cz_make(cr[nt][r], ci[nt][r]);
+    int mrow_c = min(mrow, rend - 1);
+    int nhalf = (b > INV_NB) ? 2 : 1;
+    for (int pass = 0; pass < nhalf; ++pass) {
+        // lower: first the left half (needs both halves of the row), then the right half (needs only itself);
+        // upper: first the right half (needs both), then the left half.
+        int h = below ? pass : (nhalf - 1 - pass);
+        int ncol0 = h * INV_NB, ncols = min(INV_NB, b - ncol0);
+        int kfirst = below ? ncol0 : 0;
+        int klen = below ? b - ncol0 : ncol0 + ncols;
+        __syncthreads();
+        for (int idx = tid; idx < SOLVE_NB * 64; idx += 256) {
+            int kk = idx % SOLVE_NB, nn = idx / SOLVE_NB;
+            cz v = cz_make(0, 0);
+            if (kk < klen && nn < ncols) {
+                int gi = kfirst + kk, gj = ncol0 + nn;          // element (gi, gj) of the super-block inverse
+                if (below) { if (gi > gj) v = Lp[(k0 + gi) + (int64_t)(k0 + gj) * ld]; else if (gi == gj) v = cz_make(1, 0); }
+                else if (gi <= gj) v = Lp[(k0 + gi) + (int64_t)(k0 + gj) * ld];
             }
+            Bs[kk][nn] = v;
+        }
+        cz av[SOLVE_NB / 4];
+#pragma unroll
+        for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
+            int kk = ks * 4 + lk;
+            cz v = Lp[mrow_c + (int64_t)(k0 + kfirst + min(kk, klen - 1)) * ld];
+            bool keep = mok && kk < klen;
+            av[ks].x = keep ? v.x : 0.0;
+            av[ks].y = keep ? v.y : 0.0;
+        }
+        __syncthreads();
+        d4 cr[4], ci[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+        int nks = (klen + 3) >> 2;
+#pragma unroll
+        for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
+            if (ks < nks) {
+                int kk = ks * 4 + lk;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    cz bv = Bs[kk][nt * 16 + li];
+                    cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);     // D[n][m] = sum_k Inv[k][n] A[m][k]
+                }
+            }
+        }
+        if (mok) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int gn = nt * 16 + lk + 4 * r;
+                    if (gn < ncols) Lp[mrow + (int64_t)(k0 + ncol0 + gn) * ld] = cz_make(cr[nt][r], ci[nt][r]);
+                }
+        }
     }
 }
 

@@ -258,10 +258,10 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     g.out = Yk; g.orow_shift = f.c0;
     if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
     else if (kind == 1) { g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2; }
-    else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
-    else if (kind == 3) { g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Yk; }
+    else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
+    else if (kind == 3) { g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk; }
     else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
-    else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; }
+    else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk; }
     int trows = min(th, g.rend - g.rbase);
     if (trows <= 16) apply_body<GATHER, 1>(g, Vs, cg, ldw);
     else if (trows <= 32) apply_body<GATHER, 2>(g, Vs, cg, ldw);
