@@ -362,6 +362,52 @@ def test_distributed_driver_rccl_world1(gpu, pkg, wl, golden):
     assert abs(info["nit"] - g["history"][-1][0]) <= 1
 
 
+def test_bitwise_reproducible_and_stream_independent(gpu, pkg, wl):
+    """Every reduction has a fixed order (no float atomics): the moment Q is bit-identical from run to run,
+    and does not depend on how the contour nodes are spread over HIP streams."""
+    import os
+    w = wl.c3_sparse_generalized(12, 19, 64)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    outs = []
+    for streams in ("2", "2", "1", "4"):
+        os.environ["FEASTHIP_STREAMS"] = streams
+        h = pkg.FeastHandle(0)
+        h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+        h.set_contour(con)
+        h.factorize()
+        h.set_x(w["X0"])
+        h.rr_step()
+        h.contour_step()
+        outs.append(h.get_block(2).copy())
+        h.close()
+    os.environ.pop("FEASTHIP_STREAMS", None)
+    for q in outs[1:]:
+        assert np.array_equal(q, outs[0])
+
+
+def test_node_shards_sum_to_full_moment(gpu, pkg, wl):
+    """two handles owning the even / odd nodes (the 2-GPU layout): their partial moments add up to the
+    single-handle moment -- the quantity the RCCL all-reduce sums"""
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+
+    def moment(first, stride):
+        h = pkg.FeastHandle(0)
+        h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+        h.set_contour(con)
+        h.set_node_shard(first, stride)
+        h.factorize()
+        h.set_x(w["X0"])
+        h.rr_step()
+        h.contour_step()
+        q = h.get_block(2).copy()
+        h.close()
+        return q
+
+    full, even, odd = moment(0, 1), moment(0, 2), moment(1, 2)
+    assert np.abs(even + odd - full).max() <= 1e-13 * np.abs(full).max()
+
+
 def test_error_codes(gpu, pkg, wl):
     with pytest.raises(ValueError, match="must be square"):
         pkg.feast(wl.rand_x0(5, 2, 1), np.zeros((5, 4)))
