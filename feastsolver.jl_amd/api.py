@@ -323,6 +323,26 @@ def nlfeast(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, store=Tr
     return lam, Xw, res
 
 
+def contour_estimate_eig(A, contour, B=None, *, samples=None, X=None, device=0, seed=None):
+    """contour_estimate_eig(A, contour, B=I; samples)  src/stochastic.jl:2-33: stochastic estimate of the number of
+    eigenvalues inside the contour.  ``X`` (n x samples complex Gaussian block) may be passed for reproducibility."""
+    n = A.shape[0]
+    if X is None:
+        m = min(100, n) if samples is None else int(samples)
+        rng = np.random.default_rng(seed)
+        X = (rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))) / np.sqrt(2.0)     # randn(ComplexF64, N, m)
+    X = np.asfortranarray(X, dtype=np.complex128)
+    h = FeastHandle(device)
+    try:
+        h.set_terms([A, B], scales=[1.0, -1.0])
+        h.set_contour(contour)
+        est = C.c_double(0.0)
+        h._ck(h.lib.feasthip_estimate_count(h.h, _vp(X), X.shape[0], X.shape[1], C.byref(est)))
+    finally:
+        h.close()
+    return est.value
+
+
 # ---------------------------------------------------------------------------
 # factorizer / left_divider / finalize! seam  (src/utils.jl:173-179)
 # ---------------------------------------------------------------------------

@@ -108,6 +108,10 @@ int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int it
     GUARD(h) return h->e->nlfeast_run(X, n, m0, iter, eps, spurious, lambda, res, inside, nit); ENDGUARD(h)
 }
 
+int feasthip_estimate_count(feasthip_handle_t h, const void* X, int64_t n, int m0, double* est) {
+    GUARD(h) return h->e->estimate_count(X, n, m0, est); ENDGUARD(h)
+}
+
 int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     GUARD(h)
     if (!o) return FEASTHIP_EARG;

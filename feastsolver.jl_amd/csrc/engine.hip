@@ -826,6 +826,34 @@ int Engine::contour_step(int refactor) {
     return 0;
 }
 
+// contour_estimate_eig (src/stochastic.jl:2-33): est = real( sum_k w_k tr(X^H (z_k B - A)^-1 X) ) / samples.
+// The engine factorises T(z) = A - z B, so (z_k B - A)^-1 X = -Y_k; the node sum is the usual accumulation
+// kernel with weights -w_k and the trace comes from the MFMA Gram kernel.  Local nodes only (partial sum).
+int Engine::estimate_count(const void* X, int64_t n_, int m0_, double* est) {
+    if (!est) return fail(FEASTHIP_EARG, "estimate_count: null output");
+    int r = set_x(X, n_, m0_);
+    if (r) return r;
+    if (!factored_) { r = factorize(); if (r < 0) return r; }
+    HIPCHK(hipSetDevice(device_));
+    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
+    for (int kk = 0; kk < Kloc; ++kk) for (int j = 0; j < m0; ++j) e0[(size_t)kk * ldw + j] = -weights_[local_[kk]];
+    HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    r = solve_all(d_X_.p);
+    if (r) return r;
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    cz* dG = d_small_.p;
+    launch_gram(stream_, n, m0, ldw, d_X_.p, d_T1_.p, d_gram_scratch_.p, dG);
+    std::vector<zc> G((size_t)m0 * m0);
+    HIPCHK(hipMemcpyAsync(G.data(), dG, G.size() * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    zc tr = 0;
+    for (int j = 0; j < m0; ++j) tr += G[j + (size_t)j * m0];
+    *est = tr.real() / (double)m0;
+    return 0;
+}
+
 int Engine::profile_solve(ProfileRow* rows) {
     if (!have_x_ || !factored_) return fail(FEASTHIP_ESTATE, "profile_solve: needs a factorised problem and iteration state");
     HIPCHK(hipSetDevice(device_));

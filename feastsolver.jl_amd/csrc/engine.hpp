@@ -88,6 +88,7 @@ public:
                     uint8_t* inside, int* nit);
     // fine-grained seam: Y = T^-1 R for the single factorised matrix of this engine (node 0)
     int ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
+    int estimate_count(const void* X, int64_t n, int m0, double* est);
     int profile_solve(ProfileRow* rows /*[8]*/);
     std::vector<double> prof_detail;   // per launch: class, ms, bytes, flops, tiles (filled by profile_solve)
 

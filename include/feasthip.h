@@ -126,6 +126,11 @@ int feasthip_feast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter
 int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps,
                          double spurious, double* lambda, double* res, uint8_t* inside, int* nit);
 
+/* ---- adjacent caller of the same seam: contour_estimate_eig, src/stochastic.jl:2-33.
+ * est = real(sum_k w_k tr(X' (z_k B - A)^-1 X)) / m0 over the LOCAL nodes of this handle, X n x m0 random block
+ * supplied by the caller (randn(ComplexF64, N, samples) in the reference). */
+int feasthip_estimate_count(feasthip_handle_t h, const void* X, int64_t n, int m0, double* est);
+
 /* ---- fine-grained seam: factorizer / left_divider / finalize!  (src/utils.jl:173-179).
  * F = factorizer(C): C is copied, never aliased (src/feast.jl:29-36).
  * left_divider(Y, F, R): Y = C^-1 R, R untouched (src/feast.jl:62).  Thread-safe

@@ -358,6 +358,21 @@ def nlfeast(T, X, nodes, iter, c=0j, r=1.0, eps=10e-12, store=True, spurious=1e-
     return lam, X, res
 
 
+def contour_estimate_eig(A, contour, B=None, X=None, samples=None, rng=None):
+    """src/stochastic.jl:2-33: est = real(sum_k w_k tr(X' (z_k B - A)^-1 X)) / samples."""
+    n = A.shape[0]
+    if X is None:
+        m = min(100, n) if samples is None else samples
+        rng = np.random.default_rng() if rng is None else rng
+        X = (rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))) / np.sqrt(2.0)
+    Bs = _eye_like(A, n) if B is None else B
+    est = 0.0
+    for z, w in zip(contour.nodes, contour.weights):
+        Y = lu(Bs * z - A).solve(X)                         # :24-25
+        est += np.trace(X.conj().T @ Y) * w / X.shape[1]    # :26-27
+    return float(np.real(est))
+
+
 def companion(coeffs):
     """src/companion.jl:1-28: dense companion linearisation of
     sum_j z^j coeffs[j]; returns (lam, X, res) for all N*L pairs."""

@@ -408,6 +408,19 @@ def test_node_shards_sum_to_full_moment(gpu, pkg, wl):
     assert np.abs(even + odd - full).max() <= 1e-13 * np.abs(full).max()
 
 
+def test_contour_estimate_eig(gpu, pkg, fo, wl):
+    """adjacent caller of the same seam (src/stochastic.jl): same random block -> same estimate as the oracle,
+    and the estimate is close to the true count"""
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    rng = np.random.default_rng(5)
+    X = (rng.standard_normal((512, 40)) + 1j * rng.standard_normal((512, 40))) / np.sqrt(2.0)
+    est = pkg.contour_estimate_eig(w["A"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), w["B"], X=X)
+    ref = fo.contour_estimate_eig(w["A"].astype(np.complex128), fo.circular_contour_trapezoidal(w["c"], w["r"], 16),
+                                  w["B"].astype(np.complex128), X=X)
+    assert abs(est - ref) < 1e-9 * max(1.0, abs(ref))
+    assert abs(est - w["n_inside"]) < 6.0
+
+
 def test_error_codes(gpu, pkg, wl):
     with pytest.raises(ValueError, match="must be square"):
         pkg.feast(wl.rand_x0(5, 2, 1), np.zeros((5, 4)))

@@ -89,6 +89,13 @@ def test_store_false_equals_store_true(fo, wl):
     assert np.abs(np.sort_complex(a[0]) - np.sort_complex(b[0])).max() < 1e-10
 
 
+def test_contour_estimate_counts_eigenvalues(fo):
+    # src/stochastic.jl: with enough samples the estimate approaches the number of eigenvalues inside
+    A = np.diag(np.arange(1, 41)).astype(np.complex128)
+    est = fo.contour_estimate_eig(A, fo.circular_contour_trapezoidal(5.5, 5.0, 32), samples=40, rng=np.random.default_rng(1))
+    assert abs(est - 10) < 2.5
+
+
 def test_dimension_errors(fo, wl):
     import pytest
     with pytest.raises(ValueError, match="must be square"):
