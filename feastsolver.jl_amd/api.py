@@ -277,9 +277,25 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     try:
         h.set_terms([A, B], scales=[1.0, -1.0])          # T(z) = A - z B
         h.set_contour(contour)
-        lam, res, ins, nit, warn = h.feast_run(Xw, iter, eps, store)
         if debug:
-            print(f"converged in {nit} iteration" if ins.any() and res[ins].max() < eps else f"stopped after {nit} iterations")
+            # same loop, driven from the host so that every iteration can be reported like
+            # iter_debug_print (src/utils.jl:2-42): nit, #inside, #inside below 1e-5, max residual inside
+            warn = h.factorize() if store else 0
+            h.set_x(Xw)
+            nit = 0
+            for nit in range(iter + 1):
+                lam, res, ins = h.rr_step()
+                inside_res = res[ins]
+                print(f"{nit:3d}: {int(ins.sum()):4d} ({int((inside_res < 1e-5).sum())})  "
+                      f"{(inside_res.max() if ins.any() else float('nan')):.3e}")
+                if ins.any() and inside_res.max() < eps:
+                    print(f"converged in {nit} iteration")
+                    break
+                if nit < iter:
+                    warn = max(warn, h.contour_step(refactor=not store))
+            Xw[...] = h.get_block(0)
+        else:
+            lam, res, ins, nit, warn = h.feast_run(Xw, iter, eps, store)
         if info is not None:
             info.update(h.stats())
             info.update(nit=nit, warn=warn, lam_all=lam.copy(), res_all=res.copy(), inside=ins.copy())

@@ -421,6 +421,17 @@ def test_contour_estimate_eig(gpu, pkg, fo, wl):
     assert abs(est - w["n_inside"]) < 6.0
 
 
+def test_debug_path_matches_library_loop(gpu, pkg, wl, golden, capsys):
+    """debug=True drives the same phases from the host and prints one line per iteration (iter_debug_print)"""
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    a = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True)
+    b = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, debug=True)
+    out = capsys.readouterr().out
+    assert "converged in" in out and len([l for l in out.splitlines() if ":" in l]) >= 3
+    assert np.array_equal(np.sort_complex(a[0]), np.sort_complex(b[0])) and np.array_equal(a[1], b[1])
+
+
 def test_error_codes(gpu, pkg, wl):
     with pytest.raises(ValueError, match="must be square"):
         pkg.feast(wl.rand_x0(5, 2, 1), np.zeros((5, 4)))
