@@ -17,6 +17,7 @@ struct FrontD {
     int64_t crow;             // row offset into the solve-contribution arena of depth&1
     int64_t child_ptr;
     int nchild, depth;
+    int64_t sk_off;           // row offset of this front's split-K partial sums in the scratch (backward U12 product), or -1
 };
 
 struct Tile { int f, a, b, c; };

@@ -205,6 +205,8 @@ bool Engine::build_plans() {
     int nd = S.maxdepth + 1;
     fplan_.assign(nd, FactorLevel());
     splan_.assign(nd, SolveLevel());
+    sk_off_.assign(S.nsuper, -1);
+    sk_rows_ = 0;
     std::vector<int> nchild(S.nsuper);
     for (int s = 0; s < S.nsuper; ++s) nchild[s] = (int)(S.child_ptr[s + 1] - S.child_ptr[s]);
     for (int d = 0; d < nd; ++d) {
@@ -300,11 +302,32 @@ bool Engine::build_plans() {
         V.f2.count = (int)(tiles.size() - V.f2.off);
         V.b1.off = (int64_t)tiles.size();
         int sl3 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
+        {   // few, long tiles (top of the tree): split the K = u loop over several workgroups
+            int64_t wgs = 0; int umax = 0;
+            for (int s : lv) if (S.u(s) > 0) { wgs += cdiv(S.p(s), 64); umax = std::max(umax, S.u(s)); }
+            int ns = 0;
+            int keff = std::max(1, Kloc / std::max<int>(1, (int)aux_streams_.size()));     // nodes per launch (stream groups)
+            if (wgs > 0 && wgs * keff < 1024 && umax >= 512) ns = (int)std::min<int64_t>(8, std::min<int64_t>(umax / 256, cdiv(2048, (int)(wgs * keff))));
+            V.b1split = ns >= 2 ? ns : 0;
+            if (V.b1split) sl3 = 4;
+        }
+        int64_t sk_level = 0;
         for (int s : lv) if (S.u(s) > 0) {
-            for (int a = 0; a < cdiv(S.p(s), 16 * sl3); ++a) tiles.push_back({s, 3 | (sl3 << 8), a, 0});
-            V.b1.bytes += (double)S.u(s) * S.p(s) * 16.0; V.b1.flops += (double)S.u(s) * S.p(s);
+            int p = S.p(s), u = S.u(s);
+            if (V.b1split) {
+                int Kp = ((cdiv(u, V.b1split)) + 31) & ~31, nparts = cdiv(u, Kp);
+                sk_off_[s] = sk_level; sk_level += (int64_t)nparts * p;
+                for (int q = 0; q < nparts; ++q) for (int a = 0; a < cdiv(p, 64); ++a) tiles.push_back({s, 3 | (sl3 << 8) | (V.b1split << 16), a, q});
+            } else {
+                for (int a = 0; a < cdiv(p, 16 * sl3); ++a) tiles.push_back({s, 3 | (sl3 << 8), a, 0});
+            }
+            V.b1.bytes += (double)u * p * 16.0; V.b1.flops += (double)u * p;
         }
         V.b1.count = (int)(tiles.size() - V.b1.off);
+        sk_rows_ = std::max(sk_rows_, sk_level);
+        V.b1red.off = (int64_t)tiles.size();
+        if (V.b1split) for (int s : lv) if (S.u(s) > 0) for (int a = 0; a < cdiv(S.p(s), 64); ++a) tiles.push_back({s, a, 0, 0});
+        V.b1red.count = (int)(tiles.size() - V.b1red.off);
         V.b2.assign(nsteps, Launch());
         for (int c = 1; c < nsteps; ++c) {
             Launch& L = V.b2[c];
@@ -392,6 +415,7 @@ int Engine::analyze() {
         f.lp = S.lp_off[s]; f.f12 = S.f12_off[s]; f.cb = S.cb_off[s];
         f.sptr = S.struct_ptr[s]; f.crow = S.crow_off[s];
         f.child_ptr = S.child_ptr[s]; f.nchild = (int)(S.child_ptr[s + 1] - S.child_ptr[s]); f.depth = S.depth[s];
+        f.sk_off = -1;
     }
     std::vector<int> c0row(n);
     for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
@@ -402,6 +426,8 @@ int Engine::analyze() {
               d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
               d_perm_.upload(S.perm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_);
     if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
+    for (int s = 0; s < S.nsuper; ++s) fr[s].sk_off = sk_off_[s];
+    if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
     dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.n = n;
     // numeric arenas
@@ -485,7 +511,7 @@ int Engine::factorize() {
 int Engine::alloc_iteration_buffers() {
     size_t blk = (size_t)n * ldw;
     bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && (q_ext_ ? (q_ext_bytes_ >= 2 * blk * sizeof(cz)) : d_Q_.alloc(2 * blk)) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
-              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * blk) && d_Y_.alloc((size_t)Kloc * blk) &&
+              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * blk) && d_Y_.alloc((size_t)Kloc * blk) && d_sk_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * ldw) &&
               d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * ldw) &&
               d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * ldw) &&
               d_e0_.alloc((size_t)Kloc * ldw) && d_e1_.alloc((size_t)Kloc * ldw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
@@ -754,7 +780,9 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
         double lvl_p = 0, lvl_u = 0;
         for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
-        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true);
+        int64_t sks = std::max<int64_t>(1, sk_rows_) * ldw;
+        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, d_sk_.p + (int64_t)kb * sks, sks);
+        if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Yp, ws, ldw, d_sk_.p + (int64_t)kb * sks, sks, kc);
         if (V.b1.count) { cur_tiles = -V.b1.count; end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1)); }
         for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
             Launch& L = V.b2[c];

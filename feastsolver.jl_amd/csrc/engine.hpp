@@ -37,7 +37,7 @@ struct Launch {        // a slice of the tile / list buffers
 
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm; };
 struct FactorLevel { Launch extend; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale; };
-struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; };
+struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0; };
 
 struct SparseTerm {
     std::vector<int64_t> colptr;
@@ -130,7 +130,9 @@ private:
     DevBuf<int> d_piv_, d_rowperm_, d_rowinv_, d_nperturb_;
     DevBuf<double> d_tiny_;
     // iteration state (row-major n x ldw)
-    DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_Y_, d_crow_[2];
+    DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_Y_, d_crow_[2], d_sk_;
+    int64_t sk_rows_ = 0;                   // rows of split-K scratch per node
+    std::vector<int64_t> sk_off_;          // per front (or -1)
     DevBuf<cz> d_e0_, d_e1_, d_small_, d_lam_, d_gram_scratch_, d_io_;
     DevBuf<double> d_nrm_, d_nrm_scratch_;
 

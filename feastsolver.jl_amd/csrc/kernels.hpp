@@ -56,7 +56,12 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 //   4 B2  backward, rows above diagonal block c:                       Y_r -= PU_rc Y_c
 //   5 B3  backward, diagonal super block b, row tile c:                W_b  = inv(U_bb) Y_b
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
-                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false);
+                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false,
+                  cz* skbuf = nullptr, int64_t sks = 0);
+// Kind-3 tiles may be split along K (Tile.a bits 16.. = number of parts, Tile.c = part): each part writes
+// -U12[:, part] * x[part] into its own slab of `skbuf`; launch_splitk_reduce then adds the slabs to Y in a fixed order.
+void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,
+                          const cz* skbuf, int64_t sks, int K);
 // (gather = true for launches made only of kind-3 tiles: V rows are gathered through struct_idx)
 // Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int K,

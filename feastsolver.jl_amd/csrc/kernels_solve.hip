@@ -241,13 +241,14 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
 template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
-                                               cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs) {
+                                               cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks) {
     __shared__ cz Vs[2][APPLY_KC][LDS_COLS];      // double buffered, filled by LDS-DMA
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y, cg = blockIdx.z * LDS_COLS;
     FrontD f = fr[t.f];
     int kind = t.a & 0xff;
-    int th = (t.a >> 8) ? 16 * (t.a >> 8) : 64;       // tile height in rows (16, 32 or 64), chosen per launch by the host
+    int th = ((t.a >> 8) & 0xff) ? 16 * ((t.a >> 8) & 0xff) : 64;   // tile height in rows (16, 32 or 64), chosen per launch by the host
+    int nsplit = t.a >> 16;                            // kind 3 only: number of K parts (0 = not split)
     int p = f.p, u = f.u, ld = p + u;
     const cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* Wk = W + (int64_t)k * ws;
@@ -259,7 +260,15 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
     else if (kind == 1) { g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2; }
     else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
-    else if (kind == 3) { g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk; }
+    else if (kind == 3) {
+        g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk;
+        if (nsplit > 0) {   // split-K part t.c: partial product into the scratch slab (part, row), reduced afterwards
+            int Kp = (((u + nsplit - 1) / nsplit) + 31) & ~31;
+            int kbeg = t.c * Kp;
+            g.A += (int64_t)kbeg * p; g.sidx += kbeg; g.Kd = min(Kp, u - kbeg);
+            g.out = skbuf + (int64_t)k * sks + (f.sk_off + (int64_t)t.c * p) * ldw; g.orow_shift = 0; g.mode = 2;
+        }
+    }
     else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
     else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk; }
     int trows = min(th, g.rend - g.rbase);
@@ -269,11 +278,39 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
 }
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
-                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather) {
+                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks) {
     if (ntiles <= 0) return;
     dim3 g(ntiles, K, (ldw + LDS_COLS - 1) / LDS_COLS);
-    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs);
-    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs);
+    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks);
+    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks);
+}
+
+// Y[c0 + r, :] += sum_part scratch[part][r, :]   (parts in increasing order: deterministic)
+__global__ void k_splitk_reduce(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int nsplit, cz* Y, int64_t ws,
+                                int ldw, const cz* __restrict__ skbuf, int64_t sks) {
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int Kp = (((f.u + nsplit - 1) / nsplit) + 31) & ~31;
+    int nparts = (f.u + Kp - 1) / Kp;
+    for (int r = t.a * 64 + wave; r < min(f.p, t.a * 64 + 64); r += 4) {
+        cz* y = Y + (int64_t)k * ws + (int64_t)(f.c0 + r) * ldw;
+        for (int j = lane; j < ldw; j += 64) {
+            cz v = y[j];
+            for (int q = 0; q < nparts; ++q) {
+                cz a = skbuf[(int64_t)k * sks + (f.sk_off + (int64_t)q * f.p + r) * ldw + j];
+                v.x += a.x; v.y += a.y;
+            }
+            y[j] = v;
+        }
+    }
+}
+
+void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,
+                          const cz* skbuf, int64_t sks, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, nsplit, Y, ws, ldw, skbuf, sks);
 }
 
 // Q0[old,:] = sum_k T_k[i,:] .* e0[k,:]  (and Q1 with e1), T_k = mode ? X[old,:] - W_k[i,:] : W_k[i,:].
