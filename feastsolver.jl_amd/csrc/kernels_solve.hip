@@ -99,6 +99,34 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // Tile kinds: see kernels.hpp (launch_apply).
 // ---------------------------------------------------------------------------
 constexpr int APPLY_KC = 32;
+#ifndef FEASTHIP_ABLATE
+#define FEASTHIP_ABLATE 0      // timing experiments only (tools/ablate.sh): 1 no factor loads, 2 no LDS-DMA, 3 no epilogue, 4 no MFMA
+#endif
+
+// LDS reads of the staged block-vector rows are issued as inline asm: the compiler cannot tell the two
+// halves of the double buffer apart and would otherwise put an s_waitcnt vmcnt(0) (= wait for the NEXT
+// chunk's LDS-DMA and factor loads) in front of every ds_read, serialising prefetch and matrix cores.
+typedef double dv2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ dv2 lds_ld16(uint32_t a) {
+    dv2 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+// k-step KS of a chunk: rows 4 KS + (lane >> 4), column tiles ct0 .. ct0 + NS - 1 (1 KiB rows, 256 B per column tile)
+template <int KS, int NS>
+__device__ __forceinline__ void lds_ld_step(dv2 (&bv)[NS], uint32_t a) {
+    bv[0] = lds_ld16<KS * 4096>(a);
+    if constexpr (NS > 1) bv[1] = lds_ld16<KS * 4096 + 256>(a);
+    if constexpr (NS > 2) { bv[2] = lds_ld16<KS * 4096 + 512>(a); bv[3] = lds_ld16<KS * 4096 + 768>(a); }
+}
+// the registers are operands so that no use of them can be scheduled above the wait
+template <int NS>
+__device__ __forceinline__ void lds_wait(dv2 (&bv)[NS]) {
+    if constexpr (NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]));
+    else if constexpr (NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+}
 
 struct ApplyGeom {
     const cz* A;         // factor slab, column-major
@@ -117,7 +145,8 @@ struct ApplyGeom {
 // busy with useful columns instead of multiplying zero rows.
 template <bool GATHER, int NS>
 __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC][LDS_COLS], int cg, int ldw) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: DMA row addresses stay in SGPRs
     const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
     const bool wave_active = g.rbase + slab * 16 < g.rend;          // wave-uniform
     const int arow = g.rbase + slab * 16 + li;
@@ -132,23 +161,37 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
     const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
     const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
     const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&Vs[0][lk][ct0 * 16 + li];
     cz av[APPLY_KC / 4], an[APPLY_KC / 4];
+    // gather kinds: lane q (< 8) holds the block-vector row of this wave's q-th DMA row, loaded one chunk
+    // before it is needed so that the DMA issue never waits on an index
+    int idxv = 0;
+    auto load_idx = [&](int kc) {
+        if (GATHER) idxv = g.sidx[min(kc + wave + 4 * (lane & 7), Kd - 1)];
+    };
     // A: one 16-byte load per lane per k-step, straight to registers.  V: LDS-DMA, one
     // global_load_lds_dwordx4 per block-vector row (64 lanes x 16 B = the 1 KiB LDS row), no VGPR staging.
     auto load_chunk = [&](int kc, int buf) {
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
             int gk = kc + ks * 4 + lk;
+#if FEASTHIP_ABLATE != 1
             an[ks] = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];
+#else
+            an[ks] = cz_make(gk, lane);
+#endif
         }
 #pragma unroll
         for (int q = 0; q < APPLY_KC / 4; ++q) {
             int r = wave + 4 * q;
-            int gk = min(kc + r, Kd - 1);
-            int vrow = GATHER ? g.sidx[gk] : g.vrow0 + gk;
+            int vrow = GATHER ? __builtin_amdgcn_readlane(idxv, q) : g.vrow0 + min(kc + r, Kd - 1);
             const cz* src = g.Vk + (int64_t)vrow * ldw + vcol_c;
+#if FEASTHIP_ABLATE != 2
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)&Vs[buf][r][0], 16, 0, 0);
+#else
+            if (src == nullptr) Vs[buf][r][lane] = cz_make(1, 2);
+#endif
         }
     };
     auto mask_a = [&](cz v, int gk) {
@@ -171,28 +214,43 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
         rok[r] = orow < g.rend;
         dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
     }
+    auto mf = [&](const cz& a, dv2 (&bv)[NS]) {
+        const double ar = a.x, ai = a.y, as = a.x + a.y;
+#if FEASTHIP_ABLATE == 4
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { t1[q][0] += ar * bv[q][0]; t2[q][0] += ai * bv[q][1]; t3[q][0] += as; }
+        return;
+#endif
+#pragma unroll
+        for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q][0], t1[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[q][1], t2[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv[q][0] + bv[q][1], t3[q], 0, 0, 0);
+    };
+    // k-step KS runs on the matrix cores while the LDS reads of k-step KS+1 are in flight
+#define FEASTHIP_KSTEP(KS, CUR, NXT)                                                  \
+    if (KS < nks) {                                                                   \
+        if (KS + 1 < APPLY_KC / 4) lds_ld_step<(KS + 1) % (APPLY_KC / 4), NS>(NXT, la); \
+        mf(av[KS], CUR);                                                              \
+        if (KS + 1 < APPLY_KC / 4) lds_wait<NS>(NXT);                                 \
+    }
     auto mfma_chunk = [&](int kc, int buf) {
         const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;    // k-steps that carry data (uniform)
         if (wave_active) {
-#pragma unroll
-            for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
-                if (ks < nks) {
-                    const int kk = ks * 4 + lk;
-                    cz bv[NS];
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) bv[q] = Vs[buf][kk][(ct0 + q) * 16 + li];
-                    const double ar = av[ks].x, ai = av[ks].y, as = av[ks].x + av[ks].y;
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q].x, t1[q], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[q].y, t2[q], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv[q].x + bv[q].y, t3[q], 0, 0, 0);
-                }
-            }
+            const uint32_t la = lds0 + buf * (APPLY_KC * LDS_COLS * 16);
+            dv2 b0[NS], b1[NS];
+            lds_ld_step<0, NS>(b0, la);
+            lds_wait<NS>(b0);
+            FEASTHIP_KSTEP(0, b0, b1) FEASTHIP_KSTEP(1, b1, b0) FEASTHIP_KSTEP(2, b0, b1) FEASTHIP_KSTEP(3, b1, b0)
+            FEASTHIP_KSTEP(4, b0, b1) FEASTHIP_KSTEP(5, b1, b0) FEASTHIP_KSTEP(6, b0, b1) FEASTHIP_KSTEP(7, b1, b0)
         }
     };
+#undef FEASTHIP_KSTEP
+    static_assert(APPLY_KC == 32 && LDS_COLS == 64, "the LDS offsets of lds_ld_step assume 32 x 64 chunks");
+    load_idx(0);
     load_chunk(0, 0);
+    load_idx(APPLY_KC);
     int it = 0, kc = 0;
     for (; kc + APPLY_KC < Kd; kc += APPLY_KC, ++it) {       // all chunks but the last: prefetch the next one
         const int buf = it & 1;
@@ -201,6 +259,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
         __syncthreads();                                      // everyone's rows landed; buffer buf^1 is free again
         load_chunk(kc + APPLY_KC, buf ^ 1);
+        load_idx(kc + 2 * APPLY_KC);
         mfma_chunk(kc, buf);
     }
     // last chunk: instead of a prefetch, issue the read-modify-write loads of the epilogue so that their
@@ -212,7 +271,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
         __syncthreads();
-        if (g.mode == 0 && wave_active) {
+        if (g.mode == 0 && wave_active && FEASTHIP_ABLATE != 3) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -234,6 +293,9 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
             cz v;
             if (g.mode != 0) v = cz_make(sgn * cr[q][r], sgn * ci[q][r]);
             else v = cz_make(old[r][q].x - cr[q][r], old[r][q].y - ci[q][r]);
+#if FEASTHIP_ABLATE == 3
+            if (v.x == 123.456)
+#endif
             if (rok[r] && col < ldw) dptr[r][col] = v;
         }
 }
@@ -241,10 +303,16 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
 template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
-                                               cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks) {
+                                               cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks,
+                                               int ntiles) {
     __shared__ cz Vs[2][APPLY_KC][LDS_COLS];      // double buffered, filled by LDS-DMA
-    Tile t = tiles[blockIdx.x];
-    int k = blockIdx.y, cg = blockIdx.z * LDS_COLS;
+    // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the
+    // (node, tile) items are handed out in node-major order with a contiguous range per XCD: the tiles of
+    // one front of one node then run on ONE XCD and re-read their block-vector rows from that L2.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    Tile t = tiles[item % ntiles];
+    int k = item / ntiles, cg = blockIdx.z * LDS_COLS;
     FrontD f = fr[t.f];
     int kind = t.a & 0xff;
     int th = ((t.a >> 8) & 0xff) ? 16 * ((t.a >> 8) & 0xff) : 64;   // tile height in rows (16, 32 or 64), chosen per launch by the host
@@ -280,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks) {
     if (ntiles <= 0) return;
-    dim3 g(ntiles, K, (ldw + LDS_COLS - 1) / LDS_COLS);
-    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks);
-    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks);
+    dim3 g(ntiles * K, 1, (ldw + LDS_COLS - 1) / LDS_COLS);
+    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles);
+    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles);
 }
 
 // Y[c0 + r, :] += sum_part scratch[part][r, :]   (parts in increasing order: deterministic)
