@@ -231,6 +231,18 @@ class FeastHandle:
                                                       float(spurious), _vp(lam), _vp(res), _vp(ins), C.byref(nit)))
         return lam, res, ins.astype(bool), nit.value, code
 
+    def nlfeast_moments_run(self, X, moments, iter, eps, spurious):
+        self.m0 = X.shape[1]
+        M = int(moments) * X.shape[1]
+        lam = np.zeros(M, dtype=np.complex128)
+        res = np.zeros(M)
+        ins = np.zeros(M, dtype=np.uint8)
+        Y = np.zeros((X.shape[0], M), dtype=np.complex128, order="F")
+        nit = C.c_int(0)
+        code = self._ck(self.lib.feasthip_nlfeast_moments_run(self.h, _vp(X), X.shape[0], X.shape[1], int(moments), int(iter), float(eps),
+                                                              float(spurious), _vp(lam), _vp(res), _vp(ins), _vp(Y), C.byref(nit)))
+        return lam, Y, res, ins.astype(bool), nit.value, code
+
     def stats(self):
         s = _lib.Stats()
         self._ck(self.lib.feasthip_get_stats(self.h, C.byref(s)))
@@ -337,6 +349,34 @@ def nlfeast(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, store=Tr
         h.close()
     _writeback(X_in, Xw)
     return lam, Xw, res
+
+
+def nlfeast_moments(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, moments=2, store=True, spurious=1e-5,
+                    device=0, info=None):
+    """nlfeast_moments!(T, X, nodes, iter; c, r, debug, eps, moments, store, spurious)  src/nlfeast.jl:173-318.
+    Returns (lam, Y, res) for all moments*m0 candidates sorted by relative residual; X is overwritten with the m0
+    best candidates, column-normalised.  T must be a PolynomialNEP.  ``store`` is accepted for signature
+    compatibility: the factors of the nodes are always kept on the device (the reference's store=true)."""
+    if not isinstance(T, PolynomialNEP):
+        raise NotImplementedError("nlfeast_moments on the GPU needs a PolynomialNEP; generic closures are a later-round row (SURVEY 8f)")
+    if not (isinstance(X, np.ndarray) and X.dtype == np.complex128):
+        raise TypeError("X must be an AbstractMatrix{ComplexF64}")       # src/nlfeast.jl:173
+    X_in, Xw = _inplace_target(X)
+    h = FeastHandle(device)
+    try:
+        h.set_terms(T.coeffs)
+        h.set_contour(circular_contour_trapezoidal(c, r, nodes))           # src/nlfeast.jl:178
+        lam, Y, res, ins, nit, warn = h.nlfeast_moments_run(Xw, moments, iter, eps, spurious)
+        if debug:
+            m0 = Xw.shape[1]
+            print(f"nit={nit} inside(first m0)={int(ins[:m0].sum())} max_res_inside={res[:m0][ins[:m0]].max() if ins[:m0].any() else float('nan'):.3e}")
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=nit, warn=warn, inside=ins.copy())
+    finally:
+        h.close()
+    _writeback(X_in, Xw)
+    return lam, Y, res
 
 
 def contour_estimate_eig(A, contour, B=None, *, samples=None, X=None, device=0, seed=None):

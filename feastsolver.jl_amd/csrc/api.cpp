@@ -108,6 +108,11 @@ int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int it
     GUARD(h) return h->e->nlfeast_run(X, n, m0, iter, eps, spurious, lambda, res, inside, nit); ENDGUARD(h)
 }
 
+int feasthip_nlfeast_moments_run(feasthip_handle_t h, void* X, int64_t n, int m0, int moments, int iter, double eps,
+                                 double spurious, double* lambda, double* res, uint8_t* inside, void* Y, int* nit) {
+    GUARD(h) return h->e->nlfeast_moments_run(X, n, m0, moments, iter, eps, spurious, lambda, res, inside, Y, nit); ENDGUARD(h)
+}
+
 int feasthip_estimate_count(feasthip_handle_t h, const void* X, int64_t n, int m0, double* est) {
     GUARD(h) return h->e->estimate_count(X, n, m0, est); ENDGUARD(h)
 }

@@ -3,6 +3,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <limits>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -560,21 +561,23 @@ int Engine::q_device(void** p, int64_t* n_, int64_t* ldq, int* nblocks) {
     return 0;
 }
 
-void Engine::apply_term(int t, const cz* V, cz* out, zc alpha, bool accumulate) {
+void Engine::apply_term(int t, const cz* V, cz* out, zc alpha, bool accumulate) { apply_term_ld(t, V, out, alpha, accumulate, ldw); }
+
+void Engine::apply_term_ld(int t, const cz* V, cz* out, zc alpha, bool accumulate, int ld) {
     SparseTerm& T = terms_[t];
     zc a = alpha * T.scale;
     if (dense) {
-        if (T.identity) launch_axpby(stream_, n, ldw, out, to_cz(a), V, accumulate ? 1 : 0);
-        else launch_dense_mv(stream_, n, T.d_dense.p, V, ldw, out, to_cz(a), accumulate ? 1 : 0);
+        if (T.identity) launch_axpby(stream_, n, ld, out, to_cz(a), V, accumulate ? 1 : 0);
+        else launch_dense_mv(stream_, n, T.d_dense.p, V, ld, out, to_cz(a), accumulate ? 1 : 0);
     } else {
-        launch_spmm_csr(stream_, n, T.d_rowptr.p, T.d_col.p, T.d_val.p, V, ldw, out, to_cz(a), accumulate ? 1 : 0);
+        launch_spmm_csr(stream_, n, T.d_rowptr.p, T.d_col.p, T.d_val.p, V, ld, out, to_cz(a), accumulate ? 1 : 0);
     }
 }
 
-int Engine::col_norms(const cz* V, std::vector<double>& out) {
-    launch_colnorm2(stream_, n, ldw, V, d_nrm_scratch_.p, d_nrm_.p);
-    out.resize(ldw);
-    HIPCHK(hipMemcpyAsync(out.data(), d_nrm_.p, ldw * sizeof(double), hipMemcpyDeviceToHost, stream_));
+int Engine::col_norms(const Tall& t, const cz* V, std::vector<double>& out) {
+    launch_colnorm2(stream_, t.rows, t.ld, V, t.nrm_scratch, t.nrm);
+    out.resize(t.ld);
+    HIPCHK(hipMemcpyAsync(out.data(), t.nrm, t.ld * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     for (double& v : out) v = std::sqrt(v);
     return 0;
@@ -584,25 +587,27 @@ int Engine::col_norms(const cz* V, std::vector<double>& out) {
 // Column-scaled CholeskyQR2: columns are normalised first (the FEAST filter scales column j by
 // rho(lambda_j), which is the dominant source of ill-conditioning), then two Cholesky passes on
 // the f64-MFMA Gram matrix.  Rtotal (optional) receives R with Q_in = Q_out * R.
-int Engine::orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
-    int m = m0;
+int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
+    const int m = t.m, rows = t.rows, ld = t.ld;
     std::vector<double> nr;
-    int r = col_norms(Q, nr);
+    int r = col_norms(t, Q, nr);
     if (r) return r;
-    std::vector<zc> sc(ldw, zc(0.0)), Rt((size_t)m * m, zc(0.0));
+    std::vector<zc> sc(ld, zc(0.0)), Rt((size_t)m * m, zc(0.0));
     for (int j = 0; j < m; ++j) {
         if (!(nr[j] > 0.0) || !std::isfinite(nr[j])) return fail(FEASTHIP_ENUM, "orthonormalize: zero or non-finite column in the subspace");
         sc[j] = 1.0 / nr[j];
         Rt[j + (size_t)j * m] = nr[j];
     }
-    HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_scale_cols(stream_, n, ldw, Q, d_lam_.p);
+    HIPCHK(hipMemcpyAsync(t.lam, sc.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, rows, ld, Q, t.lam);
     HIPCHK(hipStreamSynchronize(stream_));
-    std::vector<zc> G((size_t)m * m), Rn((size_t)m * m), up((size_t)ldw * ldw);
-    cz* dG = d_small_.p;
-    cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
-    for (int pass = 0; pass < 2; ++pass) {
-        launch_gram(stream_, n, m, ldw, Q, Q, d_gram_scratch_.p, dG);
+    std::vector<zc> G((size_t)m * m), Rn((size_t)m * m);
+    cz* dG = t.small;
+    cz* dM = t.small + (size_t)2 * ld * ld;
+    // two clean passes; a pass that needed a shift (numerically rank-deficient block) is followed by one more
+    int need = 2;
+    for (int pass = 0; pass < 6 && need > 0; ++pass) {
+        launch_gram(stream_, rows, m, ld, Q, Q, t.gram, dG);
         HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (G[i + (size_t)j * m] + std::conj(G[j + (size_t)i * m])); G[i + (size_t)j * m] = a; G[j + (size_t)i * m] = std::conj(a); }
@@ -619,7 +624,9 @@ int Engine::orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
                 shift *= 100.0;
             }
             if (info) return fail(FEASTHIP_ENUM, "orthonormalize: Gram matrix not positive definite");
-            if (pass == 1) pass = 0;   // one more clean-up pass after a shifted one
+            need = 1;
+        } else {
+            --need;
         }
         if (Rtotal) {   // Rt <- R * Rt (only the Beyn step needs the accumulated factor)
             matmul(m, Gc.data(), Rt.data(), Rn.data());
@@ -627,11 +634,92 @@ int Engine::orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
         }
         trtri_upper(m, Gc.data());
         HIPCHK(hipMemcpyAsync(dM, Gc.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
-        launch_ts_gemm(stream_, n, m, ldw, Q, dM, tmp);
-        HIPCHK(hipMemcpyAsync(Q, tmp, (size_t)n * ldw * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+        launch_ts_gemm(stream_, rows, m, ld, Q, dM, tmp);
+        HIPCHK(hipMemcpyAsync(Q, tmp, (size_t)rows * ld * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
     }
     if (Rtotal) *Rtotal = Rt;
+    return 0;
+}
+
+// Rank-revealing variant for numerically rank-deficient blocks (the block-Hankel matrix of nlfeast_moments! has
+// rank = #eigenvalues inside as soon as the iteration converges).  Iterated pivoted block Gram-Schmidt built from
+// the same two device operations as above (MFMA Gram, tall-skinny GEMM): per pass a pivoted partial Cholesky of the
+// Gram matrix on the host accepts the columns that kept at least 1e-8 of their squared norm (the rest would be
+// decided on cancellation noise), orthonormalises them and projects them out of the others explicitly; columns
+// whose explicitly formed remainder is below 1e-13 of their original norm are dropped (zeroed).  On return
+// Q_in = Q_out * Rtot, kept columns of Q_out are orthonormal, dropped ones (keep[j] = 0) are zero.
+int Engine::orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rtot, std::vector<uint8_t>& keep) {
+    const int m = t.m, rows = t.rows, ld = t.ld;
+    std::vector<double> nr;
+    int r = col_norms(t, Q, nr);
+    if (r) return r;
+    std::vector<zc> sc(ld, zc(0.0));
+    Rtot.assign((size_t)m * m, zc(0.0));
+    keep.assign(m, 1);
+    for (int j = 0; j < m; ++j) {
+        if (!std::isfinite(nr[j])) return fail(FEASTHIP_ENUM, "orthonormalize: non-finite column in the subspace");
+        if (nr[j] > 0.0) { sc[j] = 1.0 / nr[j]; Rtot[j + (size_t)j * m] = nr[j]; } else keep[j] = 0;
+    }
+    HIPCHK(hipMemcpyAsync(t.lam, sc.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, rows, ld, Q, t.lam);
+    HIPCHK(hipStreamSynchronize(stream_));
+    const double tol_keep = 1e-8, tol_drop2 = 1e-26;       // squared-norm thresholds (columns are scaled to unit norm)
+    std::vector<zc> G((size_t)m * m), W((size_t)m * m), T((size_t)m * m), Ti((size_t)m * m), Rn((size_t)m * m), R11, R11i;
+    cz* dG = t.small;
+    cz* dM = t.small + (size_t)2 * ld * ld;
+    for (int pass = 0; pass < 10; ++pass) {
+        launch_gram(stream_, rows, m, ld, Q, Q, t.gram, dG);
+        HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (G[i + (size_t)j * m] + std::conj(G[j + (size_t)i * m])); G[i + (size_t)j * m] = a; G[j + (size_t)i * m] = std::conj(a); }
+        W = G;
+        std::vector<double> d0(m);
+        std::vector<int> state(m, 0), acc;                   // 0 undecided, 1 accepted, 2 dropped
+        double defect = 0;
+        for (int j = 0; j < m; ++j) {
+            d0[j] = G[j + (size_t)j * m].real();
+            if (!keep[j] || !(d0[j] >= tol_drop2)) { state[j] = 2; keep[j] = 0; }
+        }
+        for (int j = 0; j < m; ++j) if (state[j] == 0) for (int i = 0; i < m; ++i) if (state[i] == 0) defect = std::max(defect, std::abs(G[i + (size_t)j * m] - (i == j ? 1.0 : 0.0)));
+        std::vector<std::vector<zc>> rowsR;                  // row t of [R11 R12] over all columns
+        for (;;) {
+            int bj = -1; double bd = 0;
+            for (int j = 0; j < m; ++j) if (state[j] == 0) { double d = W[j + (size_t)j * m].real(); if (d >= tol_keep * d0[j] && d > bd) { bd = d; bj = j; } }
+            if (bj < 0) break;
+            double piv = std::sqrt(bd);
+            std::vector<zc> row(m, zc(0.0));
+            for (int i = 0; i < m; ++i) if (state[i] == 0) row[i] = W[bj + (size_t)i * m] / piv;
+            row[bj] = piv;
+            state[bj] = 1;
+            for (int b = 0; b < m; ++b) if (state[b] == 0) for (int a = 0; a < m; ++a) if (state[a] == 0) W[a + (size_t)b * m] -= std::conj(row[a]) * row[b];
+            acc.push_back(bj);
+            rowsR.push_back(row);
+        }
+        int ra = (int)acc.size(), ndef = 0;
+        for (int j = 0; j < m; ++j) if (state[j] == 0) ++ndef;   // deferred: projected now, decided on the next pass
+        // R11 (ra x ra, upper triangular in acceptance order) and its inverse
+        R11.assign((size_t)ra * ra, zc(0.0));
+        for (int tt = 0; tt < ra; ++tt) for (int s2 = tt; s2 < ra; ++s2) R11[tt + (size_t)s2 * ra] = rowsR[tt][acc[s2]];
+        R11i = R11;
+        if (ra > 0) trtri_upper(ra, R11i.data());
+        std::fill(T.begin(), T.end(), zc(0.0));
+        std::fill(Ti.begin(), Ti.end(), zc(0.0));
+        for (int s2 = 0; s2 < ra; ++s2) for (int tt = 0; tt <= s2; ++tt) T[acc[tt] + (size_t)acc[s2] * m] = R11i[tt + (size_t)s2 * ra];
+        for (int tt = 0; tt < ra; ++tt) for (int i = 0; i < m; ++i) if (state[i] != 2) Ti[acc[tt] + (size_t)i * m] = rowsR[tt][i];
+        for (int b = 0; b < m; ++b) if (state[b] == 0) {
+            T[b + (size_t)b * m] = 1.0; Ti[b + (size_t)b * m] = 1.0;
+            for (int tt = 0; tt < ra; ++tt) { zc v = 0; for (int s2 = tt; s2 < ra; ++s2) v += R11i[tt + (size_t)s2 * ra] * rowsR[s2][b]; T[acc[tt] + (size_t)b * m] = -v; }
+        }
+        matmul(m, Ti.data(), Rtot.data(), Rn.data());        // Q_orig = Q_cur Rtot = (Q_cur T)(T^-1 Rtot)
+        Rtot.swap(Rn);
+        HIPCHK(hipMemcpyAsync(dM, T.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        launch_ts_gemm(stream_, rows, m, ld, Q, dM, tmp);
+        HIPCHK(hipMemcpyAsync(Q, tmp, (size_t)rows * ld * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        // done once a pass started from an orthonormal kept set (Gram = I to 1e-10) and deferred nothing
+        if (ndef == 0 && defect < 1e-10) break;
+    }
     return 0;
 }
 
@@ -954,6 +1042,44 @@ static double frob_inner_sparse(const SparseTerm& A, const SparseTerm& B, int n,
     return 0;
 }
 
+int Engine::build_frob_table() {
+    if (!frob_.empty()) return 0;
+    {
+        frob_.assign(nterms, std::vector<double>(2 * nterms, 0.0));
+        for (int s = 0; s < nterms; ++s)
+            for (int t = 0; t < nterms; ++t) {
+                zc ip = 0;
+                if (dense) {
+                    // dense inner products: download once (n <= a few thousand on this path)
+                    std::vector<zc> a, b;
+                    auto fetch = [&](int q, std::vector<zc>& o) -> int {
+                        o.assign((size_t)n * n, zc(0.0));
+                        if (terms_[q].identity) { for (int i = 0; i < n; ++i) o[i + (size_t)i * n] = 1.0; return 0; }
+                        if (hipMemcpy(o.data(), terms_[q].d_dense.p, (size_t)n * n * sizeof(zc), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+                        return 0;
+                    };
+                    if (fetch(s, a) || fetch(t, b)) return fail(FEASTHIP_EHIP, "nl_rr_step: download failed");
+                    for (size_t e = 0; e < (size_t)n * n; ++e) ip += std::conj(a[e]) * b[e];
+                } else {
+                    frob_inner_sparse(terms_[s], terms_[t], n, ip);
+                }
+                ip *= std::conj(terms_[s].scale) * terms_[t].scale;
+                frob_[s][2 * t] = ip.real(); frob_[s][2 * t + 1] = ip.imag();
+            }
+    }
+    return 0;
+}
+
+double Engine::poly_frob_norm(zc lam) {
+    zc acc = 0, ls = 1.0;
+    for (int s = 0; s < nterms; ++s) {
+        zc lt = 1.0;
+        for (int t = 0; t < nterms; ++t) { acc += std::conj(ls) * lt * zc(frob_[s][2 * t], frob_[s][2 * t + 1]); lt *= lam; }
+        ls *= lam;
+    }
+    return std::sqrt(std::max(acc.real(), 0.0));
+}
+
 int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside) {
     if (!have_x_) return fail(FEASTHIP_ESTATE, "nl_rr_step: call set_x first");
     HIPCHK(hipSetDevice(device_));
@@ -999,38 +1125,10 @@ int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside) {
     if (r) return r;
     // residuals(R,lam,T): ||R_i|| / ||T(lam_i)||_F   src/utils.jl:151-157, Frobenius norm from the
     // table <M_s, M_t>_F (computed once per problem)
-    if (frob_.empty()) {
-        frob_.assign(nterms, std::vector<double>(2 * nterms, 0.0));
-        for (int s = 0; s < nterms; ++s)
-            for (int t = 0; t < nterms; ++t) {
-                zc ip = 0;
-                if (dense) {
-                    // dense inner products: download once (n <= a few thousand on this path)
-                    std::vector<zc> a, b;
-                    auto fetch = [&](int q, std::vector<zc>& o) -> int {
-                        o.assign((size_t)n * n, zc(0.0));
-                        if (terms_[q].identity) { for (int i = 0; i < n; ++i) o[i + (size_t)i * n] = 1.0; return 0; }
-                        if (hipMemcpy(o.data(), terms_[q].d_dense.p, (size_t)n * n * sizeof(zc), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-                        return 0;
-                    };
-                    if (fetch(s, a) || fetch(t, b)) return fail(FEASTHIP_EHIP, "nl_rr_step: download failed");
-                    for (size_t e = 0; e < (size_t)n * n; ++e) ip += std::conj(a[e]) * b[e];
-                } else {
-                    frob_inner_sparse(terms_[s], terms_[t], n, ip);
-                }
-                ip *= std::conj(terms_[s].scale) * terms_[t].scale;
-                frob_[s][2 * t] = ip.real(); frob_[s][2 * t + 1] = ip.imag();
-            }
-    }
+    r = build_frob_table();
+    if (r) return r;
     for (int j = 0; j < m; ++j) {
-        zc acc = 0, ls = 1.0;
-        for (int s = 0; s < nterms; ++s) {
-            zc lt = 1.0;
-            for (int t = 0; t < nterms; ++t) { acc += std::conj(ls) * lt * zc(frob_[s][2 * t], frob_[s][2 * t + 1]); lt *= lam[j]; }
-            ls *= lam[j];
-        }
-        double tn = std::sqrt(std::max(acc.real(), 0.0));
-        res[j] = nr[j] / tn;
+        res[j] = nr[j] / poly_frob_norm(lam[j]);
         lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag();
     }
     lambda_ = lam;
@@ -1055,6 +1153,195 @@ int Engine::nl_finalize_x() {
     launch_scale_cols(stream_, n, ldw, d_X_.p, d_lam_.p);
     HIPCHK(hipStreamSynchronize(stream_));
     return 0;
+}
+
+// ---------------------------------------------------------------------------
+// nlfeast_moments!  (src/nlfeast.jl:173-318): 2*moments contour moments, block-Hankel Beyn step
+// ---------------------------------------------------------------------------
+int Engine::nlm_alloc(int moments) {
+    mm_ = moments;
+    int M = mm_ * m0;
+    ldM_ = ((M + 15) / 16) * 16;
+    size_t blk = (size_t)n * ldw, hrows = (size_t)mm_ * n, tall = hrows * ldM_, wide = (size_t)n * ldM_;
+    bool ok = d_Qm_.alloc(2 * (size_t)mm_ * blk) && d_H0_.alloc(tall) && d_H1_.alloc(tall) && d_Ht_.alloc(tall) && d_Ym_.alloc(wide) &&
+              d_Rm_.alloc(wide) && d_MXm_.alloc(wide * std::max(2, nterms)) && d_em_.alloc(2 * (size_t)mm_ * Kloc * ldw) &&
+              d_smallM_.alloc((size_t)8 * ldM_ * ldM_) && d_lamM_.alloc(ldM_) && d_gramM_.alloc(gram_scratch_elems((int)hrows, ldM_)) &&
+              d_nrmM_.alloc(ldM_) && d_nrmMs_.alloc(colnorm_scratch_elems((int)hrows, ldM_)) && d_colidx_.alloc(ldM_);
+    if (!ok) return fail(FEASTHIP_EHIP, "out of device memory for the moment buffers");
+    return 0;
+}
+
+// Q_j = sum_k w_k z_k^j T(z_k)^-1 X (first pass, :193-212) or sum_k w_k z_k^j / (z_k - lam) .* (X - T(z_k)^-1 R) (:246-268)
+int Engine::nlm_contour_step(int first) {
+    HIPCHK(hipSetDevice(device_));
+    const int L = 2 * mm_;
+    std::vector<zc> e((size_t)L * Kloc * ldw, zc(0.0));
+    for (int kk = 0; kk < Kloc; ++kk) {
+        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
+        for (int j = 0; j < m0; ++j) {
+            zc v = first ? w : w / (z - lambda_[j]);
+            for (int q = 0; q < L; ++q) { e[((size_t)q * Kloc + kk) * ldw + j] = v; v *= z; }
+        }
+    }
+    HIPCHK(hipMemcpyAsync(d_em_.p, e.data(), e.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int r = solve_all(first ? d_X_.p : d_R_.p);
+    if (r) return r;
+    size_t blk = (size_t)n * ldw, eb = (size_t)Kloc * ldw;
+    for (int q = 0; q < L; q += 2)      // two moments per pass over the K solution blocks
+        launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)blk, ldw, Kloc, d_em_.p + q * eb, d_em_.p + (q + 1) * eb, first ? 0 : 1,
+                          d_Qm_.p + q * blk, d_Qm_.p + (q + 1) * blk);
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    solve_ms = ms;
+    return 0;
+}
+
+// Hankel matrices, thin SVD of the first through its orthonormal basis, reduced eigenproblem, candidate
+// vectors Y = U[1:N,:] vecs, update_R_moments! (src/utils.jl:118-134).  On return lam/res (moments*m0) are
+// sorted by residual, d_Ym_/d_Rm_ hold the sorted candidates, d_X_/d_R_ the m0 best.
+int Engine::nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res) {
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    const int M = mm_ * m0, ld = ldM_, hrows = mm_ * n;
+    Tall th{hrows, M, ld, d_smallM_.p, d_lamM_.p, d_gramM_.p, d_nrmM_.p, d_nrmMs_.p};
+    Tall tn{n, M, ld, d_smallM_.p, d_lamM_.p, d_gramM_.p, d_nrmM_.p, d_nrmMs_.p};
+    launch_hankel(stream_, n, m0, ldw, mm_, ld, 0, d_Qm_.p, d_H0_.p);       // :213-216
+    launch_hankel(stream_, n, m0, ldw, mm_, ld, 1, d_Qm_.p, d_H1_.p);
+    std::vector<zc> Rr;
+    std::vector<uint8_t> keepc;
+    int r = orthonormalize_rr(th, d_H0_.p, d_Ht_.p, Rr, keepc);               // svd!(Q0) :218 through Q0 = Qo Rr, rank revealing
+    if (r) return r;
+    int rk = 0;
+    for (int j = 0; j < M; ++j) rk += keepc[j] ? 1 : 0;
+    if (rk == 0) return fail(FEASTHIP_ENUM, "nlfeast_moments: the moment matrix is numerically zero");
+    std::vector<zc> Ur((size_t)M * M), Vr((size_t)M * M), G1((size_t)M * M), T((size_t)M * M), vec((size_t)M * M, zc(0.0));
+    std::vector<double> sv(M);
+    jacobi_svd(M, Rr.data(), Ur.data(), sv.data(), Vr.data());               // singular values descending: the first rk are the numerical range
+    cz* dG = d_smallM_.p;
+    cz* dM = d_smallM_.p + (size_t)2 * ld * ld;
+    launch_gram(stream_, hrows, M, ld, d_H0_.p, d_H1_.p, d_gramM_.p, dG);   // Qo^H Q1
+    HIPCHK(hipMemcpyAsync(G1.data(), dG, (size_t)M * M * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    // A = U^H Q1 V S^-1 restricted to the rk significant singular triplets (:219-221); the reference divides by the
+    // rounding-level singular values as well, which only adds candidates made of noise (they sort last by residual)
+    std::vector<zc> Ar((size_t)rk * rk), T1((size_t)M * rk, zc(0.0)), lr(rk), vr((size_t)rk * rk);
+    for (int j = 0; j < rk; ++j) for (int i = 0; i < M; ++i) { zc s = 0; for (int k = 0; k < M; ++k) s += G1[i + (size_t)k * M] * Vr[k + (size_t)j * M]; T1[i + (size_t)j * M] = s / sv[j]; }
+    for (int j = 0; j < rk; ++j) for (int i = 0; i < rk; ++i) { zc s = 0; for (int k = 0; k < M; ++k) s += std::conj(Ur[k + (size_t)i * M]) * T1[k + (size_t)j * M]; Ar[i + (size_t)j * rk] = s; }
+    int info = eig_general(rk, Ar.data(), lr.data(), vr.data());            // :222
+    if (info) return fail(FEASTHIP_ENUM, "nlfeast_moments: reduced eigenproblem failed to converge");
+    lam.assign(M, zc(std::numeric_limits<double>::quiet_NaN(), std::numeric_limits<double>::quiet_NaN()));
+    for (int j = 0; j < rk; ++j) { lam[j] = lr[j]; for (int i = 0; i < rk; ++i) vec[i + (size_t)j * M] = vr[i + (size_t)j * rk]; }
+    matmul(M, Ur.data(), vec.data(), T.data());                             // Y = U[1:N,:] vecs = Qo[1:N,:] (Ur vecs)  :223
+    HIPCHK(hipMemcpyAsync(dM, T.data(), (size_t)M * M * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_ts_gemm(stream_, n, M, ld, d_H0_.p, dM, d_Ym_.p);
+    // update_R_moments!: normalise, R[:,i] = T(lam_i) y_i, relative residuals, sort by residual
+    std::vector<double> nr;
+    r = col_norms(tn, d_Ym_.p, nr);
+    if (r) return r;
+    std::vector<zc> sc(ld, zc(0.0)), lamp(ld, zc(0.0));
+    for (int j = 0; j < M; ++j) { sc[j] = (nr[j] > 0 && std::isfinite(nr[j])) ? 1.0 / nr[j] : 1.0; lamp[j] = j < rk ? lam[j] : zc(0.0); }
+    HIPCHK(hipMemcpyAsync(d_lamM_.p, sc.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, n, ld, d_Ym_.p, d_lamM_.p);
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipMemcpyAsync(d_lamM_.p, lamp.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    int64_t wide = (int64_t)n * ld;
+    for (int t = 0; t < nterms; ++t) apply_term_ld(t, d_Ym_.p, d_MXm_.p + (size_t)t * wide, 1.0, false, ld);
+    launch_poly_combine(stream_, n, ld, d_MXm_.p, wide, nterms, d_lamM_.p, d_Rm_.p);
+    r = col_norms(tn, d_Rm_.p, nr);
+    if (r) return r;
+    r = build_frob_table();
+    if (r) return r;
+    std::vector<double> rs(M);
+    for (int j = 0; j < M; ++j) {      // candidates beyond the numerical rank do not exist: residual +inf, zero vector
+        rs[j] = j < rk ? nr[j] / poly_frob_norm(lam[j]) : std::numeric_limits<double>::infinity();
+        if (!std::isfinite(rs[j])) rs[j] = std::numeric_limits<double>::infinity();
+    }
+    std::vector<int> p(ld, 0);
+    for (int j = 0; j < M; ++j) p[j] = j;
+    std::stable_sort(p.begin(), p.begin() + M, [&](int a, int b) { return rs[a] < rs[b]; });     // sortperm(res)  utils.jl:125
+    std::vector<zc> lam2(M);
+    res.assign(M, 0.0);
+    for (int j = 0; j < M; ++j) { lam2[j] = lam[p[j]]; res[j] = rs[p[j]]; }
+    lam.swap(lam2);
+    HIPCHK(hipMemcpyAsync(d_colidx_.p, p.data(), ld * sizeof(int), hipMemcpyHostToDevice, stream_));
+    cz* tmp = d_MXm_.p;
+    launch_gather_cols(stream_, n, ld, d_Ym_.p, ld, M, d_colidx_.p, tmp);
+    HIPCHK(hipMemcpyAsync(d_Ym_.p, tmp, (size_t)wide * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+    launch_gather_cols(stream_, n, ld, d_Rm_.p, ld, M, d_colidx_.p, tmp);
+    HIPCHK(hipMemcpyAsync(d_Rm_.p, tmp, (size_t)wide * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (int j = 0; j < ld; ++j) p[j] = j < M ? j : 0;                       // X .= Y[:,1:m0], R[:,1:m0]  :230
+    HIPCHK(hipMemcpyAsync(d_colidx_.p, p.data(), ld * sizeof(int), hipMemcpyHostToDevice, stream_));
+    launch_gather_cols(stream_, n, ld, d_Ym_.p, ldw, m0, d_colidx_.p, d_X_.p);
+    launch_gather_cols(stream_, n, ld, d_Rm_.p, ldw, m0, d_colidx_.p, d_R_.p);
+    lambda_.assign(lam.begin(), lam.begin() + m0);
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    rr_ms = ms;
+    return 0;
+}
+
+int Engine::nlfeast_moments_run(void* X, int64_t n_, int m0_, int moments, int iter, double eps, double spurious, double* lambda,
+                                double* res, uint8_t* inside, void* Y, int* nit_out) {
+    if (moments < 1 || moments > 16) return fail(FEASTHIP_EARG, "nlfeast_moments: moments must be in 1..16");
+    if ((int64_t)moments * m0_ > (int64_t)moments * n_) return fail(FEASTHIP_EARG, "nlfeast_moments: m0 must not exceed n");
+    if (shard_stride_ != 1) return fail(FEASTHIP_ESTATE, "nlfeast_moments: node shards are not supported on this path");
+    int r = set_x(X, n_, m0_);
+    if (r) return r;
+    r = nlm_alloc(moments);
+    if (r) return r;
+    int warn = factorize();                                                         // :187-201 (store=true)
+    if (warn < 0) return warn;
+    const int M = moments * m0;
+    std::vector<zc> lam;
+    std::vector<double> rs;
+    std::vector<uint8_t> ins(m0);
+    int nit = 0;
+    for (nit = 0; nit <= iter; ++nit) {
+        r = nlm_contour_step(nit == 0);
+        if (r < 0) return r;
+        r = nlm_rr_step(lam, rs);
+        if (r) return r;
+        inside_test(lam.data(), ins.data());
+        if (getenv("FEASTHIP_RR_TRACE")) {
+            int ni = 0; double mxi = 0;
+            for (int j = 0; j < m0; ++j) if (ins[j]) { ++ni; mxi = std::max(mxi, rs[j]); }
+            fprintf(stderr, "[feasthip] nlfeast_moments nit=%d inside(first m0)=%d max_res_inside=%.3e res[0..3]=%.2e %.2e %.2e %.2e\n", nit, ni, mxi,
+                    rs[0], rs[std::min(1, M - 1)], rs[std::min(2, M - 1)], rs[std::min(3, M - 1)]);
+        }
+        if (nit == 0) continue;                                                     // the reference tests inside `for nit = 1:iter` only
+        bool any = false, anys = false;
+        double mx = 0, mxs = 0;
+        for (int j = 0; j < m0; ++j) if (ins[j]) { any = true; mx = std::max(mx, rs[j]); if (rs[j] < spurious) { anys = true; mxs = std::max(mxs, rs[j]); } }
+        if (any && mx < eps) break;                                                 // :296-299
+        if (nit > 1 && anys && mxs < eps) break;                                    // :300-302
+    }
+    if (nit_out) *nit_out = std::min(nit, iter);
+    r = nl_finalize_x();                                                            // normalize!(X) :311
+    if (r) return r;
+    r = get_block(0, X);
+    if (r) return r;
+    for (int j = 0; j < M; ++j) {
+        lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag(); res[j] = rs[j];
+        if (inside) inside[j] = region_kind_ == FEASTHIP_REGION_RECT
+                                    ? ((region_[0] < lam[j].real() && lam[j].real() < region_[2] && region_[1] < lam[j].imag() && lam[j].imag() < region_[3]) ? 1 : 0)
+                                    : ((std::abs(lam[j] - zc(region_[0], region_[1])) <= region_[2]) ? 1 : 0);
+    }
+    if (Y) {      // all candidates, column-major n x M
+        DevBuf<cz> cm;
+        if (!cm.alloc((size_t)n * M)) return fail(FEASTHIP_EHIP, "nlfeast_moments: out of device memory");
+        launch_rm_to_cm(stream_, n, M, ldM_, d_Ym_.p, cm.p, n);
+        HIPCHK(hipMemcpyAsync(Y, cm.p, (size_t)n * M * sizeof(cz), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+    }
+    return warn;
 }
 
 // ---------------------------------------------------------------------------

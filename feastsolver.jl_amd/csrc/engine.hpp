@@ -86,6 +86,9 @@ public:
                   uint8_t* inside, int* nit);
     int nlfeast_run(void* X, int64_t n, int m0, int iter, double eps, double spurious, double* lambda, double* res,
                     uint8_t* inside, int* nit);
+    // nlfeast_moments! (src/nlfeast.jl:173-318): lambda/res/inside have moments*m0 entries, Y is n x moments*m0
+    int nlfeast_moments_run(void* X, int64_t n, int m0, int moments, int iter, double eps, double spurious, double* lambda,
+                            double* res, uint8_t* inside, void* Y, int* nit);
     // fine-grained seam: Y = T^-1 R for the single factorised matrix of this engine (node 0)
     int ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
     int estimate_count(const void* X, int64_t n, int m0, double* est);
@@ -144,8 +147,25 @@ private:
     bool build_plans();
     int alloc_iteration_buffers();
     void apply_term(int t, const cz* V, cz* out, zc alpha, bool accumulate);
-    int orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal);
-    int col_norms(const cz* V, std::vector<double>& out);
+    // a tall row-major block (rows x ld, m meaningful columns) and the scratch its reductions use
+    struct Tall { int rows, m, ld; cz* small; cz* lam; cz* gram; double* nrm; double* nrm_scratch; };
+    Tall tall_default() { return Tall{n, m0, ldw, d_small_.p, d_lam_.p, d_gram_scratch_.p, d_nrm_.p, d_nrm_scratch_.p}; }
+    int orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal) { return orthonormalize(tall_default(), Q, tmp, Rtotal); }
+    int orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal);
+    int orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rtot, std::vector<uint8_t>& keep);
+    int col_norms(const cz* V, std::vector<double>& out) { return col_norms(tall_default(), V, out); }
+    int col_norms(const Tall& t, const cz* V, std::vector<double>& out);
+    void apply_term_ld(int t, const cz* V, cz* out, zc alpha, bool accumulate, int ld);
+    double poly_frob_norm(zc lam);           // ||T(lam)||_F from the <M_s, M_t>_F table
+    int build_frob_table();
+    // nlfeast_moments state
+    int mm_ = 0, ldM_ = 0;
+    DevBuf<cz> d_Qm_, d_H0_, d_H1_, d_Ht_, d_Ym_, d_Rm_, d_MXm_, d_em_, d_smallM_, d_lamM_, d_gramM_;
+    DevBuf<double> d_nrmM_, d_nrmMs_;
+    DevBuf<int> d_colidx_;
+    int nlm_alloc(int moments);
+    int nlm_contour_step(int first);
+    int nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res);
     int solve_all(const cz* rhs);            // W_k = T(z_k)^-1 rhs for all local nodes
     void inside_test(const zc* lam, uint8_t* inside) const;
     int solve_all_impl(const cz* rhs, ProfileRow* prof);

@@ -87,6 +87,10 @@ void launch_axpby(hipStream_t st, int n, int ldw, cz* out, cz alpha, const cz* V
 void launch_residual_combine(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* R);
 // R = sum_t MX[t] .* lam[j]^t   (polynomial NEP residual; MX blocks contiguous with stride blk)
 void launch_poly_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t blk, int nterms, const cz* lam, cz* R);
+// block-Hankel matrix of contour moments: H (mm n x ldh, row-major), block (i, j) = Q_{i+j+shift}
+void launch_hankel(hipStream_t st, int n, int m0, int ldw, int mm, int ldh, int shift, const cz* Qm, cz* H);
+// out[:, j] = in[:, idx[j]] (j < mo), padding columns zeroed; row-major blocks with leading dimensions ldi / ldo
+void launch_gather_cols(hipStream_t st, int n, int ldi, const cz* in, int ldo, int mo, const int* idx, cz* out);
 // column-major (ld n) <-> row-major (ld ldw) conversion of n x m0 blocks, zero padding columns m0..ldw
 void launch_cm_to_rm(hipStream_t st, int n, int m0, int ldw, const cz* cm, int64_t ldcm, cz* rm);
 void launch_rm_to_cm(hipStream_t st, int n, int m0, int ldw, const cz* rm, cz* cm, int64_t ldcm);

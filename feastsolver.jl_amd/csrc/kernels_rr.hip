@@ -278,6 +278,38 @@ void launch_poly_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t b
     hipLaunchKernelGGL(k_poly_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, ldw, MX, blk, nterms, lam, R);
 }
 
+// Block-Hankel matrix of the contour moments (src/nlfeast.jl:213-216, 270-273):
+// H[(i n + r), j m0 + c] = Q_{i+j+shift}[r, c], i, j < mm; row-major (mm n) x ldh, zero beyond mm m0.
+__global__ void k_hankel(int n, int m0, int ldw, int mm, int ldh, int shift, const cz* __restrict__ Qm, int64_t blk, cz* H) {
+    int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= (int64_t)mm * n) return;
+    int i = (int)(row / n), r = (int)(row % n);
+    for (int col = lane; col < ldh; col += 64) {
+        int j = col / m0, c = col % m0;
+        H[row * ldh + col] = (j < mm) ? Qm[(int64_t)(i + j + shift) * blk + (int64_t)r * ldw + c] : cz_make(0, 0);
+    }
+}
+
+void launch_hankel(hipStream_t st, int n, int m0, int ldw, int mm, int ldh, int shift, const cz* Qm, cz* H) {
+    int64_t rows = (int64_t)mm * n;
+    hipLaunchKernelGGL(k_hankel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, n, m0, ldw, mm, ldh, shift, Qm, (int64_t)n * ldw, H);
+}
+
+// out[r, j] = in[r, idx[j]] for j < mo (idx on device), zero for the padding columns
+__global__ void k_gather_cols(int n, int ldi, const cz* __restrict__ in, int ldo, int mo, const int* __restrict__ idx, cz* out) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * ldo) return;
+    int64_t r = e / ldo;
+    int j = (int)(e % ldo);
+    out[e] = (j < mo) ? in[r * ldi + idx[j]] : cz_make(0, 0);
+}
+
+void launch_gather_cols(hipStream_t st, int n, int ldi, const cz* in, int ldo, int mo, const int* idx, cz* out) {
+    int64_t total = (int64_t)n * ldo;
+    hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, ldi, in, ldo, mo, idx, out);
+}
+
 __global__ void k_cm_to_rm(int n, int m0, int ldw, const cz* __restrict__ cm, int64_t ldcm, cz* rm) {
     __shared__ cz tile[32][33];
     int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;

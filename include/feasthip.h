@@ -125,6 +125,13 @@ int feasthip_feast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter
                        int store, double* lambda, double* res, uint8_t* inside, int* nit);
 int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps,
                          double spurious, double* lambda, double* res, uint8_t* inside, int* nit);
+/* nlfeast_moments!(T, X, nodes, iter; c, r, eps, moments, store=true, spurious)  src/nlfeast.jl:173-318
+ * (SURVEY 8f rank 1): 2*moments contour moments from the same shifted block solves, block-Hankel Beyn step.
+ * M = moments*m0 candidates are returned sorted by relative residual (update_R_moments!, src/utils.jl:118-134):
+ * lambda (M complex128 as re/im pairs), res (M), inside (M, may be NULL), Y (n x M column-major complex128, may be
+ * NULL); X (n x m0, in/out) receives the m0 best candidates, column-normalised. */
+int feasthip_nlfeast_moments_run(feasthip_handle_t h, void* X, int64_t n, int m0, int moments, int iter, double eps,
+                                 double spurious, double* lambda, double* res, uint8_t* inside, void* Y, int* nit);
 
 /* ---- adjacent caller of the same seam: contour_estimate_eig, src/stochastic.jl:2-33.
  * est = real(sum_k w_k tr(X' (z_k B - A)^-1 X)) / m0 over the LOCAL nodes of this handle, X n x m0 random block

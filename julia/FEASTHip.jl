@@ -107,4 +107,39 @@ function gen_feast!(X::Matrix{ComplexF64}, A::SparseMatrixCSC{TA,Int64}, B::Spar
     Λ[in_c], X[:, in_c], res[in_c]
 end
 
+# nlfeast_moments!(T, X, nodes, iter; c, r, ϵ, moments, spurious)  (src/nlfeast.jl:173-318) for a polynomial
+# T(z) = Σ_j z^j coeffs[j+1] with sparse coefficients (test/polynomial.jl:5-20): returns (Λ, Y, res) for all
+# moments*m₀ candidates sorted by residual, X overwritten with the m₀ best (normalised).
+function nlfeast_moments!(coeffs::Vector{SparseMatrixCSC{ComplexF64,Int64}}, X::Matrix{ComplexF64}, nodes::Integer, iter::Integer;
+                          c=complex(0.0, 0.0), r=1.0, ϵ=10e-12, moments::Integer=2, spurious=1e-5, device::Integer=0)
+    N, m₀ = size(X)
+    M = moments * m₀
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(C_NULL, ccall((:feasthip_create, lib), Cint, (Ref{Ptr{Cvoid}}, Cint), h, device))
+    Λ, res, inside, Y, nit = zeros(ComplexF64, M), zeros(M), zeros(UInt8, M), zeros(ComplexF64, N, M), Ref{Cint}(0)
+    try
+        nt = length(coeffs)
+        colptr = [pointer(A.colptr) for A in coeffs]
+        rowval = [pointer(A.rowval) for A in coeffs]
+        nzval = [Ptr{Cvoid}(pointer(A.nzval)) for A in coeffs]
+        GC.@preserve coeffs X begin
+            check(h[], ccall((:feasthip_set_csc, lib), Cint,
+                (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Cvoid}}, Ptr{Cint}, Ptr{ComplexF64}, Cint),
+                h[], N, nt, colptr, rowval, nzval, fill(Cint(C128), nt), ones(ComplexF64, nt), 1))
+            θ = LinRange(π / nodes, 2π - π / nodes, nodes)                              # src/nlfeast.jl:178
+            z, w = ComplexF64.(r .* exp.(θ .* im) .+ c), ComplexF64.(r .* exp.(θ .* im) ./ nodes)
+            check(h[], ccall((:feasthip_set_contour, lib), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{ComplexF64}, Ptr{ComplexF64}, Cint, Ptr{Float64}),
+                h[], nodes, z, w, 0, Float64[real(c), imag(c), r, 0.0]))
+            check(h[], ccall((:feasthip_nlfeast_moments_run, lib), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Cint, Cint, Float64, Float64, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8},
+                 Ptr{ComplexF64}, Ref{Cint}),
+                h[], X, N, m₀, moments, iter, ϵ, spurious, Λ, res, inside, Y, nit))
+        end
+    finally
+        ccall((:feasthip_destroy, lib), Cint, (Ptr{Cvoid},), h[])
+    end
+    Λ, Y, res
+end
+
 end # module

@@ -358,6 +358,82 @@ def nlfeast(T, X, nodes, iter, c=0j, r=1.0, eps=10e-12, store=True, spurious=1e-
     return lam, X, res
 
 
+def update_R_moments(Y, R, lam, res, T):
+    """``update_R_moments!`` src/utils.jl:118-134: normalise, R[:,i] = T(lam_i) y_i, relative
+    residuals, then everything sorted by residual (ascending, stable like Julia's sortperm)."""
+    for i in range(Y.shape[1]):
+        Y[:, i] /= np.linalg.norm(Y[:, i])
+        R[:, i] = _matmul(T(lam[i]), Y[:, i])
+    res[...] = residuals_nl(R, lam, T)
+    p = np.argsort(res, kind="stable")
+    res[...] = res[p]
+    Y[...] = Y[:, p]
+    lam[...] = lam[p]
+    R[...] = R[:, p]
+
+
+def nlfeast_moments(T, X, nodes, iter, c=0j, r=1.0, eps=10e-12, moments=2, store=True, spurious=1e-5,
+                    factorizer=lu, left_divider=ldiv, history=None):
+    """``nlfeast_moments!`` src/nlfeast.jl:173-318.  2*moments contour moments
+    Q_j = sum_k w_k z_k^j T(z_k)^-1 (.) , block-Hankel matrices of moments x moments blocks,
+    Beyn linearisation through the thin SVD of the first one.  Returns (lam, Y, res) for all
+    moments*m0 candidates sorted by residual; X is overwritten with the m0 best, normalised."""
+    X = np.asarray(X)
+    assert X.dtype == np.complex128
+    N, m0 = X.shape
+    M = moments * m0
+    theta = np.linspace(np.pi / nodes, 2 * np.pi - np.pi / nodes, nodes)    # :178
+    zs = r * np.exp(1j * theta) + c
+    ws = r * np.exp(1j * theta) / nodes
+    lam = np.zeros(M, dtype=np.complex128)
+    res = np.zeros(M)
+    Y = np.zeros((N, M), dtype=np.complex128)
+    R = np.zeros((N, M), dtype=np.complex128)
+    facts = [factorizer(T(zs[k])) for k in range(nodes)] if store else None
+    tinv = np.zeros((N, m0), dtype=np.complex128)
+
+    def hankel_step(Q):                                                     # :213-224 == :270-281
+        Q0 = np.zeros((moments * N, M), dtype=np.complex128)
+        Q1 = np.zeros((moments * N, M), dtype=np.complex128)
+        for i in range(moments):
+            for j in range(moments):
+                Q0[i * N:(i + 1) * N, j * m0:(j + 1) * m0] = Q[i + j]
+                Q1[i * N:(i + 1) * N, j * m0:(j + 1) * m0] = Q[i + j + 1]
+        U, S, Vh = np.linalg.svd(Q0, full_matrices=False)
+        A = ((U.conj().T @ Q1) @ Vh.conj().T) * (1.0 / S)[None, :]
+        vals, vecs = np.linalg.eig(A)
+        Y[...] = U[:N, :] @ vecs
+        lam[...] = vals
+        update_R_moments(Y, R, lam, res, T)                                 # :229 / :286
+        X[...] = Y[:, :m0]
+
+    for nit in range(iter + 1):
+        Q = np.zeros((2 * moments, N, m0), dtype=np.complex128)
+        for k in range(nodes):
+            F = facts[k] if store else factorizer(T(zs[k]))
+            if nit == 0:                                                    # :193-212
+                left_divider(tinv, F, X)
+                temp = tinv * ws[k]
+            else:                                                           # :246-268
+                resolvent = (1.0 / (zs[k] - lam[:m0])) * ws[k]
+                left_divider(tinv, F, R[:, :m0])
+                temp = (X - tinv) * resolvent[None, :]
+            for j in range(2 * moments):
+                Q[j] += temp * zs[k] ** j
+        hankel_step(Q)
+        ins = in_contour(lam[:m0], c, r)
+        res_inside = res[:m0][ins]
+        if history is not None:
+            history.append((nit, int(ins.sum()), float(res_inside.max()) if ins.any() else float("nan")))
+        if nit >= 1:                                                        # the reference tests only inside its loop
+            if res_inside.size > 0 and res_inside.max() < eps:              # :296-299
+                break
+            if nit > 1 and (res_inside < spurious).sum() > 0 and res_inside[res_inside < spurious].max() < eps:
+                break                                                       # :300-302
+    X /= np.linalg.norm(X, axis=0, keepdims=True)                           # :305-311 (res is already sorted)
+    return lam, Y, res
+
+
 def contour_estimate_eig(A, contour, B=None, X=None, samples=None, rng=None):
     """src/stochastic.jl:2-33: est = real(sum_k w_k tr(X' (z_k B - A)^-1 X)) / samples."""
     n = A.shape[0]

@@ -56,7 +56,40 @@ def run_linear(w, store=True):
                 iter=w["iter"], eps=w["eps"])
 
 
+def moments_fixtures():
+    """nlfeast_moments! (src/nlfeast.jl:173-318) on the reference's own data: the configurations of
+    test/paper.jl:147 (deficient quadratic), test/butterfly.jl:73 and test/polynomial.jl:20 (system5, with
+    m0 = 60 instead of 80 to keep the fixture small).  Stored: inputs by seed, the per-iteration history and the
+    converged candidates inside the contour."""
+    out = {}
+    cases = {
+        "moments_deficient_quadratic": dict(coeffs=wl.deficient_quadratic_coeffs(), n=15, m0=4, seed=6001, nodes=16, iter=10,
+                                            c=0j, r=0.25, moments=2, eps=1e-13),
+        "moments_butterfly": dict(coeffs=wl.c4_butterfly()["coeffs"], n=64, m0=15, seed=6002, nodes=16, iter=40,
+                                  c=1 + 1j, r=0.5, moments=2, eps=1e-13),
+        "moments_system5": dict(coeffs=wl.system5_coeffs(sparse=True), n=1000, m0=60, seed=6003, nodes=32, iter=10,
+                                c=-1.55 + 0j, r=0.05, moments=2, eps=1e-13),
+    }
+    for name, cs in cases.items():
+        hist = []
+        X = wl.rand_x0(cs["n"], cs["m0"], cs["seed"])
+        lam, Y, res = fo.nlfeast_moments(fo.poly_T(cs["coeffs"]), X, cs["nodes"], cs["iter"], c=cs["c"], r=cs["r"], eps=cs["eps"],
+                                         moments=cs["moments"], history=hist)
+        ins = (np.abs(lam - cs["c"]) <= cs["r"]) & (res < 1e-9)
+        out[name] = dict(n=cs["n"], m0=cs["m0"], seed=cs["seed"], nodes=cs["nodes"], iter=cs["iter"], c=[cs["c"].real, cs["c"].imag],
+                         r=cs["r"], moments=cs["moments"], eps=cs["eps"], history=hist,
+                         lam_inside=cplx(np.sort_complex(lam[ins])), res_inside=[float(x) for x in res[ins]])
+    return out
+
+
 def main():
+    if "--moments-only" in sys.argv:       # add / refresh the nlfeast_moments! cases without touching the others
+        gp = os.path.join(HERE, "golden.json")
+        out = json.load(open(gp))
+        out.update(moments_fixtures())
+        json.dump(out, open(gp, "w"), indent=1)
+        print({k: len(v["lam_inside"]) for k, v in out.items() if k.startswith("moments_")})
+        return
     full = "--full" in sys.argv
     out = {}
 
@@ -117,6 +150,7 @@ def main():
     # C5 (ii): system5 companion pencil 2000 x 2000, 32 nodes, m0 = 128
     out["c5_system5_companion"] = run_linear(wl.c5_system5_companion(128))
 
+    out.update(moments_fixtures())
     json.dump(out, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
     print({k: (len(v["lam"]) if isinstance(v, dict) and "lam" in v else "-") for k, v in out.items()})
 

@@ -198,6 +198,40 @@ def test_c4_butterfly_nlfeast(gpu, pkg, wl, golden):
         assert abs(np.linalg.norm(Tl @ Xo[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
 
 
+@pytest.mark.parametrize("case,comp_key", [("moments_deficient_quadratic", "deficient_quadratic"),
+                                           ("moments_butterfly", "c4_butterfly"), ("moments_system5", "system5")])
+def test_nlfeast_moments_parity(gpu, pkg, fo, wl, golden, case, comp_key):
+    """nlfeast_moments! (src/nlfeast.jl:173-318) through feasthip_nlfeast_moments_run against the
+    committed oracle fixture and the companion spectrum; dense (deficient, butterfly) and sparse (system5) terms."""
+    g = golden[case]
+    coeffs = {"moments_deficient_quadratic": wl.deficient_quadratic_coeffs, "moments_butterfly": lambda: wl.c4_butterfly()["coeffs"],
+              "moments_system5": lambda: wl.system5_coeffs(sparse=True)}[case]()
+    T = pkg.PolynomialNEP(coeffs)
+    X = wl.rand_x0(g["n"], g["m0"], g["seed"])
+    c = complex(*g["c"])
+    info = {}
+    lam, Y, res = pkg.nlfeast_moments(T, X, g["nodes"], g["iter"], c=c, r=g["r"], eps=g["eps"], moments=g["moments"], info=info)
+    M = g["moments"] * g["m0"]
+    assert lam.shape == (M,) and Y.shape == (g["n"], M) and res.shape == (M,)
+    assert np.all(np.diff(res[np.isfinite(res)]) >= 0)                                    # sorted by residual (utils.jl:125)
+    ins = (np.abs(lam - c) <= g["r"]) & (res < 1e-9)
+    comp = c2n(golden[comp_key]["companion_inside"])
+    assert ins.sum() == len(comp)
+    assert match_sets(lam[ins], comp) < 1e-9 and match_sets(comp, lam[ins]) < 1e-9
+    assert match_sets(lam[ins], c2n(g["lam_inside"])) < 1e-10                             # vs the oracle fixture
+    assert res[ins].max() < 1e-11
+    assert abs(info["nit"] - g["history"][-1][0]) <= 1
+    # Y columns are the normalised candidates and res is the relative residual of (lam, Y) (src/utils.jl:118-123, 159-164)
+    for j in np.nonzero(ins)[0][:8]:
+        Tl = T(lam[j])
+        Tl = Tl.toarray() if sp.issparse(Tl) else Tl
+        assert abs(np.linalg.norm(Y[:, j]) - 1.0) < 1e-12
+        assert abs(np.linalg.norm(Tl @ Y[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
+    # X holds the m0 best candidates, normalised (src/nlfeast.jl:309-311)
+    assert np.allclose(np.linalg.norm(X, axis=0), 1.0)
+    assert np.abs(X - Y[:, :g["m0"]]).max() < 1e-12
+
+
 def test_c5_system5_companion_m128(gpu, pkg, wl, golden):
     """C5 (ii): system5 quadratic, companion pencil 2000 x 2000, 32 nodes, m0 = 128."""
     g = golden["c5_system5_companion"]

@@ -2,6 +2,7 @@
 answers (test/runtests.jl) and against companion-linearisation spectra of the
 reference's data files (src/companion.jl).  CPU only."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 
@@ -68,6 +69,31 @@ def test_deficient_and_system5_counts(fo, wl, golden):
     fin = np.isfinite(cl)
     assert (np.abs(cl[fin]) <= 0.25).sum() == 4
     assert len(golden["system5"]["companion_inside"]) == 50
+
+
+@pytest.mark.parametrize("case,comp_key", [("moments_deficient_quadratic", "deficient_quadratic"),
+                                           ("moments_butterfly", "c4_butterfly"), ("moments_system5", "system5")])
+def test_nlfeast_moments_matches_companion(fo, wl, golden, case, comp_key):
+    """nlfeast_moments! (src/nlfeast.jl:173-318) on the reference's data files finds exactly the eigenvalues the
+    companion linearisation (src/companion.jl) has inside the contour, and reproduces its committed fixture."""
+    g = golden[case]
+    coeffs = {"moments_deficient_quadratic": wl.deficient_quadratic_coeffs, "moments_butterfly": lambda: wl.c4_butterfly()["coeffs"],
+              "moments_system5": lambda: wl.system5_coeffs(sparse=True)}[case]()
+    X = wl.rand_x0(g["n"], g["m0"], g["seed"])
+    c = complex(*g["c"])
+    hist = []
+    lam, Y, res = fo.nlfeast_moments(fo.poly_T(coeffs), X, g["nodes"], g["iter"], c=c, r=g["r"], eps=g["eps"], moments=g["moments"],
+                                     history=hist)
+    M = g["moments"] * g["m0"]
+    assert lam.shape == (M,) and Y.shape == (g["n"], M) and np.all(np.diff(res) >= 0)       # all candidates, sorted by residual
+    ins = (np.abs(lam - c) <= g["r"]) & (res < 1e-9)
+    comp = np.array([complex(a, b) for a, b in golden[comp_key]["companion_inside"]])
+    assert ins.sum() == len(comp)
+    assert max(np.abs(comp - x).min() for x in lam[ins]) < 1e-9 and max(np.abs(lam[ins] - x).min() for x in comp) < 1e-9
+    glam = np.array([complex(a, b) for a, b in g["lam_inside"]])
+    assert max(np.abs(glam - x).min() for x in lam[ins]) < 1e-10
+    assert hist[-1][0] == g["history"][-1][0]
+    assert np.allclose(np.linalg.norm(X, axis=0), 1.0)
 
 
 def test_golden_c3_small_reproduces(fo, wl, golden):
