@@ -57,7 +57,7 @@ Engine::Engine(int device) : device_(device) {
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
     int nst = 2;
-    if (const char* v = getenv("FEASTHIP_STREAMS")) nst = std::max(1, std::min(8, atoi(v)));
+    if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
     if (nst > 1) {
         (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
         for (int i = 0; i < nst; ++i) {
@@ -307,7 +307,7 @@ bool Engine::build_plans() {
             int64_t wgs = 0; int umax = 0;
             for (int s : lv) if (S.u(s) > 0) { wgs += cdiv(S.p(s), 64); umax = std::max(umax, S.u(s)); }
             int ns = 0;
-            int keff = std::max(1, Kloc / std::max<int>(1, (int)aux_streams_.size()));     // nodes per launch (stream groups)
+            int keff = std::max(1, Kloc / stream_groups());     // nodes per launch
             if (wgs > 0 && wgs * keff < 1024 && umax >= 512) ns = (int)std::min<int64_t>(8, std::min<int64_t>(umax / 256, cdiv(2048, (int)(wgs * keff))));
             V.b1split = ns >= 2 ? ns : 0;
             if (V.b1split) sl3 = 4;
@@ -589,28 +589,31 @@ int Engine::col_norms(const Tall& t, const cz* V, std::vector<double>& out) {
 // the f64-MFMA Gram matrix.  Rtotal (optional) receives R with Q_in = Q_out * R.
 int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
     const int m = t.m, rows = t.rows, ld = t.ld;
-    std::vector<double> nr;
-    int r = col_norms(t, Q, nr);
-    if (r) return r;
-    std::vector<zc> sc(ld, zc(0.0)), Rt((size_t)m * m, zc(0.0));
-    for (int j = 0; j < m; ++j) {
-        if (!(nr[j] > 0.0) || !std::isfinite(nr[j])) return fail(FEASTHIP_ENUM, "orthonormalize: zero or non-finite column in the subspace");
-        sc[j] = 1.0 / nr[j];
-        Rt[j + (size_t)j * m] = nr[j];
-    }
-    HIPCHK(hipMemcpyAsync(t.lam, sc.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_scale_cols(stream_, rows, ld, Q, t.lam);
-    HIPCHK(hipStreamSynchronize(stream_));
-    std::vector<zc> G((size_t)m * m), Rn((size_t)m * m);
+    std::vector<zc> G((size_t)m * m), Rn((size_t)m * m), Rt, Tm((size_t)m * m);
+    if (Rtotal) { Rt.assign((size_t)m * m, zc(0.0)); for (int j = 0; j < m; ++j) Rt[j + (size_t)j * m] = 1.0; }
     cz* dG = t.small;
     cz* dM = t.small + (size_t)2 * ld * ld;
-    // two clean passes; a pass that needed a shift (numerically rank-deficient block) is followed by one more
+    cz* src = Q;
+    cz* dst = tmp;
+    // two clean passes; a pass that needed a shift (numerically rank-deficient block) is followed by one more.
+    // The column scaling is folded into the first pass on the host: the Gram matrix of the scaled block is
+    // D G D with D = diag(G)^-1/2 (each G_ij carries a relative error eps in units of |q_i||q_j| either way),
+    // which saves a norm pass, a scaling pass and a host round trip over the n x m block.
     int need = 2;
     for (int pass = 0; pass < 6 && need > 0; ++pass) {
-        launch_gram(stream_, rows, m, ld, Q, Q, t.gram, dG);
+        launch_gram(stream_, rows, m, ld, src, src, t.gram, dG);
         HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (G[i + (size_t)j * m] + std::conj(G[j + (size_t)i * m])); G[i + (size_t)j * m] = a; G[j + (size_t)i * m] = std::conj(a); }
+        std::vector<double> dsc(m, 1.0);
+        if (pass == 0) {
+            for (int j = 0; j < m; ++j) {
+                double g = G[j + (size_t)j * m].real();
+                if (!(g > 0.0) || !std::isfinite(g)) return fail(FEASTHIP_ENUM, "orthonormalize: zero or non-finite column in the subspace");
+                dsc[j] = std::sqrt(g);
+            }
+            for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) G[i + (size_t)j * m] /= dsc[i] * dsc[j];
+        }
         std::vector<zc> Gc(G);
         int info = cholesky_upper(m, Gc.data());
         if (info) {   // shifted CholeskyQR for a numerically rank-deficient block
@@ -628,16 +631,19 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
         } else {
             --need;
         }
-        if (Rtotal) {   // Rt <- R * Rt (only the Beyn step needs the accumulated factor)
-            matmul(m, Gc.data(), Rt.data(), Rn.data());
+        if (Rtotal) {   // Q_src = Q_dst (R D^-1)  ->  Rt <- (R D^-1) Rt   (only the Beyn step needs the accumulated factor)
+            std::vector<zc> Rd(Gc);
+            for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) Rd[i + (size_t)j * m] *= dsc[j];
+            matmul(m, Rd.data(), Rt.data(), Rn.data());
             Rt.swap(Rn);
         }
         trtri_upper(m, Gc.data());
-        HIPCHK(hipMemcpyAsync(dM, Gc.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
-        launch_ts_gemm(stream_, rows, m, ld, Q, dM, tmp);
-        HIPCHK(hipMemcpyAsync(Q, tmp, (size_t)rows * ld * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
-        HIPCHK(hipStreamSynchronize(stream_));
+        for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) Tm[i + (size_t)j * m] = Gc[i + (size_t)j * m] / dsc[i];     // T = D^-1 R^-1
+        HIPCHK(hipMemcpyAsync(dM, Tm.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        launch_ts_gemm(stream_, rows, m, ld, src, dM, dst);
+        std::swap(src, dst);
     }
+    if (src != Q) HIPCHK(hipMemcpyAsync(Q, src, (size_t)rows * ld * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
     if (Rtotal) *Rtotal = Rt;
     return 0;
 }
@@ -887,9 +893,18 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
     return 0;
 }
 
+// Node groups that run on their own streams.  Two groups overlap the launch tails and the latency-bound small
+// launches of one group with the large launches of the other when there are many nodes; with few local nodes
+// (multi-GPU shards) one fuller launch per step is faster (measured: 16 nodes 2 groups, <= 8 nodes 1 group).
+int Engine::stream_groups() const {
+    int ns = std::min<int>((int)aux_streams_.size(), Kloc);
+    if (!streams_forced_ && Kloc < 12) ns = 1;
+    return std::max(1, ns);
+}
+
 int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
     if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
-    int ns = std::min<int>((int)aux_streams_.size(), Kloc);
+    int ns = stream_groups();
     if (prof || ns <= 1) return solve_range(stream_, 0, Kloc, rhs, prof);
     // The nodes are independent: split them over a few streams so that the tails and the latency-bound small
     // launches of one group overlap with the large launches of another.

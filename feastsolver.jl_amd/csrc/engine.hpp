@@ -170,6 +170,8 @@ private:
     void inside_test(const zc* lam, uint8_t* inside) const;
     int solve_all_impl(const cz* rhs, ProfileRow* prof);
     int solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof);
+    int stream_groups() const;
+    bool streams_forced_ = false;
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;
     hipEvent_t ev_fork_ = nullptr;

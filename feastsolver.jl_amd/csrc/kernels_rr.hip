@@ -92,8 +92,9 @@ void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, c
 // Tall-skinny projection G = V^H W on the f64 matrix cores.  Stage 1: each
 // workgroup reduces GRAM_ROWS rows; wave jobs are (16-row i tile) x (64-col j group),
 // operands are read straight from the row-major blocks (16 consecutive columns of a
-// row per lane group = 256 B segments).  Stage 2 sums the partials in a fixed order.
-constexpr int GRAM_ROWS = 512;
+// row per lane group = 256 B segments), two k-steps (8 rows, ten 16-byte loads per lane)
+// in flight per iteration.  Stage 2 sums the partials in a fixed order.
+constexpr int GRAM_ROWS = 256;
 
 size_t gram_scratch_elems(int n, int m) {
     size_t chunks = ((size_t)n + GRAM_ROWS - 1) / GRAM_ROWS;
@@ -110,18 +111,31 @@ __global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, co
     cz* out = scratch + (size_t)chunk * mp * mp;
     for (int job = wave; job < nit * njg; job += 4) {
         int it = job / njg, jg = job % njg;
-        d4 cr[4], ci[4];
+        d4 t1[4], t2[4], t3[4];          // 3M product of conj(a) * b
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
-        for (int r = r0; r < r1; r += 4) {
-            int row = r + lk;
-            bool ok = row < r1;
-            cz a = ok ? V[(int64_t)row * ldw + it * 16 + li] : cz_make(0, 0);
+        for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
+        int colb[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                int col = jg * 64 + nt * 16 + li;
-                cz b = (ok && col < mp) ? W[(int64_t)row * ldw + col] : cz_make(0, 0);
-                cmfma3(cr[nt], ci[nt], a.x, -a.y, b.x, b.y);   // conj(V)
+        for (int nt = 0; nt < 4; ++nt) colb[nt] = min(jg * 64 + nt * 16 + li, mp - 1);      // clamped: the extra columns are not stored
+        for (int r = r0; r < r1; r += 8) {
+            cz a[2], b[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int row = min(r + 4 * h + lk, n - 1);
+                a[h] = V[(int64_t)row * ldw + it * 16 + li];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b[h][nt] = W[(int64_t)row * ldw + colb[nt]];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bool ok = r + 4 * h + lk < r1;
+                double ar = ok ? a[h].x : 0.0, ai = ok ? -a[h].y : 0.0, as = ar + ai;     // conj(V)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    t1[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b[h][nt].x, t1[nt], 0, 0, 0);
+                    t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b[h][nt].y, t2[nt], 0, 0, 0);
+                    t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b[h][nt].x + b[h][nt].y, t3[nt], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -129,70 +143,98 @@ __global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, co
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int i = it * 16 + lk + 4 * r, j = jg * 64 + nt * 16 + li;
-                if (j < mp) out[i + (size_t)j * mp] = cz_make(cr[nt][r], ci[nt][r]);
+                if (j < mp) out[i + (size_t)j * mp] = cz_make(t1[nt][r] - t2[nt][r], t3[nt][r] - t1[nt][r] - t2[nt][r]);
             }
     }
 }
 
-__global__ void k_gram_reduce(int nchunks, int mp, int m, const cz* __restrict__ scratch, cz* G) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= m * m) return;
-    int i = e % m, j = e / m;
-    cz acc = cz_make(0, 0);
-    for (int c = 0; c < nchunks; ++c) acc = cz_add(acc, scratch[(size_t)c * mp * mp + i + (size_t)j * mp]);
-    G[i + (size_t)j * m] = acc;
+// 64 consecutive elements per workgroup; the chunks are summed in 4 interleaved groups (one per wave, four
+// independent accumulators each) that are combined in a fixed order: deterministic, and the 1 KiB lines of
+// a chunk are read by one wave.
+__global__ __launch_bounds__(256) void k_gram_reduce(int nchunks, int mp, int m, const cz* __restrict__ scratch, cz* G) {
+    __shared__ cz part[4][64];
+    int e = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    bool ok = e < m * m;
+    int i = ok ? e % m : 0, j = ok ? e / m : 0;
+    const cz* p = scratch + i + (size_t)j * mp;
+    size_t cs = (size_t)mp * mp;
+    cz a0 = cz_make(0, 0), a1 = a0, a2 = a0, a3 = a0;
+    int c = g;
+    for (; c + 12 < nchunks; c += 16) {
+        a0 = cz_add(a0, p[(size_t)c * cs]); a1 = cz_add(a1, p[(size_t)(c + 4) * cs]);
+        a2 = cz_add(a2, p[(size_t)(c + 8) * cs]); a3 = cz_add(a3, p[(size_t)(c + 12) * cs]);
+    }
+    for (; c < nchunks; c += 4) a0 = cz_add(a0, p[(size_t)c * cs]);
+    part[g][threadIdx.x & 63] = cz_add(cz_add(a0, a1), cz_add(a2, a3));
+    __syncthreads();
+    if (g == 0 && ok) {
+        int l = threadIdx.x;
+        G[i + (size_t)j * m] = cz_add(cz_add(part[0][l], part[1][l]), cz_add(part[2][l], part[3][l]));
+    }
 }
 
 void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G) {
     int chunks = (n + GRAM_ROWS - 1) / GRAM_ROWS;
     int mp = ((m + 15) / 16) * 16;    // ldw >= mp by construction
     hipLaunchKernelGGL(k_gram_partial, dim3(chunks), dim3(256), 0, st, n, mp, ldw, V, W, scratch);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 255) / 256), dim3(256), 0, st, chunks, mp, m, scratch, G);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 63) / 64), dim3(256), 0, st, chunks, mp, m, scratch, G);
 }
 
-// out[r,:] = V[r,:] * M  (M m x m column-major).  One wave per row, lane = output column;
-// M is staged in LDS in slabs of TS_KC rows x 64 columns (blockIdx.y = column group).
+// out = V * M  (V n x ldw row-major, M m x m column-major) on the f64 matrix cores.  A workgroup owns 64 rows
+// (one 16-row slab per wave) and 64 output columns; M^T^T = M is staged in LDS row-major [k][64 cols] in chunks of
+// TS_KC rows; the V fragment (row = lane & 15, k = lane >> 4) comes straight from global memory: the four lane
+// groups read 64 consecutive bytes of a row, consecutive k-steps walk along the same lines.
 constexpr int TS_KC = 64;
 
 __global__ __launch_bounds__(256) void k_ts_gemm(int n, int m, int ldw, const cz* __restrict__ V, const cz* __restrict__ M, cz* out) {
-    __shared__ cz Ms[TS_KC * 64];               // [i][64]
-    __shared__ cz Vr[4 * TS_KC];                // 4 rows x TS_KC
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int cg = blockIdx.y * 64, col = cg + lane;
-    cz* vr = Vr + (size_t)wave * TS_KC;
-    for (int ic = 0; ic < m; ic += TS_KC) {
-        int kc = min(TS_KC, m - ic);
+    __shared__ cz Ms[TS_KC][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int r0 = blockIdx.x * 64 + wave * 16, cg = blockIdx.y * 64;
+    const int64_t arow = min(r0 + li, n - 1);
+    d4 t1[4], t2[4], t3[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
+    for (int kc = 0; kc < m; kc += TS_KC) {
         __syncthreads();
-        for (int idx = threadIdx.x; idx < kc * 64; idx += 256) {
-            int i = idx >> 6, jl = idx & 63;
-            Ms[idx] = (cg + jl < m) ? M[(ic + i) + (size_t)(cg + jl) * m] : cz_make(0, 0);
+        for (int idx = tid; idx < TS_KC * 64; idx += 256) {
+            int k = idx >> 6, c = idx & 63;
+            Ms[k][c] = (kc + k < m && cg + c < m) ? M[(kc + k) + (size_t)(cg + c) * m] : cz_make(0, 0);
         }
+        cz av[TS_KC / 4];
+#pragma unroll
+        for (int ks = 0; ks < TS_KC / 4; ++ks) av[ks] = V[arow * ldw + min(kc + ks * 4 + lk, ldw - 1)];
         __syncthreads();
-        for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
-            for (int i = lane; i < kc; i += 64) vr[i] = V[(int64_t)row * ldw + ic + i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (col < ldw) {
-                cz acc = (ic == 0) ? cz_make(0, 0) : out[(int64_t)row * ldw + col];
-                for (int i = 0; i < kc; ++i) cz_madd(acc, vr[i], Ms[(size_t)i * 64 + lane]);
-                out[(int64_t)row * ldw + col] = acc;
+#pragma unroll
+        for (int ks = 0; ks < TS_KC / 4; ++ks) {
+            const bool kok = kc + ks * 4 + lk < m;                // padding columns of V never enter the product
+            const double ar = kok ? av[ks].x : 0.0, ai = kok ? av[ks].y : 0.0, as = ar + ai;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                cz bv = Ms[ks * 4 + lk][nt * 16 + li];
+                t1[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv.x, t1[nt], 0, 0, 0);
+                t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv.y, t2[nt], 0, 0, 0);
+                t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv.x + bv.y, t3[nt], 0, 0, 0);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int orow = r0 + lk + 4 * r;
+        if (orow >= n) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int col = cg + nt * 16 + li;
+            if (col < ldw) out[(int64_t)orow * ldw + col] = cz_make(t1[nt][r] - t2[nt][r], t3[nt][r] - t1[nt][r] - t2[nt][r]);
         }
     }
 }
 
 void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* M, cz* out) {
-    int blocks = (n + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_ts_gemm, dim3(blocks, (ldw + 63) / 64), dim3(256), 0, st, n, m, ldw, V, M, out);
+    hipLaunchKernelGGL(k_ts_gemm, dim3((n + 63) / 64, (ldw + 63) / 64), dim3(256), 0, st, n, m, ldw, V, M, out);
 }
 
 // column sums of |V|^2, two deterministic stages
-constexpr int CN_ROWS = 1024;
+constexpr int CN_ROWS = 128;
 size_t colnorm_scratch_elems(int n, int ldw) { return ((size_t)n + CN_ROWS - 1) / CN_ROWS * (size_t)ldw; }
 
 __global__ __launch_bounds__(256) void k_colnorm_partial(int n, int ldw, const cz* __restrict__ V, double* scratch) {
