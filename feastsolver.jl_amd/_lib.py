@@ -55,6 +55,10 @@ PROTOTYPES = {
     "feasthip_set_q_buffer": (I, [VP, VP, C.c_size_t]),
     "feasthip_feast_run": (I, [VP, VP, I64, I, I, D, I, VP, VP, VP, C.POINTER(I)]),
     "feasthip_nlfeast_run": (I, [VP, VP, I64, I, I, D, D, VP, VP, VP, C.POINTER(I)]),
+    "feasthip_set_coef_functions": (I, [VP, VP, VP]),
+    "feasthip_set_node_coefficients": (I, [VP, VP, I, I]),
+    "feasthip_nl_beyn_step": (I, [VP, VP, VP]),
+    "feasthip_nl_set_r": (I, [VP, VP]),
     "feasthip_nlfeast_moments_run": (I, [VP, VP, I64, I, I, I, D, D, VP, VP, VP, VP, C.POINTER(I)]),
     "feasthip_estimate_count": (I, [VP, VP, I64, I, C.POINTER(D)]),
     "feasthip_lu_dense": (I, [I, VP, I64, PVP]),
@@ -72,6 +76,10 @@ PROTOTYPES = {
 
 def library_path():
     return os.path.join(_HERE, "libfeasthip.so")
+
+
+# void (*feasthip_coef_fn)(const double* z, int count, double* f, void* user)
+COEF_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_void_p)
 
 
 def load_library():

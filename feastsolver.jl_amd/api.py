@@ -76,6 +76,25 @@ class PolynomialNEP:
         return out
 
 
+class SplitNEP:
+    """T(z) = sum_t f_t(z) M_t (sum of products of matrices and scalar functions): the form of the reference's
+    non-polynomial test problems (test/gun2.jl:30-37, test/hadeler.jl:27-59).  Callable like a reference closure;
+    ``nlfeast`` / ``nlfeast_moments`` run it on the device (the M_t are resident, the f_t are evaluated on the host
+    through one callback, include/feasthip.h: feasthip_set_coef_functions)."""
+
+    def __init__(self, mats, funcs):
+        if len(mats) != len(funcs):
+            raise ValueError("one scalar function per matrix")
+        self.coeffs = list(mats)
+        self.funcs = list(funcs)
+
+    def __call__(self, z):
+        out = self.coeffs[0] * complex(self.funcs[0](z))
+        for M, f in zip(self.coeffs[1:], self.funcs[1:]):
+            out = out + M * complex(f(z))
+        return out
+
+
 class FeastHandle:
     """Owns one feasthip_handle_t (one GPU).  Used by feast/gen_feast/nlfeast and by the
     multi-GPU driver (distributed.py)."""
@@ -158,6 +177,42 @@ class FeastHandle:
 
     def set_node_shard(self, first, stride):
         self._ck(self.lib.feasthip_set_node_shard(self.h, int(first), int(stride)))
+
+    def set_coef_functions(self, funcs):
+        """f_t(z) of a split-form NEP (None restores the polynomial default z^t)."""
+        if funcs is None:
+            self._coef_cb = None
+            self._ck(self.lib.feasthip_set_coef_functions(self.h, None, None))
+            return
+        funcs = list(funcs)
+        nt = len(funcs)
+
+        def cb(zp, count, fp, _user):
+            for i in range(count):
+                z = complex(zp[2 * i], zp[2 * i + 1])
+                for t in range(nt):
+                    v = complex(funcs[t](z))
+                    fp[2 * (i * nt + t)] = v.real
+                    fp[2 * (i * nt + t) + 1] = v.imag
+
+        self._coef_cb = _lib.COEF_FN(cb)          # keep the trampoline alive as long as the handle
+        self._ck(self.lib.feasthip_set_coef_functions(self.h, C.cast(self._coef_cb, C.c_void_p), None))
+
+    def set_node_coefficients(self, table):
+        if table is None:
+            self._ck(self.lib.feasthip_set_node_coefficients(self.h, None, 0, 0))
+            return
+        tab = np.ascontiguousarray(table, dtype=np.complex128)
+        self._ck(self.lib.feasthip_set_node_coefficients(self.h, _vp(tab), tab.shape[0], tab.shape[1]))
+
+    def nl_beyn_step(self):
+        lam, _, ins = self._outs()
+        self._ck(self.lib.feasthip_nl_beyn_step(self.h, _vp(lam), _vp(ins)))
+        return lam, ins.astype(bool)
+
+    def nl_set_r(self, R):
+        R = np.asfortranarray(R, dtype=np.complex128)
+        self._ck(self.lib.feasthip_nl_set_r(self.h, _vp(R)))
 
     def analyze(self):
         self._ck(self.lib.feasthip_analyze(self.h))
@@ -328,18 +383,70 @@ def feast(X, A, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, eps=1e-12, debug
                      factorizer=factorizer, left_divider=left_divider, device=device, info=info)
 
 
+def _fro(M):
+    return float(np.sqrt((abs(M) ** 2).sum())) if _issparse(M) else float(np.linalg.norm(M))
+
+
+def _nlfeast_closure(T, Xw, nodes, iter, c, r, eps, spurious, device, info):
+    """nlfeast! for an arbitrary closure z -> matrix (the reference's interface, src/nlfeast.jl:2): T(z_k) for every
+    node goes to the device once (one term per node), the loop runs from the host with the phase calls and the
+    residual block R[:,i] = T(lam_i) x_i is formed on the host like the reference's update_R! (src/utils.jl:104-109)."""
+    con = circular_contour_trapezoidal(c, r, nodes)
+    h = FeastHandle(device)
+    try:
+        h.set_terms([T(z) for z in con.nodes])
+        h.set_contour(con)
+        h.set_node_coefficients(np.eye(nodes, dtype=np.complex128))
+        h.set_x(Xw)
+        h.nl_orthonormalize_x()                                            # src/nlfeast.jl:12-13
+        warn = h.factorize()                                               # :17-28
+        m0 = Xw.shape[1]
+        res = np.zeros(m0)
+        R = np.zeros(Xw.shape, dtype=np.complex128, order="F")
+        nit = 0
+        for nit in range(iter + 1):
+            h.nl_contour_step(nit == 0)                                    # :36-61
+            lam, ins = h.nl_beyn_step()                                    # :64
+            Xc = h.get_block(0)
+            for i in range(m0):                                            # update_R!, residuals  :66-67
+                Tl = T(lam[i])
+                R[:, i] = Tl @ Xc[:, i]
+                res[i] = np.linalg.norm(R[:, i]) / _fro(Tl)
+            h.nl_set_r(R)
+            ri = res[ins]
+            if ri.size > 0 and ri.max() < eps:                             # :73-76
+                break
+            if nit > 1 and (ri < spurious).sum() > 0 and ri[ri < spurious].max() < eps:   # :77-79
+                break
+        h.nl_finalize_x()                                                  # :82
+        Xw[...] = h.get_block(0)
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=min(nit, iter), warn=warn, inside=ins.copy())
+    finally:
+        h.close()
+    return lam, res
+
+
 def nlfeast(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, store=True, spurious=1e-5,
             factorizer=None, left_divider=None, device=0, info=None):
     """nlfeast!(T, X, nodes, iter; ...)  src/nlfeast.jl:2-84.  Returns (lam, X, res) for ALL m0
-    pairs (unfiltered).  T must be a PolynomialNEP (device fast path)."""
-    if not isinstance(T, PolynomialNEP):
-        raise NotImplementedError("nlfeast on the GPU needs a PolynomialNEP; generic closures are a later-round row (SURVEY 8f)")
+    pairs (unfiltered).  ``T`` is a PolynomialNEP or SplitNEP (device fast path: matrices resident, residuals on
+    the GPU) or any callable z -> matrix (node matrices on the device, residual block formed on the host)."""
     if not (isinstance(X, np.ndarray) and X.dtype == np.complex128):
         raise TypeError("X must be an AbstractMatrix{ComplexF64}")       # src/nlfeast.jl:2
+    if not callable(T):
+        raise TypeError("T must be callable: z -> matrix")
     X_in, Xw = _inplace_target(X)
+    if not isinstance(T, (PolynomialNEP, SplitNEP)):
+        lam, res = _nlfeast_closure(T, Xw, nodes, iter, c, r, eps, spurious, device, info)
+        _writeback(X_in, Xw)
+        return lam, Xw, res
     h = FeastHandle(device)
     try:
         h.set_terms(T.coeffs)
+        if isinstance(T, SplitNEP):
+            h.set_coef_functions(T.funcs)
         h.set_contour(circular_contour_trapezoidal(c, r, nodes))           # src/nlfeast.jl:8
         lam, res, ins, nit, warn = h.nlfeast_run(Xw, iter, eps, spurious)
         if info is not None:
@@ -357,14 +464,16 @@ def nlfeast_moments(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, 
     Returns (lam, Y, res) for all moments*m0 candidates sorted by relative residual; X is overwritten with the m0
     best candidates, column-normalised.  T must be a PolynomialNEP.  ``store`` is accepted for signature
     compatibility: the factors of the nodes are always kept on the device (the reference's store=true)."""
-    if not isinstance(T, PolynomialNEP):
-        raise NotImplementedError("nlfeast_moments on the GPU needs a PolynomialNEP; generic closures are a later-round row (SURVEY 8f)")
+    if not isinstance(T, (PolynomialNEP, SplitNEP)):
+        raise NotImplementedError("nlfeast_moments on the GPU needs a PolynomialNEP or SplitNEP (matrices resident on the device)")
     if not (isinstance(X, np.ndarray) and X.dtype == np.complex128):
         raise TypeError("X must be an AbstractMatrix{ComplexF64}")       # src/nlfeast.jl:173
     X_in, Xw = _inplace_target(X)
     h = FeastHandle(device)
     try:
         h.set_terms(T.coeffs)
+        if isinstance(T, SplitNEP):
+            h.set_coef_functions(T.funcs)
         h.set_contour(circular_contour_trapezoidal(c, r, nodes))           # src/nlfeast.jl:178
         lam, Y, res, ins, nit, warn = h.nlfeast_moments_run(Xw, moments, iter, eps, spurious)
         if debug:

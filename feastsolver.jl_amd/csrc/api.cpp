@@ -108,6 +108,22 @@ int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int it
     GUARD(h) return h->e->nlfeast_run(X, n, m0, iter, eps, spurious, lambda, res, inside, nit); ENDGUARD(h)
 }
 
+int feasthip_set_coef_functions(feasthip_handle_t h, feasthip_coef_fn fn, void* user) {
+    GUARD(h) return h->e->set_coef_functions(fn, user); ENDGUARD(h)
+}
+
+int feasthip_set_node_coefficients(feasthip_handle_t h, const double* coef, int K, int nterms) {
+    GUARD(h) return h->e->set_node_coefficients(coef, K, nterms); ENDGUARD(h)
+}
+
+int feasthip_nl_beyn_step(feasthip_handle_t h, double* lambda, uint8_t* inside) {
+    GUARD(h) return h->e->nl_rr_step(lambda, nullptr, inside, 1); ENDGUARD(h)
+}
+
+int feasthip_nl_set_r(feasthip_handle_t h, const void* R) {
+    GUARD(h) return h->e->nl_set_r(R); ENDGUARD(h)
+}
+
 int feasthip_nlfeast_moments_run(feasthip_handle_t h, void* X, int64_t n, int m0, int moments, int iter, double eps,
                                  double spurious, double* lambda, double* res, uint8_t* inside, void* Y, int* nit) {
     GUARD(h) return h->e->nlfeast_moments_run(X, n, m0, moments, iter, eps, spurious, lambda, res, inside, Y, nit); ENDGUARD(h)

@@ -443,16 +443,46 @@ int Engine::analyze() {
     return 0;
 }
 
+// f_t(z) of T(z) = sum_t f_t(z) scale_t M_t at the given points: powers z^t by default (polynomial NEP, linear pencil),
+// or the caller's functions (split form, feasthip_set_coef_functions).  out is point-major: out[i*nterms + t].
+void Engine::eval_coefs(const zc* pts, int count, std::vector<zc>& out) {
+    out.assign((size_t)count * nterms, zc(0.0));
+    if (coef_fn_) {
+        coef_fn_(reinterpret_cast<const double*>(pts), count, reinterpret_cast<double*>(out.data()), coef_user_);
+        return;
+    }
+    for (int i = 0; i < count; ++i) { zc zp = 1.0; for (int t = 0; t < nterms; ++t) { out[(size_t)i * nterms + t] = zp; zp *= pts[i]; } }
+}
+
+int Engine::set_coef_functions(feasthip_coef_fn fn, void* user) {
+    coef_fn_ = fn; coef_user_ = user;
+    factored_ = false;
+    return 0;
+}
+
+int Engine::set_node_coefficients(const double* coef, int K_, int nterms_) {
+    if (!coef) { node_coef_.clear(); factored_ = false; return 0; }
+    if (K_ != K || nterms_ != nterms) return fail(FEASTHIP_EARG, "set_node_coefficients: table must be K x nterms (set the contour and the terms first)");
+    node_coef_.assign(reinterpret_cast<const zc*>(coef), reinterpret_cast<const zc*>(coef) + (size_t)K * nterms);
+    factored_ = false;
+    return 0;
+}
+
 int Engine::factorize() {
     if (!analyzed_) { int r = analyze(); if (r) return r; }
     HIPCHK(hipSetDevice(device_));
-    // per-node polynomial coefficients scale_t * z_k^t and pivot thresholds
-    std::vector<zc> coef((size_t)Kloc * nterms);
+    // per-node coefficients scale_t * f_t(z_k) (f_t = z^t unless overridden) and pivot thresholds
+    std::vector<zc> coef((size_t)Kloc * nterms), fz, zloc(Kloc);
     std::vector<double> tiny(Kloc);
+    for (int kk = 0; kk < Kloc; ++kk) zloc[kk] = nodes_[local_[kk]];
+    if (node_coef_.empty()) eval_coefs(zloc.data(), Kloc, fz);
     for (int kk = 0; kk < Kloc; ++kk) {
-        zc z = nodes_[local_[kk]], zp = 1.0;
         double nrm = 0;
-        for (int t = 0; t < nterms; ++t) { coef[(size_t)kk * nterms + t] = terms_[t].scale * zp; nrm += std::abs(coef[(size_t)kk * nterms + t]) * terms_[t].maxabs; zp *= z; }
+        for (int t = 0; t < nterms; ++t) {
+            zc f = node_coef_.empty() ? fz[(size_t)kk * nterms + t] : node_coef_[(size_t)local_[kk] * nterms + t];
+            coef[(size_t)kk * nterms + t] = terms_[t].scale * f;
+            nrm += std::abs(coef[(size_t)kk * nterms + t]) * terms_[t].maxabs;
+        }
         tiny[kk] = std::max(nrm * 2.2e-19, 1e-300);
     }
     HIPCHK(hipMemcpyAsync(d_coef_.p, coef.data(), coef.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
@@ -1086,16 +1116,28 @@ int Engine::build_frob_table() {
 }
 
 double Engine::poly_frob_norm(zc lam) {
-    zc acc = 0, ls = 1.0;
-    for (int s = 0; s < nterms; ++s) {
-        zc lt = 1.0;
-        for (int t = 0; t < nterms; ++t) { acc += std::conj(ls) * lt * zc(frob_[s][2 * t], frob_[s][2 * t + 1]); lt *= lam; }
-        ls *= lam;
-    }
+    std::vector<zc> f;
+    eval_coefs(&lam, 1, f);
+    zc acc = 0;
+    for (int s = 0; s < nterms; ++s)
+        for (int t = 0; t < nterms; ++t) acc += std::conj(f[s]) * f[t] * zc(frob_[s][2 * t], frob_[s][2 * t + 1]);
     return std::sqrt(std::max(acc.real(), 0.0));
 }
 
-int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside) {
+// R[:, j] = T(lam_j) X[:, j] = sum_t f_t(lam_j) (scale_t M_t X)[:, j]  (src/utils.jl:107) for a block with leading dimension ld
+int Engine::residual_block(const cz* X, cz* MX, cz* R, const std::vector<zc>& lam, int mcols, int ld, cz* d_coeftab) {
+    int64_t blk = (int64_t)n * ld;
+    for (int t = 0; t < nterms; ++t) apply_term_ld(t, X, MX + (size_t)t * blk, 1.0, false, ld);
+    std::vector<zc> f, tab((size_t)nterms * ld, zc(0.0));
+    eval_coefs(lam.data(), mcols, f);
+    for (int j = 0; j < mcols; ++j) for (int t = 0; t < nterms; ++t) tab[(size_t)t * ld + j] = f[(size_t)j * nterms + t];
+    HIPCHK(hipMemcpyAsync(d_coeftab, tab.data(), tab.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_coef_combine(stream_, n, ld, MX, blk, nterms, d_coeftab, R);
+    HIPCHK(hipStreamSynchronize(stream_));      // tab is a stack-owned host buffer
+    return 0;
+}
+
+int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside, int external_residual) {
     if (!have_x_) return fail(FEASTHIP_ESTATE, "nl_rr_step: call set_x first");
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipEventRecord(ev0_, stream_));
@@ -1132,10 +1174,15 @@ int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside) {
     HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
     launch_scale_cols(stream_, n, ldw, d_X_.p, d_lam_.p);
     HIPCHK(hipStreamSynchronize(stream_));
-    HIPCHK(hipMemcpyAsync(d_lam_.p, lamp.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    int64_t blk = (int64_t)n * ldw;
-    for (int t = 0; t < nterms; ++t) apply_term(t, d_X_.p, d_MX_.p + (size_t)t * blk, 1.0, false);
-    launch_poly_combine(stream_, n, ldw, d_MX_.p, blk, nterms, d_lam_.p, d_R_.p);
+    if (external_residual) {     // generic closure T: the caller forms R[:,i] = T(lam_i) x_i itself and hands it back (feasthip_nl_set_r)
+        lambda_ = lam;
+        for (int j = 0; j < m; ++j) { lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag(); if (res) res[j] = 0.0; }
+        if (inside) inside_test(lam.data(), inside);
+        return 0;
+    }
+    if (!d_coeftab_.alloc((size_t)nterms * ldw)) return fail(FEASTHIP_EHIP, "out of device memory");
+    r = residual_block(d_X_.p, d_MX_.p, d_R_.p, lam, m, ldw, d_coeftab_.p);
+    if (r) return r;
     r = col_norms(d_R_.p, nr);
     if (r) return r;
     // residuals(R,lam,T): ||R_i|| / ||T(lam_i)||_F   src/utils.jl:151-157, Frobenius norm from the
@@ -1153,6 +1200,15 @@ int Engine::nl_rr_step(double* lambda, double* res, uint8_t* inside) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
     rr_ms = ms;
+    return 0;
+}
+
+int Engine::nl_set_r(const void* R) {
+    if (!have_x_ || !R) return fail(FEASTHIP_ESTATE, "nl_set_r: call set_x first");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipMemcpyAsync(d_io_.p, R, (size_t)n * m0 * sizeof(cz), hipMemcpyHostToDevice, stream_));
+    launch_cm_to_rm(stream_, n, m0, ldw, d_io_.p, n, d_R_.p);
+    HIPCHK(hipStreamSynchronize(stream_));
     return 0;
 }
 
@@ -1263,10 +1319,14 @@ int Engine::nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res) {
     HIPCHK(hipMemcpyAsync(d_lamM_.p, sc.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
     launch_scale_cols(stream_, n, ld, d_Ym_.p, d_lamM_.p);
     HIPCHK(hipStreamSynchronize(stream_));
-    HIPCHK(hipMemcpyAsync(d_lamM_.p, lamp.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
     int64_t wide = (int64_t)n * ld;
-    for (int t = 0; t < nterms; ++t) apply_term_ld(t, d_Ym_.p, d_MXm_.p + (size_t)t * wide, 1.0, false, ld);
-    launch_poly_combine(stream_, n, ld, d_MXm_.p, wide, nterms, d_lamM_.p, d_Rm_.p);
+    if (!d_coeftab_.alloc((size_t)nterms * ld)) return fail(FEASTHIP_EHIP, "out of device memory");
+    {
+        std::vector<zc> lamk(lam.begin(), lam.begin() + rk);
+        lamk.resize(M, zc(0.0));
+        r = residual_block(d_Ym_.p, d_MXm_.p, d_Rm_.p, lamk, M, ld, d_coeftab_.p);
+        if (r) return r;
+    }
     r = col_norms(tn, d_Rm_.p, nr);
     if (r) return r;
     r = build_frob_table();

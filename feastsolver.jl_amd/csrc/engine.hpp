@@ -2,6 +2,7 @@
 // launch plans built from the symbolic analysis, numeric factorisation of all
 // local contour nodes, block solves + moment accumulation, Rayleigh-Ritz step.
 #pragma once
+#include "../../include/feasthip.h"
 #include <complex>
 #include <cstdint>
 #include <string>
@@ -71,6 +72,9 @@ public:
     int set_contour(int K, const double* nodes, const double* weights, int kind, const double* region);
     int set_shard(int first, int stride);
     int set_q_buffer(void* dptr, size_t bytes);
+    int set_coef_functions(feasthip_coef_fn fn, void* user);
+    int set_node_coefficients(const double* coef, int K, int nterms);
+    int nl_set_r(const void* R);
     int analyze();
     int factorize();
     int set_x(const void* X, int64_t n, int m0);
@@ -78,7 +82,7 @@ public:
     int rr_step(double* lambda, double* res, uint8_t* inside);
     int contour_step(int refactor);
     int nl_contour_step(int first);
-    int nl_rr_step(double* lambda, double* res, uint8_t* inside);
+    int nl_rr_step(double* lambda, double* res, uint8_t* inside, int external_residual = 0);
     int nl_orthonormalize_x();
     int nl_finalize_x();
     int q_device(void** p, int64_t* n, int64_t* ldq, int* nblocks);
@@ -156,7 +160,13 @@ private:
     int col_norms(const cz* V, std::vector<double>& out) { return col_norms(tall_default(), V, out); }
     int col_norms(const Tall& t, const cz* V, std::vector<double>& out);
     void apply_term_ld(int t, const cz* V, cz* out, zc alpha, bool accumulate, int ld);
-    double poly_frob_norm(zc lam);           // ||T(lam)||_F from the <M_s, M_t>_F table
+    double poly_frob_norm(zc lam);
+    void eval_coefs(const zc* pts, int count, std::vector<zc>& out);
+    int residual_block(const cz* X, cz* MX, cz* R, const std::vector<zc>& lam, int mcols, int ld, cz* d_coeftab);
+    feasthip_coef_fn coef_fn_ = nullptr;
+    void* coef_user_ = nullptr;
+    std::vector<zc> node_coef_;              // optional K x nterms override of f_t(z_k) (per-node matrices)
+    DevBuf<cz> d_coeftab_;           // ||T(lam)||_F from the <M_s, M_t>_F table
     int build_frob_table();
     // nlfeast_moments state
     int mm_ = 0, ldM_ = 0;

@@ -91,6 +91,8 @@ void launch_poly_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t b
 void launch_hankel(hipStream_t st, int n, int m0, int ldw, int mm, int ldh, int shift, const cz* Qm, cz* H);
 // out[:, j] = in[:, idx[j]] (j < mo), padding columns zeroed; row-major blocks with leading dimensions ldi / ldo
 void launch_gather_cols(hipStream_t st, int n, int ldi, const cz* in, int ldo, int mo, const int* idx, cz* out);
+// R = sum_t MX[t] .* tab[t, j]   (split-form NEP residual; tab is nterms x ldw on the device)
+void launch_coef_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t blk, int nterms, const cz* tab, cz* R);
 // column-major (ld n) <-> row-major (ld ldw) conversion of n x m0 blocks, zero padding columns m0..ldw
 void launch_cm_to_rm(hipStream_t st, int n, int m0, int ldw, const cz* cm, int64_t ldcm, cz* rm);
 void launch_rm_to_cm(hipStream_t st, int n, int m0, int ldw, const cz* rm, cz* cm, int64_t ldcm);

@@ -352,6 +352,22 @@ void launch_gather_cols(hipStream_t st, int n, int ldi, const cz* in, int ldo, i
     hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, ldi, in, ldo, mo, idx, out);
 }
 
+// R[r, j] = sum_t tab[t, j] MX_t[r, j]   (T(lam_j) x_j for a NEP in split form T(z) = sum_t f_t(z) M_t, tab[t, j] = f_t(lam_j))
+__global__ void k_coef_combine(int64_t total, int ldw, const cz* __restrict__ MX, int64_t blk, int nterms,
+                               const cz* __restrict__ tab, cz* R) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    int j = (int)(e % ldw);
+    cz acc = cz_make(0, 0);
+    for (int t = 0; t < nterms; ++t) cz_madd(acc, tab[(size_t)t * ldw + j], MX[(int64_t)t * blk + e]);
+    R[e] = acc;
+}
+
+void launch_coef_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t blk, int nterms, const cz* tab, cz* R) {
+    int64_t total = (int64_t)n * ldw;
+    hipLaunchKernelGGL(k_coef_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, ldw, MX, blk, nterms, tab, R);
+}
+
 __global__ void k_cm_to_rm(int n, int m0, int ldw, const cz* __restrict__ cm, int64_t ldcm, cz* rm) {
     __shared__ cz tile[32][33];
     int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;

@@ -156,3 +156,17 @@ def c5_system5_companion(m0=128, seed=5001):
         C2[:N, N * i:N * (i + 1)] = -A[i + 1]
     return dict(A=C1, B=C2, c=-1.55 + 0j, r=0.05, nodes=32, m0=m0, X0=rand_x0(N * L, m0, seed),
                 iter=20, eps=1e-10, n_inside=50)
+
+
+def hadeler_split(n=200, b0=100.0):
+    """Hadeler NEP T(z) = (e^z - 1) M1 + z^2 M2 - M0 as written out in test/hadeler.jl:35-52 (the nlevp_native_hadeler
+    gallery problem the script solves): M0 = b0 I, M1[i,j] = (n+1-max(i,j)) i j, M2[i,j] = n d_ij + 1/(i+j).
+    Returns (mats, funcs) of the split form sum_t f_t(z) M_t, and the contour of test/hadeler.jl:56-57."""
+    i = np.arange(1, n + 1)[:, None]
+    j = np.arange(1, n + 1)[None, :]
+    M1 = ((n + 1 - np.maximum(i, j)) * i * j).astype(np.complex128)
+    M2 = (n * (i == j) + 1.0 / (i + j)).astype(np.complex128)
+    M0 = b0 * np.eye(n, dtype=np.complex128)
+    funcs = [lambda z: np.exp(z) - 1.0, lambda z: z * z, lambda z: -1.0 + 0.0 * z]
+    return dict(mats=[M1, M2, M0], funcs=funcs, c=-30.0 + 0j, r=10.0, nodes=16, m0=15, iter=20, eps=1e-13, spurious=1e-2,
+                seed=7001)

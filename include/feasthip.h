@@ -125,6 +125,25 @@ int feasthip_feast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter
                        int store, double* lambda, double* res, uint8_t* inside, int* nit);
 int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps,
                          double spurious, double* lambda, double* res, uint8_t* inside, int* nit);
+/* ---- NEPs that are not polynomials (SURVEY 8b "generic-T NLFEAST"; the reference takes any closure z -> matrix,
+ * src/nlfeast.jl:2,21, src/utils.jl:107; test/gun2.jl:30-37, test/hadeler.jl:27-59).
+ * (1) split form T(z) = sum_t f_t(z) M_t: the M_t are the terms of feasthip_set_dense/_csc, the scalar functions are
+ *     supplied as ONE callback evaluated on the host whenever coefficients are needed (nodes at factorisation,
+ *     Ritz values at every residual): z = count complex points (re,im), f = count x nterms complex, point-major.
+ *     Everything else (feasthip_nlfeast_run, feasthip_nlfeast_moments_run, the phase calls) is unchanged.
+ *     fn = NULL restores the polynomial default f_t(z) = z^t. */
+typedef void (*feasthip_coef_fn)(const double* z, int count, double* f, void* user);
+int feasthip_set_coef_functions(feasthip_handle_t h, feasthip_coef_fn fn, void* user);
+/* (2) arbitrary closure: hand over T(z_k) for every node as terms 0..K-1 together with the K x nterms table of node
+ *     coefficients (row k = coefficients of T(z_k); identity for one matrix per node), run the loop from the host with
+ *     feasthip_nl_contour_step / feasthip_nl_beyn_step, form R[:,i] = T(lambda_i) x_i on the host (the reference's
+ *     update_R!, src/utils.jl:104-109) and return it with feasthip_nl_set_r.  coef = NULL removes the table. */
+int feasthip_set_node_coefficients(feasthip_handle_t h, const double* coef, int K, int nterms);
+/* Beyn SVD step only (src/utils.jl:69-77): Ritz values + column-normalised X on the device, no residual. */
+int feasthip_nl_beyn_step(feasthip_handle_t h, double* lambda, uint8_t* inside);
+/* R (n x m0 column-major complex128) for the next contour step. */
+int feasthip_nl_set_r(feasthip_handle_t h, const void* R);
+
 /* nlfeast_moments!(T, X, nodes, iter; c, r, eps, moments, store=true, spurious)  src/nlfeast.jl:173-318
  * (SURVEY 8f rank 1): 2*moments contour moments from the same shifted block solves, block-Hankel Beyn step.
  * M = moments*m0 candidates are returned sorted by relative residual (update_R_moments!, src/utils.jl:118-134):

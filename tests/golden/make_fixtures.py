@@ -79,6 +79,19 @@ def moments_fixtures():
         out[name] = dict(n=cs["n"], m0=cs["m0"], seed=cs["seed"], nodes=cs["nodes"], iter=cs["iter"], c=[cs["c"].real, cs["c"].imag],
                          r=cs["r"], moments=cs["moments"], eps=cs["eps"], history=hist,
                          lam_inside=cplx(np.sort_complex(lam[ins])), res_inside=[float(x) for x in res[ins]])
+    # non-polynomial NEP in split form (test/hadeler.jl:27-59), plain nlfeast! and the moments variant
+    w = wl.hadeler_split()
+    T = lambda z: sum(M * f(z) for M, f in zip(w["mats"], w["funcs"]))      # noqa: E731
+    hist = []
+    lam, _, res = fo.nlfeast(T, wl.rand_x0(200, w["m0"], w["seed"]), w["nodes"], w["iter"], c=w["c"], r=w["r"], eps=w["eps"],
+                             spurious=w["spurious"], history=hist)
+    ins = np.abs(lam - w["c"]) <= w["r"]
+    out["hadeler_nlfeast"] = dict(history=hist, lam_inside=cplx(np.sort_complex(lam[ins])), res_inside=[float(x) for x in res[ins]])
+    hist = []
+    lam, _, res = fo.nlfeast_moments(T, wl.rand_x0(200, w["m0"], w["seed"]), w["nodes"], w["iter"], c=w["c"], r=w["r"], eps=w["eps"],
+                                     moments=2, spurious=w["spurious"], history=hist)
+    ins = (np.abs(lam - w["c"]) <= w["r"]) & (res < 1e-9)
+    out["hadeler_moments"] = dict(history=hist, lam_inside=cplx(np.sort_complex(lam[ins])), res_inside=[float(x) for x in res[ins]])
     return out
 
 
@@ -88,7 +101,7 @@ def main():
         out = json.load(open(gp))
         out.update(moments_fixtures())
         json.dump(out, open(gp, "w"), indent=1)
-        print({k: len(v["lam_inside"]) for k, v in out.items() if k.startswith("moments_")})
+        print({k: len(v["lam_inside"]) for k, v in out.items() if k.startswith("moments_") or k.startswith("hadeler_")})
         return
     full = "--full" in sys.argv
     out = {}

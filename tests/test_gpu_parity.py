@@ -232,6 +232,36 @@ def test_nlfeast_moments_parity(gpu, pkg, fo, wl, golden, case, comp_key):
     assert np.abs(X - Y[:, :g["m0"]]).max() < 1e-12
 
 
+@pytest.mark.parametrize("path", ["split", "closure", "moments"])
+def test_hadeler_nonpolynomial_nep(gpu, pkg, wl, golden, path):
+    """Generic-T NLFEAST: the Hadeler problem of test/hadeler.jl in split form on the device
+    (feasthip_set_coef_functions), as an opaque closure (node matrices + host residual, feasthip_set_node_coefficients /
+    feasthip_nl_beyn_step / feasthip_nl_set_r) and through nlfeast_moments!, against the oracle fixture."""
+    w = wl.hadeler_split()
+    nep = pkg.SplitNEP(w["mats"], w["funcs"])
+    X = wl.rand_x0(200, w["m0"], w["seed"])
+    info = {}
+    kw = dict(c=w["c"], r=w["r"], eps=w["eps"], spurious=w["spurious"], info=info)
+    if path == "split":
+        lam, Xo, res = pkg.nlfeast(nep, X, w["nodes"], w["iter"], **kw)
+        g = golden["hadeler_nlfeast"]
+    elif path == "closure":
+        lam, Xo, res = pkg.nlfeast(lambda z: nep(z), X, w["nodes"], w["iter"], **kw)      # opaque callable
+        g = golden["hadeler_nlfeast"]
+    else:
+        lam, Xo, res = pkg.nlfeast_moments(nep, X, w["nodes"], w["iter"], moments=2, **kw)
+        g = golden["hadeler_moments"]
+    ins = (np.abs(lam - w["c"]) <= w["r"]) & (res < 1e-9)
+    gl = c2n(g["lam_inside"])
+    assert ins.sum() == len(gl) == 12
+    assert match_sets(lam[ins], gl) < 1e-9 and match_sets(gl, lam[ins]) < 1e-9
+    assert res[ins].max() < 1e-11
+    assert abs(info["nit"] - g["history"][-1][0]) <= 1
+    for j in np.nonzero(ins)[0][:4]:                        # relative residual definition (src/utils.jl:151-157)
+        Tl = nep(lam[j])
+        assert abs(np.linalg.norm(Tl @ Xo[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
+
+
 def test_c5_system5_companion_m128(gpu, pkg, wl, golden):
     """C5 (ii): system5 quadratic, companion pencil 2000 x 2000, 32 nodes, m0 = 128."""
     g = golden["c5_system5_companion"]

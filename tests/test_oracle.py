@@ -96,6 +96,22 @@ def test_nlfeast_moments_matches_companion(fo, wl, golden, case, comp_key):
     assert np.allclose(np.linalg.norm(X, axis=0), 1.0)
 
 
+def test_hadeler_split_form_fixture(fo, wl, golden):
+    """non-polynomial NEP written out in test/hadeler.jl:35-52: the oracle's nlfeast!/nlfeast_moments! reproduce the
+    committed eigenvalues, and each of them makes T(lam) singular (smallest singular value ~ 0)."""
+    w = wl.hadeler_split()
+    T = lambda z: sum(M * f(z) for M, f in zip(w["mats"], w["funcs"]))      # noqa: E731
+    lam, X, res = fo.nlfeast(T, wl.rand_x0(200, w["m0"], w["seed"]), w["nodes"], w["iter"], c=w["c"], r=w["r"], eps=w["eps"],
+                             spurious=w["spurious"])
+    ins = np.abs(lam - w["c"]) <= w["r"]
+    g = c2n(golden["hadeler_nlfeast"]["lam_inside"])
+    assert ins.sum() == len(g) == 12 and np.abs(np.sort_complex(lam[ins]) - g).max() < 1e-9
+    assert np.abs(c2n(golden["hadeler_moments"]["lam_inside"]) - g).max() < 1e-9
+    for z in g[:4]:
+        Tz = T(z)
+        assert np.linalg.svd(Tz, compute_uv=False)[-1] < 1e-9 * np.linalg.norm(Tz)
+
+
 def test_golden_c3_small_reproduces(fo, wl, golden):
     g = golden["c3_g8_s19_m16"]
     w = wl.c3_sparse_generalized(8, 19, 16)
