@@ -18,6 +18,7 @@ struct FrontD {
     int64_t child_ptr;
     int nchild, depth;
     int64_t sk_off;           // row offset of this front's split-K partial sums in the scratch (backward U12 product), or -1
+    int64_t cmap;             // offset into the contribution-row pull map (u x nchild ints), or -1 without children
 };
 
 struct Tile { int f, a, b, c; };

@@ -221,8 +221,13 @@ bool Engine::build_plans() {
         for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s) + S.u(s), 64); for (int a = 0; a < nt; ++a) for (int b = 0; b < nt; ++b) tiles.push_back({s, a, b, 0}); }
         F.extend.count = (int)(tiles.size() - F.extend.off);
         V.assemble.off = (int64_t)tiles.size();
-        for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s) + S.u(s), 64); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }
+        for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s), 64); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }      // pivot-block rows only
         V.assemble.count = (int)(tiles.size() - V.assemble.off);
+        for (int s : lv)
+            for (int64_t c = S.child_ptr[s]; c < S.child_ptr[s + 1]; ++c) {
+                int gch = S.child_idx[c];
+                for (int i = 0; i < S.u(gch); ++i) { if (S.rel[S.struct_ptr[gch] + i] < S.p(s)) V.asm_rows += 1; else V.pull_rows += 1; }
+            }
         // factor steps
         for (int k0 = 0; k0 < pmax; k0 += FACT_NB) {
             FactorStep st;
@@ -417,7 +422,27 @@ int Engine::analyze() {
         f.sptr = S.struct_ptr[s]; f.crow = S.crow_off[s];
         f.child_ptr = S.child_ptr[s]; f.nchild = (int)(S.child_ptr[s + 1] - S.child_ptr[s]); f.depth = S.depth[s];
         f.sk_off = -1;
+        f.cmap = -1;
     }
+    // pull map of the forward sweep: for every contribution row of a front and every child slot, the row of the child's
+    // contribution block that is added to it (rel >= p), as an absolute row of the children's arena; -1 if none
+    std::vector<int> cmap;
+    for (int s = 0; s < S.nsuper; ++s) {
+        int nch = fr[s].nchild, u = fr[s].u, p = fr[s].p;
+        if (nch == 0 || u == 0) continue;
+        fr[s].cmap = (int64_t)cmap.size();
+        size_t base = cmap.size();
+        cmap.resize(base + (size_t)u * nch, -1);
+        for (int c = 0; c < nch; ++c) {
+            int gch = S.child_idx[S.child_ptr[s] + c];
+            int ug = S.u(gch);
+            for (int i = 0; i < ug; ++i) {
+                int dst = S.rel[S.struct_ptr[gch] + i];
+                if (dst >= p) cmap[base + (size_t)(dst - p) * nch + c] = (int)(S.crow_off[gch] + i);
+            }
+        }
+    }
+    if (cmap.empty()) cmap.push_back(-1);
     std::vector<int> c0row(n);
     for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
     std::vector<int> one(1, 0);
@@ -425,12 +450,13 @@ int Engine::analyze() {
               d_struct_.upload(S.struct_idx.empty() ? one.data() : S.struct_idx.data(), std::max<size_t>(1, S.struct_idx.size()), stream_) &&
               d_rel_.upload(S.rel.empty() ? one.data() : S.rel.data(), std::max<size_t>(1, S.rel.size()), stream_) &&
               d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
-              d_perm_.upload(S.perm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_);
+              d_perm_.upload(S.perm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
+              d_cmap_.upload(cmap.data(), cmap.size(), stream_);
     if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
     for (int s = 0; s < S.nsuper; ++s) fr[s].sk_off = sk_off_[s];
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
-    dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.n = n;
+    dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.n = n;
     // numeric arenas
     ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
          d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
@@ -883,7 +909,7 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
         begin();
         launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs,
                             (d_crow_[par ^ 1].p + (int64_t)kb * crsc), crsc, rinv, kc, 0);
-        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * kc, 0); }
+        if (V.assemble.count) end(1, 3.0 * V.asm_rows * rowb * kc, 0);
         double lvl_rows = 0;
         for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
         for (Launch& L : V.f1) {
@@ -892,12 +918,11 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
         }
         begin();
-        launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs, kc);
-        if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows), stat_flops(V.f2)); }
-        begin();
-        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs,
-                            (d_crow_[par ^ 1].p + (int64_t)kb * crsc), crsc, rinv, kc, 1);
-        if (V.assemble.count) { double rows = d < S.maxdepth ? (double)S.crow_used[d + 1] : 0; end(1, 1.5 * rows * rowb * kc, 0); }
+        // contribution rows of the children that pass through to this level's contribution rows are pulled in the
+        // epilogue of the F2a tiles (kind 1), so there is no second assembly pass
+        launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs, kc, false,
+                     nullptr, 0, (d_crow_[par ^ 1].p + (int64_t)kb * crsc), crsc);
+        if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows + V.pull_rows), stat_flops(V.f2)); }
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
         SolveLevel& V = splan_[d];
@@ -955,7 +980,11 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
 double Engine::solve_bytes() const {
     // factor entries streamed once per node and sweep pair + block-vector traffic
     double rowb = (double)ldw * 16.0;
-    double per_node = (double)S.fact_size * 16.0 + (double)S.sum_u * 4.0 + (4.0 * n + 3.0 * (double)S.sum_u) * rowb;
+    // contribution rows: written once by their front; then either pulled by the parent's F2a epilogue (1 read) or
+    // assembled into the parent's pivot block (read + read-modify-write)
+    double asm_rows = 0, pull_rows = 0;
+    for (const SolveLevel& V : splan_) { asm_rows += V.asm_rows; pull_rows += V.pull_rows; }
+    double per_node = (double)S.fact_size * 16.0 + (double)S.sum_u * 4.0 + (4.0 * n + (double)S.sum_u + pull_rows + 3.0 * asm_rows) * rowb;
     return per_node * Kloc + 3.0 * n * rowb;
 }
 

@@ -38,7 +38,8 @@ struct Launch {        // a slice of the tile / list buffers
 
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm; };
 struct FactorLevel { Launch extend; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale; };
-struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0; };
+struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
+                    double asm_rows = 0, pull_rows = 0; };   // children's contribution rows landing in pivot blocks / in contribution rows of this level
 
 struct SparseTerm {
     std::vector<int64_t> colptr;
@@ -125,7 +126,7 @@ private:
 
     // device symbolic
     DevBuf<FrontD> d_fr_;
-    DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_c0row_;
+    DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_c0row_, d_cmap_;
     DevBuf<Tile> d_tiles_;
     DevBuf<int> d_lists_;
     std::vector<FactorLevel> fplan_;

@@ -16,6 +16,7 @@ struct DevSym {          // device copies of the symbolic structure
     const int* child_idx;
     const int* perm;     // new -> old
     const int* c0_of_row;  // first column of the supernode owning (new) row i
+    const int* cmap;       // per front with children: [contribution row][child slot] -> row in the children's arena, or -1
     int n;
 };
 
@@ -50,14 +51,15 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // Block substitution on the solve-ready factors: every tile is out (-)= A * V on the f64 matrix cores.
 // Tile.a = kind, Tile.b = row tile (or diagonal block), Tile.c = step block index:
 //   0 F1  forward, rows of the pivot block below diagonal block c:   W_r -= P_rc W_c
-//   1 F2a forward, contribution rows:                                  C_I  = -P21 W_J         (K = p)
+//   1 F2a forward, contribution rows:                                  C_I  = sum_children C_child[I] - P21 W_J   (K = p; the
+//                                                                      children's rows are pulled in the epilogue through DevSym::cmap)
 //   2 F2b forward, diagonal super block b, row tile c:                 Y_b  = inv(L_bb) W_b
 //   3 B1  backward, pivot rows:                                        Y_J -= U12 W[struct]    (K = u, gathered; final x lives in W)
 //   4 B2  backward, rows above diagonal block c:                       Y_r -= PU_rc Y_c
 //   5 B3  backward, diagonal super block b, row tile c:                W_b  = inv(U_bb) Y_b
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false,
-                  cz* skbuf = nullptr, int64_t sks = 0);
+                  cz* skbuf = nullptr, int64_t sks = 0, const cz* crow_child = nullptr, int64_t crs_child = 0);
 // Kind-3 tiles may be split along K (Tile.a bits 16.. = number of parts, Tile.c = part): each part writes
 // -U12[:, part] * x[part] into its own slab of `skbuf`; launch_splitk_reduce then adds the slabs to Y in a fixed order.
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,

@@ -137,7 +137,10 @@ struct ApplyGeom {
     int vrow0;           // first V row (contiguous kinds)
     cz* out;             // output rows base: row r of the tile is out + r * ldw   (r relative to orow0)
     int orow_shift;      // output row index = orow + orow_shift
-    int mode;            // 0: out -= acc, 1: out = acc, 2: out = -acc
+    int mode;            // 0: out -= acc, 1: out = acc, 2: out = -acc, 3: out = pulled child rows - acc
+    const int* pull;     // mode 3: [output row][child slot] -> row of the children's contribution arena, or -1
+    int npull;           // child slots per row
+    const cz* pullbase;  // children's contribution arena of this node
 };
 
 // NS = number of 16-row slabs of this tile that carry data (1, 2 or 4).  The 4 waves are arranged
@@ -276,6 +279,30 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][min(cg + (ct0 + q) * 16 + li, ldw - 1)];
+        } else if (g.mode == 3 && wave_active) {
+            // extend-add of the forward sweep fused into the producer: pull the children's contribution rows that
+            // land on this tile's rows (fixed child order: deterministic), instead of a separate read-modify-write pass
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < NS; ++q) old[r][q] = cz_make(0, 0);
+            for (int c = 0; c < g.npull; ++c) {
+                int src[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int orow = g.rbase + slab * 16 + lk + 4 * r;
+                    src[r] = rok[r] ? g.pull[(int64_t)(orow + g.orow_shift) * g.npull + c] : -1;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (src[r] >= 0) {
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) {
+                            cz v = g.pullbase[(int64_t)src[r] * ldw + min(cg + (ct0 + q) * 16 + li, ldw - 1)];
+                            old[r][q].x += v.x; old[r][q].y += v.y;
+                        }
+                    }
+            }
         }
         mfma_chunk(kc, buf);
     }
@@ -291,7 +318,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
         for (int q = 0; q < NS; ++q) {
             int col = cg + (ct0 + q) * 16 + li;
             cz v;
-            if (g.mode != 0) v = cz_make(sgn * cr[q][r], sgn * ci[q][r]);
+            if (g.mode == 1 || g.mode == 2) v = cz_make(sgn * cr[q][r], sgn * ci[q][r]);
             else v = cz_make(old[r][q].x - cr[q][r], old[r][q].y - ci[q][r]);
 #if FEASTHIP_ABLATE == 3
             if (v.x == 123.456)
@@ -304,7 +331,7 @@ template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
                                                cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks,
-                                               int ntiles) {
+                                               int ntiles, const int* __restrict__ cmap, const cz* __restrict__ crow_child, int64_t crs_child) {
     __shared__ cz Vs[2][APPLY_KC][LDS_COLS];      // double buffered, filled by LDS-DMA
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the
     // (node, tile) items are handed out in node-major order with a contiguous range per XCD: the tiles of
@@ -322,11 +349,14 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     cz* Wk = W + (int64_t)k * ws;
     cz* Yk = Y + (int64_t)k * ws;
     ApplyGeom g;
-    g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0;
+    g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0; g.pull = nullptr; g.npull = 0; g.pullbase = nullptr;
     g.sidx = struct_idx + f.sptr;
     g.out = Yk; g.orow_shift = f.c0;
     if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
-    else if (kind == 1) { g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2; }
+    else if (kind == 1) {
+        g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2;
+        if (f.cmap >= 0) { g.mode = 3; g.pull = cmap + f.cmap; g.npull = f.nchild; g.pullbase = crow_child + (int64_t)k * crs_child; }
+    }
     else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
     else if (kind == 3) {
         g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk;
@@ -346,11 +376,12 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
 }
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
-                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks) {
+                  cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
+                  const cz* crow_child, int64_t crs_child) {
     if (ntiles <= 0) return;
     dim3 g(ntiles * K, 1, (ldw + LDS_COLS - 1) / LDS_COLS);
-    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles);
-    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles);
+    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
+    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
 }
 
 // Y[c0 + r, :] += sum_part scratch[part][r, :]   (parts in increasing order: deterministic)
