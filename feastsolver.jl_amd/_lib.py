@@ -55,6 +55,7 @@ PROTOTYPES = {
     "feasthip_set_q_buffer": (I, [VP, VP, C.c_size_t]),
     "feasthip_feast_run": (I, [VP, VP, I64, I, I, D, I, VP, VP, VP, C.POINTER(I)]),
     "feasthip_nlfeast_run": (I, [VP, VP, I64, I, I, D, D, VP, VP, VP, C.POINTER(I)]),
+    "feasthip_set_precision": (I, [VP, I]),
     "feasthip_set_coef_functions": (I, [VP, VP, VP]),
     "feasthip_set_node_coefficients": (I, [VP, VP, I, I]),
     "feasthip_nl_beyn_step": (I, [VP, VP, VP]),
@@ -62,6 +63,7 @@ PROTOTYPES = {
     "feasthip_nlfeast_moments_run": (I, [VP, VP, I64, I, I, I, D, D, VP, VP, VP, VP, C.POINTER(I)]),
     "feasthip_estimate_count": (I, [VP, VP, I64, I, C.POINTER(D)]),
     "feasthip_lu_dense": (I, [I, VP, I64, PVP]),
+    "feasthip_lu_dense_c64": (I, [I, VP, I64, PVP]),
     "feasthip_lu_csc": (I, [I, I64, VP, VP, VP, I, I, PVP]),
     "feasthip_ldiv": (I, [VP, VP, I64, VP, I64, I]),
     "feasthip_fact_free": (I, [VP]),

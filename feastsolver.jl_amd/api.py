@@ -178,6 +178,10 @@ class FeastHandle:
     def set_node_shard(self, first, stride):
         self._ck(self.lib.feasthip_set_node_shard(self.h, int(first), int(stride)))
 
+    def set_precision(self, mixed):
+        """mixed_prec of feast! (src/feast.jl:19-25): complex64 shifted solves, complex128 accumulation."""
+        self._ck(self.lib.feasthip_set_precision(self.h, 1 if mixed else 0))
+
     def set_coef_functions(self, funcs):
         """f_t(z) of a split-form NEP (None restores the polynomial default z^t)."""
         if funcs is None:
@@ -327,7 +331,7 @@ def _writeback(X_in, Xw):
 
 
 def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=False, store=False, eps=1e-12,
-              factorizer=None, left_divider=None, device=0, info=None):
+              factorizer=None, left_divider=None, device=0, info=None, _mixed_prec=False):
     """gen_feast!(X, A, B[, contour]; ...)  src/feast.jl:82-156.  B=None gives feast!.
 
     ``factorizer``/``left_divider`` are accepted for signature parity; the built-in
@@ -344,6 +348,8 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     try:
         h.set_terms([A, B], scales=[1.0, -1.0])          # T(z) = A - z B
         h.set_contour(contour)
+        if _mixed_prec:
+            h.set_precision(True)
         if debug:
             # same loop, driven from the host so that every iteration can be reported like
             # iter_debug_print (src/utils.jl:2-42): nit, #inside, #inside below 1e-5, max residual inside
@@ -377,10 +383,9 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
 def feast(X, A, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, eps=1e-12, debug=False, store=False,
           mixed_prec=False, factorizer=None, left_divider=None, device=0, info=None):
     """feast!(X, A[, contour]; ...)  src/feast.jl:3-80."""
-    if mixed_prec:
-        raise NotImplementedError("mixed_prec (ComplexF32 factor/solve, src/feast.jl:19-25) is a later-round row (SURVEY 8f)")
+    # mixed_prec (src/feast.jl:10,19-25): complex64 shifted solves with complex128 accumulation (feasthip_set_precision)
     return gen_feast(X, A, None, contour, nodes=nodes, iter=iter, c=c, r=r, debug=debug, store=store, eps=eps,
-                     factorizer=factorizer, left_divider=left_divider, device=device, info=info)
+                     factorizer=factorizer, left_divider=left_divider, device=device, info=info, _mixed_prec=bool(mixed_prec))
 
 
 def _fro(M):
@@ -526,15 +531,22 @@ class HipLU:
 
 
 def lu(Cm, device=0):
-    """factorizer(C): GPU LU of the assembled shifted matrix; C is copied (src/feast.jl:29-36)."""
+    """factorizer(C): GPU LU of the assembled shifted matrix; C is copied (src/feast.jl:29-36).  A complex64 matrix
+    (the ComplexF32 ZmA of the mixed_prec path, src/feast.jl:19-25) gives a factor object that solves in complex64."""
     lib = _lib.load_library()
     F = C.c_void_p()
     if Cm.shape[0] != Cm.shape[1]:
         raise ValueError("Incorrect dimensions of A, must be square")
     n = Cm.shape[0]
+    c64 = Cm.dtype == np.complex64
     if _issparse(Cm):
         (cp, rv, vl), ty = _csc_arg(Cm)
+        if c64:
+            vl, ty = np.ascontiguousarray(vl, dtype=np.complex64), 3          # FEASTHIP_C64
         code = lib.feasthip_lu_csc(int(device), n, _vp(cp), _vp(rv), _vp(vl), ty, 0, C.byref(F))
+    elif c64:
+        arr = np.asfortranarray(Cm, dtype=np.complex64)
+        code = lib.feasthip_lu_dense_c64(int(device), _vp(arr), n, C.byref(F))
     else:
         arr = np.asfortranarray(Cm, dtype=np.complex128)
         code = lib.feasthip_lu_dense(int(device), _vp(arr), n, C.byref(F))

@@ -1,6 +1,7 @@
 // extern "C" surface of libfeasthip.so (include/feasthip.h).  Nothing here
 // throws across the ABI: every entry point catches and maps to a status code.
 #include <cstring>
+#include <complex>
 #include <mutex>
 #include <new>
 #include <string>
@@ -108,6 +109,10 @@ int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int it
     GUARD(h) return h->e->nlfeast_run(X, n, m0, iter, eps, spurious, lambda, res, inside, nit); ENDGUARD(h)
 }
 
+int feasthip_set_precision(feasthip_handle_t h, int mixed) {
+    GUARD(h) return h->e->set_precision(mixed); ENDGUARD(h)
+}
+
 int feasthip_set_coef_functions(feasthip_handle_t h, feasthip_coef_fn fn, void* user) {
     GUARD(h) return h->e->set_coef_functions(fn, user); ENDGUARD(h)
 }
@@ -194,6 +199,24 @@ int feasthip_lu_dense(int device_id, const void* C, int64_t n, feasthip_fact_t* 
     } catch (...) { return FEASTHIP_EARG; }
 }
 
+int feasthip_lu_dense_c64(int device_id, const void* C, int64_t n, feasthip_fact_t* F) {
+    if (!C || !F || n <= 0) return FEASTHIP_EARG;
+    *F = nullptr;
+    try {
+        std::vector<std::complex<double>> wide((size_t)n * n);
+        const std::complex<float>* src = static_cast<const std::complex<float>*>(C);
+        for (size_t i = 0; i < wide.size(); ++i) wide[i] = std::complex<double>(src[i].real(), src[i].imag());
+        Engine* e = new Engine(device_id);
+        if (e->status) { int st = e->status; { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return st; }
+        const void* mats[1] = {wide.data()};
+        int types[1] = {FEASTHIP_C128};
+        int r = e->set_dense(n, 1, mats, types, nullptr);
+        if (r == 0) r = e->set_precision(1);
+        if (r) { { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return r; }
+        return make_fact(e, F);
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
 int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64_t* rowval, const void* nzval, int type,
                     int index_base, feasthip_fact_t* F) {
     if (!colptr || !rowval || !nzval || !F || n <= 0) return FEASTHIP_EARG;
@@ -201,6 +224,17 @@ int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64
     try {
         Engine* e = new Engine(device_id);
         if (e->status) { int st = e->status; { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return st; }
+        std::vector<std::complex<double>> wide;
+        if (type == FEASTHIP_C64) {          // ComplexF32 shifted matrix: widen the values, solve in complex64
+            int64_t nnz = colptr[n] - index_base;
+            if (nnz < 0) { delete e; return FEASTHIP_EARG; }
+            const std::complex<float>* src = static_cast<const std::complex<float>*>(nzval);
+            wide.resize((size_t)nnz);
+            for (int64_t i = 0; i < nnz; ++i) wide[i] = std::complex<double>(src[i].real(), src[i].imag());
+            nzval = wide.data();
+            type = FEASTHIP_C128;
+            e->set_precision(1);
+        }
         const int64_t* cps[1] = {colptr};
         const int64_t* rvs[1] = {rowval};
         const void* vs[1] = {nzval};

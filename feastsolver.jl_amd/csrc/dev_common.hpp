@@ -6,6 +6,7 @@
 namespace feasthip {
 
 typedef double2 cz;                                             // complex128 (re, im)
+typedef float2 cf;                                              // complex64, mixed-precision solve path
 typedef double d4 __attribute__((ext_vector_type(4)));         // f64 MFMA accumulator fragment
 
 // One supernodal front.  Its L panel is (p+u) x p column-major (ld = p+u) and

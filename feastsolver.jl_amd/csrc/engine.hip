@@ -56,6 +56,7 @@ Engine::Engine(int device) : device_(device) {
     own_stream_ = true;
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
+    if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
     if (nst > 1) {
@@ -550,6 +551,10 @@ int Engine::factorize() {
         launch_couple_inverse(stream_, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(stream_, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
     }
+    if (mixed_) {      // complex64 copy of the solve-ready factors for the mixed-precision sweeps
+        if (!d_fact32_.alloc((size_t)Kloc * fs)) return fail(FEASTHIP_EHIP, "out of device memory for the complex64 factors");
+        launch_to_f32(stream_, (int64_t)Kloc * fs, d_fact_.p, d_fact32_.p);
+    }
     HIPCHK(hipEventRecord(ev1_, stream_));
     std::vector<int> np(Kloc);
     HIPCHK(hipMemcpyAsync(np.data(), d_nperturb_.p, Kloc * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -574,7 +579,16 @@ int Engine::alloc_iteration_buffers() {
               d_e0_.alloc((size_t)Kloc * ldw) && d_e1_.alloc((size_t)Kloc * ldw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
               d_lam_.alloc(ldw) && d_gram_scratch_.alloc(gram_scratch_elems(n, ldw)) && d_io_.alloc((size_t)n * std::max(1, m0)) &&
               d_nrm_.alloc(ldw) && d_nrm_scratch_.alloc(colnorm_scratch_elems(n, ldw));
+    if (ok && mixed_)
+        ok = d_W32_.alloc((size_t)Kloc * blk) && d_Y32_.alloc((size_t)Kloc * blk) && d_sk32_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * ldw) &&
+             d_crow32_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * ldw) &&
+             d_crow32_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * ldw);
     if (!ok) return fail(FEASTHIP_EHIP, "out of device memory for the iteration buffers");
+    return 0;
+}
+
+int Engine::set_precision(int mixed) {
+    if ((mixed != 0) != mixed_) { mixed_ = mixed != 0; factored_ = false; have_x_ = false; }
     return 0;
 }
 
@@ -874,10 +888,17 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
 int Engine::solve_all(const cz* rhs) { return solve_all_impl(rhs, nullptr); }
 
 int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof) {
+    if (mixed_) return solve_range_t<cf>(st, kb, kc, rhs, prof, d_fact32_.p, d_W32_.p, d_Y32_.p, d_crow32_[0].p, d_crow32_[1].p, d_sk32_.p);
+    return solve_range_t<cz>(st, kb, kc, rhs, prof, d_fact_.p, d_W_.p, d_Y_.p, d_crow_[0].p, d_crow_[1].p, d_sk_.p);
+}
+
+template <typename T>
+int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall) {
     int64_t fs = S.fact_size, ws = (int64_t)n * ldw;
-    cz* Fp = d_fact_.p + (int64_t)kb * fs;
-    cz* Wp = d_W_.p + (int64_t)kb * ws;
-    cz* Yp = d_Y_.p + (int64_t)kb * ws;
+    T* crowb[2] = {crow0, crow1};
+    T* Fp = fact + (int64_t)kb * fs;
+    T* Wp = Wall + (int64_t)kb * ws;
+    T* Yp = Yall + (int64_t)kb * ws;
     const int* rperm = d_rowperm_.p + (int64_t)kb * n;
     const int* rinv = d_rowinv_.p + (int64_t)kb * n;
     const Tile* tl = d_tiles_.p;
@@ -895,33 +916,33 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
         prof[row].ms += ms; prof[row].bytes += bytes; prof[row].flops += flops; prof[row].launches++;
         prof_detail.insert(prof_detail.end(), {(double)row, (double)ms, bytes, flops, (double)cur_tiles});
     };
-    double rowb = (double)ldw * 16.0;
+    double rowb = (double)ldw * sizeof(T);
     begin();
     launch_gather_rhs(st, dsym_, rhs, ldw, Wp, ws, rperm, kc);
     end(0, 2.0 * n * rowb * kc, 0);
     // Launch::bytes counts factor bytes, Launch::flops complex multiply-adds per block-vector column (one node)
-    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes + vec_rows * rowb) * kc; };
+    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes * (sizeof(T) / 16.0) + vec_rows * rowb) * kc; };
     auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * kc; };
     for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
         SolveLevel& V = splan_[d];
         int par = d & 1;
         int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
         begin();
-        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs,
-                            (d_crow_[par ^ 1].p + (int64_t)kb * crsc), crsc, rinv, kc, 0);
+        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs,
+                            (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, rinv, kc, 0);
         if (V.assemble.count) end(1, 3.0 * V.asm_rows * rowb * kc, 0);
         double lvl_rows = 0;
         for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
         for (Launch& L : V.f1) {
             begin();
-            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs, kc);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc);
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
         }
         begin();
         // contribution rows of the children that pass through to this level's contribution rows are pulled in the
         // epilogue of the F2a tiles (kind 1), so there is no second assembly pass
-        launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (d_crow_[par].p + (int64_t)kb * crs), crs, kc, false,
-                     nullptr, 0, (d_crow_[par ^ 1].p + (int64_t)kb * crsc), crsc);
+        launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
+                     nullptr, 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc);
         if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows + V.pull_rows), stat_flops(V.f2)); }
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
@@ -930,8 +951,8 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
         for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
         int64_t sks = std::max<int64_t>(1, sk_rows_) * ldw;
-        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, d_sk_.p + (int64_t)kb * sks, sks);
-        if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Yp, ws, ldw, d_sk_.p + (int64_t)kb * sks, sks, kc);
+        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, skall + (int64_t)kb * sks, sks);
+        if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Yp, ws, ldw, skall + (int64_t)kb * sks, sks, kc);
         if (V.b1.count) { cur_tiles = -V.b1.count; end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1)); }
         for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
             Launch& L = V.b2[c];
@@ -951,6 +972,12 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
 // Node groups that run on their own streams.  Two groups overlap the launch tails and the latency-bound small
 // launches of one group with the large launches of the other when there are many nodes; with few local nodes
 // (multi-GPU shards) one fuller launch per step is faster (measured: 16 nodes 2 groups, <= 8 nodes 1 group).
+// Q0 (Q1) = sum_k T_k .* e0[k,:] (e1[k,:]) over the solution blocks of the last sweep (fp64 accumulation in either precision)
+void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
+    if (mixed_) launch_accumulate(stream_, dsym_, d_X_.p, d_W32_.p, (int64_t)n * ldw, ldw, K_, e0, e1, mode, Q0, Q1);
+    else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, K_, e0, e1, mode, Q0, Q1);
+}
+
 int Engine::stream_groups() const {
     int ns = std::min<int>((int)aux_streams_.size(), Kloc);
     if (!streams_forced_ && Kloc < 12) ns = 1;
@@ -984,7 +1011,8 @@ double Engine::solve_bytes() const {
     // assembled into the parent's pivot block (read + read-modify-write)
     double asm_rows = 0, pull_rows = 0;
     for (const SolveLevel& V : splan_) { asm_rows += V.asm_rows; pull_rows += V.pull_rows; }
-    double per_node = (double)S.fact_size * 16.0 + (double)S.sum_u * 4.0 + (4.0 * n + (double)S.sum_u + pull_rows + 3.0 * asm_rows) * rowb;
+    double es = mixed_ ? 0.5 : 1.0;     // complex64 factors and block vectors in the mixed-precision sweeps
+    double per_node = (double)S.fact_size * 16.0 * es + (double)S.sum_u * 4.0 + (4.0 * n + (double)S.sum_u + pull_rows + 3.0 * asm_rows) * rowb * es;
     return per_node * Kloc + 3.0 * n * rowb;
 }
 
@@ -1006,7 +1034,7 @@ int Engine::contour_step(int refactor) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);   // :68-70
+    accumulate_solutions(Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);                                // :68-70
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
@@ -1031,7 +1059,7 @@ int Engine::estimate_count(const void* X, int64_t n_, int m0_, double* est) {
     HIPCHK(hipStreamSynchronize(stream_));
     r = solve_all(d_X_.p);
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    accumulate_solutions(Kloc, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
     cz* dG = d_small_.p;
     launch_gram(stream_, n, m0, ldw, d_X_.p, d_T1_.p, d_gram_scratch_.p, dG);
     std::vector<zc> G((size_t)m0 * m0);
@@ -1053,7 +1081,7 @@ int Engine::profile_solve(ProfileRow* rows) {
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     HIPCHK(hipEventRecord(a, stream_));
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
+    accumulate_solutions(Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
     HIPCHK(hipEventRecord(b, stream_));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0;
@@ -1091,8 +1119,7 @@ int Engine::nl_contour_step(int first) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(first ? d_X_.p : d_R_.p);               // :41 / :49
     if (r) return r;
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, Qp(),
-                      Qp() + (size_t)n * ldw);
+    accumulate_solutions(Kloc, d_e0_.p, d_e1_.p, first ? 0 : 1, Qp(), Qp() + (size_t)n * ldw);
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
@@ -1290,8 +1317,7 @@ int Engine::nlm_contour_step(int first) {
     if (r) return r;
     size_t blk = (size_t)n * ldw, eb = (size_t)Kloc * ldw;
     for (int q = 0; q < L; q += 2)      // two moments per pass over the K solution blocks
-        launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)blk, ldw, Kloc, d_em_.p + q * eb, d_em_.p + (q + 1) * eb, first ? 0 : 1,
-                          d_Qm_.p + q * blk, d_Qm_.p + (q + 1) * blk);
+        accumulate_solutions(Kloc, d_em_.p + q * eb, d_em_.p + (q + 1) * eb, first ? 0 : 1, d_Qm_.p + q * blk, d_Qm_.p + (q + 1) * blk);
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
@@ -1522,7 +1548,7 @@ int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
     std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
     for (int j = 0; j < ldw; ++j) e0[j] = 1.0;        // node 0 only
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, 1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    accumulate_solutions(1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
     launch_rm_to_cm(stream_, n, m0, ldw, d_T1_.p, d_io_.p, n);
     if (ldy == n) HIPCHK(hipMemcpyAsync(Y, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
     else HIPCHK(hipMemcpy2DAsync(Y, (size_t)ldy * sizeof(cz), d_io_.p, (size_t)n * sizeof(cz), (size_t)n * sizeof(cz), m0, hipMemcpyDeviceToHost, stream_));

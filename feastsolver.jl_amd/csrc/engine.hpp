@@ -73,6 +73,8 @@ public:
     int set_contour(int K, const double* nodes, const double* weights, int kind, const double* region);
     int set_shard(int first, int stride);
     int set_q_buffer(void* dptr, size_t bytes);
+    int set_precision(int mixed);
+    bool mixed() const { return mixed_; }
     int set_coef_functions(feasthip_coef_fn fn, void* user);
     int set_node_coefficients(const double* coef, int K, int nterms);
     int nl_set_r(const void* R);
@@ -181,7 +183,13 @@ private:
     void inside_test(const zc* lam, uint8_t* inside) const;
     int solve_all_impl(const cz* rhs, ProfileRow* prof);
     int solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof);
+    template <typename T>
+    int solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall);
+    // mixed precision (feast!'s mixed_prec, src/feast.jl:19-25): complex64 copies of factors and block vectors
+    bool mixed_ = false;
+    DevBuf<cf> d_fact32_, d_W32_, d_Y32_, d_crow32_[2], d_sk32_;
     int stream_groups() const;
+    void accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
     bool streams_forced_ = false;
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;

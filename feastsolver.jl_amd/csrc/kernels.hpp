@@ -60,6 +60,20 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false,
                   cz* skbuf = nullptr, int64_t sks = 0, const cz* crow_child = nullptr, int64_t crs_child = 0);
+// complex64 twins for the mixed-precision solve path (same tiles, same plans)
+void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
+                  cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather = false,
+                  cf* skbuf = nullptr, int64_t sks = 0, const cf* crow_child = nullptr, int64_t crs_child = 0);
+void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cf* W, int64_t ws,
+                       const int* rowperm, int K);
+void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
+                         cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
+                         const int* rowinv, int K, int phase);
+void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* Y, int64_t ws, int ldw,
+                          const cf* skbuf, int64_t sks, int K);
+void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int K,
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
+void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out);
 // Kind-3 tiles may be split along K (Tile.a bits 16.. = number of parts, Tile.c = part): each part writes
 // -U12[:, part] * x[part] into its own slab of `skbuf`; launch_splitk_reduce then adds the slabs to Y in a fixed order.
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,

@@ -25,32 +25,44 @@ __device__ inline void cmfma2(d4& cr, d4& ci, double ar, double ai, double br, d
     ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
 }
 
+// The mixed-precision path (feast!'s mixed_prec, src/feast.jl:19-25) runs the same sweeps on complex64 copies of
+// the factors and block vectors: the small kernels are templates over the element type T (cz or cf).
+template <typename T> __device__ inline T el_make(double x, double y);
+template <> __device__ inline cz el_make<cz>(double x, double y) { return cz_make(x, y); }
+template <> __device__ inline cf el_make<cf>(double x, double y) { cf r; r.x = (float)x; r.y = (float)y; return r; }
+
 // W_k[i,:] = src[perm[c0 + rowperm_k[i]], :]   (fill-reducing + pivot permutation folded into one gather)
+template <typename T>
 __global__ void k_gather_rhs(const int* __restrict__ perm, const int* __restrict__ c0_of_row, int n,
-                             const cz* __restrict__ src, int ldw, cz* W, int64_t ws, const int* __restrict__ rowperm) {
+                             const cz* __restrict__ src, int ldw, T* W, int64_t ws, const int* __restrict__ rowperm) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     int k = blockIdx.y, lane = threadIdx.x & 63;
     if (i >= n) return;
     int c0 = c0_of_row[i];
     int srow = perm[c0 + rowperm[(int64_t)k * n + i]];
     const cz* s = src + (int64_t)srow * ldw;
-    cz* d = W + (int64_t)k * ws + (int64_t)i * ldw;
-    for (int j = lane; j < ldw; j += 64) d[j] = s[j];
+    T* d = W + (int64_t)k * ws + (int64_t)i * ldw;
+    for (int j = lane; j < ldw; j += 64) d[j] = el_make<T>(s[j].x, s[j].y);
 }
 
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cz* W, int64_t ws,
                        const int* rowperm, int K) {
-    hipLaunchKernelGGL(k_gather_rhs, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, W, ws, rowperm);
+    hipLaunchKernelGGL(k_gather_rhs<cz>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, W, ws, rowperm);
+}
+void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cf* W, int64_t ws,
+                       const int* rowperm, int K) {
+    hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, W, ws, rowperm);
 }
 
 // Forward sweep, assembly of the children's contribution rows into the parent:
 // rows that map into the pivot block go to W (at their pivoted position), the
 // rest into the parent's own contribution rows.  A workgroup owns 64 destination
 // rows and pulls from the children in a fixed order (deterministic, no atomics).
+template <typename T>
 __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                       const int* __restrict__ rel, const int* __restrict__ child_idx,
-                                                      cz* W, int64_t ws, int ldw, cz* crp, int64_t crsp,
-                                                      const cz* __restrict__ crc, int64_t crsc,
+                                                      T* W, int64_t ws, int ldw, T* crp, int64_t crsp,
+                                                      const T* __restrict__ crc, int64_t crsc,
                                                       const int* __restrict__ rowinv, int n, int phase) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
@@ -67,11 +79,11 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
         for (int i = ia + wave; i < ib; i += 4) {
             int dst = rc[i];
             if ((dst < p) != (phase == 0)) continue;
-            const cz* s = crc + (int64_t)k * crsc + (g.crow + i) * (int64_t)ldw;
-            cz* d;
+            const T* s = crc + (int64_t)k * crsc + (g.crow + i) * (int64_t)ldw;
+            T* d;
             if (dst < p) d = W + (int64_t)k * ws + (int64_t)(f.c0 + rowinv[(int64_t)k * n + f.c0 + dst]) * ldw;
             else d = crp + (int64_t)k * crsp + (f.crow + dst - p) * (int64_t)ldw;
-            for (int j = lane; j < ldw; j += 64) { cz a = d[j], b = s[j]; a.x += b.x; a.y += b.y; d[j] = a; }
+            for (int j = lane; j < ldw; j += 64) { T a = d[j], b = s[j]; a.x += b.x; a.y += b.y; d[j] = a; }
         }
         __syncthreads();
     }
@@ -81,7 +93,14 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
                          const int* rowinv, int K, int phase) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, W, ws, ldw,
+    hipLaunchKernelGGL(k_fwd_assemble<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, W, ws, ldw,
+                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase);
+}
+void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
+                         cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
+                         const int* rowinv, int K, int phase) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_fwd_assemble<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, W, ws, ldw,
                        crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase);
 }
 
@@ -128,20 +147,63 @@ __device__ __forceinline__ void lds_wait(dv2 (&bv)[NS]) {
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
 }
 
-struct ApplyGeom {
-    const cz* A;         // factor slab, column-major
+template <typename T>
+struct ApplyGeomT {
+    const T* A;          // factor slab, column-major
     int64_t lda;
     int rbase, rend, Kd, k0, mask;          // mask 1: unit lower (F2b), 2: upper incl. diagonal (B3)
-    const cz* Vk;        // block vector the V rows come from (this node)
+    const T* Vk;         // block vector the V rows come from (this node)
     const int* sidx;     // struct_idx of the front (gather kinds)
     int vrow0;           // first V row (contiguous kinds)
-    cz* out;             // output rows base: row r of the tile is out + r * ldw   (r relative to orow0)
+    T* out;              // output rows base: row r of the tile is out + r * ldw   (r relative to orow0)
     int orow_shift;      // output row index = orow + orow_shift
     int mode;            // 0: out -= acc, 1: out = acc, 2: out = -acc, 3: out = pulled child rows - acc
     const int* pull;     // mode 3: [output row][child slot] -> row of the children's contribution arena, or -1
     int npull;           // child slots per row
-    const cz* pullbase;  // children's contribution arena of this node
+    const T* pullbase;   // children's contribution arena of this node
 };
+typedef ApplyGeomT<cz> ApplyGeom;
+
+// tile -> geometry (kernels.hpp: launch_apply lists the kinds); returns the number of rows of the tile
+template <typename T>
+__device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, const Tile& t, int k, const int* struct_idx,
+                                           const T* fact, int64_t fs, T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs,
+                                           T* skbuf, int64_t sks, const int* cmap, const T* crow_child, int64_t crs_child) {
+    int kind = t.a & 0xff;
+    int th = ((t.a >> 8) & 0xff) ? 16 * ((t.a >> 8) & 0xff) : 64;   // tile height in rows (16, 32 or 64), chosen per launch by the host
+    int nsplit = t.a >> 16;                            // kind 3 only: number of K parts (0 = not split)
+    int p = f.p, u = f.u, ld = p + u;
+    const T* Lp = fact + (int64_t)k * fs + f.lp;
+    T* Wk = W + (int64_t)k * ws;
+    T* Yk = Y + (int64_t)k * ws;
+    g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0; g.pull = nullptr; g.npull = 0; g.pullbase = nullptr;
+    g.sidx = struct_idx + f.sptr;
+    g.out = Yk; g.orow_shift = f.c0;
+    if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
+    else if (kind == 1) {
+        g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2;
+        if (f.cmap >= 0) { g.mode = 3; g.pull = cmap + f.cmap; g.npull = f.nchild; g.pullbase = crow_child + (int64_t)k * crs_child; }
+    }
+    else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
+    else if (kind == 3) {
+        g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk;
+        if (nsplit > 0) {   // split-K part t.c: partial product into the scratch slab (part, row), reduced afterwards
+            int Kp = (((u + nsplit - 1) / nsplit) + 31) & ~31;
+            int kbeg = t.c * Kp;
+            g.A += (int64_t)kbeg * p; g.sidx += kbeg; g.Kd = min(Kp, u - kbeg);
+            g.out = skbuf + (int64_t)k * sks + (f.sk_off + (int64_t)t.c * p) * ldw; g.orow_shift = 0; g.mode = 2;
+        }
+    }
+    else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
+    else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk; }
+    return min(th, g.rend - g.rbase);
+}
+
+// node-major item mapping with a contiguous range per XCD (see k_apply)
+__device__ __forceinline__ int xcd_item() {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+}
 
 // NS = number of 16-row slabs of this tile that carry data (1, 2 or 4).  The 4 waves are arranged
 // as NS slabs x 4/NS column parts, so a tile with <= 16 (<= 32) rows still keeps every matrix core
@@ -336,40 +398,12 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the
     // (node, tile) items are handed out in node-major order with a contiguous range per XCD: the tiles of
     // one front of one node then run on ONE XCD and re-read their block-vector rows from that L2.
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int item = xcd_item();
     Tile t = tiles[item % ntiles];
     int k = item / ntiles, cg = blockIdx.z * LDS_COLS;
     FrontD f = fr[t.f];
-    int kind = t.a & 0xff;
-    int th = ((t.a >> 8) & 0xff) ? 16 * ((t.a >> 8) & 0xff) : 64;   // tile height in rows (16, 32 or 64), chosen per launch by the host
-    int nsplit = t.a >> 16;                            // kind 3 only: number of K parts (0 = not split)
-    int p = f.p, u = f.u, ld = p + u;
-    const cz* Lp = fact + (int64_t)k * fs + f.lp;
-    cz* Wk = W + (int64_t)k * ws;
-    cz* Yk = Y + (int64_t)k * ws;
     ApplyGeom g;
-    g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0; g.pull = nullptr; g.npull = 0; g.pullbase = nullptr;
-    g.sidx = struct_idx + f.sptr;
-    g.out = Yk; g.orow_shift = f.c0;
-    if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
-    else if (kind == 1) {
-        g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2;
-        if (f.cmap >= 0) { g.mode = 3; g.pull = cmap + f.cmap; g.npull = f.nchild; g.pullbase = crow_child + (int64_t)k * crs_child; }
-    }
-    else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
-    else if (kind == 3) {
-        g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk;
-        if (nsplit > 0) {   // split-K part t.c: partial product into the scratch slab (part, row), reduced afterwards
-            int Kp = (((u + nsplit - 1) / nsplit) + 31) & ~31;
-            int kbeg = t.c * Kp;
-            g.A += (int64_t)kbeg * p; g.sidx += kbeg; g.Kd = min(Kp, u - kbeg);
-            g.out = skbuf + (int64_t)k * sks + (f.sk_off + (int64_t)t.c * p) * ldw; g.orow_shift = 0; g.mode = 2;
-        }
-    }
-    else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
-    else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk; }
-    int trows = min(th, g.rend - g.rbase);
+    int trows = decode_tile<cz>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
     if (trows <= 16) apply_body<GATHER, 1>(g, Vs, cg, ldw);
     else if (trows <= 32) apply_body<GATHER, 2>(g, Vs, cg, ldw);
     else apply_body<GATHER, 4>(g, Vs, cg, ldw);
@@ -384,9 +418,192 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
     else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
 }
 
+// ---------------------------------------------------------------------------
+// Mixed precision (feast!'s mixed_prec, src/feast.jl:19-25): the same tiles on complex64 copies of the solve-ready
+// factors and block vectors -- half the bytes per sweep, f32 matrix cores (v_mfma_f32_16x16x4_f32, 4 real products
+// per complex one).  The kernel is HBM-bound, so the V rows go through registers (global load one chunk ahead,
+// ds_write into the other half of a padded double buffer) and 4 waves per SIMD fit.
+// D layout of the f32 instruction: register r of lane l holds row 4 (l >> 4) + r, column l & 15.
+// ---------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int A32_KC = 32;
+constexpr int A32_LD = 80;     // LDS row stride in complex64 (640 B): rows k and k+1 fall on disjoint halves of the banks
+
+template <bool GATHER, int NS>
+__device__ __forceinline__ void apply32_body(const ApplyGeomT<cf>& g, cf (*Vs)[A32_KC][A32_LD], int cg, int ldw) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;
+    const bool wave_active = g.rbase + slab * 16 < g.rend;
+    const int arow = g.rbase + slab * 16 + li;
+    const bool aok = arow < g.rend;
+    const int adiag = arow - g.k0;
+    const int Kd = g.Kd;
+    const int arow_c = min(arow, g.rend - 1);
+    const int lo_keep = (g.mask == 2) ? adiag : 0;
+    const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
+    const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
+    // V staging: thread t moves rows (t >> 5) + 8 q, q < 4, column pair t & 31 (16 bytes) of every chunk
+    const int vr = tid >> 5, vcp = min(cg + 2 * (tid & 31), ldw - 2);
+    cf an[A32_KC / 4], av[A32_KC / 4];
+    float4 vn[4];
+    int idxn[4] = {0, 0, 0, 0};
+    auto load_idx = [&](int kc) {
+        if (GATHER) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) idxn[q] = g.sidx[min(kc + vr + 8 * q, Kd - 1)];
+        }
+    };
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int ks = 0; ks < A32_KC / 4; ++ks) an[ks] = g.A[arow_c + (int64_t)min(kc + ks * 4 + lk, Kd - 1) * g.lda];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int vrow = GATHER ? idxn[q] : g.vrow0 + min(kc + vr + 8 * q, Kd - 1);
+            vn[q] = *reinterpret_cast<const float4*>(g.Vk + (int64_t)vrow * ldw + vcp);
+        }
+    };
+    auto stage = [&](int kc, int buf) {      // registers -> LDS / masked A
+#pragma unroll
+        for (int ks = 0; ks < A32_KC / 4; ++ks) {
+            int gk = kc + ks * 4 + lk;
+            bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
+            av[ks].x = keep ? an[ks].x : (gk == unit_at ? 1.0f : 0.0f);
+            av[ks].y = keep ? an[ks].y : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(&Vs[buf][vr + 8 * q][2 * (tid & 31)]) = vn[q];
+    };
+    f4 cr[NS], ci[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { cr[q] = (f4){0, 0, 0, 0}; ci[q] = (f4){0, 0, 0, 0}; }
+    cf* dptr[4];
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int orow = g.rbase + slab * 16 + 4 * lk + r;
+        rok[r] = orow < g.rend;
+        dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
+    }
+    auto mfma_chunk = [&](int kc, int buf) {
+        const int nks = (min(A32_KC, Kd - kc) + 3) >> 2;
+        if (wave_active) {
+#pragma unroll
+            for (int ks = 0; ks < A32_KC / 4; ++ks) {
+                if (ks < nks) {
+                    const int kk = ks * 4 + lk;
+                    const float ar = av[ks].x, ai = av[ks].y;
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        cf b = Vs[buf][kk][(ct0 + q) * 16 + li];
+                        cr[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, b.x, cr[q], 0, 0, 0);
+                        cr[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(-ai, b.y, cr[q], 0, 0, 0);
+                        ci[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, b.y, ci[q], 0, 0, 0);
+                        ci[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.x, ci[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    load_idx(0);
+    load_chunk(0);
+    load_idx(A32_KC);
+    stage(0, 0);
+    __syncthreads();
+    int it = 0, kc = 0;
+    for (; kc + A32_KC < Kd; kc += A32_KC, ++it) {
+        const int buf = it & 1;
+        load_chunk(kc + A32_KC);                 // in flight during this chunk's MFMAs
+        load_idx(kc + 2 * A32_KC);
+        mfma_chunk(kc, buf);
+        stage(kc + A32_KC, buf ^ 1);             // everyone passed the previous barrier, so nobody still reads buf ^ 1
+        __syncthreads();
+    }
+    cf old[4][NS];
+    if (g.mode == 0 && wave_active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][min(cg + (ct0 + q) * 16 + li, ldw - 1)];
+    } else if (g.mode == 3 && wave_active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { old[r][q].x = 0.0f; old[r][q].y = 0.0f; }
+        for (int c = 0; c < g.npull; ++c) {
+            int src[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int orow = g.rbase + slab * 16 + 4 * lk + r;
+                src[r] = rok[r] ? g.pull[(int64_t)(orow + g.orow_shift) * g.npull + c] : -1;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (src[r] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        cf v = g.pullbase[(int64_t)src[r] * ldw + min(cg + (ct0 + q) * 16 + li, ldw - 1)];
+                        old[r][q].x += v.x; old[r][q].y += v.y;
+                    }
+                }
+        }
+    }
+    mfma_chunk(kc, it & 1);
+    if (!wave_active) return;
+    const float sgn = (g.mode == 2) ? -1.0f : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            int col = cg + (ct0 + q) * 16 + li;
+            cf v;
+            if (g.mode == 1 || g.mode == 2) { v.x = sgn * cr[q][r]; v.y = sgn * ci[q][r]; }
+            else { v.x = old[r][q].x - cr[q][r]; v.y = old[r][q].y - ci[q][r]; }
+            if (rok[r] && col < ldw) dptr[r][col] = v;
+        }
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_apply32(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                                 const int* __restrict__ struct_idx, const cf* __restrict__ fact, int64_t fs,
+                                                 cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, cf* skbuf, int64_t sks,
+                                                 int ntiles, const int* __restrict__ cmap, const cf* __restrict__ crow_child, int64_t crs_child) {
+    __shared__ cf Vs[2][A32_KC][A32_LD];
+    const int item = xcd_item();
+    Tile t = tiles[item % ntiles];
+    int k = item / ntiles, cg = blockIdx.z * LDS_COLS;
+    FrontD f = fr[t.f];
+    ApplyGeomT<cf> g;
+    int trows = decode_tile<cf>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
+    if (trows <= 16) apply32_body<GATHER, 1>(g, Vs, cg, ldw);
+    else if (trows <= 32) apply32_body<GATHER, 2>(g, Vs, cg, ldw);
+    else apply32_body<GATHER, 4>(g, Vs, cg, ldw);
+}
+
+void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
+                  cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather, cf* skbuf, int64_t sks,
+                  const cf* crow_child, int64_t crs_child) {
+    if (ntiles <= 0) return;
+    dim3 g(ntiles * K, 1, (ldw + LDS_COLS - 1) / LDS_COLS);
+    if (gather) hipLaunchKernelGGL(k_apply32<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
+    else hipLaunchKernelGGL(k_apply32<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
+}
+
+__global__ void k_to_f32(int64_t total, const cz* __restrict__ in, cf* out) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    cz v = in[e];
+    cf r; r.x = (float)v.x; r.y = (float)v.y;
+    out[e] = r;
+}
+
+void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out) {
+    hipLaunchKernelGGL(k_to_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, in, out);
+}
+
 // Y[c0 + r, :] += sum_part scratch[part][r, :]   (parts in increasing order: deterministic)
-__global__ void k_splitk_reduce(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int nsplit, cz* Y, int64_t ws,
-                                int ldw, const cz* __restrict__ skbuf, int64_t sks) {
+template <typename T>
+__global__ void k_splitk_reduce(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int nsplit, T* Y, int64_t ws,
+                                int ldw, const T* __restrict__ skbuf, int64_t sks) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -394,11 +611,11 @@ __global__ void k_splitk_reduce(const FrontD* __restrict__ fr, const Tile* __res
     int Kp = (((f.u + nsplit - 1) / nsplit) + 31) & ~31;
     int nparts = (f.u + Kp - 1) / Kp;
     for (int r = t.a * 64 + wave; r < min(f.p, t.a * 64 + 64); r += 4) {
-        cz* y = Y + (int64_t)k * ws + (int64_t)(f.c0 + r) * ldw;
+        T* y = Y + (int64_t)k * ws + (int64_t)(f.c0 + r) * ldw;
         for (int j = lane; j < ldw; j += 64) {
-            cz v = y[j];
+            T v = y[j];
             for (int q = 0; q < nparts; ++q) {
-                cz a = skbuf[(int64_t)k * sks + (f.sk_off + (int64_t)q * f.p + r) * ldw + j];
+                T a = skbuf[(int64_t)k * sks + (f.sk_off + (int64_t)q * f.p + r) * ldw + j];
                 v.x += a.x; v.y += a.y;
             }
             y[j] = v;
@@ -409,12 +626,18 @@ __global__ void k_splitk_reduce(const FrontD* __restrict__ fr, const Tile* __res
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,
                           const cz* skbuf, int64_t sks, int K) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, nsplit, Y, ws, ldw, skbuf, sks);
+    hipLaunchKernelGGL(k_splitk_reduce<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, nsplit, Y, ws, ldw, skbuf, sks);
+}
+void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* Y, int64_t ws, int ldw,
+                          const cf* skbuf, int64_t sks, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_splitk_reduce<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, nsplit, Y, ws, ldw, skbuf, sks);
 }
 
 // Q0[old,:] = sum_k T_k[i,:] .* e0[k,:]  (and Q1 with e1), T_k = mode ? X[old,:] - W_k[i,:] : W_k[i,:].
 // Fixed summation order over k: run-to-run reproducible (src/feast.jl:68-70, src/nlfeast.jl:56-59).
-__global__ void k_accumulate(const int* __restrict__ perm, int n, const cz* __restrict__ X, const cz* __restrict__ W,
+template <typename T>
+__global__ void k_accumulate(const int* __restrict__ perm, int n, const cz* __restrict__ X, const T* __restrict__ W,
                              int64_t ws, int ldw, int K, const cz* __restrict__ e0, const cz* __restrict__ e1, int mode,
                              cz* Q0, cz* Q1) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -425,7 +648,8 @@ __global__ void k_accumulate(const int* __restrict__ perm, int n, const cz* __re
         cz x = mode ? X[old * ldw + j] : cz_make(0, 0);
         cz q0 = cz_make(0, 0), q1 = cz_make(0, 0);
         for (int k = 0; k < K; ++k) {
-            cz w = W[(int64_t)k * ws + (int64_t)i * ldw + j];
+            T wt = W[(int64_t)k * ws + (int64_t)i * ldw + j];
+            cz w = cz_make(wt.x, wt.y);                 // accumulation is always fp64 (src/feast.jl:68-70)
             cz tv = mode ? cz_sub(x, w) : w;
             cz_madd(q0, tv, e0[(int64_t)k * ldw + j]);
             if (Q1) cz_madd(q1, tv, e1[(int64_t)k * ldw + j]);
@@ -437,7 +661,11 @@ __global__ void k_accumulate(const int* __restrict__ perm, int n, const cz* __re
 
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
-    hipLaunchKernelGGL(k_accumulate, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, K, e0, e1, mode, Q0, Q1);
+    hipLaunchKernelGGL(k_accumulate<cz>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, K, e0, e1, mode, Q0, Q1);
+}
+void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int K,
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
+    hipLaunchKernelGGL(k_accumulate<cf>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, K, e0, e1, mode, Q0, Q1);
 }
 
 }  // namespace feasthip

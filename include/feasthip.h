@@ -43,7 +43,7 @@ enum {
 };
 
 /* element type tags for matrix values */
-enum { FEASTHIP_F64 = 0, FEASTHIP_C128 = 1, FEASTHIP_I64 = 2 };
+enum { FEASTHIP_F64 = 0, FEASTHIP_C128 = 1, FEASTHIP_I64 = 2, FEASTHIP_C64 = 3 /* lu_dense_c64 / lu_csc only: ComplexF32 shifted matrix of the mixed_prec path */ };
 /* contour region kinds for the inside test (src/contour.jl:88-100) */
 enum { FEASTHIP_REGION_DISC = 0, FEASTHIP_REGION_RECT = 1 };
 
@@ -125,6 +125,12 @@ int feasthip_feast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter
                        int store, double* lambda, double* res, uint8_t* inside, int* nit);
 int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int iter, double eps,
                          double spurious, double* lambda, double* res, uint8_t* inside, int* nit);
+/* mixed_prec of feast! (src/feast.jl:10,19-25): mixed != 0 runs the shifted block solves on complex64 copies of the
+ * factors and block vectors (factorisation itself stays complex128, the copy is made once per factorisation), the
+ * accumulation Q += (X - temp) diag(w/(z-lambda)) stays complex128 (src/feast.jl:68-70).  Call before feasthip_set_x /
+ * feasthip_factorize; default 0. */
+int feasthip_set_precision(feasthip_handle_t h, int mixed);
+
 /* ---- NEPs that are not polynomials (SURVEY 8b "generic-T NLFEAST"; the reference takes any closure z -> matrix,
  * src/nlfeast.jl:2,21, src/utils.jl:107; test/gun2.jl:30-37, test/hadeler.jl:27-59).
  * (1) split form T(z) = sum_t f_t(z) M_t: the M_t are the terms of feasthip_set_dense/_csc, the scalar functions are
@@ -162,6 +168,10 @@ int feasthip_estimate_count(feasthip_handle_t h, const void* X, int64_t n, int m
  * left_divider(Y, F, R): Y = C^-1 R, R untouched (src/feast.jl:62).  Thread-safe
  * across distinct factor objects (src/nlfeast.jl:19-26, 36-55). */
 int feasthip_lu_dense(int device_id, const void* C, int64_t n, feasthip_fact_t* F);
+/* factorizer(ZmA) with ZmA::Matrix{ComplexF32} (mixed_prec, src/feast.jl:19-36): C is complex64 column-major; the
+ * factor object then solves in complex64 (feasthip_ldiv still takes/returns complex128 buffers, the caller's
+ * ComplexF32 `temp` is a cast of Y).  feasthip_lu_csc does the same for type == FEASTHIP_C64. */
+int feasthip_lu_dense_c64(int device_id, const void* C, int64_t n, feasthip_fact_t* F);
 int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64_t* rowval,
                     const void* nzval, int type, int index_base, feasthip_fact_t* F);
 int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);

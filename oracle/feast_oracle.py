@@ -133,19 +133,24 @@ def in_contour(lam, contour, r=None):
 # the factorizer / left_divider / finalize! seam            src/utils.jl:173-179
 # --------------------------------------------------------------------------
 class _DenseLU:
+    """LU in the element type of C: complex128, or complex64 on the mixed_prec path (Julia's lu of a
+    Matrix{ComplexF32}, src/feast.jl:25-36)."""
+
     def __init__(self, C):
-        self.lu, self.piv = sla.lu_factor(np.array(C, dtype=np.complex128), check_finite=False)
+        self.dtype = np.complex64 if np.asarray(C).dtype == np.complex64 else np.complex128
+        self.lu, self.piv = sla.lu_factor(np.array(C, dtype=self.dtype), check_finite=False)
 
     def solve(self, R):
-        return sla.lu_solve((self.lu, self.piv), R, check_finite=False)
+        return sla.lu_solve((self.lu, self.piv), np.asarray(R).astype(self.dtype), check_finite=False)
 
 
 class _SparseLU:
     def __init__(self, C):
-        self.f = spla.splu(sp.csc_matrix(C, dtype=np.complex128))
+        self.dtype = np.complex64 if C.dtype == np.complex64 else np.complex128
+        self.f = spla.splu(sp.csc_matrix(C, dtype=self.dtype))
 
     def solve(self, R):
-        return self.f.solve(np.ascontiguousarray(R, dtype=np.complex128))
+        return self.f.solve(np.ascontiguousarray(R, dtype=self.dtype))
 
 
 def lu(C):
@@ -234,13 +239,15 @@ def beyn_svd_step(Q0, Q1, X, lam):
 # solvers                                        src/feast.jl, src/nlfeast.jl
 # --------------------------------------------------------------------------
 def gen_feast(X, A, B, contour, iter=10, eps=1e-12, store=False,
-              factorizer=lu, left_divider=ldiv, history=None):
+              factorizer=lu, left_divider=ldiv, history=None, mixed_prec=False):
     """``gen_feast!`` src/feast.jl:89-156; with ``B=None`` it is ``feast!``
     src/feast.jl:10-80 (the two loops are identical up to B).
 
     X is overwritten in place (the ``!`` convention).  Returns
     (lam[inside], X[:, inside], res[inside]).  ``history`` (a list) receives
-    per-iteration (nit, count_inside, max_res_inside).
+    per-iteration (nit, count_inside, max_res_inside).  ``mixed_prec`` (feast! only in the
+    reference, src/feast.jl:10,19-25): the shifted matrix, its factors and ``temp`` are ComplexF32,
+    everything else ComplexF64.
     """
     X = np.asarray(X)
     N, m0 = X.shape
@@ -263,15 +270,20 @@ def gen_feast(X, A, B, contour, iter=10, eps=1e-12, store=False,
     Bs = B if generalized else _eye_like(A, N)
     lam = np.zeros(m0, dtype=np.complex128)
     res = np.zeros(m0)
-    temp = np.zeros((N, m0), dtype=np.complex128)
+    ctype = np.complex64 if mixed_prec else np.complex128     # :19
+    temp = np.zeros((N, m0), dtype=ctype)                     # :22
     R = np.zeros((N, m0), dtype=np.complex128)
     Q = X.astype(np.complex128).copy()
     nodes, weights = contour.nodes, contour.weights
     K = nodes.shape[0]
 
+    def shifted(k):                                           # ZmA .= A - I*z  into a Ctype buffer  :25-29
+        M = A - Bs * nodes[k]
+        return M.astype(ctype) if mixed_prec else M
+
     facts = None
     if store:  # src/feast.jl:28-38 / :104-114
-        facts = [factorizer(A - Bs * nodes[k]) for k in range(K)]
+        facts = [factorizer(shifted(k)) for k in range(K)]
 
     for nit in range(iter + 1):
         Q, _ = np.linalg.qr(Q, mode="reduced")               # :41 / :117
@@ -298,9 +310,9 @@ def gen_feast(X, A, B, contour, iter=10, eps=1e-12, store=False,
                 if store:
                     left_divider(temp, facts[k], R)
                 else:
-                    linsolve(temp, A - Bs * nodes[k], R, factorizer, left_divider)
-                temp[...] = X - temp                          # :68
-                temp *= (resolvent * weights[k])[None, :]     # :69
+                    linsolve(temp, shifted(k), R, factorizer, left_divider)
+                temp[...] = X - temp                          # :68  (rounded to Ctype: temp is a Ctype array)
+                temp *= (resolvent * weights[k])[None, :].astype(ctype)     # :69
                 Q += temp                                     # :70
     inside = in_contour(lam, contour)
     return lam[inside].copy(), X[:, inside].copy(), res[inside].copy()

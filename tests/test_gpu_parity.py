@@ -262,6 +262,72 @@ def test_hadeler_nonpolynomial_nep(gpu, pkg, wl, golden, path):
         assert abs(np.linalg.norm(Tl @ Xo[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
 
 
+# ---------------------------------------------------------------------------------------
+# mixed_prec (src/feast.jl:10,19-25)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_mixed_prec_seam(gpu, pkg, wl, kind):
+    """factorizer(ZmA::ComplexF32) / left_divider(temp::ComplexF32, F, R): the complex64 sweeps reach single precision
+    (a few eps32 times the condition number), and the ComplexF32 `temp` of the reference is a cast of the result."""
+    rng = np.random.default_rng(99)
+    if kind == "dense":
+        n, m0 = 300, 40
+        Cm = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex64)
+        ref_solve = lambda R: np.linalg.solve(Cm.astype(np.complex128), R)                 # noqa: E731
+        cond = np.linalg.cond(Cm.astype(np.complex128))
+    else:
+        A = wl.laplacian_3d(14, 19).astype(np.complex128) - (0.3 + 0.2j) * sp.identity(14 ** 3, format="csc")
+        Cm = sp.csc_matrix(A, dtype=np.complex64)
+        n, m0 = A.shape[0], 64
+        f = spla.splu(sp.csc_matrix(Cm, dtype=np.complex128))
+        ref_solve, cond = f.solve, 50.0
+    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
+    F = pkg.lu(Cm)
+    temp = np.zeros((n, m0), dtype=np.complex64, order="F")
+    pkg.ldiv(temp, F, R)
+    pkg.finalize(F)
+    ref = ref_solve(R)
+    err = np.abs(temp - ref).max() / np.abs(ref).max()
+    assert 1e-9 < err < 2e-7 * cond                                   # single precision: not fp64, and not garbage
+
+
+def test_mixed_prec_feast_dense(gpu, pkg, fo, wl, golden):
+    """feast!(...; mixed_prec=true) on C1.  The oracle restates the reference literally (ComplexF32 factors AND a
+    ComplexF32 `temp = X - temp`, src/feast.jl:22,68), which stalls at a residual of ~5e-7; here only the solves are
+    complex64 and the RII update is accumulated in complex128, so the iteration follows the reference while it still
+    converges and then continues to the fp64 answer with the iteration count of the fp64 run."""
+    w = wl.c1_dense_hermitian(512, 16)
+    con = fo.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
+    hist = []
+    fo.gen_feast(w["X0"].copy(), w["A"], None, con, iter=6, eps=1e-12, store=True, history=hist, mixed_prec=True)
+    assert 1e-7 < hist[-1][2] < 5e-6                                   # the reference's single-precision floor
+    info = {}
+    X = w["X0"].copy()
+    lam, V, res = pkg.feast(X, w["A"], nodes=w["nodes"], iter=20, c=w["c"], r=w["r"], eps=1e-12, store=True, mixed_prec=True, info=info)
+    g = golden["c1_n512"]
+    assert len(lam) == 8 and match_sets(lam, c2n(g["lam"])) < 1e-10
+    assert res.max() < 1e-12
+    assert abs(info["nit"] - g["history"][-1][0]) <= 1
+    for j in range(len(lam)):
+        assert np.linalg.norm(w["A"] @ V[:, j] - lam[j] * V[:, j]) < 1e-11
+    # same early history as the literal restatement (before its floor)
+    info2 = {}
+    pkg.feast(w["X0"].copy(), w["A"], nodes=w["nodes"], iter=2, c=w["c"], r=w["r"], eps=1e-30, store=True, mixed_prec=True, info=info2)
+    r2 = info2["res_all"][info2["inside"]].max()
+    assert 0.3 < r2 / hist[2][2] < 3.0
+
+
+def test_mixed_prec_feast_sparse_store_false(gpu, pkg, wl):
+    """sparse standard problem, store=false (factor + complex64 copy every iteration): eigenvalues of the 19-point
+    Laplacian to fp64 accuracy."""
+    A = wl.laplacian_3d(12, 19)
+    ev = np.sort(np.linalg.eigvalsh(A.toarray()))
+    c, r = 0.5 * (ev[0] + ev[6]), 0.5 * (ev[6] - ev[0]) + 0.4 * (ev[7] - ev[6])
+    X0 = wl.rand_x0(12 ** 3, 16, 12)
+    lam, V, res = pkg.feast(X0, A, nodes=16, iter=20, c=c, r=r, eps=1e-12, store=False, mixed_prec=True)
+    assert len(lam) == 7 and np.abs(np.sort(lam.real) - ev[:7]).max() < 1e-11 and res.max() < 1e-12
+
+
 def test_c5_system5_companion_m128(gpu, pkg, wl, golden):
     """C5 (ii): system5 quadratic, companion pencil 2000 x 2000, 32 nodes, m0 = 128."""
     g = golden["c5_system5_companion"]

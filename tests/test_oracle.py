@@ -112,6 +112,18 @@ def test_hadeler_split_form_fixture(fo, wl, golden):
         assert np.linalg.svd(Tz, compute_uv=False)[-1] < 1e-9 * np.linalg.norm(Tz)
 
 
+def test_mixed_prec_restatement_floor(fo, wl):
+    """feast!(...; mixed_prec=true) restated literally (src/feast.jl:19-25,68): ComplexF32 factors and a ComplexF32
+    `temp` put a floor of a few 1e-7 under the residual, the fp64 run goes on to 1e-13."""
+    w = wl.c1_dense_hermitian(256, 16)
+    con = fo.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
+    h64, h32 = [], []
+    fo.gen_feast(w["X0"].copy(), w["A"], None, con, iter=10, eps=1e-12, store=True, history=h64)
+    fo.gen_feast(w["X0"].copy(), w["A"], None, con, iter=10, eps=1e-12, store=True, history=h32, mixed_prec=True)
+    assert h64[-1][2] < 1e-12 and 1e-8 < h32[-1][2] < 1e-5
+    assert abs(np.log10(h32[1][2] / h64[1][2])) < 0.5
+
+
 def test_golden_c3_small_reproduces(fo, wl, golden):
     g = golden["c3_g8_s19_m16"]
     w = wl.c3_sparse_generalized(8, 19, 16)
