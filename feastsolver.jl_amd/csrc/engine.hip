@@ -307,6 +307,11 @@ bool Engine::build_plans() {
             V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, SOLVE_NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, SOLVE_NB);
         }
         V.f2.count = (int)(tiles.size() - V.f2.off);
+        // longest tiles first (LPT): the K loop of a tile is p (kind 1) or at most SOLVE_NB (kind 2); fronts stay together
+        std::stable_sort(tiles.begin() + V.f2.off, tiles.end(), [&](const Tile& a, const Tile& b) {
+            int ka = (a.a & 0xff) == 1 ? S.p(a.f) : std::min(SOLVE_NB, S.p(a.f)), kb2 = (b.a & 0xff) == 1 ? S.p(b.f) : std::min(SOLVE_NB, S.p(b.f));
+            return ka > kb2;
+        });
         V.b1.off = (int64_t)tiles.size();
         int sl3 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
         {   // few, long tiles (top of the tree): split the K = u loop over several workgroups
@@ -331,6 +336,7 @@ bool Engine::build_plans() {
             V.b1.bytes += (double)u * p * 16.0; V.b1.flops += (double)u * p;
         }
         V.b1.count = (int)(tiles.size() - V.b1.off);
+        std::stable_sort(tiles.begin() + V.b1.off, tiles.end(), [&](const Tile& a, const Tile& b) { return S.u(a.f) > S.u(b.f); });   // K = u
         sk_rows_ = std::max(sk_rows_, sk_level);
         V.b1red.off = (int64_t)tiles.size();
         if (V.b1split) for (int s : lv) if (S.u(s) > 0) for (int a = 0; a < cdiv(S.p(s), 64); ++a) tiles.push_back({s, a, 0, 0});
