@@ -54,6 +54,7 @@ PROTOTYPES = {
     "feasthip_q_device": (I, [VP, PVP, C.POINTER(I64), C.POINTER(I64), C.POINTER(I)]),
     "feasthip_set_q_buffer": (I, [VP, VP, C.c_size_t]),
     "feasthip_feast_run": (I, [VP, VP, I64, I, I, D, I, VP, VP, VP, C.POINTER(I)]),
+    "feasthip_dual_feast_run": (I, [VP, VP, VP, I64, I, I, D, I, VP, VP, VP, VP, C.POINTER(I)]),
     "feasthip_nlfeast_run": (I, [VP, VP, I64, I, I, D, D, VP, VP, VP, C.POINTER(I)]),
     "feasthip_set_precision": (I, [VP, I]),
     "feasthip_set_coef_functions": (I, [VP, VP, VP]),

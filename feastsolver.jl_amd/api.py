@@ -237,6 +237,10 @@ class FeastHandle:
         self._ck(self.lib.feasthip_get_block(self.h, which, _vp(out)))
         return out
 
+    @staticmethod
+    def _outs_m(m0):
+        return np.zeros(m0, dtype=np.complex128), np.zeros(m0), np.zeros(m0, dtype=np.uint8)
+
     def _outs(self):
         return (np.zeros(self.m0, dtype=np.complex128), np.zeros(self.m0), np.zeros(self.m0, dtype=np.uint8))
 
@@ -378,6 +382,56 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     if not ins.any():
         print("no eigenvalues found in contour!")                # src/feast.jl:78
     return lam[ins], Xw[:, ins], res[ins]
+
+
+def _adjoint(M):
+    return M.conj().T.tocsc() if _issparse(M) else np.ascontiguousarray(np.asarray(M).conj().T)
+
+
+def dual_gen_feast(Xr, Xl, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=False, store=False, eps=1e-12,
+                   factorizer=None, left_divider=None, device=0, info=None):
+    """dual_gen_feast!(Xr, Xl, A, B[, contour]; ...)  src/feast.jl:158-257: right and left eigenvectors of A x = lam B x
+    (y' A = lam y' B).  Returns (lam[inside], Xr[:, inside], Xl[:, inside], resr[inside]); Xr, Xl are overwritten."""
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Incorrect dimensions of A, must be square")
+    if Xl.shape[0] != A.shape[0] or Xr.shape != Xl.shape:
+        raise ValueError("Incorrect dimensions of X, must match A")
+    if contour is None:
+        contour = circular_contour_trapezoidal(c, r, nodes)
+    if B is None:
+        B = sp.identity(A.shape[0], format="csc", dtype=np.complex128) if _issparse(A) else np.eye(A.shape[0], dtype=np.complex128)
+    (Xr_in, Xrw), (Xl_in, Xlw) = _inplace_target(Xr), _inplace_target(Xl)
+    K = len(contour.nodes)
+    z = np.asarray(contour.nodes, dtype=np.complex128)
+    w = np.asarray(contour.weights, dtype=np.complex128)
+    import copy
+    dual_contour = copy.copy(contour)
+    dual_contour.nodes, dual_contour.weights = np.concatenate([z, z.conj()]), np.concatenate([w, w.conj()])
+    table = np.zeros((2 * K, 4), dtype=np.complex128)
+    table[:K, 0], table[:K, 1] = 1.0, z                        # A - z_k B          (scales 1, -1)
+    table[K:, 2], table[K:, 3] = 1.0, z.conj()                 # A' - conj(z_k) B'  (the reference's lfacts, :185-197)
+    h = FeastHandle(device)
+    try:
+        h.set_terms([A, B, _adjoint(A), _adjoint(B)], scales=[1.0, -1.0, 1.0, -1.0])
+        h.set_contour(dual_contour)
+        h.set_node_coefficients(table)
+        m0 = Xrw.shape[1]
+        lam, resr, ins = h._outs_m(m0)
+        resl = np.zeros(m0)
+        nit = C.c_int(0)
+        warn = h._ck(h.lib.feasthip_dual_feast_run(h.h, _vp(Xrw), _vp(Xlw), Xrw.shape[0], m0, int(iter), float(eps), 1 if store else 0,
+                                                   _vp(lam), _vp(resr), _vp(resl), _vp(ins), C.byref(nit)))
+        ins = ins.astype(bool)
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=nit.value, warn=warn, lam_all=lam.copy(), resr_all=resr.copy(), resl_all=resl.copy(), inside=ins.copy())
+    finally:
+        h.close()
+    _writeback(Xr_in, Xrw)
+    _writeback(Xl_in, Xlw)
+    if not ins.any():
+        print("no eigenvalues found in contour!")                # src/feast.jl:255
+    return lam[ins], Xrw[:, ins], Xlw[:, ins], resr[ins]
 
 
 def feast(X, A, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, eps=1e-12, debug=False, store=False,

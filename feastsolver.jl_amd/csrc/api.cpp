@@ -134,6 +134,11 @@ int feasthip_nlfeast_moments_run(feasthip_handle_t h, void* X, int64_t n, int m0
     GUARD(h) return h->e->nlfeast_moments_run(X, n, m0, moments, iter, eps, spurious, lambda, res, inside, Y, nit); ENDGUARD(h)
 }
 
+int feasthip_dual_feast_run(feasthip_handle_t h, void* Xr, void* Xl, int64_t n, int m0, int iter, double eps, int store,
+                            double* lambda, double* resr, double* resl, uint8_t* inside, int* nit) {
+    GUARD(h) return h->e->dual_run(Xr, Xl, n, m0, iter, eps, store, lambda, resr, resl, inside, nit); ENDGUARD(h)
+}
+
 int feasthip_estimate_count(feasthip_handle_t h, const void* X, int64_t n, int m0, double* est) {
     GUARD(h) return h->e->estimate_count(X, n, m0, est); ENDGUARD(h)
 }

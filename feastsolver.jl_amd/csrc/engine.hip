@@ -1481,6 +1481,184 @@ int Engine::nlfeast_moments_run(void* X, int64_t n_, int m0_, int moments, int i
 }
 
 // ---------------------------------------------------------------------------
+// dual_gen_feast!  (src/feast.jl:165-257): right and left eigenvectors of A x = lam B x.
+// The reference factorises (A - z_k B)' separately (lfacts, :185-197); here the adjoint systems are simply K more
+// "nodes" of the same batched factorisation: terms {A, B, A', B'}, node k < K has coefficients (1, -z_k, 0, 0), node
+// K + k has (0, 0, 1, -conj(z_k)) (feasthip_set_node_coefficients), so no transposed-solve kernels are needed and the
+// two halves of the sweep run concurrently.  Fixes of the reference's slips (fix, do not reproduce): the
+// bi-orthonormalisation scales both bases with S^-1/2 (the reference writes Diagonal(1.0/S.S), :200-201), the left
+// residual uses conj(lam) (A' y = conj(lam) B' y), and left Ritz vectors are paired with the right ones by eigenvalue.
+// ---------------------------------------------------------------------------
+int Engine::dual_contour_step() {
+    const int Kh = Kloc / 2;
+    size_t blk = (size_t)n * ldw;
+    std::vector<zc> e((size_t)Kloc * ldw, zc(0.0));
+    for (int kk = 0; kk < Kloc; ++kk) {
+        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
+        for (int j = 0; j < m0; ++j) e[(size_t)kk * ldw + j] = w / (z - (kk < Kh ? lambda_[j] : std::conj(lambda_[j])));      // :226,236
+    }
+    HIPCHK(hipMemcpyAsync(d_e0_.p, e.data(), e.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    if (aux_streams_.size() >= 2) {      // right systems on one stream, adjoint systems on the other
+        HIPCHK(hipEventRecord(ev_fork_, stream_));
+        for (int g = 0; g < 2; ++g) {
+            HIPCHK(hipStreamWaitEvent(aux_streams_[g], ev_fork_, 0));
+            int r = solve_range(aux_streams_[g], g * Kh, Kh, g == 0 ? d_R_.p : d_Rl_.p, nullptr);
+            if (r) return r;
+            HIPCHK(hipEventRecord(ev_join_[g], aux_streams_[g]));
+            HIPCHK(hipStreamWaitEvent(stream_, ev_join_[g], 0));
+        }
+    } else {
+        int r = solve_range(stream_, 0, Kh, d_R_.p, nullptr);
+        if (r == 0) r = solve_range(stream_, Kh, Kh, d_Rl_.p, nullptr);
+        if (r) return r;
+    }
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)blk, ldw, Kh, d_e0_.p, nullptr, 1, Qp(), nullptr);                          // :232-234
+    launch_accumulate(stream_, dsym_, d_Xl_.p, d_W_.p + (size_t)Kh * blk, (int64_t)blk, ldw, Kh, d_e0_.p + (size_t)Kh * ldw, nullptr, 1,
+                      Qp() + blk, nullptr);                                                                                             // :242-244
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    solve_ms = ms;
+    return 0;
+}
+
+int Engine::dual_rr_step(double* lambda, double* resr, double* resl, uint8_t* inside) {
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    const int m = m0;
+    size_t blk = (size_t)n * ldw;
+    cz* Qr = Qp();
+    cz* Ql = Qp() + blk;
+    cz* dG = d_small_.p;
+    cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
+    std::vector<zc> G((size_t)m * m), U((size_t)m * m), V((size_t)m * m), Aq((size_t)m * m), Bq((size_t)m * m), Aqh((size_t)m * m), Bqh((size_t)m * m);
+    std::vector<double> sv(m);
+    // S = svd(Ql' B Qr); Qr <- Qr V S^-1/2, Ql <- Ql U S^-1/2   (:199-201)
+    apply_term(1, Qr, d_T1_.p, -1.0, false);                                       // B Qr  (term 1 carries scale -1)
+    launch_gram(stream_, n, m, ldw, Ql, d_T1_.p, d_gram_scratch_.p, dG);
+    HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    jacobi_svd(m, G.data(), U.data(), sv.data(), V.data());
+    double smax = sv[0];
+    if (!(smax > 0.0) || !std::isfinite(smax)) return fail(FEASTHIP_ENUM, "dual_gen_feast: Ql' B Qr is zero or not finite");
+    for (int j = 0; j < m; ++j) {
+        double sc = 1.0 / std::sqrt(std::max(sv[j], 1e-300));
+        for (int i = 0; i < m; ++i) { U[i + (size_t)j * m] *= sc; V[i + (size_t)j * m] *= sc; }
+    }
+    HIPCHK(hipMemcpyAsync(dM, V.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_ts_gemm(stream_, n, m, ldw, Qr, dM, d_T2_.p);
+    HIPCHK(hipMemcpyAsync(Qr, d_T2_.p, blk * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipMemcpyAsync(dM, U.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_ts_gemm(stream_, n, m, ldw, Ql, dM, d_T2_.p);
+    HIPCHK(hipMemcpyAsync(Ql, d_T2_.p, blk * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+    // Aq = Ql' A Qr, Bq = Ql' B Qr   (:202-205)
+    apply_term(0, Qr, d_R_.p, 1.0, false);
+    launch_gram(stream_, n, m, ldw, Ql, d_R_.p, d_gram_scratch_.p, dG);
+    HIPCHK(hipMemcpyAsync(Aq.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    apply_term(1, Qr, d_T1_.p, -1.0, false);
+    launch_gram(stream_, n, m, ldw, Ql, d_T1_.p, d_gram_scratch_.p, dG);
+    HIPCHK(hipMemcpyAsync(Bq.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { Aqh[i + (size_t)j * m] = std::conj(Aq[j + (size_t)i * m]); Bqh[i + (size_t)j * m] = std::conj(Bq[j + (size_t)i * m]); }
+    std::vector<zc> lam(m), Xq((size_t)m * m), mu(m), Yq((size_t)m * m), Ym((size_t)m * m);
+    if (eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data())) return fail(FEASTHIP_ENUM, "dual_gen_feast: reduced eigenproblem failed");      // :206
+    if (eig_generalized(m, Aqh.data(), Bqh.data(), mu.data(), Yq.data())) return fail(FEASTHIP_ENUM, "dual_gen_feast: adjoint reduced eigenproblem failed");   // :210
+    std::vector<char> used(m, 0);
+    for (int i = 0; i < m; ++i) {        // pair the left vector whose eigenvalue is conj(lam_i)
+        int best = -1; double bd = 0;
+        for (int j = 0; j < m; ++j) if (!used[j]) { double d = std::abs(mu[j] - std::conj(lam[i])); if (best < 0 || d < bd) { best = j; bd = d; } }
+        used[best] = 1;
+        for (int q = 0; q < m; ++q) Ym[q + (size_t)i * m] = Yq[q + (size_t)best * m];
+    }
+    auto ritz = [&](const std::vector<zc>& Mq, cz* Qb, cz* Xb) -> int {      // X = Q Mq, columns normalised (update_R!)
+        HIPCHK(hipMemcpyAsync(dM, Mq.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        launch_ts_gemm(stream_, n, m, ldw, Qb, dM, Xb);
+        std::vector<double> nr;
+        int r = col_norms(Xb, nr);
+        if (r) return r;
+        std::vector<zc> sc(ldw, zc(0.0));
+        for (int j = 0; j < m; ++j) sc[j] = nr[j] > 0 ? 1.0 / nr[j] : 1.0;
+        HIPCHK(hipMemcpyAsync(d_lam_.p, sc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        launch_scale_cols(stream_, n, ldw, Xb, d_lam_.p);
+        HIPCHK(hipStreamSynchronize(stream_));
+        return 0;
+    };
+    int r = ritz(Xq, Qr, d_X_.p);                                                   // :208-209
+    if (r == 0) r = ritz(Ym, Ql, d_Xl_.p);                                          // :210-212
+    if (r) return r;
+    // Rr = A Xr - B Xr lam ; Rl = A' Xl - B' Xl conj(lam)   (:213-214)
+    std::vector<zc> lp(ldw, zc(0.0)), lc(ldw, zc(0.0));
+    for (int j = 0; j < m; ++j) { lp[j] = lam[j]; lc[j] = std::conj(lam[j]); }
+    std::vector<double> nr, nl;
+    HIPCHK(hipMemcpyAsync(d_lam_.p, lp.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    apply_term(0, d_X_.p, d_T1_.p, 1.0, false);
+    apply_term(1, d_X_.p, d_T2_.p, -1.0, false);
+    launch_residual_combine(stream_, n, ldw, d_T1_.p, d_T2_.p, d_lam_.p, d_R_.p);
+    r = col_norms(d_R_.p, nr);
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(d_lam_.p, lc.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    apply_term(2, d_Xl_.p, d_T1_.p, 1.0, false);
+    apply_term(3, d_Xl_.p, d_T2_.p, -1.0, false);
+    launch_residual_combine(stream_, n, ldw, d_T1_.p, d_T2_.p, d_lam_.p, d_Rl_.p);
+    r = col_norms(d_Rl_.p, nl);
+    if (r) return r;
+    lambda_ = lam;
+    for (int j = 0; j < m; ++j) { lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag(); resr[j] = nr[j]; if (resl) resl[j] = nl[j]; }
+    inside_test(lam.data(), inside);
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    rr_ms = ms;
+    return 0;
+}
+
+int Engine::dual_run(void* Xr, void* Xl, int64_t n_, int m0_, int iter, double eps, int store, double* lambda, double* resr,
+                     double* resl, uint8_t* inside, int* nit_out) {
+    if (nterms != 4 || (K & 1) || node_coef_.empty() || shard_stride_ != 1 || mixed_)
+        return fail(FEASTHIP_ESTATE, "dual_gen_feast: needs the terms {A, B, A', B'}, 2K nodes with a node coefficient table, one GPU, fp64");
+    if (!Xl) return fail(FEASTHIP_EARG, "dual_gen_feast: null Xl");
+    int r = set_x(Xr, n_, m0_);
+    if (r) return r;
+    size_t blk = (size_t)n * ldw;
+    if (!d_Xl_.alloc(blk) || !d_Rl_.alloc(blk)) return fail(FEASTHIP_EHIP, "out of device memory");
+    HIPCHK(hipMemcpyAsync(d_io_.p, Xl, (size_t)n * m0 * sizeof(cz), hipMemcpyHostToDevice, stream_));
+    launch_cm_to_rm(stream_, n, m0, ldw, d_io_.p, n, d_Xl_.p);
+    HIPCHK(hipMemcpyAsync(Qp() + blk, d_Xl_.p, blk * sizeof(cz), hipMemcpyDeviceToDevice, stream_));      // Ql = copy(Xl)  :176
+    HIPCHK(hipMemsetAsync(d_Rl_.p, 0, blk * sizeof(cz), stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    int warn = 0;
+    if (store) { r = factorize(); if (r < 0) return r; warn = r; }
+    int nit = 0;
+    for (nit = 0; nit <= iter; ++nit) {
+        r = dual_rr_step(lambda, resr, resl, inside);
+        if (r) return r;
+        bool any = false;
+        double mx = 0;
+        for (int j = 0; j < m0; ++j) if (inside[j]) { any = true; mx = std::max(mx, resr[j]); }
+        if (any && mx < eps) break;                                                 // :218-221
+        if (nit < iter) {                                                           // :222
+            if (!store || !factored_) { r = factorize(); if (r < 0) return r; if (r > 0) warn = r; }
+            r = dual_contour_step();
+            if (r) return r;
+        }
+    }
+    if (nit_out) *nit_out = std::min(nit, iter);
+    r = get_block(0, Xr);
+    if (r) return r;
+    launch_rm_to_cm(stream_, n, m0, ldw, d_Xl_.p, d_io_.p, n);
+    HIPCHK(hipMemcpyAsync(Xl, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return warn;
+}
+
+// ---------------------------------------------------------------------------
 // whole loops
 // ---------------------------------------------------------------------------
 int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int store, double* lambda, double* res,

@@ -93,6 +93,9 @@ public:
                   uint8_t* inside, int* nit);
     int nlfeast_run(void* X, int64_t n, int m0, int iter, double eps, double spurious, double* lambda, double* res,
                     uint8_t* inside, int* nit);
+    // dual_gen_feast! (src/feast.jl:165-257): terms {A, B, A', B'}, 2K nodes (K right + K adjoint systems)
+    int dual_run(void* Xr, void* Xl, int64_t n, int m0, int iter, double eps, int store, double* lambda, double* resr,
+                 double* resl, uint8_t* inside, int* nit);
     // nlfeast_moments! (src/nlfeast.jl:173-318): lambda/res/inside have moments*m0 entries, Y is n x moments*m0
     int nlfeast_moments_run(void* X, int64_t n, int m0, int moments, int iter, double eps, double spurious, double* lambda,
                             double* res, uint8_t* inside, void* Y, int* nit);
@@ -176,6 +179,9 @@ private:
     DevBuf<cz> d_Qm_, d_H0_, d_H1_, d_Ht_, d_Ym_, d_Rm_, d_MXm_, d_em_, d_smallM_, d_lamM_, d_gramM_;
     DevBuf<double> d_nrmM_, d_nrmMs_;
     DevBuf<int> d_colidx_;
+    DevBuf<cz> d_Xl_, d_Rl_;
+    int dual_contour_step();
+    int dual_rr_step(double* lambda, double* resr, double* resl, uint8_t* inside);
     int nlm_alloc(int moments);
     int nlm_contour_step(int first);
     int nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res);

@@ -158,6 +158,15 @@ int feasthip_nl_set_r(feasthip_handle_t h, const void* R);
 int feasthip_nlfeast_moments_run(feasthip_handle_t h, void* X, int64_t n, int m0, int moments, int iter, double eps,
                                  double spurious, double* lambda, double* res, uint8_t* inside, void* Y, int* nit);
 
+/* ---- dual_gen_feast!(Xr, Xl, A, B, contour; iter, eps, store)  src/feast.jl:158-257: right AND left
+ * eigenvectors.  Set-up: terms {A, B, A', B'} with scales {1, -1, 1, -1} (feasthip_set_dense/_csc), a contour of 2K
+ * entries {z_1..z_K, conj(z_1)..conj(z_K)} / {w_1..w_K, conj(w_1)..conj(w_K)} and the 2K x 4 node coefficient table
+ * {(1, z_k, 0, 0)} U {(0, 0, 1, conj(z_k))}: the adjoint systems (A - z_k B)' the reference factorises separately
+ * (lfacts, :185-197) are K more nodes of the same batched factorisation.  Xr, Xl n x m0 in/out; lambda, resr, resl, inside
+ * have m0 entries (resl may be NULL); the caller filters with `inside` (:256). */
+int feasthip_dual_feast_run(feasthip_handle_t h, void* Xr, void* Xl, int64_t n, int m0, int iter, double eps, int store,
+                            double* lambda, double* resr, double* resl, uint8_t* inside, int* nit);
+
 /* ---- adjacent caller of the same seam: contour_estimate_eig, src/stochastic.jl:2-33.
  * est = real(sum_k w_k tr(X' (z_k B - A)^-1 X)) / m0 over the LOCAL nodes of this handle, X n x m0 random block
  * supplied by the caller (randn(ComplexF64, N, samples) in the reference). */

@@ -318,6 +318,79 @@ def gen_feast(X, A, B, contour, iter=10, eps=1e-12, store=False,
     return lam[inside].copy(), X[:, inside].copy(), res[inside].copy()
 
 
+def dual_gen_feast(Xr, Xl, A, B, contour, iter=10, eps=1e-12, store=False, factorizer=lu, left_divider=ldiv, history=None):
+    """``dual_gen_feast!`` src/feast.jl:165-257: two-sided FEAST, right (Xr) and left (Xl) eigenvectors.
+    Restated with the three slips of the reference repaired ("fix rather than reproduce"):
+    (i) :200-201 ``Diagonal(1.0/S.S)`` -> both bases scaled by S^-1/2, so that Ql' B Qr = I;
+    (ii) :214 the left residual is A' y - conj(lam) B' y (the reference passes lam itself);
+    (iii) :210-212 the left Ritz vectors come from eigen(Aq', Bq') in ITS eigenvalue order; here they are paired
+    with the right ones by eigenvalue (conj).  Returns (lam[in], Xr[:, in], Xl[:, in], resr[in])."""
+    Xr, Xl = np.asarray(Xr), np.asarray(Xl)
+    N, m0 = Xl.shape
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Incorrect dimensions of A, must be square")
+    if A.shape[0] != N:
+        raise ValueError("Incorrect dimensions of X, must match A")
+    A = sp.csc_matrix(A, dtype=np.complex128) if sp.issparse(A) else np.asarray(A).astype(np.complex128)
+    B = sp.csc_matrix(B, dtype=np.complex128) if sp.issparse(B) else np.asarray(B).astype(np.complex128)
+    Ah, Bh = A.conj().T, B.conj().T
+    lam = np.zeros(m0, dtype=np.complex128)
+    resr = np.zeros(m0)
+    temp = np.zeros((N, m0), dtype=np.complex128)
+    Rr = np.zeros((N, m0), dtype=np.complex128)
+    Rl = np.zeros((N, m0), dtype=np.complex128)
+    Qr, Ql = Xr.astype(np.complex128).copy(), Xl.astype(np.complex128).copy()
+    nodes, weights = contour.nodes, contour.weights
+    K = nodes.shape[0]
+    rfacts = lfacts = None
+    if store:                                                  # :178-197
+        rfacts = [factorizer(A - B * nodes[k]) for k in range(K)]
+        lfacts = [factorizer((A - B * nodes[k]).conj().T) for k in range(K)]
+    for nit in range(iter + 1):
+        U, S, Vh = np.linalg.svd(Ql.conj().T @ _matmul(B, Qr))          # :199
+        Qr = (Qr @ Vh.conj().T) / np.sqrt(S)[None, :]                   # :200  (repaired)
+        Ql = (Ql @ U) / np.sqrt(S)[None, :]                             # :201
+        Aq = Ql.conj().T @ _matmul(A, Qr)                               # :202-203
+        Bq = Ql.conj().T @ _matmul(B, Qr)                               # :204-205
+        lam[...], Xq = _sorted_eig(Aq, Bq)                              # :206-208
+        mu, Yq = _sorted_eig(Aq.conj().T, Bq.conj().T)                  # :210-211
+        used = np.zeros(m0, dtype=bool)
+        Ym = np.zeros_like(Yq)
+        for i in range(m0):
+            d = np.where(used, np.inf, np.abs(mu - np.conj(lam[i])))
+            j = int(np.argmin(d))
+            used[j] = True
+            Ym[:, i] = Yq[:, j]
+        Xr[...] = Qr @ Xq                                               # :209
+        Xl[...] = Ql @ Ym                                               # :212
+        update_R(Xr, Rr, lam, A, B)                                     # :213
+        update_R(Xl, Rl, np.conj(lam), Ah, Bh)                          # :214  (repaired)
+        resr[...] = residuals_linear(Rr)                                # :215
+        inside = in_contour(lam, contour)
+        if history is not None:
+            history.append((nit, int(inside.sum()), float(resr[inside].max()) if inside.any() else float("nan")))
+        if inside.any() and resr[inside].max() < eps:                   # :218
+            break
+        if nit < iter:                                                  # :222
+            Qr = np.zeros((N, m0), dtype=np.complex128)
+            Ql = np.zeros((N, m0), dtype=np.complex128)
+            for k in range(K):
+                resolvent = 1.0 / (nodes[k] - lam)                      # :226
+                if store:
+                    left_divider(temp, rfacts[k], Rr)
+                else:
+                    linsolve(temp, A - B * nodes[k], Rr, factorizer, left_divider)
+                Qr += (Xr - temp) * (resolvent * weights[k])[None, :]   # :232-234
+                resolvent = 1.0 / (np.conj(nodes[k]) - np.conj(lam))    # :236
+                if store:
+                    left_divider(temp, lfacts[k], Rl)
+                else:
+                    linsolve(temp, (A - B * nodes[k]).conj().T, Rl, factorizer, left_divider)
+                Ql += (Xl - temp) * (resolvent * np.conj(weights[k]))[None, :]   # :242-244
+    inside = in_contour(lam, contour)
+    return lam[inside].copy(), Xr[:, inside].copy(), Xl[:, inside].copy(), resr[inside].copy()
+
+
 def feast(X, A, contour, **kw):
     """``feast!`` src/feast.jl:10-80"""
     return gen_feast(X, A, None, contour, **kw)

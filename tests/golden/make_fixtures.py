@@ -92,6 +92,12 @@ def moments_fixtures():
                                      moments=2, spurious=w["spurious"], history=hist)
     ins = (np.abs(lam - w["c"]) <= w["r"]) & (res < 1e-9)
     out["hadeler_moments"] = dict(history=hist, lam_inside=cplx(np.sort_complex(lam[ins])), res_inside=[float(x) for x in res[ins]])
+    # dual_gen_feast! (src/feast.jl:165-257) on a C2-type dense non-Hermitian pencil: 12 eigenvalues inside
+    w = wl.c2_dense_generalized(256, 32, n_inside=12)
+    hist = []
+    lam, _, _, res = fo.dual_gen_feast(wl.rand_x0(256, 32, 8001), wl.rand_x0(256, 32, 8002), w["A"], w["B"],
+                                       fo.circular_contour_trapezoidal(w["c"], w["r"], 16), iter=20, eps=1e-11, store=True, history=hist)
+    out["dual_c2_n256"] = dict(r=w["r"], history=hist, lam=cplx(np.sort_complex(lam)), res=[float(x) for x in res])
     return out
 
 
@@ -101,7 +107,7 @@ def main():
         out = json.load(open(gp))
         out.update(moments_fixtures())
         json.dump(out, open(gp, "w"), indent=1)
-        print({k: len(v["lam_inside"]) for k, v in out.items() if k.startswith("moments_") or k.startswith("hadeler_")})
+        print({k: len(v["lam_inside"]) for k, v in out.items() if k.startswith("moments_") or k.startswith("hadeler_")}, len(out["dual_c2_n256"]["lam"]))
         return
     full = "--full" in sys.argv
     out = {}

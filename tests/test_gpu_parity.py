@@ -263,6 +263,50 @@ def test_hadeler_nonpolynomial_nep(gpu, pkg, wl, golden, path):
 
 
 # ---------------------------------------------------------------------------------------
+# dual_gen_feast! (src/feast.jl:158-257)
+# ---------------------------------------------------------------------------------------
+def test_dual_gen_feast_dense(gpu, pkg, wl, golden):
+    g = golden["dual_c2_n256"]
+    w = wl.c2_dense_generalized(256, 32, n_inside=12, radius=g["r"])
+    Xr, Xl = wl.rand_x0(256, 32, 8001), wl.rand_x0(256, 32, 8002)
+    info = {}
+    lam, xr, xl, res = pkg.dual_gen_feast(Xr, Xl, w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-11, store=True, info=info)
+    assert len(lam) == 12 and match_sets(lam, c2n(g["lam"])) < 1e-9 and match_sets(c2n(g["lam"]), lam) < 1e-9
+    assert res.max() < 1e-11 and abs(info["nit"] - g["history"][-1][0]) <= 1
+    A, B = w["A"], w["B"]
+    for i in range(len(lam)):
+        assert abs(np.linalg.norm(A @ xr[:, i] - lam[i] * (B @ xr[:, i])) - res[i]) < 1e-12      # absolute residual (utils.jl:166-171)
+        assert np.linalg.norm(xl[:, i].conj() @ A - lam[i] * (xl[:, i].conj() @ B)) < 1e-10       # left eigenvector
+    G = xl.conj().T @ B @ xr
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 and np.abs(np.diag(G)).min() > 1e-4
+    assert np.array_equal(Xr[:, info["inside"]], xr) and np.array_equal(Xl[:, info["inside"]], xl)   # in-place
+
+
+def test_dual_gen_feast_sparse_nonsymmetric(gpu, pkg, wl):
+    """sparse, structurally symmetric but non-Hermitian (convection-diffusion on a 10^3 grid), store=false: the adjoint
+    systems are factorised as extra nodes from the terms A', B'."""
+    g = 10
+    L = wl.laplacian_3d(g, 7)
+    n = g ** 3
+    idx = np.arange(n)
+    conv = sp.csc_matrix((np.r_[np.full(n - 1, 0.35), np.full(n - 1, -0.35)], (np.r_[idx[:-1], idx[1:]], np.r_[idx[1:], idx[:-1]])), shape=(n, n))
+    A = sp.csc_matrix(L + conv)
+    rng = np.random.default_rng(5)
+    B = sp.diags(rng.uniform(0.5, 1.5, n), format="csc")
+    import scipy.linalg as sla
+    ev = sla.eigvals(A.toarray(), B.toarray())
+    dist = np.sort(np.abs(ev - 0.8))
+    k = next(i for i in range(8, 20) if dist[i] - dist[i - 1] > 5e-3)          # do not cut through a conjugate pair
+    c, r = 0.8 + 0j, 0.5 * (dist[k - 1] + dist[k])
+    inside_ref = ev[np.abs(ev - c) <= r]
+    Xr, Xl = wl.rand_x0(n, 32, 31), wl.rand_x0(n, 32, 32)
+    lam, xr, xl, res = pkg.dual_gen_feast(Xr, Xl, A, B, nodes=16, iter=25, c=c, r=r, eps=1e-11, store=False)
+    assert len(lam) == k and match_sets(lam, inside_ref) < 1e-9 and match_sets(inside_ref, lam) < 1e-9 and res.max() < 1e-11
+    for i in range(len(lam)):
+        assert np.linalg.norm(xl[:, i].conj() @ A - lam[i] * (xl[:, i].conj() @ B)) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------
 # mixed_prec (SURVEY 8f rank 2, src/feast.jl:10,19-25)
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind", ["dense", "sparse"])

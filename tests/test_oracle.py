@@ -124,6 +124,26 @@ def test_mixed_prec_restatement_floor(fo, wl):
     assert abs(np.log10(h32[1][2] / h64[1][2])) < 0.5
 
 
+def test_dual_gen_feast_restatement(fo, wl, golden):
+    """dual_gen_feast! (src/feast.jl:165-257, repaired as documented in the oracle): right and left eigenvectors of a
+    non-Hermitian pencil, checked against scipy's generalized eigenvalues and their defining equations."""
+    import scipy.linalg as sla
+    g = golden["dual_c2_n256"]
+    w = wl.c2_dense_generalized(256, 32, n_inside=12, radius=g["r"])
+    con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    lam, xr, xl, res = fo.dual_gen_feast(wl.rand_x0(256, 32, 8001), wl.rand_x0(256, 32, 8002), w["A"], w["B"], con, iter=20, eps=1e-11, store=True)
+    ev = sla.eigvals(w["A"], w["B"])
+    ev = ev[np.abs(ev - w["c"]) <= w["r"]]
+    assert len(lam) == len(ev) == 12 and max(np.abs(ev - x).min() for x in lam) < 1e-10
+    assert np.abs(np.sort_complex(lam) - c2n(g["lam"])).max() < 1e-10
+    A, B = w["A"], w["B"]
+    for i in range(len(lam)):
+        assert np.linalg.norm(A @ xr[:, i] - lam[i] * (B @ xr[:, i])) < 1e-10
+        assert np.linalg.norm(xl[:, i].conj() @ A - lam[i] * (xl[:, i].conj() @ B)) < 1e-10
+    G = xl.conj().T @ B @ xr                                            # bi-orthogonality of left and right vectors
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9
+
+
 def test_golden_c3_small_reproduces(fo, wl, golden):
     g = golden["c3_g8_s19_m16"]
     w = wl.c3_sparse_generalized(8, 19, 16)
