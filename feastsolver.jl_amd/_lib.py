@@ -71,6 +71,10 @@ PROTOTYPES = {
     "feasthip_get_stats": (I, [VP, C.POINTER(Stats)]),
     "feasthip_profile_solve": (I, [VP, VP]),
     "feasthip_profile_detail": (I, [VP, VP, I]),
+    "feasthip_mm_last_error": (C.c_char_p, []),
+    "feasthip_mm_info": (I, [C.c_char_p, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I)]),
+    "feasthip_mm_read_csc": (I, [C.c_char_p, VP, VP, VP, I64]),
+    "feasthip_mm_write_csc": (I, [C.c_char_p, I64, I64, VP, VP, VP, I, I]),
     "feasthip_symbolic_probe": (I, [I64, VP, VP, I, I, VP, VP, VP, VP]),
     "feasthip_symbolic_contains": (I, [I64, VP, VP, I, I, VP, VP, I64]),
     "feasthip_small_eig": (I, [I, VP, VP, VP, VP]),

@@ -384,6 +384,30 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     return lam[ins], Xw[:, ins], res[ins]
 
 
+def mmread(path):
+    """MatrixMarket coordinate file -> scipy CSC complex128 through the library's own reader (feasthip_mm_read_csc);
+    what MatrixMarket.mmread does in the reference's scripts (test/butterfly.jl:57-59, test/polynomial.jl:5-11)."""
+    lib = _lib.load_library()
+    rows, cols, nnz, field = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+    bp = str(path).encode()
+    if lib.feasthip_mm_info(bp, C.byref(rows), C.byref(cols), C.byref(nnz), C.byref(field)) != 0:
+        raise ValueError("mmread: " + (lib.feasthip_mm_last_error() or b"").decode())
+    cp = np.zeros(cols.value + 1, dtype=np.int64)
+    rv = np.zeros(max(1, nnz.value), dtype=np.int64)
+    vl = np.zeros(max(1, nnz.value), dtype=np.complex128)
+    if lib.feasthip_mm_read_csc(bp, _vp(cp), _vp(rv), _vp(vl), nnz.value) != 0:
+        raise ValueError("mmread: " + (lib.feasthip_mm_last_error() or b"").decode())
+    return sp.csc_matrix((vl[:nnz.value], rv[:nnz.value], cp), shape=(rows.value, cols.value))
+
+
+def mmwrite(path, M):
+    """scipy sparse / dense matrix -> MatrixMarket `coordinate <field> general` (the reference's writer, test/gen_butterfly.jl:6-41)."""
+    lib = _lib.load_library()
+    (cp, rv, vl), ty = _csc_arg(sp.csc_matrix(M))
+    if lib.feasthip_mm_write_csc(str(path).encode(), M.shape[0], M.shape[1], _vp(cp), _vp(rv), _vp(vl), ty, 0) != 0:
+        raise ValueError("mmwrite: " + (lib.feasthip_mm_last_error() or b"").decode())
+
+
 def _adjoint(M):
     return M.conj().T.tocsc() if _issparse(M) else np.ascontiguousarray(np.asarray(M).conj().T)
 

@@ -207,6 +207,18 @@ int feasthip_profile_solve(feasthip_handle_t h, double* out);
 /* per-launch rows of the last feasthip_profile_solve: {class, ms, bytes, flops, tiles}; returns the row count */
 int feasthip_profile_detail(feasthip_handle_t h, double* out, int cap);
 
+/* ---- MatrixMarket coordinate files: the on-disk format of the reference's data sets (the data/ .mtx files,
+ * written by test/gen_butterfly.jl:6-41, read with MatrixMarket.jl in test/butterfly.jl:57-59, test/polynomial.jl:5-11).
+ * Host only.  feasthip_mm_info -> sizes (nnz after expanding symmetric/hermitian/skew storage and merging duplicates;
+ * field 0 real, 1 complex, 2 integer, 3 pattern); feasthip_mm_read_csc fills caller-allocated CSC arrays (colptr cols+1,
+ * rowval/nzval nnz; 0-based int64 indices, sorted rows, values always complex128) -- the layout feasthip_set_csc takes with
+ * index_base = 0.  feasthip_mm_write_csc writes `coordinate <field> general` like the reference's writer. */
+const char* feasthip_mm_last_error(void);
+int feasthip_mm_info(const char* path, int64_t* rows, int64_t* cols, int64_t* nnz, int* field);
+int feasthip_mm_read_csc(const char* path, int64_t* colptr, int64_t* rowval, void* nzval, int64_t nnz_capacity);
+int feasthip_mm_write_csc(const char* path, int64_t rows, int64_t cols, const int64_t* colptr, const int64_t* rowval,
+                          const void* nzval, int type, int index_base);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------- */
 /* symbolic analysis of a pattern: stats[0..7] = nsuper, nnz_l, nnz_u, fact_elems,
  * max_front, max_p, depth, flops(as int64).  perm_out (n ints, new->old) optional. */

@@ -166,3 +166,31 @@ def test_argument_validation_without_gpu(pkg):
         pkg.nlfeast_moments(lambda z: np.eye(3), np.ones((3, 2), dtype=complex), 8, 2)
     nep = pkg.SplitNEP([np.eye(2), np.ones((2, 2))], [lambda z: z * z, np.exp])
     assert np.allclose(nep(0.5), 0.25 * np.eye(2) + np.exp(0.5) * np.ones((2, 2)))
+
+
+def test_matrixmarket_io_matches_scipy(pkg, wl, tmp_path):
+    """the library's MatrixMarket reader/writer against scipy.io on the reference's data files and on
+    symmetric / hermitian / pattern storage; host only."""
+    import os
+    import scipy.io
+    for name in ["butterflyM1.mtx", "quadraticM0.mtx", "system5A1.mtx"]:
+        path = os.path.join(wl.GOLDEN_DIR, "data", name)
+        M = pkg.mmread(path)
+        ref = sp.csc_matrix(scipy.io.mmread(path), dtype=np.complex128)
+        assert M.shape == ref.shape and abs(M - ref).max() == 0
+    rng = np.random.default_rng(0)
+    A = sp.random(30, 30, density=0.2, random_state=1, format="csc") + 1j * sp.random(30, 30, density=0.2, random_state=2, format="csc")
+    H = sp.csc_matrix(A + A.conj().T)
+    for mat, kw in [(H, dict(symmetry="hermitian")), (sp.csc_matrix((A + A.T).real), dict(symmetry="symmetric")),
+                    (sp.csc_matrix(A.real != 0, dtype=np.int64), dict(field="pattern"))]:
+        p = str(tmp_path / "m.mtx")
+        scipy.io.mmwrite(p, mat, **kw)
+        got = pkg.mmread(p)
+        assert abs(got - sp.csc_matrix(mat, dtype=np.complex128)).max() < 1e-15
+    for mat in [A, sp.csc_matrix(A.real), sp.csc_matrix(np.arange(12).reshape(3, 4))]:
+        p = str(tmp_path / "w.mtx")
+        pkg.mmwrite(p, mat)                                   # round trip through scipy's reader
+        back = sp.csc_matrix(scipy.io.mmread(p), dtype=np.complex128)
+        assert back.shape == mat.shape and abs(back - sp.csc_matrix(mat, dtype=np.complex128)).max() < 1e-15
+    with pytest.raises(ValueError):
+        pkg.mmread(str(tmp_path / "missing.mtx"))
