@@ -45,9 +45,9 @@ struct Symbolic {
 };
 
 struct SymbolicOptions {
-    int leaf_size = 24;       // nested dissection stops below this many vertices
+    int leaf_size = 64;       // nested dissection stops below this many vertices
     int relax_small = 32;     // always merge a child if the merged supernode has <= this many columns
-    int relax_mid = 96;       // merge up to this many columns if the zero fraction stays below zmid
+    int relax_mid = 64;       // merge up to this many columns if the zero fraction stays below zmid
     double zmid = 0.35;
     double zbig = 0.05;       // larger merges only below this zero fraction
     int ordering = 0;         // 0 = nested dissection, 1 = natural (identity)
