@@ -39,6 +39,38 @@ def test_seam_dense_lu_ldiv(gpu, pkg, n, m0):
     assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y)
 
 
+def test_seam_is_reentrant_across_host_threads(gpu, pkg, wl):
+    """The reference calls `factorizer` from Threads.@threads (src/feast.jl:34-37, src/nlfeast.jl:19-26) and
+    `left_divider` concurrently in nlfeast! (src/nlfeast.jl:36-55): factor objects created and used from several host
+    threads at once give exactly the serial results."""
+    import threading
+    rng = np.random.default_rng(17)
+    mats = [rng.standard_normal((150 + 10 * t, 150 + 10 * t)) + 1j * rng.standard_normal((150 + 10 * t, 150 + 10 * t)) for t in range(3)]
+    mats += [sp.csc_matrix(wl.laplacian_3d(8 + t, 19).astype(np.complex128) - (0.2 + 0.1j * (t + 1)) * sp.identity((8 + t) ** 3)) for t in range(3)]
+    rhs = [np.asfortranarray(rng.standard_normal((M.shape[0], 24)) + 1j * rng.standard_normal((M.shape[0], 24))) for M in mats]
+
+    def work(i, out):
+        F = pkg.lu(mats[i])
+        Y = np.zeros(rhs[i].shape, dtype=np.complex128, order="F")
+        for _ in range(3):
+            pkg.ldiv(Y, F, rhs[i])
+        pkg.finalize(F)
+        out[i] = Y
+
+    serial, threaded = {}, {}
+    for i in range(len(mats)):
+        work(i, serial)
+    ths = [threading.Thread(target=work, args=(i, threaded)) for i in range(len(mats))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(len(mats)):
+        assert np.array_equal(serial[i], threaded[i])
+        M = mats[i]
+        assert np.linalg.norm(M @ serial[i] - rhs[i]) <= 1e-10 * np.linalg.norm(rhs[i]) * (np.linalg.cond(M) if not sp.issparse(M) else 100.0)
+
+
 @pytest.mark.parametrize("case", ["lap1d", "grid2d", "grid3d_7", "grid3d_19", "random_unsym", "block"])
 @pytest.mark.parametrize("m0", [1, 20, 64])
 def test_seam_sparse_lu_ldiv(gpu, pkg, wl, case, m0):
