@@ -141,12 +141,19 @@ def main():
     st = h.stats()
     h.set_x(w["X0"])
 
+    phase = {"rr": 0.0, "contour": 0.0, "allreduce": 0.0}      # host-synchronous phases: the Amdahl breakdown per N
+
     def step():
+        t0 = time.perf_counter()
         lam, res, ins = h.rr_step()
+        t1 = time.perf_counter()
         h.contour_step()
+        t2 = time.perf_counter()
         if use_dist:
             dist.all_reduce(qbuf[: n * ldw * 2])
             torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        phase["rr"] += t1 - t0; phase["contour"] += t2 - t1; phase["allreduce"] += t3 - t2
         return lam, res, ins
 
     for _ in range(args.warmup):
@@ -154,6 +161,8 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+    for k in phase:
+        phase[k] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lam, res, ins = step()
@@ -202,6 +211,7 @@ def main():
                                  "TFLOPs": st2["solve_flops"] / (st2["solve_ms"] * 1e-3) / 1e12},
                 "kernel_classes_ms": {k: v["ms"] for k, v in prof.items()},
             },
+            "breakdown_ms_per_step": {k: 1e3 * v / args.steps for k, v in phase.items()},      # rank 0; rr is replicated, contour is this rank's node shard
             "setup": {"analyze_s": t_analyze, "factor_ms": st["factor_ms"], "factor_TFLOPs": st["flops_factor"] * st["local_nodes"] / (st["factor_ms"] * 1e-3) / 1e12,
                       "perturbed_pivots": int(warn), "store_false_iterations_per_s": 1.0 / (dt / args.steps + st["factor_ms"] * 1e-3)},
             "result": {"inside": int(ins.sum()), "expected_inside": w["n_inside"], "max_res_inside": float(res[ins].max()) if ins.any() else None,
