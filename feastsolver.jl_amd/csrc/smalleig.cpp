@@ -9,6 +9,15 @@ namespace {
 inline double cabs1(zc z) { return std::fabs(z.real()) + std::fabs(z.imag()); }
 const double EPS = 2.220446049250313e-16;
 
+// sqrt(a^2 + b^2) without the overflow/underflow ceremony of libm's hypot (EISPACK pythag): one divide, one sqrt
+inline double pythag(double a, double b) {
+    a = std::fabs(a); b = std::fabs(b);
+    if (a < b) std::swap(a, b);
+    if (a == 0.0) return 0.0;
+    double r = b / a;
+    return a * std::sqrt(1.0 + r * r);
+}
+
 // Householder reduction to upper Hessenberg form, H = Z^H A Z.
 void hessenberg(int m, zc* H, zc* Z) {
     for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Z[i + (size_t)j * m] = (i == j) ? 1.0 : 0.0;
@@ -205,68 +214,148 @@ double hermitian_defect(int m, const zc* M) {
     return mx > 0 ? df / mx : 0.0;
 }
 
+// Split storage (separate real and imaginary planes, column-major) keeps every inner loop a stride-1 real loop
+// the compiler vectorises; this routine sits on the critical path of every FEAST iteration (GPU idle meanwhile).
+namespace {
+struct Planes {
+    int m;
+    std::vector<double> re, im;
+    explicit Planes(int m_) : m(m_), re((size_t)m_ * m_, 0.0), im((size_t)m_ * m_, 0.0) {}
+    double* r(int j) { return re.data() + (size_t)j * m; }
+    double* i(int j) { return im.data() + (size_t)j * m; }
+};
+
+// M <- R^-H M, column by column (R upper triangular with real positive diagonal): forward substitution with R^H
+void solve_rh_cols(int m, Planes& R, Planes& M) {
+    for (int j = 0; j < m; ++j) {
+        double* yr = M.r(j);
+        double* yi = M.i(j);
+        for (int i = 0; i < m; ++i) {
+            const double* rr = R.r(i);
+            const double* ri = R.i(i);
+            double sr = 0, si = 0;
+            for (int k = 0; k < i; ++k) {       // conj(R_ki) * y_k
+                sr += rr[k] * yr[k] + ri[k] * yi[k];
+                si += rr[k] * yi[k] - ri[k] * yr[k];
+            }
+            double d = rr[i];                    // diagonal of a Cholesky factor is real
+            yr[i] = (yr[i] - sr) / d;
+            yi[i] = (yi[i] - si) / d;
+        }
+    }
+}
+
+void conj_transpose(int m, Planes& M) {
+    for (int j = 0; j < m; ++j) {
+        M.im[j + (size_t)j * m] = -M.im[j + (size_t)j * m];
+        for (int i = 0; i < j; ++i) {
+            double ar = M.re[i + (size_t)j * m], ai = M.im[i + (size_t)j * m], br = M.re[j + (size_t)i * m], bi = M.im[j + (size_t)i * m];
+            M.re[i + (size_t)j * m] = br; M.im[i + (size_t)j * m] = -bi;
+            M.re[j + (size_t)i * m] = ar; M.im[j + (size_t)i * m] = -ai;
+        }
+    }
+}
+}  // namespace
+
 int eig_hermitian(int m, zc* A, zc* B, zc* lam, zc* V) {
     if (m <= 0) return 0;
-    std::vector<zc> R;
+    Planes Ap(m), Rp(m), Qp(m);
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { Ap.re[i + (size_t)j * m] = A[i + (size_t)j * m].real(); Ap.im[i + (size_t)j * m] = A[i + (size_t)j * m].imag(); }
     if (B) {   // C = R^-H A R^-1 with B = R^H R
-        R.assign(B, B + (size_t)m * m);
+        std::vector<zc> R(B, B + (size_t)m * m);
         for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (R[i + (size_t)j * m] + std::conj(R[j + (size_t)i * m])); R[i + (size_t)j * m] = a; }
         if (cholesky_upper(m, R.data())) return 1;
-        // A <- R^-H A : solve R^H X = A column by column (forward substitution, R^H lower)
-        for (int j = 0; j < m; ++j)
-            for (int i = 0; i < m; ++i) {
-                zc s = A[i + (size_t)j * m];
-                for (int k = 0; k < i; ++k) s -= std::conj(R[k + (size_t)i * m]) * A[k + (size_t)j * m];
-                A[i + (size_t)j * m] = s / std::conj(R[i + (size_t)i * m]);
-            }
-        // A <- A R^-1 : solve X R = A row by row
-        for (int i = 0; i < m; ++i)
-            for (int j = 0; j < m; ++j) {
-                zc s = A[i + (size_t)j * m];
-                for (int k = 0; k < j; ++k) s -= A[i + (size_t)k * m] * R[k + (size_t)j * m];
-                A[i + (size_t)j * m] = s / R[j + (size_t)j * m];
-            }
+        for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { Rp.re[i + (size_t)j * m] = R[i + (size_t)j * m].real(); Rp.im[i + (size_t)j * m] = R[i + (size_t)j * m].imag(); }
+        solve_rh_cols(m, Rp, Ap);          // T = R^-H A
+        conj_transpose(m, Ap);             // T^H = A R^-1 ... (A Hermitian): C^H = R^-H T^H
+        solve_rh_cols(m, Rp, Ap);
+        conj_transpose(m, Ap);
     }
     // symmetrise
-    for (int j = 0; j < m; ++j) { A[j + (size_t)j * m] = A[j + (size_t)j * m].real(); for (int i = 0; i < j; ++i) { zc a = 0.5 * (A[i + (size_t)j * m] + std::conj(A[j + (size_t)i * m])); A[i + (size_t)j * m] = a; A[j + (size_t)i * m] = std::conj(a); } }
+    for (int j = 0; j < m; ++j) {
+        Ap.im[j + (size_t)j * m] = 0.0;
+        for (int i = 0; i < j; ++i) {
+            double ar = 0.5 * (Ap.re[i + (size_t)j * m] + Ap.re[j + (size_t)i * m]), ai = 0.5 * (Ap.im[i + (size_t)j * m] - Ap.im[j + (size_t)i * m]);
+            Ap.re[i + (size_t)j * m] = ar; Ap.im[i + (size_t)j * m] = ai;
+            Ap.re[j + (size_t)i * m] = ar; Ap.im[j + (size_t)i * m] = -ai;
+        }
+    }
     // Householder tridiagonalisation, Q accumulated
-    std::vector<zc> Q((size_t)m * m, zc(0.0)), v(m), w(m);
-    for (int i = 0; i < m; ++i) Q[i + (size_t)i * m] = 1.0;
+    for (int i = 0; i < m; ++i) Qp.re[i + (size_t)i * m] = 1.0;
+    std::vector<double> vr(m), vi(m), wr(m), wi(m);
     for (int k = 0; k + 2 < m; ++k) {
+        double* ckr = Ap.r(k);
+        double* cki = Ap.i(k);
         double nrm = 0;
-        for (int i = k + 1; i < m; ++i) nrm += std::norm(A[i + (size_t)k * m]);
+        for (int i = k + 1; i < m; ++i) nrm += ckr[i] * ckr[i] + cki[i] * cki[i];
         nrm = std::sqrt(nrm);
         if (nrm == 0.0) continue;
-        zc x0 = A[k + 1 + (size_t)k * m];
-        zc ph = std::abs(x0) == 0.0 ? zc(1.0) : x0 / std::abs(x0);
-        zc alpha = -ph * nrm;
+        double x0r = ckr[k + 1], x0i = cki[k + 1], x0a = pythag(x0r, x0i);
+        double phr = x0a == 0.0 ? 1.0 : x0r / x0a, phi = x0a == 0.0 ? 0.0 : x0i / x0a;
+        double alr = -phr * nrm, ali = -phi * nrm;
         double vn = 0;
-        for (int i = k + 1; i < m; ++i) { v[i] = A[i + (size_t)k * m]; if (i == k + 1) v[i] -= alpha; vn += std::norm(v[i]); }
+        for (int i = k + 1; i < m; ++i) { vr[i] = ckr[i]; vi[i] = cki[i]; }
+        vr[k + 1] -= alr; vi[k + 1] -= ali;
+        for (int i = k + 1; i < m; ++i) vn += vr[i] * vr[i] + vi[i] * vi[i];
         vn = std::sqrt(vn);
         if (vn == 0.0) continue;
-        for (int i = k + 1; i < m; ++i) v[i] /= vn;
-        // A <- H A H on the trailing block, H = I - 2 v v^H :  w = A v, K = v^H w, A -= 2 v w^H + 2 w v^H - 4 K v v^H
-        for (int i = k + 1; i < m; ++i) { zc s = 0; const zc* col = A + (size_t)i * m; for (int j = k + 1; j < m; ++j) s += std::conj(col[j]) * v[j]; w[i] = s; }   // A Hermitian: row i = conj(column i)
-        zc K = 0;
-        for (int i = k + 1; i < m; ++i) K += std::conj(v[i]) * w[i];
-        for (int i = k + 1; i < m; ++i) w[i] = 2.0 * (w[i] - K * v[i]);
-        for (int j = k + 1; j < m; ++j) for (int i = k + 1; i < m; ++i) A[i + (size_t)j * m] -= v[i] * std::conj(w[j]) + w[i] * std::conj(v[j]);
-        A[k + 1 + (size_t)k * m] = alpha; A[k + (size_t)(k + 1) * m] = std::conj(alpha);
-        for (int i = k + 2; i < m; ++i) { A[i + (size_t)k * m] = 0.0; A[k + (size_t)i * m] = 0.0; }
-        // Q <- Q H
-        std::fill(w.begin(), w.end(), zc(0.0));
-        for (int j = k + 1; j < m; ++j) { const zc* col = Q.data() + (size_t)j * m; zc vj = v[j]; for (int i = 0; i < m; ++i) w[i] += col[i] * vj; }
-        for (int j = k + 1; j < m; ++j) { zc* col = Q.data() + (size_t)j * m; zc cv = 2.0 * std::conj(v[j]); for (int i = 0; i < m; ++i) col[i] -= w[i] * cv; }
+        double ivn = 1.0 / vn;
+        for (int i = k + 1; i < m; ++i) { vr[i] *= ivn; vi[i] *= ivn; }
+        // w = A v on the trailing block (A Hermitian: row i = conj(column i)), K = v^H w, w <- 2 (w - K v)
+        double Kr = 0, Ki = 0;
+        for (int i = k + 1; i < m; ++i) {
+            const double* cr = Ap.r(i);
+            const double* ci = Ap.i(i);
+            double sr = 0, si = 0;
+            for (int j = k + 1; j < m; ++j) {   // conj(A_ji) * v_j
+                sr += cr[j] * vr[j] + ci[j] * vi[j];
+                si += cr[j] * vi[j] - ci[j] * vr[j];
+            }
+            wr[i] = sr; wi[i] = si;
+            Kr += vr[i] * sr + vi[i] * si;      // conj(v_i) * w_i
+            Ki += vr[i] * si - vi[i] * sr;
+        }
+        for (int i = k + 1; i < m; ++i) {
+            double tr = wr[i] - (Kr * vr[i] - Ki * vi[i]), ti = wi[i] - (Kr * vi[i] + Ki * vr[i]);
+            wr[i] = 2.0 * tr; wi[i] = 2.0 * ti;
+        }
+        // A -= v w^H + w v^H
+        for (int j = k + 1; j < m; ++j) {
+            double* cr = Ap.r(j);
+            double* ci = Ap.i(j);
+            double wjr = wr[j], wji = -wi[j], vjr = vr[j], vji = -vi[j];     // conj(w_j), conj(v_j)
+            for (int i = k + 1; i < m; ++i) {
+                cr[i] -= vr[i] * wjr - vi[i] * wji + wr[i] * vjr - wi[i] * vji;
+                ci[i] -= vr[i] * wji + vi[i] * wjr + wr[i] * vji + wi[i] * vjr;
+            }
+        }
+        ckr[k + 1] = alr; cki[k + 1] = ali;
+        Ap.re[k + (size_t)(k + 1) * m] = alr; Ap.im[k + (size_t)(k + 1) * m] = -ali;
+        for (int i = k + 2; i < m; ++i) { ckr[i] = 0.0; cki[i] = 0.0; Ap.re[k + (size_t)i * m] = 0.0; Ap.im[k + (size_t)i * m] = 0.0; }
+        // Q <- Q H = Q - 2 (Q v) v^H
+        std::fill(wr.begin(), wr.end(), 0.0);
+        std::fill(wi.begin(), wi.end(), 0.0);
+        for (int j = k + 1; j < m; ++j) {
+            const double* qr = Qp.r(j);
+            const double* qi = Qp.i(j);
+            double vjr = vr[j], vji = vi[j];
+            for (int i = 0; i < m; ++i) { wr[i] += qr[i] * vjr - qi[i] * vji; wi[i] += qr[i] * vji + qi[i] * vjr; }
+        }
+        for (int j = k + 1; j < m; ++j) {
+            double* qr = Qp.r(j);
+            double* qi = Qp.i(j);
+            double cr2 = 2.0 * vr[j], ci2 = -2.0 * vi[j];       // 2 conj(v_j)
+            for (int i = 0; i < m; ++i) { qr[i] -= wr[i] * cr2 - wi[i] * ci2; qi[i] -= wr[i] * ci2 + wi[i] * cr2; }
+        }
     }
     // real tridiagonal: T = D^H A D, D = diag(phases)
-    std::vector<double> d(m), e(m, 0.0);
-    std::vector<zc> phs(m, zc(1.0));
-    for (int i = 0; i < m; ++i) d[i] = A[i + (size_t)i * m].real();
+    std::vector<double> d(m), e(m, 0.0), phr(m, 1.0), phi(m, 0.0);
+    for (int i = 0; i < m; ++i) d[i] = Ap.re[i + (size_t)i * m];
     for (int i = 0; i + 1 < m; ++i) {
-        zc c = A[i + 1 + (size_t)i * m];
-        double a = std::abs(c);
+        double cr = Ap.re[i + 1 + (size_t)i * m], ci = Ap.im[i + 1 + (size_t)i * m], a = pythag(cr, ci);
         e[i + 1] = a;                                    // tql2 convention: e[i] couples i-1 and i
-        phs[i + 1] = a > 0 ? phs[i] * c / a : phs[i];
+        if (a > 0) { phr[i + 1] = (phr[i] * cr - phi[i] * ci) / a; phi[i + 1] = (phr[i] * ci + phi[i] * cr) / a; }
+        else { phr[i + 1] = phr[i]; phi[i + 1] = phi[i]; }
     }
     // implicit QL with accumulation (EISPACK tql2)
     std::vector<double> Z((size_t)m * m, 0.0);
@@ -282,7 +371,7 @@ int eig_hermitian(int m, zc* A, zc* B, zc* lam, zc* V) {
             int iter = 0;
             do {
                 if (++iter > 60) return 1;
-                double g = d[l], p = (d[l + 1] - g) / (2.0 * e[l]), r = std::hypot(p, 1.0);
+                double g = d[l], p = (d[l + 1] - g) / (2.0 * e[l]), r = pythag(p, 1.0);
                 d[l] = e[l] / (p + (p < 0 ? -r : r));
                 d[l + 1] = e[l] * (p + (p < 0 ? -r : r));
                 double dl1 = d[l + 1], h = g - d[l];
@@ -293,14 +382,16 @@ int eig_hermitian(int m, zc* A, zc* B, zc* lam, zc* V) {
                 for (int i = mm - 1; i >= l; --i) {
                     c3 = c2; c2 = c; s2 = s;
                     g = c * e[i]; h = c * p;
-                    r = std::hypot(p, e[i]);
+                    r = pythag(p, e[i]);
                     e[i + 1] = s * r; s = e[i] / r; c = p / r;
                     p = c * d[i] - s * g;
                     d[i + 1] = h + s * (c * g + s * d[i]);
+                    double* z1 = Z.data() + (size_t)(i + 1) * m;
+                    double* z0 = Z.data() + (size_t)i * m;
                     for (int kk = 0; kk < m; ++kk) {
-                        double hh = Z[kk + (size_t)(i + 1) * m];
-                        Z[kk + (size_t)(i + 1) * m] = s * Z[kk + (size_t)i * m] + c * hh;
-                        Z[kk + (size_t)i * m] = c * Z[kk + (size_t)i * m] - s * hh;
+                        double hh = z1[kk];
+                        z1[kk] = s * z0[kk] + c * hh;
+                        z0[kk] = c * z0[kk] - s * hh;
                     }
                 }
                 p = -s * s2 * c3 * el1 * e[l] / dl1;
@@ -315,18 +406,33 @@ int eig_hermitian(int m, zc* A, zc* B, zc* lam, zc* V) {
     std::vector<int> order(m);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
-    std::vector<zc> x(m), y(m);
+    std::vector<double> xr(m), xi(m);
     for (int kk = 0; kk < m; ++kk) {
         int j = order[kk];
-        for (int i = 0; i < m; ++i) y[i] = phs[i] * Z[i + (size_t)j * m];
-        std::fill(x.begin(), x.end(), zc(0.0));
-        for (int q = 0; q < m; ++q) { const zc* col = Q.data() + (size_t)q * m; zc yq = y[q]; for (int i = 0; i < m; ++i) x[i] += col[i] * yq; }
-        if (B) for (int i = m - 1; i >= 0; --i) { zc s = x[i]; for (int q = i + 1; q < m; ++q) s -= R[i + (size_t)q * m] * x[q]; x[i] = s / R[i + (size_t)i * m]; }
+        const double* zj = Z.data() + (size_t)j * m;
+        std::fill(xr.begin(), xr.end(), 0.0);
+        std::fill(xi.begin(), xi.end(), 0.0);
+        for (int q = 0; q < m; ++q) {
+            double yr = phr[q] * zj[q], yi = phi[q] * zj[q];
+            const double* qr = Qp.r(q);
+            const double* qi = Qp.i(q);
+            for (int i = 0; i < m; ++i) { xr[i] += qr[i] * yr - qi[i] * yi; xi[i] += qr[i] * yi + qi[i] * yr; }
+        }
+        if (B) {    // x <- R^-1 x, column-oriented back substitution
+            for (int q = m - 1; q >= 0; --q) {
+                const double* rr = Rp.r(q);
+                const double* ri = Rp.i(q);
+                double dq = rr[q];
+                xr[q] /= dq; xi[q] /= dq;
+                double tr = xr[q], ti = xi[q];
+                for (int i = 0; i < q; ++i) { xr[i] -= rr[i] * tr - ri[i] * ti; xi[i] -= rr[i] * ti + ri[i] * tr; }
+            }
+        }
         double nr = 0;
-        for (int i = 0; i < m; ++i) nr += std::norm(x[i]);
-        nr = std::sqrt(nr);
+        for (int i = 0; i < m; ++i) nr += xr[i] * xr[i] + xi[i] * xi[i];
+        nr = 1.0 / std::sqrt(nr);
         lam[kk] = d[j];
-        for (int i = 0; i < m; ++i) V[i + (size_t)kk * m] = x[i] / nr;
+        for (int i = 0; i < m; ++i) V[i + (size_t)kk * m] = zc(xr[i] * nr, xi[i] * nr);
     }
     return 0;
 }

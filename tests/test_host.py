@@ -140,6 +140,26 @@ def test_small_eig_hermitian_and_defective(lib):
     assert np.abs(lam - 2.0).max() < 1e-6
 
 
+def test_small_eig_hermitian_definite_pencil(lib):
+    """the path every FEAST iteration of a Hermitian(-definite) problem takes (Julia's eigen! on Hermitian input):
+    eigenvalues and B-normalised residuals against LAPACK zhegv, odd and even sizes."""
+    rng = np.random.default_rng(23)
+    for m in (1, 2, 3, 17, 64, 100):
+        G = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        A = np.asfortranarray(G + G.conj().T)
+        H = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        B = np.asfortranarray(H @ H.conj().T + m * np.eye(m))
+        lam = np.zeros(m, dtype=np.complex128)
+        V = np.zeros((m, m), dtype=np.complex128, order="F")
+        assert lib.feasthip_small_eig(m, A.ctypes.data, B.ctypes.data, lam.ctypes.data, V.ctypes.data) == 0
+        ref = sla.eigh(A, B, eigvals_only=True)
+        assert np.abs(lam.imag).max() == 0 and np.abs(lam.real - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+        assert np.linalg.norm(A @ V - (B @ V) * lam[None, :], axis=0).max() < 1e-11 * np.linalg.norm(A)
+        assert np.allclose(np.linalg.norm(V, axis=0), 1.0)
+        off = V.conj().T @ B @ V
+        assert np.abs(off - np.diag(np.diag(off))).max() < 1e-10 * np.abs(np.diag(off)).max()     # B-orthogonal eigenvectors
+
+
 def test_contours_match_oracle(pkg, fo):
     for N in (4, 8, 16, 32):
         for name in ("circular_contour_trapezoidal", "circular_contour_gauss"):
