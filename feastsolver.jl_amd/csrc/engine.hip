@@ -873,7 +873,9 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
         if (!b_is_identity) { launch_ts_gemm(stream_, n, m, ldw, d_T1_.p, dM, d_MX_.p); BX = d_MX_.p; }
         launch_residual_combine(stream_, n, ldw, d_T2_.p, BX, d_lam_.p, d_R_.p);
     } else {
-        apply_term(0, d_X_.p, d_T1_.p, 1.0, false);                      // A X
+        // A X = (A Q) Xq: one tall-skinny GEMM on the product the projection already formed instead of a second
+        // SpMM with A (the gather of 19 block-vector rows per row costs twice as much); B X is a cheap SpMM
+        launch_ts_gemm(stream_, n, m, ldw, d_R_.p, dM, d_T1_.p);        // A X
         if (!b_is_identity) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
         launch_residual_combine(stream_, n, ldw, d_T1_.p, BX, d_lam_.p, d_R_.p);
     }
