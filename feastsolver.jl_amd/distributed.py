@@ -24,7 +24,12 @@ def allreduce_moment(q, group=None):
     memory for nccl/RCCL, host memory for gloo); a no-op without an initialised process group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(q, op=dist.ReduceOp.SUM, group=group)
+        if q.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal without RCCL (several ranks on one GPU): stage through the host
+            tmp = q.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+            q.copy_(tmp)
+        else:
+            dist.all_reduce(q, op=dist.ReduceOp.SUM, group=group)
     return q
 
 

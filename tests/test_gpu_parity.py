@@ -568,6 +568,57 @@ def test_distributed_driver_rccl_world1(gpu, pkg, wl, golden):
     assert abs(info["nit"] - g["history"][-1][0]) <= 1
 
 
+def _two_rank_worker(rank, world, port, out):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import importlib
+    import json
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = graft.load_package()
+        dm = importlib.import_module(graft.PKG_NAME + ".distributed")
+        wl = importlib.import_module(graft.PKG_NAME + ".workloads")
+        w = wl.c3_sparse_generalized(12, 19, 64)
+        con = pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
+        info = {}
+        lam, X, res = dm.gen_feast_distributed(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, device=0, info=info)
+        out.put((rank, [[float(z.real), float(z.imag)] for z in lam], float(res.max()), int(info["nit"]), int(info["local_nodes"]),
+                 float(np.abs(X).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_driver_two_ranks_share_one_gpu(gpu, golden):
+    """The multi-GPU driver with world_size 2 on real kernels: two processes (each with half of the contour nodes and
+    their factors) share this box's one GPU, the moment is summed through gloo instead of RCCL.  Both ranks must
+    return the same converged result as the single-process fixture."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = golden["c3_g12_s19"]
+    for rank, lam, rmax, nit, local, xsum in res:
+        assert local == 8
+        assert match_sets(c2n(lam), c2n(g["lam"])) < 1e-10 and len(lam) == len(g["lam"]) and rmax < 1e-10
+        assert abs(nit - g["history"][-1][0]) <= 1
+    assert res[0][1] == res[1][1] and res[0][5] == res[1][5]          # replicated Rayleigh-Ritz: bitwise identical on both ranks
+
+
 def test_bitwise_reproducible_and_stream_independent(gpu, pkg, wl):
     """Every reduction has a fixed order (no float atomics): the moment Q is bit-identical from run to run,
     and does not depend on how the contour nodes are spread over HIP streams."""
