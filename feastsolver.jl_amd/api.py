@@ -175,6 +175,11 @@ class FeastHandle:
         self._ck(self.lib.feasthip_set_contour(self.h, len(nodes), _vp(nodes), _vp(weights), kind, _vp(region)))
         self.K = len(nodes)
 
+    def set_stream(self, stream_ptr):
+        """Run the library's launches on a caller-owned HIP stream (e.g. ``torch.cuda.Stream().cuda_stream``); 0 / None
+        selects the null stream."""
+        self._ck(self.lib.feasthip_set_stream(self.h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
     def set_node_shard(self, first, stride):
         self._ck(self.lib.feasthip_set_node_shard(self.h, int(first), int(stride)))
 

@@ -619,6 +619,29 @@ def test_distributed_driver_two_ranks_share_one_gpu(gpu, golden):
     assert res[0][1] == res[1][1] and res[0][5] == res[1][5]          # replicated Rayleigh-Ritz: bitwise identical on both ranks
 
 
+def test_caller_owned_stream(gpu, pkg, wl, golden):
+    """feasthip_set_stream: the whole loop on a torch-owned HIP stream gives the fixture result, and work queued on that
+    stream afterwards is ordered behind the library's launches."""
+    import torch
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    st = torch.cuda.Stream()
+    h = pkg.FeastHandle(0)
+    try:
+        h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+        h.set_contour(pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"]))
+        h.set_stream(st.cuda_stream)
+        X = w["X0"].copy()
+        lam, res, ins, nit, warn = h.feast_run(X, w["iter"], w["eps"], True)
+        with torch.cuda.stream(st):
+            marker = torch.ones(4, device="cuda") * 3.0
+        st.synchronize()
+        assert float(marker.sum()) == 12.0
+    finally:
+        h.close()
+    g = golden["c3_g8_s19_m16"]
+    assert match_sets(lam[ins], c2n(g["lam"])) < 1e-10 and ins.sum() == len(g["lam"]) and res[ins].max() < w["eps"]
+
+
 def test_bitwise_reproducible_and_stream_independent(gpu, pkg, wl):
     """Every reduction has a fixed order (no float atomics): the moment Q is bit-identical from run to run,
     and does not depend on how the contour nodes are spread over HIP streams."""
