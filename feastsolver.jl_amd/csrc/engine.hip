@@ -278,6 +278,7 @@ bool Engine::build_plans() {
         auto pick_slabs = [&](auto&& rows_of) {     // rows_of(callback(rows)) enumerates the row extents of the launch
             int64_t wgs = 0;
             rows_of([&](int rows) { wgs += cdiv(rows, 64); });
+            if (wgs * Kloc < 128) return 1;      // latency-bound launch (few nodes left on this GPU): 16-row tiles, four waves share the columns
             return (wgs * Kloc >= 1024) ? 4 : 2;
         };
         double rowb = 1.0;   // bytes are scaled by 16*ldw at run time: count block-vector ROWS here
