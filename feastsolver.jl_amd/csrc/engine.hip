@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <limits>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -396,17 +397,32 @@ int Engine::analyze() {
         if (const char* v = getenv("FEASTHIP_ZMID")) opt.zmid = atof(v);
         if (const char* v = getenv("FEASTHIP_ZBIG")) opt.zbig = atof(v);
         if (const char* v = getenv("FEASTHIP_LEAF")) opt.leaf_size = atoi(v);
+        const bool trace = getenv("FEASTHIP_ANALYZE_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[feasthip analyze] pattern union                %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         std::string e = analyze_pattern(n, cp.data(), ri.data(), opt, S);
         if (!e.empty()) return fail(FEASTHIP_EARG, "analyze: " + e);
+        if (trace) fprintf(stderr, "[feasthip analyze] analyze_pattern total        %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         // arena destinations + CSR copies for SpMM
         for (auto& T : terms_) {
             int64_t nnz = T.colptr[n];
             std::vector<int64_t> dest(nnz);
-            for (int j = 0; j < n; ++j)
-                for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
-                    dest[e2] = entry_dest(S, T.rowval[e2], j);
-                    if (dest[e2] < 0) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
-                }
+            // arena destination of every entry (a binary search in the supernode's row structure): independent per column
+            {
+                int nth = (int)std::min<int64_t>(16, std::max<int64_t>(1, nnz / 100000));
+                std::vector<std::thread> pool;
+                std::vector<char> bad(nth, 0);
+                for (int tix = 0; tix < nth; ++tix)
+                    pool.emplace_back([&, tix]() {
+                        int j0 = (int)((int64_t)n * tix / nth), j1 = (int)((int64_t)n * (tix + 1) / nth);
+                        for (int j = j0; j < j1; ++j)
+                            for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
+                                dest[e2] = entry_dest(S, T.rowval[e2], j);
+                                if (dest[e2] < 0) bad[tix] = 1;
+                            }
+                    });
+                for (auto& th : pool) th.join();
+                for (char b : bad) if (b) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
+            }
             std::vector<int64_t> rp(n + 1, 0);
             for (int64_t e2 = 0; e2 < nnz; ++e2) rp[T.rowval[e2] + 1]++;
             for (int i = 0; i < n; ++i) rp[i + 1] += rp[i];
@@ -421,6 +437,7 @@ int Engine::analyze() {
             if (!ok) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
         }
     }
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + arena destinations, CSR    %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     // device symbolic
     std::vector<FrontD> fr(S.nsuper);
     for (int s = 0; s < S.nsuper; ++s) {
@@ -472,6 +489,7 @@ int Engine::analyze() {
          d_tiny_.alloc(Kloc) && d_coef_.alloc((size_t)Kloc * nterms);
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
     analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads, buffers    %.1f ms (cumulative)\n", analyze_seconds * 1e3);
     analyzed_ = true;
     factored_ = false;
     return 0;

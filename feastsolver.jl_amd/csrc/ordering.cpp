@@ -7,6 +7,9 @@
 // balls) miss; the fill of the top fronts, and with it the factor bytes every FEAST
 // iteration streams, drops accordingly.
 #include "ordering.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdint>
@@ -273,6 +276,9 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
     int n = g0.n;
     if (n < 8) return false;
     XorShift rng(seed + (uint64_t)n);
+    const bool trace = n > 50000 && getenv("FEASTHIP_ANALYZE_TRACE");
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* nm) { if (!trace) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[feasthip nd n=%d] %-18s %.1f ms\n", n, nm, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     std::vector<WGraph> levels;
     std::vector<std::vector<int>> cmaps;
     levels.push_back(g0);
@@ -283,8 +289,10 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
         levels.push_back(std::move(c));
         cmaps.push_back(std::move(cmap));
     }
+    lap("coarsening");
     std::vector<int> part;
     initial_partition(levels.back(), part, rng);
+    lap("initial partition");
     for (int l = (int)levels.size() - 1; l >= 0; --l) {
         if (l < (int)levels.size() - 1) {
             std::vector<int> fine(levels[l].n);
@@ -294,8 +302,10 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
         FM fm(levels[l], part);
         for (int it = 0; it < 8; ++it) if (!fm.pass(0.54)) break;
     }
+    lap("FM refinement");
     std::vector<char> in_sep;
     vertex_cover(g0, part, in_sep);
+    lap("vertex cover");
     label.resize(n);
     for (int v = 0; v < n; ++v) label[v] = in_sep[v] ? 2 : part[v];
     int64_t c[3] = {0, 0, 0};

@@ -2,6 +2,9 @@
 // supernode detection, relaxed amalgamation and front/arena layout.
 // See symbolic.hpp for the role of this phase on the hot path.
 #include "symbolic.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "ordering.hpp"
 
 #include <algorithm>
@@ -81,6 +84,8 @@ public:
 private:
     const Graph& g_;
     int leaf_;
+    int ml_min_ = 64;      // below this size only BFS level-set separators are tried (256..4000 measured: faster ordering, but more fill and slower sweeps)
+    int par_depth_ = std::thread::hardware_concurrency() >= 32 ? 5 : 4;     // recursion levels whose two halves run on their own threads (16 or 32)
     std::vector<int> part_, vis_, lvl_, order_, loc_;
     std::atomic<int> next_id_{0}, stamp_{0};          // sub-problems run on disjoint vertex sets, possibly in parallel
     struct Bfs { std::vector<int> queue, lptr; int stamp = 0; };
@@ -104,10 +109,21 @@ private:
             w.xadj[i + 1] = (int)w.adj.size();
         }
         w.ewgt.assign(w.adj.size(), 1);
-        std::vector<int> label;
         int trials = m >= 20000 ? 2 : 1;     // the top separators dominate the fill: try harder there
+        // the trials are independent (fixed seeds): run them side by side, then judge them in trial order so that the
+        // outcome does not depend on thread timing
+        std::vector<std::vector<int>> labels(trials);
+        std::vector<char> okv(trials, 0);
+        {
+            std::vector<std::thread> pool;
+            for (int tr = 1; tr < trials; ++tr)
+                pool.emplace_back([&, tr]() { okv[tr] = multilevel_separator(w, labels[tr], seed * 7919u + 17u + 104729u * tr) ? 1 : 0; });
+            okv[0] = multilevel_separator(w, labels[0], seed * 7919u + 17u) ? 1 : 0;
+            for (auto& th : pool) th.join();
+        }
         for (int tr = 0; tr < trials; ++tr) {
-            if (!multilevel_separator(w, label, seed * 7919u + 17u + 104729u * tr)) continue;
+            if (!okv[tr]) continue;
+            const std::vector<int>& label = labels[tr];
             Split sp;
             for (int i = 0; i < m; ++i) (label[i] == 0 ? sp.a : label[i] == 1 ? sp.b : sp.s).push_back(verts[i]);
             if (sp.a.empty() || sp.b.empty() || sp.s.empty()) continue;
@@ -214,7 +230,15 @@ private:
             dissect(rest, lo + ncomp, depth);
             return;
         }
-        Split best;
+        const bool tr_ = depth <= 2 && getenv("FEASTHIP_ANALYZE_TRACE");
+        auto t_a = std::chrono::steady_clock::now();
+        Split best, best_ml;
+        // large subgraphs: the multilevel candidate is computed on its own thread while this one walks the BFS
+        // level structures (disjoint scratch: loc_ vs vis_/lvl_); merged below in the same order as the serial code
+        const uint64_t ml_seed = (uint64_t)lo * 2654435761ull + (uint64_t)m;      // independent of thread timing
+        std::thread tml;
+        const bool ml_async = m >= 20000;
+        if (ml_async) tml = std::thread([&]() { multilevel_candidate(verts, id, ml_seed, best_ml); });
         int height = (int)lptr_.size() - 1;
         candidate(m, best, B);
         for (int it = 0; it < 6; ++it) {
@@ -232,14 +256,18 @@ private:
             if (h2 <= height) break;
             height = h2;
         }
-        if (m >= 64) multilevel_candidate(verts, id, (uint64_t)lo * 2654435761ull + (uint64_t)m, best);   // seed independent of thread timing
+        auto t_b = std::chrono::steady_clock::now();
+        if (ml_async) { tml.join(); if (best_ml.cost < best.cost) best = std::move(best_ml); }
+        if (tr_) fprintf(stderr, "[feasthip nd depth %d m=%d] bfs candidates %.1f ms, + wait for multilevel %.1f ms\n", depth, m,
+                         std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
+        else if (m >= ml_min_) multilevel_candidate(verts, id, ml_seed, best);
         if (best.s.empty() || best.a.empty() || best.b.empty()) { emit(verts, lo); return; }
         verts.clear(); verts.shrink_to_fit();
         int na = (int)best.a.size(), nb = (int)best.b.size();
         emit(best.s, lo + na + nb);
         std::vector<int> a(std::move(best.a)), b(std::move(best.b));
         best.s.clear(); best.s.shrink_to_fit();
-        if (depth < 4 && std::min(na, nb) >= 2000) {     // the two halves are independent: up to 16 host threads
+        if (depth < par_depth_ && std::min(na, nb) >= 2000) {     // the two halves are independent: 16 (or 32) host threads
             std::thread th([&]() { dissect(a, lo, depth + 1); });
             dissect(b, lo + na, depth + 1);
             th.join();
@@ -328,6 +356,14 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
     }
     Graph g = symmetrize(n, colptr, rowidx);
 
+    const bool trace = getenv("FEASTHIP_ANALYZE_TRACE") != nullptr;
+    auto tph = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!trace) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[feasthip analyze] %-28s %.1f ms\n", name, std::chrono::duration<double, std::milli>(t1 - tph).count());
+        tph = t1;
+    };
     // ---- 1. fill-reducing ordering --------------------------------------
     std::vector<int> perm(n), iperm(n);
     if (opt.ordering == 1) {
@@ -342,6 +378,7 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
     }
     Graph h = permute_graph(g, perm, iperm);
 
+    phase("ordering");
     // ---- 2. elimination tree (Liu) + postorder ---------------------------
     std::vector<int> parent(n, -1), anc(n, -1);
     for (int j = 0; j < n; ++j)
@@ -380,19 +417,42 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         h = permute_graph(g, perm, iperm);
     }
 
-    // ---- 3. column counts via row subtrees --------------------------------
-    std::vector<int> cc(n, 0), mark(n, -1), nchild(n, 0);
-    for (int i = 0; i < n; ++i) {
-        mark[i] = i;
-        for (int64_t t = h.xadj[i]; t < h.xadj[i + 1]; ++t) {
-            int k = h.adj[t];
-            if (k >= i) break;
+    phase("etree + postorder");
+    // ---- 3. column counts (Gilbert, Ng, Peyton: skeleton leaves + least common ancestors, O(nnz(A) alpha)) ----
+    // cc[j] = number of off-diagonal entries of column j of L.  The graph is postordered, so post(k) = k.
+    std::vector<int> cc(n, 0), nchild(n, 0);
+    {
+        std::vector<int> first(n, -1), maxfirst(n, -1), prevleaf(n, -1), ancestor(n), delta(n, 0);
+        for (int k = 0; k < n; ++k) {
             int j = k;
-            while (mark[j] != i) { mark[j] = i; cc[j]++; j = parent[j]; }
+            delta[j] = first[j] == -1 ? 1 : 0;                 // j is a leaf of the elimination tree
+            for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k;
         }
+        for (int i = 0; i < n; ++i) ancestor[i] = i;
+        for (int j = 0; j < n; ++j) {
+            if (parent[j] != -1) delta[parent[j]]--;
+            for (int64_t t = h.xadj[j]; t < h.xadj[j + 1]; ++t) {
+                int i = h.adj[t];
+                if (i <= j || first[j] <= maxfirst[i]) continue;    // j is not a leaf of the i-th row subtree
+                maxfirst[i] = first[j];
+                int jprev = prevleaf[i];
+                prevleaf[i] = j;
+                delta[j]++;
+                if (jprev != -1) {                                  // subsequent leaf: remove the overlap at the least common ancestor
+                    int q = jprev;
+                    while (q != ancestor[q]) q = ancestor[q];
+                    for (int sv = jprev; sv != q;) { int sp = ancestor[sv]; ancestor[sv] = q; sv = sp; }
+                    delta[q]--;
+                }
+            }
+            if (parent[j] != -1) ancestor[j] = parent[j];
+        }
+        for (int j = 0; j < n; ++j) if (parent[j] != -1) delta[parent[j]] += delta[j];
+        for (int j = 0; j < n; ++j) cc[j] = delta[j] - 1;           // without the diagonal
     }
     for (int j = 0; j < n; ++j) if (parent[j] >= 0) nchild[parent[j]]++;
 
+    phase("column counts");
     // ---- 4. fundamental supernodes ----------------------------------------
     std::vector<int> fstart;   // first column of each fundamental supernode
     for (int j = 0; j < n; ++j) {
@@ -409,6 +469,7 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         fparent[s] = parent[last] < 0 ? -1 : fof[parent[last]];
     }
 
+    phase("fundamental supernodes");
     // ---- 5. relaxed amalgamation on the supernode tree --------------------
     std::vector<int64_t> P(nf), U(nf);
     std::vector<double> Z(nf, 0.0);
@@ -491,6 +552,7 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
     S.sn_of.resize(n);
     for (int s = 0; s < ns; ++s) for (int j = S.sn_start[s]; j < S.sn_start[s + 1]; ++j) S.sn_of[j] = s;
 
+    phase("amalgamation");
     // ---- 6. supernode row structures, tree, relative indices ---------------
     S.sn_parent.assign(ns, -1);
     S.struct_ptr.assign(ns + 1, 0);
@@ -543,7 +605,9 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
             S.rel[S.struct_ptr[c] + k] = r;
         }
     }
+    phase("structures + relative indices");
     finish_layout(S);
+    phase("layout");
     return "";
 }
 
