@@ -28,7 +28,7 @@ void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz
 void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,
                        cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K, int phase);
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
-                  int* piv, const double* tiny, int* nperturb, int K);
+                  int* piv, const double* tiny, int* nperturb, int K, bool tall = false);
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                  const int* piv, int K);
 void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K);

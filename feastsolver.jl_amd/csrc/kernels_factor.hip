@@ -127,9 +127,10 @@ void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 // panel factorisation with partial pivoting restricted to the fully summed
 // rows [k0+j, p) of the front.  One workgroup per (front, node).
 // ---------------------------------------------------------------------------
-constexpr int PANEL_NT = 256;
+constexpr int PANEL_NT_SMALL = 256, PANEL_NT_TALL = 1024;      // threads per panel workgroup (tall panels: the row loops are the work)
 constexpr int PANEL_SB = 8;      // sub-panel width: columns right of the sub-panel are touched once per 8 pivots
 
+template <int PANEL_NT>
 __global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
                                                      cz* fact, int64_t fs, int* piv, int npiv,
                                                      const double* __restrict__ tiny, int* nperturb) {
@@ -241,9 +242,10 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ f
 }
 
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
-                  int* piv, const double* tiny, int* nperturb, int K) {
+                  int* piv, const double* tiny, int* nperturb, int K, bool tall) {
     if (nlist <= 0) return;
-    hipLaunchKernelGGL(k_panel, dim3(nlist, K), dim3(PANEL_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
+    if (tall) hipLaunchKernelGGL(k_panel<PANEL_NT_TALL>, dim3(nlist, K), dim3(PANEL_NT_TALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
+    else hipLaunchKernelGGL(k_panel<PANEL_NT_SMALL>, dim3(nlist, K), dim3(PANEL_NT_SMALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
 }
 
 // ---------------------------------------------------------------------------
