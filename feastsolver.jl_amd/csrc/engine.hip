@@ -57,6 +57,7 @@ Engine::Engine(int device) : device_(device) {
     own_stream_ = true;
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
+    if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
@@ -69,6 +70,12 @@ Engine::Engine(int device) : device_(device) {
             aux_streams_.push_back(s2); ev_join_.push_back(e2);
         }
     }
+    {   // look-ahead stream of the factorisation: its small panel kernels must be dispatched ahead of the trailing updates
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        if (hipStreamCreateWithPriority(&la_stream_, hipStreamNonBlocking, phi) != hipSuccess) la_stream_ = nullptr;
+        for (int i = 0; i < 6; ++i) { hipEvent_t e3 = nullptr; (void)hipEventCreateWithFlags(&e3, hipEventDisableTiming); ev_la_.push_back(e3); }
+    }
 }
 
 Engine::~Engine() {
@@ -77,6 +84,8 @@ Engine::~Engine() {
     for (hipStream_t s2 : aux_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipEvent_t e2 : ev_join_) (void)hipEventDestroy(e2);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    for (hipEvent_t e3 : ev_la_) if (e3) (void)hipEventDestroy(e3);
+    if (la_stream_) { (void)hipStreamSynchronize(la_stream_); (void)hipStreamDestroy(la_stream_); }
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -565,11 +574,47 @@ int Engine::factorize() {
         int level_ld = 0;
         for (int s2 : S.levels[d]) level_ld = std::max(level_ld, S.p(s2) + S.u(s2));
         const bool tall = level_ld >= 1024;      // 1024-thread panel workgroups for tall fronts (430 -> 396 ms for the 16 factorisations of C3)
-        for (FactorStep& st : F.steps) {
-            launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall);
-            launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
-            launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
-            launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
+        int level_p = 0;
+        for (int s2 : S.levels[d]) level_p = std::max(level_p, S.p(s2));
+        const bool lookahead = look_ahead_ && level_p >= 256 && la_stream_ && F.steps.size() >= 4;
+        if (!lookahead) {
+            for (FactorStep& st : F.steps) {
+                launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall);
+                launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
+                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
+                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
+            }
+        } else {
+            // LU with look-ahead for the big fronts at the top of the tree (few fronts x nodes: the panel factorisation runs on a
+            // handful of workgroups and would otherwise leave the GPU idle between two trailing updates).  Stream P updates the
+            // LOOKAHEAD_COLS columns right of panel i (window) and factors panel i+1 while the main stream applies step i to
+            // all the other columns (rest).  The window of step i+1 reaches 32 columns into the rest of step i, hence eRest.
+            hipStream_t P = la_stream_;
+            HIPCHK(hipEventRecord(ev_la_[4], stream_));
+            HIPCHK(hipStreamWaitEvent(P, ev_la_[4], 0));
+            const size_t ns = F.steps.size();
+            launch_panel(P, dsym_, ls + F.steps[0].panel.off, F.steps[0].panel.count, F.steps[0].k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall);
+            HIPCHK(hipEventRecord(ev_la_[0], P));
+            for (size_t i = 0; i < ns; ++i) {
+                FactorStep& st = F.steps[i];
+                hipEvent_t ePanel = ev_la_[i & 1], ePanelNext = ev_la_[(i + 1) & 1], eRest = ev_la_[2 + (i & 1)], eRestPrev = ev_la_[2 + ((i + 1) & 1)];
+                if (i > 0) HIPCHK(hipStreamWaitEvent(P, eRestPrev, 0));
+                launch_swap(P, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc, 1);
+                launch_trsm_u(P, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc, 1);
+                launch_gemm_nn(P, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc, 1);
+                HIPCHK(hipStreamWaitEvent(stream_, ePanel, 0));            // panel i (and everything P did before it) is complete
+                if (i + 1 < ns) {
+                    FactorStep& nx = F.steps[i + 1];
+                    launch_panel(P, dsym_, ls + nx.panel.off, nx.panel.count, nx.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall);
+                    HIPCHK(hipEventRecord(ePanelNext, P));
+                }
+                launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc, 2);
+                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc, 2);
+                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc, 2);
+                HIPCHK(hipEventRecord(eRest, stream_));
+            }
+            HIPCHK(hipEventRecord(ev_la_[5], P));
+            HIPCHK(hipStreamWaitEvent(stream_, ev_la_[5], 0));
         }
         launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
         launch_extend_add(stream_, dsym_, tl + F.extend.off, F.extend.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,

@@ -5,6 +5,7 @@
 namespace feasthip {
 
 constexpr int FACT_NB = 32;     // panel width of the blocked front factorisation
+constexpr int LOOKAHEAD_COLS = 128;   // columns right of the panel that the look-ahead stream updates before it factors the next panel
 constexpr int SOLVE_NB = 128;   // diagonal (super)block of the inverse-based block substitution
 constexpr int INV_NB = 64;      // size of the directly inverted triangular blocks (two are coupled into a super block)
 constexpr int LDS_COLS = 64;    // block-vector columns processed per workgroup pass
@@ -30,11 +31,11 @@ void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
                   int* piv, const double* tiny, int* nperturb, int K, bool tall = false);
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                 const int* piv, int K);
-void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K);
+                 const int* piv, int K, int win = 0);
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, int win = 0);
 // kinds: 0 = L-panel trailing update, 1 = U12 trailing update, 2 = contribution block (K = p)
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                    cz* cb, int64_t cbs, int K);
+                    cz* cb, int64_t cbs, int K, int win = 0);
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled
 void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);

@@ -251,8 +251,10 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
 // ---------------------------------------------------------------------------
 // apply the panel's row interchanges to every other column of the front
 // ---------------------------------------------------------------------------
+// `win` selects the columns for the look-ahead schedule of Engine::factorize: 0 all, 1 only the LOOKAHEAD_COLS
+// columns right of the panel, 2 everything else.
 __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
-                       const int* __restrict__ piv, int npiv) {
+                       const int* __restrict__ piv, int npiv, int win) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -261,6 +263,10 @@ __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ t
     int v = t.a * 256 + threadIdx.x;
     int nv = (p - b) + u;
     if (v >= nv) return;
+    if (win) {
+        bool inwin = v >= k0 && v < k0 + LOOKAHEAD_COLS && v < p - b;
+        if ((win == 1) != inwin) return;
+    }
     cz* col;
     if (v < k0) col = fact + (int64_t)k * fs + f.lp + (int64_t)v * ld;
     else if (v < p - b) col = fact + (int64_t)k * fs + f.lp + (int64_t)(v + b) * ld;
@@ -273,19 +279,22 @@ __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ t
 }
 
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                 const int* piv, int K) {
+                 const int* piv, int K, int win) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n);
+    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n, win);
 }
 
 // ---------------------------------------------------------------------------
 // U row block: columns right of the panel (inside the pivot block and U12)
 // get x <- L11^-1 x, one thread per column.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs) {
+__global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
+                                               int win) {
     __shared__ cz s_l[FACT_NB * FACT_NB];
     __shared__ cz s_x[128][FACT_NB + 1];          // the slab of 128 columns x b rows, staged with coalesced accesses
     Tile t = tiles[blockIdx.x];
+    static_assert(LOOKAHEAD_COLS == 128, "the look-ahead window is the pivot-block part of the first 128-column tile");
+    if (win == 1 && t.a != 0) return;
     int k = blockIdx.y;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
@@ -297,17 +306,19 @@ __global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, c
     }
     int nin = p - k0 - b, ncol = nin + u;
     int v0 = t.a * 128;
+    // look-ahead window = pivot-block columns of tile 0; a column is processed only in the pass it belongs to
+    auto mine = [&](int v) { return win == 0 || ((win == 1) == (t.a == 0 && v < nin)); };
     auto colptr = [&](int v) -> cz* {
         return (v < nin) ? fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0
                          : fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
     };
     for (int idx = threadIdx.x; idx < 128 * b; idx += 128) {     // b consecutive threads read one column's b rows
         int i = idx % b, c = idx / b;
-        if (v0 + c < ncol) s_x[c][i] = colptr(v0 + c)[i];
+        if (v0 + c < ncol && mine(v0 + c)) s_x[c][i] = colptr(v0 + c)[i];
     }
     __syncthreads();
     int c = threadIdx.x;
-    if (v0 + c < ncol) {
+    if (v0 + c < ncol && mine(v0 + c)) {
         for (int i = 1; i < b; ++i) {
             cz xi = s_x[c][i];
             for (int kk = 0; kk < i; ++kk) cz_msub(xi, s_l[i + kk * FACT_NB], s_x[c][kk]);
@@ -317,13 +328,13 @@ __global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, c
     __syncthreads();
     for (int idx = threadIdx.x; idx < 128 * b; idx += 128) {
         int i = idx % b, cc = idx / b;
-        if (v0 + cc < ncol) colptr(v0 + cc)[i] = s_x[cc][i];
+        if (v0 + cc < ncol && mine(v0 + cc)) colptr(v0 + cc)[i] = s_x[cc][i];
     }
 }
 
-void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K) {
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, int win) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(128), 0, st, S.fr, tiles, k0, fact, fs);
+    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(128), 0, st, S.fr, tiles, k0, fact, fs, win);
 }
 
 // ---------------------------------------------------------------------------
@@ -337,9 +348,10 @@ void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntile
 constexpr int GEMM_KC = 32;
 
 __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
-                                                  cz* fact, int64_t fs, cz* cb, int64_t cbs) {
+                                                  cz* fact, int64_t fs, cz* cb, int64_t cbs, int win) {
     __shared__ cz Bs[GEMM_KC][65];
     Tile t = tiles[blockIdx.x];
+    if (win && (win == 1) != (t.a == 0 && t.c < LOOKAHEAD_COLS / 64)) return;      // window = the first two 64-column tiles of the pivot block
     int k = blockIdx.y;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
@@ -434,9 +446,9 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
 }
 
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                    cz* cb, int64_t cbs, int K) {
+                    cz* cb, int64_t cbs, int K, int win) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_gemm_nn, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, cb, cbs);
+    hipLaunchKernelGGL(k_gemm_nn, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, cb, cbs, win);
 }
 
 // ---------------------------------------------------------------------------
