@@ -61,6 +61,11 @@ PROTOTYPES = {
     "feasthip_set_node_coefficients": (I, [VP, VP, I, I]),
     "feasthip_nl_beyn_step": (I, [VP, VP, VP]),
     "feasthip_nl_set_r": (I, [VP, VP]),
+    "feasthip_nlm_begin": (I, [VP, VP, I64, I, I]),
+    "feasthip_nlm_contour_step": (I, [VP, I]),
+    "feasthip_nlm_candidates": (I, [VP, VP, VP]),
+    "feasthip_nlm_finish": (I, [VP, VP, VP, VP, VP, VP]),
+    "feasthip_nlm_get_y": (I, [VP, VP]),
     "feasthip_nlfeast_moments_run": (I, [VP, VP, I64, I, I, I, D, D, VP, VP, VP, VP, C.POINTER(I)]),
     "feasthip_estimate_count": (I, [VP, VP, I64, I, C.POINTER(D)]),
     "feasthip_lu_dense": (I, [I, VP, I64, PVP]),

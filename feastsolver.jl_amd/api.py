@@ -546,17 +546,74 @@ def nlfeast(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, store=Tr
     return lam, Xw, res
 
 
+def _nlfeast_moments_closure(T, Xw, nodes, iter, c, r, eps, moments, spurious, device, info):
+    """nlfeast_moments! for an arbitrary closure z -> matrix (test/gun.jl:36, test/fiber.jl:33): node matrices on the
+    device, the loop of src/nlfeast.jl:236-303 on the host with the phase calls, residual block of the candidates formed
+    on the host like update_R_moments! (src/utils.jl:118-123)."""
+    con = circular_contour_trapezoidal(c, r, nodes)
+    n, m0 = Xw.shape
+    M = int(moments) * m0
+    h = FeastHandle(device)
+    try:
+        h.set_terms([T(z) for z in con.nodes])
+        h.set_contour(con)
+        h.set_node_coefficients(np.eye(nodes, dtype=np.complex128))
+        warn = h._ck(h.lib.feasthip_nlm_begin(h.h, _vp(Xw), n, m0, int(moments)))
+        h.m0 = m0                                                          # get_block sizes its output from it
+        lam = np.zeros(M, dtype=np.complex128)
+        lam_s = np.zeros(M, dtype=np.complex128)
+        res = np.zeros(M)
+        ins = np.zeros(M, dtype=np.uint8)
+        Y = np.zeros((n, M), dtype=np.complex128, order="F")
+        R = np.zeros((n, M), dtype=np.complex128, order="F")
+        res_in = np.zeros(M)
+        nit = 0
+        for nit in range(iter + 1):
+            h._ck(h.lib.feasthip_nlm_contour_step(h.h, 1 if nit == 0 else 0))
+            h._ck(h.lib.feasthip_nlm_candidates(h.h, _vp(lam), _vp(Y)))
+            for i in range(M):
+                if not np.isfinite(lam[i]):                               # beyond the numerical rank of the Hankel matrix
+                    R[:, i] = 0.0
+                    res_in[i] = np.inf
+                    continue
+                Tl = T(lam[i])
+                R[:, i] = Tl @ Y[:, i]
+                res_in[i] = np.linalg.norm(R[:, i]) / _fro(Tl)
+            h._ck(h.lib.feasthip_nlm_finish(h.h, _vp(R), _vp(res_in), _vp(lam_s), _vp(res), _vp(ins)))
+            if nit == 0:
+                continue                                                   # the reference tests inside `for nit = 1:iter` only
+            i0 = ins[:m0].astype(bool)
+            ri = res[:m0][i0]
+            if ri.size > 0 and ri.max() < eps:                             # :296-299
+                break
+            if nit > 1 and (ri < spurious).sum() > 0 and ri[ri < spurious].max() < eps:   # :300-302
+                break
+        h.nl_finalize_x()                                                  # normalize!(X) :311
+        Xw[...] = h.get_block(0)
+        h._ck(h.lib.feasthip_nlm_get_y(h.h, _vp(Y)))
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=min(nit, iter), warn=warn, inside=ins.astype(bool))
+    finally:
+        h.close()
+    return lam_s, Y, res
+
+
 def nlfeast_moments(T, X, nodes, iter, *, c=0j, r=1.0, debug=False, eps=10e-12, moments=2, store=True, spurious=1e-5,
                     device=0, info=None):
     """nlfeast_moments!(T, X, nodes, iter; c, r, debug, eps, moments, store, spurious)  src/nlfeast.jl:173-318.
     Returns (lam, Y, res) for all moments*m0 candidates sorted by relative residual; X is overwritten with the m0
     best candidates, column-normalised.  T must be a PolynomialNEP.  ``store`` is accepted for signature
     compatibility: the factors of the nodes are always kept on the device (the reference's store=true)."""
-    if not isinstance(T, (PolynomialNEP, SplitNEP)):
-        raise NotImplementedError("nlfeast_moments on the GPU needs a PolynomialNEP or SplitNEP (matrices resident on the device)")
     if not (isinstance(X, np.ndarray) and X.dtype == np.complex128):
         raise TypeError("X must be an AbstractMatrix{ComplexF64}")       # src/nlfeast.jl:173
+    if not callable(T):
+        raise TypeError("T must be callable: z -> matrix")
     X_in, Xw = _inplace_target(X)
+    if not isinstance(T, (PolynomialNEP, SplitNEP)):
+        lam, Y, res = _nlfeast_moments_closure(T, Xw, nodes, iter, c, r, eps, moments, spurious, device, info)
+        _writeback(X_in, Xw)
+        return lam, Y, res
     h = FeastHandle(device)
     try:
         h.set_terms(T.coeffs)

@@ -134,6 +134,22 @@ int feasthip_nlfeast_moments_run(feasthip_handle_t h, void* X, int64_t n, int m0
     GUARD(h) return h->e->nlfeast_moments_run(X, n, m0, moments, iter, eps, spurious, lambda, res, inside, Y, nit); ENDGUARD(h)
 }
 
+int feasthip_nlm_begin(feasthip_handle_t h, const void* X, int64_t n, int m0, int moments) {
+    GUARD(h) return h->e->nlm_begin(X, n, m0, moments); ENDGUARD(h)
+}
+int feasthip_nlm_contour_step(feasthip_handle_t h, int first) {
+    GUARD(h) return h->e->nlm_step_contour(first); ENDGUARD(h)
+}
+int feasthip_nlm_candidates(feasthip_handle_t h, double* lambda, void* Y) {
+    GUARD(h) if (!lambda) return FEASTHIP_EARG; return h->e->nlm_step_candidates(lambda, Y); ENDGUARD(h)
+}
+int feasthip_nlm_finish(feasthip_handle_t h, const void* R, const double* res_in, double* lambda, double* res, uint8_t* inside) {
+    GUARD(h) if (!lambda || !res) return FEASTHIP_EARG; return h->e->nlm_step_finish(R, res_in, lambda, res, inside); ENDGUARD(h)
+}
+int feasthip_nlm_get_y(feasthip_handle_t h, void* Y) {
+    GUARD(h) if (!Y) return FEASTHIP_EARG; return h->e->nlm_get_y(Y); ENDGUARD(h)
+}
+
 int feasthip_dual_feast_run(feasthip_handle_t h, void* Xr, void* Xl, int64_t n, int m0, int iter, double eps, int store,
                             double* lambda, double* resr, double* resl, uint8_t* inside, int* nit) {
     GUARD(h) return h->e->dual_run(Xr, Xl, n, m0, iter, eps, store, lambda, resr, resl, inside, nit); ENDGUARD(h)

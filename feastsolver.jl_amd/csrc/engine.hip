@@ -1405,7 +1405,9 @@ int Engine::nlm_contour_step(int first) {
 // Hankel matrices, thin SVD of the first through its orthonormal basis, reduced eigenproblem, candidate
 // vectors Y = U[1:N,:] vecs, update_R_moments! (src/utils.jl:118-134).  On return lam/res (moments*m0) are
 // sorted by residual, d_Ym_/d_Rm_ hold the sorted candidates, d_X_/d_R_ the m0 best.
-int Engine::nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res) {
+// Part 1: candidates.  Hankel matrices, rank-revealing basis, reduced eigenproblem; on return d_Ym_ holds the
+// column-normalised candidate vectors, lam their eigenvalues (NaN beyond the numerical rank nlm_rank_).
+int Engine::nlm_candidates(std::vector<zc>& lam) {
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     const int M = mm_ * m0, ld = ldM_, hrows = mm_ * n;
@@ -1449,22 +1451,40 @@ int Engine::nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res) {
     HIPCHK(hipMemcpyAsync(d_lamM_.p, sc.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
     launch_scale_cols(stream_, n, ld, d_Ym_.p, d_lamM_.p);
     HIPCHK(hipStreamSynchronize(stream_));
+    nlm_rank_ = rk;
+    return 0;
+}
+
+// Part 2: residuals (on the device for polynomial / split-form T, or handed in by the caller for an opaque closure:
+// ext_R n x M column-major, ext_res M), then update_R_moments!'s sort and the selection of the m0 best.
+int Engine::nlm_finish(std::vector<zc>& lam, std::vector<double>& res, const void* ext_R, const double* ext_res) {
+    const int M = mm_ * m0, ld = ldM_, rk = nlm_rank_;
+    Tall tn{n, M, ld, d_smallM_.p, d_lamM_.p, d_gramM_.p, d_nrmM_.p, d_nrmMs_.p};
+    std::vector<double> nr;
+    int r = 0;
     int64_t wide = (int64_t)n * ld;
-    if (!d_coeftab_.alloc((size_t)nterms * ld)) return fail(FEASTHIP_EHIP, "out of device memory");
-    {
+    std::vector<double> rs(M);
+    if (ext_R) {
+        DevBuf<cz> cm;
+        if (!cm.alloc((size_t)n * M)) return fail(FEASTHIP_EHIP, "out of device memory");
+        HIPCHK(hipMemcpyAsync(cm.p, ext_R, (size_t)n * M * sizeof(cz), hipMemcpyHostToDevice, stream_));
+        launch_cm_to_rm(stream_, n, M, ld, cm.p, n, d_Rm_.p);
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (int j = 0; j < M; ++j) rs[j] = (j < rk && std::isfinite(ext_res[j])) ? ext_res[j] : std::numeric_limits<double>::infinity();
+    } else {
+        if (!d_coeftab_.alloc((size_t)nterms * ld)) return fail(FEASTHIP_EHIP, "out of device memory");
         std::vector<zc> lamk(lam.begin(), lam.begin() + rk);
         lamk.resize(M, zc(0.0));
         r = residual_block(d_Ym_.p, d_MXm_.p, d_Rm_.p, lamk, M, ld, d_coeftab_.p);
         if (r) return r;
-    }
-    r = col_norms(tn, d_Rm_.p, nr);
-    if (r) return r;
-    r = build_frob_table();
-    if (r) return r;
-    std::vector<double> rs(M);
-    for (int j = 0; j < M; ++j) {      // candidates beyond the numerical rank do not exist: residual +inf, zero vector
-        rs[j] = j < rk ? nr[j] / poly_frob_norm(lam[j]) : std::numeric_limits<double>::infinity();
-        if (!std::isfinite(rs[j])) rs[j] = std::numeric_limits<double>::infinity();
+        r = col_norms(tn, d_Rm_.p, nr);
+        if (r) return r;
+        r = build_frob_table();
+        if (r) return r;
+        for (int j = 0; j < M; ++j) {      // candidates beyond the numerical rank do not exist: residual +inf, zero vector
+            rs[j] = j < rk ? nr[j] / poly_frob_norm(lam[j]) : std::numeric_limits<double>::infinity();
+            if (!std::isfinite(rs[j])) rs[j] = std::numeric_limits<double>::infinity();
+        }
     }
     std::vector<int> p(ld, 0);
     for (int j = 0; j < M; ++j) p[j] = j;
@@ -1490,6 +1510,64 @@ int Engine::nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
     rr_ms = ms;
+    return 0;
+}
+
+int Engine::nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res) {
+    int r = nlm_candidates(lam);
+    if (r) return r;
+    return nlm_finish(lam, res, nullptr, nullptr);
+}
+
+// Phase calls of the moments variant for a caller-side loop (opaque closure T: the residual block of the candidates is
+// formed on the host, like the reference's update_R_moments!, and handed back).
+int Engine::nlm_begin(const void* X, int64_t n_, int m0_, int moments) {
+    if (moments < 1 || moments > 16) return fail(FEASTHIP_EARG, "nlfeast_moments: moments must be in 1..16");
+    if (shard_stride_ != 1) return fail(FEASTHIP_ESTATE, "nlfeast_moments: node shards are not supported on this path");
+    int r = set_x(X, n_, m0_);
+    if (r) return r;
+    r = nlm_alloc(moments);
+    if (r) return r;
+    return factorize();
+}
+
+int Engine::nlm_step_contour(int first) {
+    if (!have_x_ || mm_ <= 0) return fail(FEASTHIP_ESTATE, "nlfeast_moments: call feasthip_nlm_begin first");
+    return nlm_contour_step(first);
+}
+
+int Engine::nlm_step_candidates(double* lambda, void* Y) {
+    if (!have_x_ || mm_ <= 0) return fail(FEASTHIP_ESTATE, "nlfeast_moments: call feasthip_nlm_begin first");
+    int r = nlm_candidates(nlm_lam_);
+    if (r) return r;
+    const int M = mm_ * m0;
+    for (int j = 0; j < M; ++j) { lambda[2 * j] = nlm_lam_[j].real(); lambda[2 * j + 1] = nlm_lam_[j].imag(); }
+    return Y ? nlm_get_y(Y) : 0;
+}
+
+int Engine::nlm_get_y(void* Y) {
+    const int M = mm_ * m0;
+    DevBuf<cz> cm;
+    if (!cm.alloc((size_t)n * M)) return fail(FEASTHIP_EHIP, "nlfeast_moments: out of device memory");
+    launch_rm_to_cm(stream_, n, M, ldM_, d_Ym_.p, cm.p, n);
+    HIPCHK(hipMemcpyAsync(Y, cm.p, (size_t)n * M * sizeof(cz), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return 0;
+}
+
+int Engine::nlm_step_finish(const void* R, const double* res_in, double* lambda, double* res, uint8_t* inside) {
+    if (!have_x_ || mm_ <= 0 || nlm_lam_.empty()) return fail(FEASTHIP_ESTATE, "nlfeast_moments: call feasthip_nlm_candidates first");
+    if ((R == nullptr) != (res_in == nullptr)) return fail(FEASTHIP_EARG, "nlfeast_moments: R and res go together");
+    std::vector<double> rs;
+    int r = nlm_finish(nlm_lam_, rs, R, res_in);
+    if (r) return r;
+    const int M = mm_ * m0;
+    for (int j = 0; j < M; ++j) {
+        lambda[2 * j] = nlm_lam_[j].real(); lambda[2 * j + 1] = nlm_lam_[j].imag(); res[j] = rs[j];
+        if (inside) inside[j] = region_kind_ == FEASTHIP_REGION_RECT
+                                    ? ((region_[0] < nlm_lam_[j].real() && nlm_lam_[j].real() < region_[2] && region_[1] < nlm_lam_[j].imag() && nlm_lam_[j].imag() < region_[3]) ? 1 : 0)
+                                    : ((std::abs(nlm_lam_[j] - zc(region_[0], region_[1])) <= region_[2]) ? 1 : 0);
+    }
     return 0;
 }
 

@@ -93,6 +93,11 @@ public:
                   uint8_t* inside, int* nit);
     int nlfeast_run(void* X, int64_t n, int m0, int iter, double eps, double spurious, double* lambda, double* res,
                     uint8_t* inside, int* nit);
+    int nlm_begin(const void* X, int64_t n, int m0, int moments);
+    int nlm_step_contour(int first);
+    int nlm_step_candidates(double* lambda, void* Y);
+    int nlm_step_finish(const void* R, const double* res_in, double* lambda, double* res, uint8_t* inside);
+    int nlm_get_y(void* Y);
     // dual_gen_feast! (src/feast.jl:165-257): terms {A, B, A', B'}, 2K nodes (K right + K adjoint systems)
     int dual_run(void* Xr, void* Xl, int64_t n, int m0, int iter, double eps, int store, double* lambda, double* resr,
                  double* resl, uint8_t* inside, int* nit);
@@ -185,6 +190,10 @@ private:
     int nlm_alloc(int moments);
     int nlm_contour_step(int first);
     int nlm_rr_step(std::vector<zc>& lam, std::vector<double>& res);
+    int nlm_candidates(std::vector<zc>& lam);
+    int nlm_finish(std::vector<zc>& lam, std::vector<double>& res, const void* ext_R, const double* ext_res);
+    int nlm_rank_ = 0;
+    std::vector<zc> nlm_lam_;
     int solve_all(const cz* rhs);            // W_k = T(z_k)^-1 rhs for all local nodes
     void inside_test(const zc* lam, uint8_t* inside) const;
     int solve_all_impl(const cz* rhs, ProfileRow* prof);

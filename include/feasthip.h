@@ -158,6 +158,19 @@ int feasthip_nl_set_r(feasthip_handle_t h, const void* R);
 int feasthip_nlfeast_moments_run(feasthip_handle_t h, void* X, int64_t n, int m0, int moments, int iter, double eps,
                                  double spurious, double* lambda, double* res, uint8_t* inside, void* Y, int* nit);
 
+/* The same variant as phase calls, for a T that is an opaque closure (the reference's gun / fiber scripts,
+ * test/gun.jl:36, test/fiber.jl:33): terms = T(z_k) per node + feasthip_set_node_coefficients, then per iteration
+ *   feasthip_nlm_contour_step(first) -> feasthip_nlm_candidates (lambda[M], normalised candidates Y n x M)
+ *   -> host: R[:,i] = T(lambda_i) y_i, res_i = |R_i| / |T(lambda_i)|_F  (update_R_moments!, src/utils.jl:118-123)
+ *   -> feasthip_nlm_finish(R, res_in, ...) : sort by residual, X / R[:,1:m0] for the next step; outputs sorted.
+ * R = res_in = NULL lets the library form the residuals itself (polynomial / split-form terms).  feasthip_nlm_get_y returns
+ * the sorted candidates, feasthip_get_x the m0 best (normalise with feasthip_nl_finalize_x at the end). */
+int feasthip_nlm_begin(feasthip_handle_t h, const void* X, int64_t n, int m0, int moments);
+int feasthip_nlm_contour_step(feasthip_handle_t h, int first);
+int feasthip_nlm_candidates(feasthip_handle_t h, double* lambda, void* Y);
+int feasthip_nlm_finish(feasthip_handle_t h, const void* R, const double* res_in, double* lambda, double* res, uint8_t* inside);
+int feasthip_nlm_get_y(feasthip_handle_t h, void* Y);
+
 /* ---- dual_gen_feast!(Xr, Xl, A, B, contour; iter, eps, store)  src/feast.jl:158-257: right AND left
  * eigenvectors.  Set-up: terms {A, B, A', B'} with scales {1, -1, 1, -1} (feasthip_set_dense/_csc), a contour of 2K
  * entries {z_1..z_K, conj(z_1)..conj(z_K)} / {w_1..w_K, conj(w_1)..conj(w_K)} and the 2K x 4 node coefficient table

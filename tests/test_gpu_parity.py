@@ -264,7 +264,7 @@ def test_nlfeast_moments_parity(gpu, pkg, fo, wl, golden, case, comp_key):
     assert np.abs(X - Y[:, :g["m0"]]).max() < 1e-12
 
 
-@pytest.mark.parametrize("path", ["split", "closure", "moments"])
+@pytest.mark.parametrize("path", ["split", "closure", "moments", "moments_closure"])
 def test_hadeler_nonpolynomial_nep(gpu, pkg, wl, golden, path):
     """Generic-T NLFEAST: the Hadeler problem of test/hadeler.jl in split form on the device
     (feasthip_set_coef_functions), as an opaque closure (node matrices + host residual, feasthip_set_node_coefficients /
@@ -280,8 +280,11 @@ def test_hadeler_nonpolynomial_nep(gpu, pkg, wl, golden, path):
     elif path == "closure":
         lam, Xo, res = pkg.nlfeast(lambda z: nep(z), X, w["nodes"], w["iter"], **kw)      # opaque callable
         g = golden["hadeler_nlfeast"]
-    else:
+    elif path == "moments":
         lam, Xo, res = pkg.nlfeast_moments(nep, X, w["nodes"], w["iter"], moments=2, **kw)
+        g = golden["hadeler_moments"]
+    else:
+        lam, Xo, res = pkg.nlfeast_moments(lambda z: nep(z), X, w["nodes"], w["iter"], moments=2, **kw)     # opaque callable
         g = golden["hadeler_moments"]
     ins = (np.abs(lam - w["c"]) <= w["r"]) & (res < 1e-9)
     gl = c2n(g["lam_inside"])

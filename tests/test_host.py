@@ -182,8 +182,10 @@ def test_argument_validation_without_gpu(pkg):
         pkg.gen_feast(np.ones((5, 2), dtype=complex), np.eye(4), None)
     with pytest.raises(TypeError):                                     # X must be ComplexF64 (src/nlfeast.jl:2)
         pkg.nlfeast(lambda z: np.eye(3), np.ones((3, 2)), 8, 2)
-    with pytest.raises(NotImplementedError):                           # the moments variant needs resident matrices
-        pkg.nlfeast_moments(lambda z: np.eye(3), np.ones((3, 2), dtype=complex), 8, 2)
+    with pytest.raises(TypeError):
+        pkg.nlfeast_moments(lambda z: np.eye(3), np.ones((3, 2)), 8, 2)
+    with pytest.raises(TypeError):
+        pkg.nlfeast_moments("not callable", np.ones((3, 2), dtype=complex), 8, 2)
     nep = pkg.SplitNEP([np.eye(2), np.ones((2, 2))], [lambda z: z * z, np.exp])
     assert np.allclose(nep(0.5), 0.25 * np.eye(2) + np.exp(0.5) * np.ones((2, 2)))
 
