@@ -238,6 +238,8 @@ class FeastHandle:
         self._ck(self.lib.feasthip_set_x(self.h, _vp(X), X.shape[0], X.shape[1]))
 
     def get_block(self, which=0):
+        if self.n <= 0 or self.m0 <= 0:
+            raise _lib.FeastHipError(-4, "get_block: no iteration state on this handle (set_x / *_run first)")
         out = np.empty((self.n, self.m0), dtype=np.complex128, order="F")
         self._ck(self.lib.feasthip_get_block(self.h, which, _vp(out)))
         return out
