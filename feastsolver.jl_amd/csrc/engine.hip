@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <chrono>
 #include <cmath>
@@ -380,6 +381,9 @@ bool Engine::build_plans() {
     return d_tiles_.upload(tiles.data(), tiles.size(), stream_) && d_lists_.upload(lists.data(), lists.size(), stream_);
 }
 
+static std::mutex g_sym_mu;
+static std::vector<std::pair<uint64_t, Symbolic>> g_sym_cache;      // most recent symbolic analyses (see Engine::analyze)
+
 int Engine::analyze() {
     if (n <= 0 || terms_.empty()) return fail(FEASTHIP_ESTATE, "analyze: no matrices set");
     if (Kloc <= 0) return fail(FEASTHIP_ESTATE, "analyze: no contour nodes on this shard");
@@ -408,8 +412,27 @@ int Engine::analyze() {
         if (const char* v = getenv("FEASTHIP_LEAF")) opt.leaf_size = atoi(v);
         const bool trace = getenv("FEASTHIP_ANALYZE_TRACE") != nullptr;
         if (trace) fprintf(stderr, "[feasthip analyze] pattern union                %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        std::string e = analyze_pattern(n, cp.data(), ri.data(), opt, S);
-        if (!e.empty()) return fail(FEASTHIP_EARG, "analyze: " + e);
+        // Ordering + symbolic analysis depend only on the pattern: FEAST is typically run several times on the same
+        // matrices (other contours / spectrum slices, README.md:12 of the reference), so the result is kept in a small
+        // process-wide cache keyed by a hash of the pattern and the options.
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+        mix((uint64_t)n); mix((uint64_t)cp[n]);
+        for (int j = 0; j <= n; ++j) mix((uint64_t)cp[j]);
+        for (int64_t t = 0; t < cp[n]; ++t) mix((uint64_t)ri[t]);
+        mix((uint64_t)opt.leaf_size); mix((uint64_t)opt.relax_small); mix((uint64_t)opt.relax_mid); mix((uint64_t)(opt.zmid * 1e6)); mix((uint64_t)(opt.zbig * 1e6)); mix((uint64_t)opt.ordering);
+        bool hit = false;
+        {
+            std::lock_guard<std::mutex> lk(g_sym_mu);
+            for (auto& c : g_sym_cache) if (c.first == key && c.second.n == n) { S = c.second; hit = true; break; }
+        }
+        if (!hit) {
+            std::string e = analyze_pattern(n, cp.data(), ri.data(), opt, S);
+            if (!e.empty()) return fail(FEASTHIP_EARG, "analyze: " + e);
+            std::lock_guard<std::mutex> lk(g_sym_mu);
+            if (g_sym_cache.size() >= 4) g_sym_cache.erase(g_sym_cache.begin());
+            g_sym_cache.emplace_back(key, S);
+        }
         if (trace) fprintf(stderr, "[feasthip analyze] analyze_pattern total        %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         // arena destinations + CSR copies for SpMM
         for (auto& T : terms_) {

@@ -622,6 +622,27 @@ def test_distributed_driver_two_ranks_share_one_gpu(gpu, golden):
     assert res[0][1] == res[1][1] and res[0][5] == res[1][5]          # replicated Rayleigh-Ritz: bitwise identical on both ranks
 
 
+def test_symbolic_analysis_cache_is_pattern_only(gpu, pkg, wl):
+    """Handles on matrices with the same pattern share the cached ordering / symbolic analysis (spectrum slicing runs many
+    contours on one pencil); the values must still be each handle's own."""
+    rng = np.random.default_rng(41)
+    A1 = wl.laplacian_3d(9, 19)
+    A2 = A1.copy()
+    A2.data = A2.data * rng.uniform(0.8, 1.2, A2.nnz)          # same pattern, different (unsymmetric) values
+    n = A1.shape[0]
+    R = np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8)))
+    infos = []
+    for A in (A1, A2, A1):
+        C = sp.csc_matrix(A.astype(np.complex128) - (0.31 + 0.2j) * sp.identity(n))
+        F = pkg.lu(C)
+        Y = np.zeros((n, 8), dtype=np.complex128, order="F")
+        pkg.ldiv(Y, F, R)
+        pkg.finalize(F)
+        assert np.linalg.norm(C @ Y - R) <= 1e-11 * np.linalg.norm(C.toarray()) * np.linalg.norm(Y)
+        infos.append(Y)
+    assert np.array_equal(infos[0], infos[2]) and not np.allclose(infos[0], infos[1])
+
+
 def test_caller_owned_stream(gpu, pkg, wl, golden):
     """feasthip_set_stream: the whole loop on a torch-owned HIP stream gives the fixture result, and work queued on that
     stream afterwards is ordered behind the library's launches."""
