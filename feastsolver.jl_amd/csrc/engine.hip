@@ -280,8 +280,8 @@ bool Engine::build_plans() {
         F.scale.off = (int64_t)tiles.size();
         for (int s : lv) for (int t = 0; t < cdiv(S.p(s), SOLVE_NB); ++t) {
             int p = S.p(s), ld = p + S.u(s), k0 = t * SOLVE_NB, b = std::min(SOLVE_NB, p - k0);
-            for (int a = 0; a < cdiv(k0, 64); ++a) tiles.push_back({s, t, a, 0});
-            for (int a = 0; a < cdiv(ld - k0 - b, 64); ++a) tiles.push_back({s, t, a, 1});
+            for (int a = 0; a < cdiv(k0, 64 * SCALE_ROWTILES); ++a) tiles.push_back({s, t, a, 0});
+            for (int a = 0; a < cdiv(ld - k0 - b, 64 * SCALE_ROWTILES); ++a) tiles.push_back({s, t, a, 1});
         }
         F.scale.count = (int)(tiles.size() - F.scale.off);
         // block substitution launches (kernels.hpp: launch_apply).  Tile height (64/32/16 rows) is chosen per

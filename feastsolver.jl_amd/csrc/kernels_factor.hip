@@ -575,11 +575,7 @@ __global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__
     bool below = t.c != 0;
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    int rbase = below ? k0 + b + t.b * 64 : t.b * 64;
-    int rend = below ? ld : k0;
-    int mrow = rbase + wave * 16 + li;
-    bool mok = mrow < rend;
-    int mrow_c = min(mrow, rend - 1);
+    const int rend = below ? ld : k0;
     int nhalf = (b > INV_NB) ? 2 : 1;
     for (int pass = 0; pass < nhalf; ++pass) {
         // lower: first the left half (needs both halves of the row), then the right half (needs only itself);
@@ -599,39 +595,48 @@ __global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__
             }
             Bs[kk][nn] = v;
         }
-        cz av[SOLVE_NB / 4];
-#pragma unroll
-        for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
-            int kk = ks * 4 + lk;
-            cz v = Lp[mrow_c + (int64_t)(k0 + kfirst + min(kk, klen - 1)) * ld];
-            bool keep = mok && kk < klen;
-            av[ks].x = keep ? v.x : 0.0;
-            av[ks].y = keep ? v.y : 0.0;
-        }
         __syncthreads();
-        d4 cr[4], ci[4];
+        // the staged inverse block is reused for SCALE_ROWTILES consecutive 64-row tiles (it is as large as a row tile's
+        // own factor bytes, so re-reading it per tile doubled the traffic of this pass)
+        for (int sub = 0; sub < SCALE_ROWTILES; ++sub) {
+            int rbase = (below ? k0 + b : 0) + (t.b * SCALE_ROWTILES + sub) * 64;
+            if (rbase >= rend) break;
+            int mrow = rbase + wave * 16 + li;
+            bool mok = mrow < rend;
+            int mrow_c = min(mrow, rend - 1);
+            cz av[SOLVE_NB / 4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
-        int nks = (klen + 3) >> 2;
-#pragma unroll
-        for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
-            if (ks < nks) {
+            for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
                 int kk = ks * 4 + lk;
+                cz v = Lp[mrow_c + (int64_t)(k0 + kfirst + min(kk, klen - 1)) * ld];
+                bool keep = mok && kk < klen;
+                av[ks].x = keep ? v.x : 0.0;
+                av[ks].y = keep ? v.y : 0.0;
+            }
+            d4 cr[4], ci[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    cz bv = Bs[kk][nt * 16 + li];
-                    cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);     // D[n][m] = sum_k Inv[k][n] A[m][k]
+            for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+            int nks = (klen + 3) >> 2;
+#pragma unroll
+            for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
+                if (ks < nks) {
+                    int kk = ks * 4 + lk;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        cz bv = Bs[kk][nt * 16 + li];
+                        cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);     // D[n][m] = sum_k Inv[k][n] A[m][k]
+                    }
                 }
             }
-        }
-        if (mok) {
+            if (mok) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int gn = nt * 16 + lk + 4 * r;
-                    if (gn < ncols) Lp[mrow + (int64_t)(k0 + ncol0 + gn) * ld] = cz_make(cr[nt][r], ci[nt][r]);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        int gn = nt * 16 + lk + 4 * r;
+                        if (gn < ncols) Lp[mrow + (int64_t)(k0 + ncol0 + gn) * ld] = cz_make(cr[nt][r], ci[nt][r]);
+                    }
+            }
         }
     }
 }
