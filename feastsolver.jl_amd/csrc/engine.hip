@@ -251,7 +251,7 @@ bool Engine::build_plans() {
             for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); int nt = cdiv(p - b + u, 256); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }
             st.swap.count = (int)(tiles.size() - st.swap.off);
             st.trsm.off = (int64_t)tiles.size();
-            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); int nc = (p - k0 - b) + u; int nt = cdiv(nc, 128); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }
+            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); int nc = (p - k0 - b) + u; int nt = cdiv(nc, TRSM_COLS); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }
             st.trsm.count = (int)(tiles.size() - st.trsm.off);
             st.gemm.off = (int64_t)tiles.size();
             for (int s : lv) if (S.p(s) > k0) {

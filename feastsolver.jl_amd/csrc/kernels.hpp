@@ -8,6 +8,7 @@ constexpr int FACT_NB = 32;     // panel width of the blocked front factorisatio
 constexpr int LOOKAHEAD_COLS = 128;   // columns right of the panel that the look-ahead stream updates before it factors the next panel
 constexpr int SOLVE_NB = 128;   // diagonal (super)block of the inverse-based block substitution
 constexpr int INV_NB = 64;      // size of the directly inverted triangular blocks (two are coupled into a super block)
+constexpr int TRSM_COLS = 64;       // columns per workgroup of the U-row triangular solves
 constexpr int SCALE_ROWTILES = 4;  // 64-row tiles per workgroup of the panel-scaling pass (they share one staged inverse block)
 constexpr int LDS_COLS = 64;    // block-vector columns processed per workgroup pass
 

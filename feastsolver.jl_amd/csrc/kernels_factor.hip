@@ -288,13 +288,15 @@ void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles,
 // U row block: columns right of the panel (inside the pivot block and U12)
 // get x <- L11^-1 x, one thread per column.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
-                                               int win) {
+__global__ __launch_bounds__(TRSM_COLS) void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
+                                                     int win) {
+    // 64 columns per workgroup: 34 KB (slab) + 16 KB (L11) of LDS lets three workgroups share a CU (the former 128-column
+    // version needed 83 KB: one workgroup of two waves per CU, and the launches of the wide levels took milliseconds)
     __shared__ cz s_l[FACT_NB * FACT_NB];
-    __shared__ cz s_x[128][FACT_NB + 1];          // the slab of 128 columns x b rows, staged with coalesced accesses
+    __shared__ cz s_x[TRSM_COLS][FACT_NB + 1];    // the slab of TRSM_COLS columns x b rows, staged with coalesced accesses
     Tile t = tiles[blockIdx.x];
-    static_assert(LOOKAHEAD_COLS == 128, "the look-ahead window is the pivot-block part of the first 128-column tile");
-    if (win == 1 && t.a != 0) return;
+    static_assert(LOOKAHEAD_COLS % TRSM_COLS == 0, "the look-ahead window is a whole number of column tiles");
+    if (win == 1 && t.a >= LOOKAHEAD_COLS / TRSM_COLS) return;
     int k = blockIdx.y;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
@@ -305,14 +307,14 @@ __global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, c
         s_l[i + kk * FACT_NB] = Lp[(k0 + i) + (int64_t)(k0 + kk) * ld];
     }
     int nin = p - k0 - b, ncol = nin + u;
-    int v0 = t.a * 128;
-    // look-ahead window = pivot-block columns of tile 0; a column is processed only in the pass it belongs to
-    auto mine = [&](int v) { return win == 0 || ((win == 1) == (t.a == 0 && v < nin)); };
+    int v0 = t.a * TRSM_COLS;
+    // look-ahead window = pivot-block columns among the first LOOKAHEAD_COLS; a column is processed only in the pass it belongs to
+    auto mine = [&](int v) { return win == 0 || ((win == 1) == (v < LOOKAHEAD_COLS && v < nin)); };
     auto colptr = [&](int v) -> cz* {
         return (v < nin) ? fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0
                          : fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
     };
-    for (int idx = threadIdx.x; idx < 128 * b; idx += 128) {     // b consecutive threads read one column's b rows
+    for (int idx = threadIdx.x; idx < TRSM_COLS * b; idx += TRSM_COLS) {     // b consecutive threads read one column's b rows
         int i = idx % b, c = idx / b;
         if (v0 + c < ncol && mine(v0 + c)) s_x[c][i] = colptr(v0 + c)[i];
     }
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, c
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 128 * b; idx += 128) {
+    for (int idx = threadIdx.x; idx < TRSM_COLS * b; idx += TRSM_COLS) {
         int i = idx % b, cc = idx / b;
         if (v0 + cc < ncol && mine(v0 + cc)) colptr(v0 + cc)[i] = s_x[cc][i];
     }
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(128) void k_trsm_u(const FrontD* __restrict__ fr, c
 
 void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, int win) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(128), 0, st, S.fr, tiles, k0, fact, fs, win);
+    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(TRSM_COLS), 0, st, S.fr, tiles, k0, fact, fs, win);
 }
 
 // ---------------------------------------------------------------------------
