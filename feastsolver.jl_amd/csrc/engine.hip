@@ -230,8 +230,12 @@ bool Engine::build_plans() {
         for (int s : lv) pmax = std::max(pmax, S.p(s));
         // extend-add / solve assembly
         F.extend.off = (int64_t)tiles.size();
-        for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s) + S.u(s), 64); for (int a = 0; a < nt; ++a) for (int b = 0; b < nt; ++b) tiles.push_back({s, a, b, 0}); }
+        // phase 0 touches the L / U12 panels (tiles with a row or a column inside the pivot block), phase 1 the contribution block
+        for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s) + S.u(s), 64), p = S.p(s); for (int a = 0; a < nt; ++a) for (int b = 0; b < nt; ++b) if (a * 64 < p || b * 64 < p) tiles.push_back({s, a, b, 0}); }
         F.extend.count = (int)(tiles.size() - F.extend.off);
+        F.extend1.off = (int64_t)tiles.size();
+        for (int s : lv) if (nchild[s] > 0 && S.u(s) > 0) { int nt = cdiv(S.p(s) + S.u(s), 64), p = S.p(s); for (int a = 0; a < nt; ++a) for (int b = 0; b < nt; ++b) if (a * 64 + 64 > p && b * 64 + 64 > p) tiles.push_back({s, a, b, 0}); }
+        F.extend1.count = (int)(tiles.size() - F.extend1.off);
         V.assemble.off = (int64_t)tiles.size();
         for (int s : lv) if (nchild[s] > 0) { int nt = cdiv(S.p(s), 64); for (int a = 0; a < nt; ++a) tiles.push_back({s, a, 0, 0}); }      // pivot-block rows only
         V.assemble.count = (int)(tiles.size() - V.assemble.off);
@@ -434,38 +438,52 @@ int Engine::analyze() {
             g_sym_cache.emplace_back(key, S);
         }
         if (trace) fprintf(stderr, "[feasthip analyze] analyze_pattern total        %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        // arena destinations + CSR copies for SpMM
-        for (auto& T : terms_) {
+        // arena destinations + CSR copies for SpMM: host work per term on its own thread (the destination map itself
+        // fans out over the columns), uploads afterwards from this thread
+        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0; };
+        std::vector<TermHost> th(terms_.size());
+        {
+            std::vector<std::thread> tpool;
+            for (size_t ti = 0; ti < terms_.size(); ++ti)
+                tpool.emplace_back([&, ti]() {
+                    SparseTerm& T = terms_[ti];
+                    TermHost& H = th[ti];
+                    int64_t nnz = T.colptr[n];
+                    H.dest.resize(nnz);
+                    // arena destination of every entry (a binary search in the supernode's row structure): independent per column
+                    int nth = (int)std::min<int64_t>(8, std::max<int64_t>(1, nnz / 100000));
+                    std::vector<std::thread> pool;
+                    std::vector<char> bad(nth, 0);
+                    for (int tix = 0; tix < nth; ++tix)
+                        pool.emplace_back([&, tix]() {
+                            int j0 = (int)((int64_t)n * tix / nth), j1 = (int)((int64_t)n * (tix + 1) / nth);
+                            for (int j = j0; j < j1; ++j)
+                                for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
+                                    H.dest[e2] = entry_dest(S, T.rowval[e2], j);
+                                    if (H.dest[e2] < 0) bad[tix] = 1;
+                                }
+                        });
+                    H.rp.assign(n + 1, 0);
+                    for (int64_t e2 = 0; e2 < nnz; ++e2) H.rp[T.rowval[e2] + 1]++;
+                    for (int i = 0; i < n; ++i) H.rp[i + 1] += H.rp[i];
+                    H.col.resize(nnz);
+                    H.v.resize(nnz);
+                    std::vector<int64_t> pos(H.rp.begin(), H.rp.end() - 1);
+                    for (int j = 0; j < n; ++j)
+                        for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; H.col[q] = j; H.v[q] = T.val[e2]; }
+                    for (auto& t2 : pool) t2.join();
+                    for (char b2 : bad) if (b2) H.bad = 1;
+                });
+            for (auto& t2 : tpool) t2.join();
+        }
+        for (size_t ti = 0; ti < terms_.size(); ++ti) {
+            SparseTerm& T = terms_[ti];
+            TermHost& H = th[ti];
+            if (H.bad) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
             int64_t nnz = T.colptr[n];
-            std::vector<int64_t> dest(nnz);
-            // arena destination of every entry (a binary search in the supernode's row structure): independent per column
-            {
-                int nth = (int)std::min<int64_t>(16, std::max<int64_t>(1, nnz / 100000));
-                std::vector<std::thread> pool;
-                std::vector<char> bad(nth, 0);
-                for (int tix = 0; tix < nth; ++tix)
-                    pool.emplace_back([&, tix]() {
-                        int j0 = (int)((int64_t)n * tix / nth), j1 = (int)((int64_t)n * (tix + 1) / nth);
-                        for (int j = j0; j < j1; ++j)
-                            for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
-                                dest[e2] = entry_dest(S, T.rowval[e2], j);
-                                if (dest[e2] < 0) bad[tix] = 1;
-                            }
-                    });
-                for (auto& th : pool) th.join();
-                for (char b : bad) if (b) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
-            }
-            std::vector<int64_t> rp(n + 1, 0);
-            for (int64_t e2 = 0; e2 < nnz; ++e2) rp[T.rowval[e2] + 1]++;
-            for (int i = 0; i < n; ++i) rp[i + 1] += rp[i];
-            std::vector<int> col(nnz);
-            std::vector<zc> v(nnz);
-            std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
-            for (int j = 0; j < n; ++j)
-                for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; col[q] = j; v[q] = T.val[e2]; }
-            bool ok = T.d_dest.upload(dest.data(), nnz, stream_) && T.d_cscval.upload((const cz*)T.val.data(), nnz, stream_) &&
-                      T.d_rowptr.upload(rp.data(), n + 1, stream_) && T.d_col.upload(col.data(), nnz, stream_) &&
-                      T.d_val.upload((const cz*)v.data(), nnz, stream_);
+            bool ok = T.d_dest.upload(H.dest.data(), nnz, stream_) && T.d_cscval.upload((const cz*)T.val.data(), nnz, stream_) &&
+                      T.d_rowptr.upload(H.rp.data(), n + 1, stream_) && T.d_col.upload(H.col.data(), nnz, stream_) &&
+                      T.d_val.upload((const cz*)H.v.data(), nnz, stream_);
             if (!ok) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
         }
     }
@@ -640,7 +658,7 @@ int Engine::factorize() {
             HIPCHK(hipStreamWaitEvent(stream_, ev_la_[5], 0));
         }
         launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
-        launch_extend_add(stream_, dsym_, tl + F.extend.off, F.extend.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
+        launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
                           std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
         launch_rowperm(stream_, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
         launch_block_inverse(stream_, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
