@@ -59,6 +59,7 @@ Engine::Engine(int device) : device_(device) {
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
     if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
+    if (const char* v = getenv("FEASTHIP_FIN_ASYNC")) finalize_async_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
@@ -605,6 +606,7 @@ int Engine::factorize() {
     }
     const Tile* tl = d_tiles_.p;
     const int* ls = d_lists_.p;
+    bool fin_used = false;
     for (int d = S.maxdepth; d >= 0; --d) {
         FactorLevel& F = fplan_[d];
         int par = d & 1;
@@ -658,13 +660,19 @@ int Engine::factorize() {
             HIPCHK(hipStreamWaitEvent(stream_, ev_la_[5], 0));
         }
         launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
+        // The solve-ready conversion of this level (row permutations, block inverses, panel scaling) only touches this
+        // level's own panels, which nothing above reads (parents take the contribution blocks): it runs on a side stream
+        // next to the factorisation of the levels above.  It must follow the Schur-complement product, which reads L21 / U12.
+        hipStream_t fin = (finalize_async_ && !aux_streams_.empty()) ? aux_streams_[0] : stream_;
+        if (fin != stream_) { HIPCHK(hipEventRecord(ev_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fork_, 0)); fin_used = true; }
+        launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
+        launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
+        launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
+        launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
         launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
                           std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
-        launch_rowperm(stream_, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
-        launch_block_inverse(stream_, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
-        launch_couple_inverse(stream_, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
-        launch_scale_panels(stream_, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
     }
+    if (fin_used) { HIPCHK(hipEventRecord(ev_join_[0], aux_streams_[0])); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0)); }
     if (mixed_) {      // complex64 copy of the solve-ready factors for the mixed-precision sweeps
         if (!d_fact32_.alloc((size_t)Kloc * fs)) return fail(FEASTHIP_EHIP, "out of device memory for the complex64 factors");
         launch_to_f32(stream_, (int64_t)Kloc * fs, d_fact_.p, d_fact32_.p);

@@ -208,7 +208,7 @@ private:
     bool streams_forced_ = false;
     hipStream_t la_stream_ = nullptr;    // high-priority stream of the look-ahead panels
     std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join
-    bool look_ahead_ = true;
+    bool look_ahead_ = true, finalize_async_ = true;
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;
     hipEvent_t ev_fork_ = nullptr;
