@@ -216,7 +216,9 @@ def main():
                 "kernel_classes_ms": {k: v["ms"] for k, v in prof.items()},
             },
             "breakdown_ms_per_step": {k: 1e3 * v / args.steps for k, v in phase.items()},      # rank 0; rr is replicated, contour is this rank's node shard
-            "setup": {"analyze_s": t_analyze, "factor_ms": st["factor_ms"], "factor_TFLOPs": st["flops_factor"] * st["local_nodes"] / (st["factor_ms"] * 1e-3) / 1e12,
+            # analyze_s: ordering + symbolic analysis + plan upload; alloc_s: hipMalloc of the arenas (0.03 .. 2 s for the same
+            # request depending on what the previous process left to scrub) -- reported separately, both count in time_to_solution_s
+            "setup": {"analyze_s": st["analyze_seconds"], "alloc_s": st["alloc_seconds"], "analyze_call_s": t_analyze, "factor_ms": st["factor_ms"], "factor_TFLOPs": st["flops_factor"] * st["local_nodes"] / (st["factor_ms"] * 1e-3) / 1e12,
                       "perturbed_pivots": int(warn), "store_false_iterations_per_s": 1.0 / (dt / args.steps + st["factor_ms"] * 1e-3)},
             "result": {"inside": int(ins.sum()), "expected_inside": w["n_inside"], "max_res_inside": float(res[ins].max()) if ins.any() else None,
                        "rr_ms": st2["rr_ms"],

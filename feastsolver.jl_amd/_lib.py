@@ -21,7 +21,7 @@ class Stats(C.Structure):
         ("flops_factor", C.c_double), ("analyze_seconds", C.c_double), ("factor_ms", C.c_double),
         ("solve_ms", C.c_double), ("rr_ms", C.c_double), ("solve_bytes", C.c_double), ("solve_flops", C.c_double),
         ("perturbed_pivots", C.c_int64), ("local_nodes", C.c_int32), ("m0", C.c_int32), ("ldw", C.c_int32),
-        ("dense", C.c_int32),
+        ("dense", C.c_int32), ("alloc_seconds", C.c_double),
     ]
 
 

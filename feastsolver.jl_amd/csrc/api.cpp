@@ -167,7 +167,7 @@ int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     o->n = e->n; o->nsuper = e->S.nsuper; o->nnz_l = e->S.nnz_l; o->nnz_u = e->S.nnz_u; o->fact_elems = e->S.fact_size;
     o->max_front = e->S.max_front; o->max_p = e->S.max_p; o->depth = e->S.maxdepth + 1;
     o->flops_factor = e->S.flops_factor; o->analyze_seconds = e->analyze_seconds; o->factor_ms = e->factor_ms;
-    o->solve_ms = e->solve_ms; o->rr_ms = e->rr_ms;
+    o->solve_ms = e->solve_ms; o->rr_ms = e->rr_ms; o->alloc_seconds = e->alloc_seconds;
     o->solve_bytes = e->ldw ? e->solve_bytes() : 0; o->solve_flops = e->ldw ? e->solve_flops() : 0;
     o->perturbed_pivots = e->perturbed; o->local_nodes = e->Kloc; o->m0 = e->m0; o->ldw = e->ldw; o->dense = e->dense ? 1 : 0;
     return 0;

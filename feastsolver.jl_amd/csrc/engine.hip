@@ -534,13 +534,15 @@ int Engine::analyze() {
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
     dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.n = n;
     // numeric arenas
+    analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    auto t_alloc = std::chrono::steady_clock::now();
     ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
          d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
          d_rowperm_.alloc((size_t)Kloc * n) && d_rowinv_.alloc((size_t)Kloc * n) && d_nperturb_.alloc(Kloc) &&
          d_tiny_.alloc(Kloc) && d_coef_.alloc((size_t)Kloc * nterms);
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
-    analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads, buffers    %.1f ms (cumulative)\n", analyze_seconds * 1e3);
+    alloc_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);
     analyzed_ = true;
     factored_ = false;
     return 0;

@@ -111,7 +111,7 @@ public:
     std::vector<double> prof_detail;   // per launch: class, ms, bytes, flops, tiles (filled by profile_solve)
 
     // stats
-    double analyze_seconds = 0, factor_ms = 0, solve_ms = 0, rr_ms = 0;
+    double analyze_seconds = 0, alloc_seconds = 0, factor_ms = 0, solve_ms = 0, rr_ms = 0;
     int64_t perturbed = 0;
     Symbolic S;
     int n = 0, nterms = 0, K = 0, Kloc = 0, m0 = 0, ldw = 0;

@@ -203,7 +203,7 @@ int feasthip_fact_free(feasthip_fact_t F);
 typedef struct {
     int64_t n, nsuper, nnz_l, nnz_u, fact_elems, max_front, max_p, depth;
     double flops_factor;        /* real flops of one numeric factorisation        */
-    double analyze_seconds;     /* host ordering + symbolic                         */
+    double analyze_seconds;     /* host ordering + symbolic + plan upload (without the arena allocation below) */
     double factor_ms;           /* last feasthip_factorize, all local nodes (HIP events) */
     double solve_ms;            /* last contour step: block solves + accumulation   */
     double rr_ms;               /* last Rayleigh-Ritz step                          */
@@ -211,6 +211,8 @@ typedef struct {
     double solve_flops;         /* real flops of one contour step                   */
     int64_t perturbed_pivots;
     int32_t local_nodes, m0, ldw, dense;
+    double alloc_seconds;       /* hipMalloc of the factor / contribution arenas at the end of feasthip_analyze (the driver may
+                                 * have to scrub tens of GB freed by a previous process: 0.03 .. 2 s for the same request) */
 } feasthip_stats_t;
 int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* out);
 /* One instrumented contour sweep: HIP-event time per kernel class.  out = 8 rows x
