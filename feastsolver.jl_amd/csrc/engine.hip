@@ -452,7 +452,7 @@ int Engine::analyze() {
                     int64_t nnz = T.colptr[n];
                     H.dest.resize(nnz);
                     // arena destination of every entry (a binary search in the supernode's row structure): independent per column
-                    int nth = (int)std::min<int64_t>(8, std::max<int64_t>(1, nnz / 100000));
+                    int nth = (int)std::min<int64_t>(std::max(1, host_cpu_budget() / 2), std::max<int64_t>(1, nnz / 100000));
                     std::vector<std::thread> pool;
                     std::vector<char> bad(nth, 0);
                     for (int tix = 0; tix < nth; ++tix)

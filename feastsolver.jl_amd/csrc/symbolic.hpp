@@ -10,6 +10,8 @@
 
 namespace feasthip {
 
+int host_cpu_budget();      // hardware threads capped by the cgroup CPU quota
+
 struct Symbolic {
     int n = 0;
     bool dense = false;
