@@ -59,6 +59,7 @@ Engine::Engine(int device) : device_(device) {
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
     if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
+    if (const char* v = getenv("FEASTHIP_GROUP")) group_panels_ = std::max(1, std::min(8, atoi(v)));
     if (const char* v = getenv("FEASTHIP_FIN_ASYNC")) finalize_async_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     int nst = 2;
@@ -76,7 +77,21 @@ Engine::Engine(int device) : device_(device) {
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
         if (hipStreamCreateWithPriority(&la_stream_, hipStreamNonBlocking, phi) != hipSuccess) la_stream_ = nullptr;
-        for (int i = 0; i < 6; ++i) { hipEvent_t e3 = nullptr; (void)hipEventCreateWithFlags(&e3, hipEventDisableTiming); ev_la_.push_back(e3); }
+        for (int i = 0; i < 7; ++i) { hipEvent_t e3 = nullptr; (void)hipEventCreateWithFlags(&e3, hipEventDisableTiming); ev_la_.push_back(e3); }
+        // A panel workgroup (1024 threads, 126 registers) needs an empty CU: behind a trailing update that fills every CU it
+        // would only start when that update drains.  The trailing updates of the look-ahead levels therefore run on a stream
+        // whose CU mask leaves reserve_cus_ CUs of every XCD alone (MI355X: 8 XCDs x 32 CUs).  The cleared bits are 32x + 8m + x
+        // (x = XCD, m < reserve_cus_): two free CUs per XCD whether the mask bits enumerate the CUs XCD by XCD or round-robin.
+        if (const char* v = getenv("FEASTHIP_RESERVE_CUS")) reserve_cus_ = std::max(0, std::min(4, atoi(v)));
+        hipDeviceProp_t prop;
+        if (la_stream_ && reserve_cus_ > 0 && hipGetDeviceProperties(&prop, device_) == hipSuccess && prop.multiProcessorCount == 256) {
+            uint32_t mask[8];
+            for (int x = 0; x < 8; ++x) {
+                mask[x] = 0xffffffffu;
+                for (int m = 0; m < reserve_cus_; ++m) mask[x] &= ~(1u << (8 * m + x));
+            }
+            if (hipExtStreamCreateWithCUMask(&rest_stream_, 8, mask) != hipSuccess) { rest_stream_ = nullptr; (void)hipGetLastError(); }
+        }
     }
 }
 
@@ -88,6 +103,7 @@ Engine::~Engine() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     for (hipEvent_t e3 : ev_la_) if (e3) (void)hipEventDestroy(e3);
     if (la_stream_) { (void)hipStreamSynchronize(la_stream_); (void)hipStreamDestroy(la_stream_); }
+    if (rest_stream_) { (void)hipStreamSynchronize(rest_stream_); (void)hipStreamDestroy(rest_stream_); }
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -223,6 +239,14 @@ bool Engine::build_plans() {
     sk_rows_ = 0;
     std::vector<int> nchild(S.nsuper);
     for (int s = 0; s < S.nsuper; ++s) nchild[s] = (int)(S.child_ptr[s + 1] - S.child_ptr[s]);
+    // product tiles of one front in 8 x 8 super-tiles (64 consecutive tiles share 8 row panels and 8 column panels; k_gemm_nn
+    // hands such runs to one XCD)
+    auto push_supertiles = [&](int s, int kind, int na, int nc) {
+        for (int A = 0; A < na; A += 8)
+            for (int C = 0; C < nc; C += 8)
+                for (int a = A; a < std::min(na, A + 8); ++a)
+                    for (int c = C; c < std::min(nc, C + 8); ++c) tiles.push_back({s, kind, a, c});
+    };
     for (int d = 0; d < nd; ++d) {
         const std::vector<int>& lv = S.levels[d];
         FactorLevel& F = fplan_[d];
@@ -262,15 +286,15 @@ bool Engine::build_plans() {
             for (int s : lv) if (S.p(s) > k0) {
                 int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0), ld = p + u;
                 int M0 = ld - k0 - b, N0 = p - k0 - b;
-                if (M0 > 0 && N0 > 0) for (int a = 0; a < cdiv(M0, 64); ++a) for (int c = 0; c < cdiv(N0, 64); ++c) tiles.push_back({s, 0, a, c});
+                if (M0 > 0 && N0 > 0) push_supertiles(s, 0, cdiv(M0, 64), cdiv(N0, 64));
                 int M1 = p - k0 - b, N1 = u;
-                if (M1 > 0 && N1 > 0) for (int a = 0; a < cdiv(M1, 64); ++a) for (int c = 0; c < cdiv(N1, 64); ++c) tiles.push_back({s, 1, a, c});
+                if (M1 > 0 && N1 > 0) push_supertiles(s, 1, cdiv(M1, 64), cdiv(N1, 64));
             }
             st.gemm.count = (int)(tiles.size() - st.gemm.off);
             F.steps.push_back(st);
         }
         F.cbgemm.off = (int64_t)tiles.size();
-        for (int s : lv) if (S.u(s) > 0) { int nt = cdiv(S.u(s), 64); for (int a = 0; a < nt; ++a) for (int c = 0; c < nt; ++c) tiles.push_back({s, 2, a, c}); }
+        for (int s : lv) if (S.u(s) > 0) { int nt = cdiv(S.u(s), 64); push_supertiles(s, 2, nt, nt); }
         F.cbgemm.count = (int)(tiles.size() - F.cbgemm.off);
         F.fronts.off = (int64_t)lists.size();
         for (int s : lv) lists.push_back(s);
@@ -609,6 +633,11 @@ int Engine::factorize() {
     const Tile* tl = d_tiles_.p;
     const int* ls = d_lists_.p;
     bool fin_used = false;
+    // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
+    const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
+    std::vector<hipEvent_t> tev;
+    auto stamp = [&]() { if (ftrace) { hipEvent_t e4; (void)hipEventCreate(&e4); (void)hipEventRecord(e4, stream_); tev.push_back(e4); } };
+    stamp();
     for (int d = S.maxdepth; d >= 0; --d) {
         FactorLevel& F = fplan_[d];
         int par = d & 1;
@@ -622,46 +651,95 @@ int Engine::factorize() {
         int level_p = 0;
         for (int s2 : S.levels[d]) level_p = std::max(level_p, S.p(s2));
         const bool lookahead = look_ahead_ && level_p >= 256 && la_stream_ && F.steps.size() >= 4;
+        stamp();
         if (!lookahead) {
             for (FactorStep& st : F.steps) {
-                launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall);
+                launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - st.k0);
                 launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
                 launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
                 launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
             }
         } else {
             // LU with look-ahead for the big fronts at the top of the tree (few fronts x nodes: the panel factorisation runs on a
-            // handful of workgroups and would otherwise leave the GPU idle between two trailing updates).  Stream P updates the
-            // LOOKAHEAD_COLS columns right of panel i (window) and factors panel i+1 while the main stream applies step i to
-            // all the other columns (rest).  The window of step i+1 reaches 32 columns into the rest of step i, hence eRest.
-            hipStream_t P = la_stream_;
+            // handful of workgroups and would otherwise leave the GPU idle between two trailing updates).  The panels are taken
+            // in groups of group_panels_ (columns [K0_g, K0_g+1)).  The high-priority stream P factors the panels of group g,
+            // updating only the group's own columns in between, and then applies the whole group, as one product of depth
+            // K0_g+1 - K0_g, to the columns of group g+1 (W below).  The main stream applies group g to everything else (the
+            // left columns' row interchanges, the pivot-block columns from K0_g+2 on and U12) while P is busy with group g+1.
+            // Deferring a group's update is legal because all its row interchanges are applied first, to L and to C alike; the
+            // U rows then come from a blocked forward substitution (a 32-row product with the panels before it, then the
+            // triangular solve with the panel's own L11) and the rest is one product.  Against per-panel updates the product
+            // reads and writes C once per group instead of once per panel, which is what bounds it.
+            hipStream_t P = la_stream_, R = rest_stream_ ? rest_stream_ : stream_;
             HIPCHK(hipEventRecord(ev_la_[4], stream_));
             HIPCHK(hipStreamWaitEvent(P, ev_la_[4], 0));
-            const size_t ns = F.steps.size();
-            launch_panel(P, dsym_, ls + F.steps[0].panel.off, F.steps[0].panel.count, F.steps[0].k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall);
-            HIPCHK(hipEventRecord(ev_la_[0], P));
-            for (size_t i = 0; i < ns; ++i) {
-                FactorStep& st = F.steps[i];
-                hipEvent_t ePanel = ev_la_[i & 1], ePanelNext = ev_la_[(i + 1) & 1], eRest = ev_la_[2 + (i & 1)], eRestPrev = ev_la_[2 + ((i + 1) & 1)];
-                if (i > 0) HIPCHK(hipStreamWaitEvent(P, eRestPrev, 0));
-                launch_swap(P, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc, 1);
-                launch_trsm_u(P, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc, 1);
-                launch_gemm_nn(P, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc, 1);
-                HIPCHK(hipStreamWaitEvent(stream_, ePanel, 0));            // panel i (and everything P did before it) is complete
-                if (i + 1 < ns) {
-                    FactorStep& nx = F.steps[i + 1];
-                    launch_panel(P, dsym_, ls + nx.panel.off, nx.panel.count, nx.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall);
-                    HIPCHK(hipEventRecord(ePanelNext, P));
+            if (R != stream_) HIPCHK(hipStreamWaitEvent(R, ev_la_[4], 0));
+            const int ns = (int)F.steps.size(), G = group_panels_, ng = (ns + G - 1) / G;
+            const int INF = 1 << 30;
+            auto K0 = [&](int g) { return g * G < ns ? F.steps[(size_t)g * G].k0 : INF; };       // first column of group g
+            // all of group g (panels already factored) applied to the columns [c_lo, c_hi) of the pivot block, and to the left
+            // columns [0, K0_g) and U12 when `others`
+            auto apply_group = [&](hipStream_t s, int g, int c_lo, int c_hi, bool others) {
+                const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
+                auto sel = [&](int origin) {          // column offsets relative to the first column right of `origin`
+                    ColSel c;
+                    c.llo = 0; c.lhi = others ? k0g : 0;
+                    c.clo = std::max(0, c_lo - origin); c.chi = c_hi >= INF ? INF : std::max(0, c_hi - origin);
+                    c.u12 = others ? 1 : 0;
+                    return c;
+                };
+                for (int j = j0; j < j1; ++j) {
+                    FactorStep& sj = F.steps[j];
+                    launch_swap(s, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, sel(sj.k0 + FACT_NB));
                 }
-                launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc, 2);
-                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc, 2);
-                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc, 2);
-                HIPCHK(hipEventRecord(eRest, stream_));
+                FactorStep& s0 = F.steps[j0];
+                for (int j = j0; j < j1; ++j) {
+                    FactorStep& sj = F.steps[j];
+                    const int bw = sj.k0 - k0g;
+                    if (bw > 0) {
+                        ColSel c = sel(sj.k0); c.llo = c.lhi = 0;
+                        launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, c, bw, FACT_NB);
+                    }
+                    ColSel c = sel(sj.k0 + FACT_NB);
+                    launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                }
+                const int bw = F.steps[j1 - 1].k0 + FACT_NB - k0g;
+                launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + bw), bw, 0);
+            };
+            for (int g = 0; g < ng; ++g) {
+                const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
+                const int kend = K0(g + 1);                     // first column after the group (INF for the last group)
+                if (g > 0) {
+                    if (g > 1) HIPCHK(hipStreamWaitEvent(P, ev_la_[2 + (g & 1)], 0));      // rest of group g-2 reaches these columns
+                    apply_group(P, g - 1, k0g, kend, false);
+                }
+                for (int j = j0; j < j1; ++j) {
+                    FactorStep& sj = F.steps[j];
+                    launch_panel(P, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall,
+                                 level_ld - sj.k0);
+                    // inside the group: interchanges on the group's earlier L columns and its remaining columns, U rows and update
+                    // of the remaining columns
+                    ColSel c;
+                    c.llo = k0g; c.lhi = sj.k0; c.clo = 0; c.chi = kend >= INF ? INF : std::max(0, kend - sj.k0 - FACT_NB); c.u12 = 0;
+                    launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
+                    if (c.chi > 0) {
+                        c.llo = c.lhi = 0;
+                        launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                        launch_gemm_nn(P, dsym_, tl + sj.gemm.off, sj.gemm.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
+                    }
+                }
+                HIPCHK(hipEventRecord(ev_la_[g & 1], P));
+                HIPCHK(hipStreamWaitEvent(R, ev_la_[g & 1], 0));
+                apply_group(R, g, K0(g + 2), INF, true);
+                HIPCHK(hipEventRecord(ev_la_[2 + (g & 1)], R));
             }
             HIPCHK(hipEventRecord(ev_la_[5], P));
             HIPCHK(hipStreamWaitEvent(stream_, ev_la_[5], 0));
+            if (R != stream_) { HIPCHK(hipEventRecord(ev_la_[6], R)); HIPCHK(hipStreamWaitEvent(stream_, ev_la_[6], 0)); }
         }
+        stamp();
         launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
+        stamp();
         // The solve-ready conversion of this level (row permutations, block inverses, panel scaling) only touches this
         // level's own panels, which nothing above reads (parents take the contribution blocks): it runs on a side stream
         // next to the factorisation of the levels above.  It must follow the Schur-complement product, which reads L21 / U12.
@@ -675,6 +753,25 @@ int Engine::factorize() {
                           std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
     }
     if (fin_used) { HIPCHK(hipEventRecord(ev_join_[0], aux_streams_[0])); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0)); }
+    if (ftrace) {
+        stamp();
+        HIPCHK(hipStreamSynchronize(stream_));
+        auto ms = [&](size_t a, size_t b) { float t = 0; (void)hipEventElapsedTime(&t, tev[a], tev[b]); return t; };
+        size_t q = 0;
+        for (int d = S.maxdepth; d >= 0; --d, q += 3) {
+            int mp = 0, mu = 0;
+            double fl_schur = 0, fl_steps = 0;
+            for (int s2 : S.levels[d]) {
+                double p2 = S.p(s2), u2 = S.u(s2);
+                mp = std::max(mp, S.p(s2)); mu = std::max(mu, S.u(s2));
+                fl_schur += 8.0 * u2 * u2 * p2 * Kloc;
+                fl_steps += 8.0 * (p2 * p2 * p2 / 3.0 + p2 * p2 * u2) * Kloc;      // LU of the pivot block, L21 and U12 (8 flops per complex multiply-add)
+            }
+            fprintf(stderr, "[feasthip factor] depth %2d  fronts %5zu  max p %5d  max u %5d  steps %3zu | extend-add %7.2f  panel steps %7.2f (%5.1f TF)  schur product %7.2f ms (%5.1f TF)\n",
+                    d, S.levels[d].size(), mp, mu, fplan_[d].steps.size(), ms(q, q + 1), ms(q + 1, q + 2), fl_steps / ms(q + 1, q + 2) * 1e-9, ms(q + 2, q + 3), fl_schur / ms(q + 2, q + 3) * 1e-9);
+        }
+        for (hipEvent_t e4 : tev) (void)hipEventDestroy(e4);
+    }
     if (mixed_) {      // complex64 copy of the solve-ready factors for the mixed-precision sweeps
         if (!d_fact32_.alloc((size_t)Kloc * fs)) return fail(FEASTHIP_EHIP, "out of device memory for the complex64 factors");
         launch_to_f32(stream_, (int64_t)Kloc * fs, d_fact_.p, d_fact32_.p);

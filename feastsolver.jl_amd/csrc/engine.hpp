@@ -207,8 +207,11 @@ private:
     void accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
     bool streams_forced_ = false;
     hipStream_t la_stream_ = nullptr;    // high-priority stream of the look-ahead panels
-    std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join
+    hipStream_t rest_stream_ = nullptr;  // trailing updates of the look-ahead levels: a CU mask keeps reserve_cus_ CUs per XCD free for la_stream_
+    int reserve_cus_ = 2;
+    std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join, [6] rest stream join
     bool look_ahead_ = true, finalize_async_ = true;
+    int group_panels_ = 2;            // panels per deferred trailing update in the look-ahead factorisation
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;
     hipEvent_t ev_fork_ = nullptr;

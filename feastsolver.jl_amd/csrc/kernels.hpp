@@ -31,13 +31,16 @@ void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz
 void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,
                        cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K, int phase);
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
-                  int* piv, const double* tiny, int* nperturb, int K, bool tall = false);
+                  int* piv, const double* tiny, int* nperturb, int K, bool tall = false, int max_rows = 1 << 30);
+// Column selection of one launch of an elimination step (look-ahead schedule): left columns [llo, lhi), pivot-block
+// columns right of the panel with offset in [clo, chi), U12 columns iff u12.  The default selects everything.
+struct ColSel { int llo = 0, lhi = 1 << 30, clo = 0, chi = 1 << 30, u12 = 1; };
+inline ColSel col_right(int clo, int chi) { ColSel c; c.llo = 0; c.lhi = 0; c.clo = clo; c.chi = chi; c.u12 = 0; return c; }
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                 const int* piv, int K, int win = 0);
-void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, int win = 0);
-// kinds: 0 = L-panel trailing update, 1 = U12 trailing update, 2 = contribution block (K = p)
+                 const int* piv, int K, ColSel cs = ColSel());
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs = ColSel());
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                    cz* cb, int64_t cbs, int K, int win = 0);
+                    cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0);
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled
 void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);

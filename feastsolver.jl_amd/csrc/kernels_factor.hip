@@ -4,6 +4,7 @@
 // the reference's `factorizer` seam (src/feast.jl:28-38, 104-114,
 // src/nlfeast.jl:17-28; dense zgetrf / UMFPACK in the reference).
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace feasthip {
 
@@ -241,9 +242,199 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ f
     }
 }
 
+// Register-resident variant for panels of at most PANEL_RPT * PANEL_NT rows.  A thread keeps its rows (k0 + tid + NT q) of the
+// current 4-column sub-panel in registers for the four pivot steps, so that a pivot step costs two barriers and no global
+// round trip: the pivot search reads registers, the two interchanged rows travel through LDS (the pivot row doubles as the
+// broadcast U row of the rank-1 update), and the columns are written back once per sub-panel.  The generic kernel above
+// updated the sub-panel in global memory, one dependent load/store chain per column and pivot (12 us per pivot at 3000 rows).
+constexpr int PANEL_RPT = 4, PANEL_SBR = 4;
+
+template <int PANEL_NT>
+__global__ __launch_bounds__(PANEL_NT) void k_panel_reg(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
+                                                         cz* fact, int64_t fs, int* piv, int npiv,
+                                                         const double* __restrict__ tiny, int* nperturb) {
+    constexpr int NW = PANEL_NT / 64;
+    __shared__ double s_val[2][NW];
+    __shared__ int s_idx[2][NW];
+    __shared__ cz s_row[2][2][PANEL_SBR];      // [parity][pivot row / row j][sub-panel column]
+    __shared__ cz s_l[PANEL_SBR][PANEL_SBR];
+    __shared__ cz s_u[PANEL_SBR][FACT_NB];
+    FrontD f = fr[list[blockIdx.x]];
+    int k = blockIdx.y;
+    int p = f.p, ld = f.p + f.u;
+    int b = min(FACT_NB, p - k0);
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrow = ld - k0, npr = p - k0;       // local row i = r - k0; pivots come from i < npr
+    const double tiny_k = tiny[k];
+    for (int sb0 = 0; sb0 < b; sb0 += PANEL_SBR) {
+        const int sbe = min(b, sb0 + PANEL_SBR), sw = sbe - sb0;
+        cz v[PANEL_RPT][PANEL_SBR];
+#pragma unroll
+        for (int q = 0; q < PANEL_RPT; ++q) {
+            int i = tid + PANEL_NT * q;
+            bool act = i >= sb0 && i < nrow;
+#pragma unroll
+            for (int c = 0; c < PANEL_SBR; ++c)
+                v[q][c] = (act && c < sw) ? Lp[(int64_t)(k0 + sb0 + c) * ld + k0 + i] : cz_make(0, 0);
+        }
+#pragma unroll
+        for (int jc = 0; jc < PANEL_SBR; ++jc) {
+            if (jc >= sw) break;
+            const int j = sb0 + jc, par = jc & 1;
+            double best = -1.0;
+            int bi = j;
+#pragma unroll
+            for (int q = 0; q < PANEL_RPT; ++q) {
+                int i = tid + PANEL_NT * q;
+                double a = cz_abs1(v[q][jc]);
+                if (i >= j && i < npr && a > best) { best = a; bi = i; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                double ob = __shfl_xor(best, off);
+                int oi = __shfl_xor(bi, off);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) { s_val[par][wave] = best; s_idx[par][wave] = bi; }
+            __syncthreads();
+            double bb = s_val[par][0];
+            int pr = s_idx[par][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                double ov = s_val[par][w];
+                int oi = s_idx[par][w];
+                if (ov > bb || (ov == bb && oi < pr)) { bb = ov; pr = oi; }
+            }
+            if (bb < 0) pr = j;
+            if (tid == 0) piv[(int64_t)k * npiv + f.c0 + k0 + j] = k0 + pr;
+#pragma unroll
+            for (int q = 0; q < PANEL_RPT; ++q) {
+                int i = tid + PANEL_NT * q;
+                if (i == pr) {
+#pragma unroll
+                    for (int c = 0; c < PANEL_SBR; ++c) s_row[par][0][c] = v[q][c];
+                }
+                if (i == j) {
+#pragma unroll
+                    for (int c = 0; c < PANEL_SBR; ++c) s_row[par][1][c] = v[q][c];
+                }
+            }
+            if (pr != j && tid < b && (tid < sb0 || tid >= sbe)) {      // panel columns outside the sub-panel: interchange in memory
+                cz* c2 = Lp + (int64_t)(k0 + tid) * ld + k0;
+                cz a = c2[j], c = c2[pr];
+                c2[j] = c; c2[pr] = a;
+            }
+            __syncthreads();
+            cz u[PANEL_SBR];
+#pragma unroll
+            for (int c = 0; c < PANEL_SBR; ++c) u[c] = s_row[par][0][c];
+            if (pr != j) {
+#pragma unroll
+                for (int q = 0; q < PANEL_RPT; ++q) {
+                    int i = tid + PANEL_NT * q;
+                    if (i == j) {
+#pragma unroll
+                        for (int c = 0; c < PANEL_SBR; ++c) v[q][c] = u[c];
+                    }
+                    if (i == pr) {
+#pragma unroll
+                        for (int c = 0; c < PANEL_SBR; ++c) v[q][c] = s_row[par][1][c];
+                    }
+                }
+            }
+            cz pv = u[jc];
+            double pa = cz_abs1(pv);
+            if (!(pa >= tiny_k)) {   // static pivot perturbation (also catches NaN)
+                pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+#pragma unroll
+                for (int q = 0; q < PANEL_RPT; ++q)
+                    if (tid + PANEL_NT * q == j) v[q][jc] = pv;
+                if (tid == 0) atomicAdd(nperturb + k, 1);
+            }
+            cz inv = cz_inv(pv);
+#pragma unroll
+            for (int q = 0; q < PANEL_RPT; ++q) {
+                int i = tid + PANEL_NT * q;
+                if (i > j && i < nrow) {
+                    cz l = cz_mul(v[q][jc], inv);
+                    v[q][jc] = l;
+#pragma unroll
+                    for (int c = jc + 1; c < PANEL_SBR; ++c) cz_msub(v[q][c], l, u[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PANEL_RPT; ++q) {
+            int i = tid + PANEL_NT * q;
+            if (i >= sb0 && i < nrow) {
+#pragma unroll
+                for (int c = 0; c < PANEL_SBR; ++c)
+                    if (c < sw) Lp[(int64_t)(k0 + sb0 + c) * ld + k0 + i] = v[q][c];
+            }
+        }
+        const int nt = b - sbe;                 // trailing panel columns
+        if (nt <= 0) break;
+        // (a) U rows of the trailing columns: forward substitution with the unit-lower sw x sw block
+#pragma unroll
+        for (int q = 0; q < PANEL_RPT; ++q) {
+            int i = tid + PANEL_NT * q - sb0;
+            if (i >= 0 && i < sw) {
+#pragma unroll
+                for (int c = 0; c < PANEL_SBR; ++c) s_l[i][c] = v[q][c];
+            }
+        }
+        __syncthreads();
+        if (tid < nt) {
+            cz* c2 = Lp + (int64_t)(k0 + sbe + tid) * ld + k0 + sb0;
+            cz x[PANEL_SBR];
+#pragma unroll
+            for (int i = 0; i < PANEL_SBR; ++i) x[i] = i < sw ? c2[i] : cz_make(0, 0);
+#pragma unroll
+            for (int i = 1; i < PANEL_SBR; ++i)
+#pragma unroll
+                for (int q = 0; q < i; ++q) if (i < sw) cz_msub(x[i], s_l[i][q], x[q]);
+#pragma unroll
+            for (int i = 0; i < PANEL_SBR; ++i) if (i < sw) { c2[i] = x[i]; s_u[i][tid] = x[i]; }
+        }
+        __syncthreads();
+        // (b) rows below the sub-panel: rank-sw update of the trailing columns with the L values still in registers.  Column by
+        // column, the thread's four rows in flight together (16 waves x 4 loads per CU cover the L2 latency; wider batches
+        // spill at 128 registers)
+        {
+            bool on[PANEL_RPT];
+#pragma unroll
+            for (int q = 0; q < PANEL_RPT; ++q) on[q] = tid + PANEL_NT * q >= sbe && tid + PANEL_NT * q < nrow;
+            cz* d0 = Lp + (int64_t)(k0 + sbe) * ld + k0 + tid;
+            for (int jj = 0; jj < nt; ++jj) {
+                cz uu[PANEL_SBR], t[PANEL_RPT];
+                cz* dj = d0 + (int64_t)jj * ld;
+#pragma unroll
+                for (int c = 0; c < PANEL_SBR; ++c) uu[c] = s_u[c][jj];
+#pragma unroll
+                for (int q = 0; q < PANEL_RPT; ++q) t[q] = on[q] ? dj[PANEL_NT * q] : cz_make(0, 0);
+#pragma unroll
+                for (int q = 0; q < PANEL_RPT; ++q)
+#pragma unroll
+                    for (int c = 0; c < PANEL_SBR; ++c) cz_msub(t[q], v[q][c], uu[c]);
+#pragma unroll
+                for (int q = 0; q < PANEL_RPT; ++q)
+                    if (on[q]) dj[PANEL_NT * q] = t[q];
+            }
+        }
+        // no barrier: the next sub-panel's loads read this thread's own rows, and s_l / s_u are rewritten only after the
+        // barriers of the pivot steps
+    }
+}
+
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
-                  int* piv, const double* tiny, int* nperturb, int K, bool tall) {
+                  int* piv, const double* tiny, int* nperturb, int K, bool tall, int max_rows) {
     if (nlist <= 0) return;
+    static const bool generic = getenv("FEASTHIP_PANEL_GENERIC") != nullptr;
+    if (!generic && max_rows <= PANEL_RPT * (tall ? PANEL_NT_TALL : PANEL_NT_SMALL)) {     // max_rows: tallest panel (ld - k0) of the launch
+        if (tall) hipLaunchKernelGGL(k_panel_reg<PANEL_NT_TALL>, dim3(nlist, K), dim3(PANEL_NT_TALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
+        else hipLaunchKernelGGL(k_panel_reg<PANEL_NT_SMALL>, dim3(nlist, K), dim3(PANEL_NT_SMALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
+        return;
+    }
     if (tall) hipLaunchKernelGGL(k_panel<PANEL_NT_TALL>, dim3(nlist, K), dim3(PANEL_NT_TALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
     else hipLaunchKernelGGL(k_panel<PANEL_NT_SMALL>, dim3(nlist, K), dim3(PANEL_NT_SMALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
 }
@@ -251,10 +442,11 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
 // ---------------------------------------------------------------------------
 // apply the panel's row interchanges to every other column of the front
 // ---------------------------------------------------------------------------
-// `win` selects the columns for the look-ahead schedule of Engine::factorize: 0 all, 1 only the LOOKAHEAD_COLS
-// columns right of the panel, 2 everything else.
+// ColSel picks the columns an elimination step touches in one launch, for the look-ahead schedule of Engine::factorize:
+// left columns (the L columns of earlier panels) with llo <= index < lhi, pivot-block columns right of the panel whose
+// offset from the first such column lies in [clo, chi), and the U12 columns when u12 is set.
 __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
-                       const int* __restrict__ piv, int npiv, int win) {
+                       const int* __restrict__ piv, int npiv, ColSel cs) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -263,14 +455,17 @@ __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ t
     int v = t.a * 256 + threadIdx.x;
     int nv = (p - b) + u;
     if (v >= nv) return;
-    if (win) {
-        bool inwin = v >= k0 && v < k0 + LOOKAHEAD_COLS && v < p - b;
-        if ((win == 1) != inwin) return;
-    }
     cz* col;
-    if (v < k0) col = fact + (int64_t)k * fs + f.lp + (int64_t)v * ld;
-    else if (v < p - b) col = fact + (int64_t)k * fs + f.lp + (int64_t)(v + b) * ld;
-    else col = fact + (int64_t)k * fs + f.f12 + (int64_t)(v - (p - b)) * p;
+    if (v < k0) {
+        if (v < cs.llo || v >= cs.lhi) return;
+        col = fact + (int64_t)k * fs + f.lp + (int64_t)v * ld;
+    } else if (v < p - b) {
+        if (v - k0 < cs.clo || v - k0 >= cs.chi) return;
+        col = fact + (int64_t)k * fs + f.lp + (int64_t)(v + b) * ld;
+    } else {
+        if (!cs.u12) return;
+        col = fact + (int64_t)k * fs + f.f12 + (int64_t)(v - (p - b)) * p;
+    }
     const int* pv = piv + (int64_t)k * npiv + f.c0 + k0;
     for (int j = 0; j < b; ++j) {
         int pr = pv[j];
@@ -279,64 +474,81 @@ __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ t
 }
 
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                 const int* piv, int K, int win) {
+                 const int* piv, int K, ColSel cs) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n, win);
+    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n, cs);
 }
 
 // ---------------------------------------------------------------------------
 // U row block: columns right of the panel (inside the pivot block and U12)
 // get x <- L11^-1 x, one thread per column.
 // ---------------------------------------------------------------------------
+template <int KB>
+__device__ __forceinline__ void trsm_sweeps(cz (&x)[FACT_NB], const cz* s_l) {
+#pragma unroll 1
+    for (int kk = KB; kk < KB + 8; ++kk) {
+        // x_kk picked with bit masks: a select chain over x[] is turned back into a dynamically indexed load, which sends
+        // the whole array to scratch memory
+        long long xr = 0, xi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            long long m = -(long long)(kk == KB + j);
+            xr |= m & __double_as_longlong(x[KB + j].x);
+            xi |= m & __double_as_longlong(x[KB + j].y);
+        }
+        cz xk = cz_make(__longlong_as_double(xr), __longlong_as_double(xi));
+        const cz* lcol = s_l + kk * FACT_NB;
+#pragma unroll
+        for (int i = KB + 1; i < FACT_NB; ++i) cz_msub(x[i], lcol[i], xk);
+    }
+}
+
 __global__ __launch_bounds__(TRSM_COLS) void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
-                                                     int win) {
-    // 64 columns per workgroup: 34 KB (slab) + 16 KB (L11) of LDS lets three workgroups share a CU (the former 128-column
-    // version needed 83 KB: one workgroup of two waves per CU, and the launches of the wide levels took milliseconds)
+                                                     ColSel cs) {
+    // One thread per column, the column's FACT_NB rows in registers (each thread reads 512 contiguous bytes), L11 broadcast
+    // from LDS; the substitution is fully unrolled.  The former version kept the slab in LDS as well (50 KB per 64-thread
+    // workgroup: three waves per CU, 50 us per workgroup, 1.7 ms per launch on the wide levels of C3).
     __shared__ cz s_l[FACT_NB * FACT_NB];
-    __shared__ cz s_x[TRSM_COLS][FACT_NB + 1];    // the slab of TRSM_COLS columns x b rows, staged with coalesced accesses
     Tile t = tiles[blockIdx.x];
-    static_assert(LOOKAHEAD_COLS % TRSM_COLS == 0, "the look-ahead window is a whole number of column tiles");
-    if (win == 1 && t.a >= LOOKAHEAD_COLS / TRSM_COLS) return;
     int k = blockIdx.y;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
     int b = min(FACT_NB, p - k0);
-    const cz* Lp = fact + (int64_t)k * fs + f.lp;
-    for (int idx = threadIdx.x; idx < b * b; idx += blockDim.x) {
-        int i = idx % b, kk = idx / b;
-        s_l[i + kk * FACT_NB] = Lp[(k0 + i) + (int64_t)(k0 + kk) * ld];
-    }
     int nin = p - k0 - b, ncol = nin + u;
-    int v0 = t.a * TRSM_COLS;
-    // look-ahead window = pivot-block columns among the first LOOKAHEAD_COLS; a column is processed only in the pass it belongs to
-    auto mine = [&](int v) { return win == 0 || ((win == 1) == (v < LOOKAHEAD_COLS && v < nin)); };
-    auto colptr = [&](int v) -> cz* {
-        return (v < nin) ? fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0
-                         : fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
-    };
-    for (int idx = threadIdx.x; idx < TRSM_COLS * b; idx += TRSM_COLS) {     // b consecutive threads read one column's b rows
-        int i = idx % b, c = idx / b;
-        if (v0 + c < ncol && mine(v0 + c)) s_x[c][i] = colptr(v0 + c)[i];
+    {   // column tile without a selected column
+        int v0 = t.a * TRSM_COLS, v1 = v0 + TRSM_COLS;
+        bool any = (v0 < nin && v0 < cs.chi && min(v1, nin) > cs.clo) || (cs.u12 && v1 > nin);
+        if (!any) return;
+    }
+    const cz* Lp = fact + (int64_t)k * fs + f.lp;
+    for (int idx = threadIdx.x; idx < FACT_NB * FACT_NB; idx += TRSM_COLS) {      // rows / columns beyond b: zero (no coupling)
+        int i = idx % FACT_NB, kk = idx / FACT_NB;
+        s_l[idx] = (i < b && kk < i) ? Lp[(k0 + i) + (int64_t)(k0 + kk) * ld] : cz_make(0, 0);
     }
     __syncthreads();
-    int c = threadIdx.x;
-    if (v0 + c < ncol && mine(v0 + c)) {
-        for (int i = 1; i < b; ++i) {
-            cz xi = s_x[c][i];
-            for (int kk = 0; kk < i; ++kk) cz_msub(xi, s_l[i + kk * FACT_NB], s_x[c][kk]);
-            s_x[c][i] = xi;
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < TRSM_COLS * b; idx += TRSM_COLS) {
-        int i = idx % b, cc = idx / b;
-        if (v0 + cc < ncol && mine(v0 + cc)) colptr(v0 + cc)[i] = s_x[cc][i];
-    }
+    int v = t.a * TRSM_COLS + threadIdx.x;
+    bool mine = v < ncol && (v < nin ? (v >= cs.clo && v < cs.chi) : (cs.u12 != 0));
+    if (!mine) return;
+    cz* col = (v < nin) ? fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0
+                        : fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
+    cz x[FACT_NB];
+#pragma unroll
+    for (int i = 0; i < FACT_NB; ++i) x[i] = i < b ? col[i] : cz_make(0, 0);
+    // column sweeps x_i -= L_ik x_k (i > k).  k runs in a real loop (the multiplier x_k is selected from the eight registers of
+    // its block of rows, s_l holds zeros on and above the diagonal), so the L reads of one sweep are all that is in flight;
+    // with the k loop unrolled too the compiler hoists all 496 LDS reads and spills 1600 registers.
+    trsm_sweeps<0>(x, s_l);
+    trsm_sweeps<8>(x, s_l);
+    trsm_sweeps<16>(x, s_l);
+    trsm_sweeps<24>(x, s_l);
+#pragma unroll
+    for (int i = 1; i < FACT_NB; ++i)
+        if (i < b) col[i] = x[i];
 }
 
-void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, int win) {
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(TRSM_COLS), 0, st, S.fr, tiles, k0, fact, fs, win);
+    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(TRSM_COLS), 0, st, S.fr, tiles, k0, fact, fs, cs);
 }
 
 // ---------------------------------------------------------------------------
@@ -348,16 +560,27 @@ void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntile
 // that C is written with 16 consecutive m per lane group (256 B segments).
 // ---------------------------------------------------------------------------
 constexpr int GEMM_KC = 32;
+constexpr int GEMM_CHUNK = 64;     // work items per XCD chunk (one 8 x 8 super-tile)
 
 __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
-                                                  cz* fact, int64_t fs, cz* cb, int64_t cbs, int win) {
+                                                  cz* fact, int64_t fs, cz* cb, int64_t cbs, ColSel cs, int bw, int mrows, int ntiles, int K) {
+    // cs: the columns updated by this launch (pivot-block columns by offset from column k0 + bw; the U12 tiles when cs.u12).
+    // bw: width of the eliminated block, FACT_NB or the width of a group of panels that is applied in one product.
+    // mrows > 0: only the first mrows rows below the block (the U rows of the next panel of the group).
     __shared__ cz Bs[GEMM_KC][65];
-    Tile t = tiles[blockIdx.x];
-    if (win && (win == 1) != (t.a == 0 && t.c < LOOKAHEAD_COLS / 64)) return;      // window = the first two 64-column tiles of the pivot block
-    int k = blockIdx.y;
+    // Workgroups go to the XCDs round-robin.  XCD x takes the work items (node, tile) in chunks of GEMM_CHUNK consecutive items:
+    // the host lists the tiles of a front in 8 x 8 super-tiles, so the tiles in flight on one XCD share their A row panels
+    // and B column panels through that XCD's L2 instead of every tile fetching both from memory.
+    const int64_t seq = blockIdx.x >> 3;
+    const int64_t item = (seq / GEMM_CHUNK) * (8 * GEMM_CHUNK) + (int64_t)(blockIdx.x & 7) * GEMM_CHUNK + seq % GEMM_CHUNK;
+    if (item >= (int64_t)ntiles * K) return;
+    const int k = (int)(item / ntiles);
+    Tile t = tiles[item % ntiles];
+    if (t.a == 0 && (t.c * 64 >= cs.chi || t.c * 64 + 64 <= cs.clo)) return;
+    if (t.a == 1 && !cs.u12) return;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
-    int b = min(FACT_NB, p - k0);
+    int b = min(bw, p - k0);
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* F12 = fact + (int64_t)k * fs + f.f12;
     const cz *A, *B;
@@ -377,7 +600,11 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
         B = F12; ldb = p; N = u;
         C = cb + (int64_t)k * cbs + f.cb; ldc = u;
     }
+    if (mrows > 0 && t.a != 2) M = min(M, min(mrows, p - k0 - b));     // pivot-block rows only
+    int nlo = 0;
+    if (t.a == 0) { N = min(N, cs.chi); nlo = cs.clo; }
     int m0 = t.b * 64, n0 = t.c * 64;
+    if (m0 >= M || n0 >= N) return;
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int mrow = m0 + wave * 16 + li;
     bool mok = mrow < M;
@@ -402,7 +629,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
         for (int q = 0; q < GEMM_KC * 64 / 256; ++q) {
             int idx = tid + 256 * q;
             int kk = idx % GEMM_KC, nn = idx / GEMM_KC;
-            bool keep = (kc + kk < Kd) && (n0 + nn < N);
+            bool keep = (kc + kk < Kd) && (n0 + nn < N) && (n0 + nn >= nlo);
             Bs[kk][nn] = keep ? bvals[q] : cz_make(0, 0);
         }
 #pragma unroll
@@ -443,14 +670,16 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int gn = n0 + nt * 16 + lk + 4 * r;
-            if (mok && gn < N) C[mrow + (int64_t)gn * ldc] = cz_make(old[nt][r].x - cr[nt][r], old[nt][r].y - ci[nt][r]);
+            if (mok && gn < N && gn >= nlo) C[mrow + (int64_t)gn * ldc] = cz_make(old[nt][r].x - cr[nt][r], old[nt][r].y - ci[nt][r]);
         }
 }
 
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                    cz* cb, int64_t cbs, int K, int win) {
+                    cz* cb, int64_t cbs, int K, ColSel cs, int bw, int mrows) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_gemm_nn, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, cb, cbs, win);
+    const int64_t items = (int64_t)ntiles * K, per = 8 * GEMM_CHUNK;
+    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((items + per - 1) / per * per)), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, cb, cbs, cs, bw, mrows,
+                       ntiles, K);
 }
 
 // ---------------------------------------------------------------------------
