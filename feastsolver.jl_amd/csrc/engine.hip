@@ -291,6 +291,14 @@ bool Engine::build_plans() {
                 if (M1 > 0 && N1 > 0) push_supertiles(s, 1, cdiv(M1, 64), cdiv(N1, 64));
             }
             st.gemm.count = (int)(tiles.size() - st.gemm.off);
+            st.gemm0.off = (int64_t)tiles.size();        // first row of product tiles only: the 32-row products of the grouped U-row solves
+            for (int s : lv) if (S.p(s) > k0) {
+                int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0);
+                int N0 = p - k0 - b;
+                for (int c = 0; c < cdiv(N0, 64); ++c) tiles.push_back({s, 0, 0, c});
+                if (N0 > 0) for (int c = 0; c < cdiv(u, 64); ++c) tiles.push_back({s, 1, 0, c});
+            }
+            st.gemm0.count = (int)(tiles.size() - st.gemm0.off);
             F.steps.push_back(st);
         }
         F.cbgemm.off = (int64_t)tiles.size();
@@ -688,23 +696,20 @@ int Engine::factorize() {
                     c.u12 = others ? 1 : 0;
                     return c;
                 };
-                for (int j = j0; j < j1; ++j) {
-                    FactorStep& sj = F.steps[j];
-                    launch_swap(s, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, sel(sj.k0 + FACT_NB));
-                }
                 FactorStep& s0 = F.steps[j0];
+                const int gw = F.steps[j1 - 1].k0 + FACT_NB - k0g;        // group width
+                launch_swap(s, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, sel(k0g + gw), gw);
                 for (int j = j0; j < j1; ++j) {
                     FactorStep& sj = F.steps[j];
                     const int bw = sj.k0 - k0g;
                     if (bw > 0) {
                         ColSel c = sel(sj.k0); c.llo = c.lhi = 0;
-                        launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, c, bw, FACT_NB);
+                        launch_gemm_nn(s, dsym_, tl + s0.gemm0.off, s0.gemm0.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, c, bw, FACT_NB);
                     }
                     ColSel c = sel(sj.k0 + FACT_NB);
                     launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
                 }
-                const int bw = F.steps[j1 - 1].k0 + FACT_NB - k0g;
-                launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + bw), bw, 0);
+                launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0);
             };
             for (int g = 0; g < ng; ++g) {
                 const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;

@@ -37,7 +37,7 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
 struct ColSel { int llo = 0, lhi = 1 << 30, clo = 0, chi = 1 << 30, u12 = 1; };
 inline ColSel col_right(int clo, int chi) { ColSel c; c.llo = 0; c.lhi = 0; c.clo = clo; c.chi = chi; c.u12 = 0; return c; }
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                 const int* piv, int K, ColSel cs = ColSel());
+                 const int* piv, int K, ColSel cs = ColSel(), int bw = FACT_NB);
 void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs = ColSel());
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                     cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0);

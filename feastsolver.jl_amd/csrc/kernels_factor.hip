@@ -446,12 +446,13 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
 // left columns (the L columns of earlier panels) with llo <= index < lhi, pivot-block columns right of the panel whose
 // offset from the first such column lies in [clo, chi), and the U12 columns when u12 is set.
 __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
-                       const int* __restrict__ piv, int npiv, ColSel cs) {
+                       const int* __restrict__ piv, int npiv, ColSel cs, int bw) {
+    // bw: FACT_NB, or the width of a group of panels whose interchanges are applied in one pass
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
-    int b = min(FACT_NB, p - k0);
+    int b = min(bw, p - k0);
     int v = t.a * 256 + threadIdx.x;
     int nv = (p - b) + u;
     if (v >= nv) return;
@@ -474,9 +475,9 @@ __global__ void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ t
 }
 
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                 const int* piv, int K, ColSel cs) {
+                 const int* piv, int K, ColSel cs, int bw) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n, cs);
+    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n, cs, bw);
 }
 
 // ---------------------------------------------------------------------------
