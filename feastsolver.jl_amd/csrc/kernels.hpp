@@ -5,7 +5,6 @@
 namespace feasthip {
 
 constexpr int FACT_NB = 32;     // panel width of the blocked front factorisation
-constexpr int LOOKAHEAD_COLS = 128;   // columns right of the panel that the look-ahead stream updates before it factors the next panel
 constexpr int SOLVE_NB = 128;   // diagonal (super)block of the inverse-based block substitution
 constexpr int INV_NB = 64;      // size of the directly inverted triangular blocks (two are coupled into a super block)
 constexpr int TRSM_COLS = 64;       // columns per workgroup of the U-row triangular solves
