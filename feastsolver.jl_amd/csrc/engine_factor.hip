@@ -1,0 +1,221 @@
+// Numeric factorisation of the shifted matrices T(z_k) of all local contour nodes (src/feast.jl:59-62, src/nlfeast.jl:33-45).
+#include "engine_impl.hpp"
+
+namespace feasthip {
+
+void Engine::eval_coefs(const zc* pts, int count, std::vector<zc>& out) {
+    out.assign((size_t)count * nterms, zc(0.0));
+    if (coef_fn_) {
+        coef_fn_(reinterpret_cast<const double*>(pts), count, reinterpret_cast<double*>(out.data()), coef_user_);
+        return;
+    }
+    for (int i = 0; i < count; ++i) { zc zp = 1.0; for (int t = 0; t < nterms; ++t) { out[(size_t)i * nterms + t] = zp; zp *= pts[i]; } }
+}
+
+int Engine::set_coef_functions(feasthip_coef_fn fn, void* user) {
+    coef_fn_ = fn; coef_user_ = user;
+    factored_ = false;
+    return 0;
+}
+
+int Engine::set_node_coefficients(const double* coef, int K_, int nterms_) {
+    if (!coef) { node_coef_.clear(); factored_ = false; return 0; }
+    if (K_ != K || nterms_ != nterms) return fail(FEASTHIP_EARG, "set_node_coefficients: table must be K x nterms (set the contour and the terms first)");
+    node_coef_.assign(reinterpret_cast<const zc*>(coef), reinterpret_cast<const zc*>(coef) + (size_t)K * nterms);
+    factored_ = false;
+    return 0;
+}
+
+int Engine::factorize() {
+    if (!analyzed_) { int r = analyze(); if (r) return r; }
+    HIPCHK(hipSetDevice(device_));
+    // per-node coefficients scale_t * f_t(z_k) (f_t = z^t unless overridden) and pivot thresholds
+    std::vector<zc> coef((size_t)Kloc * nterms), fz, zloc(Kloc);
+    std::vector<double> tiny(Kloc);
+    for (int kk = 0; kk < Kloc; ++kk) zloc[kk] = nodes_[local_[kk]];
+    if (node_coef_.empty()) eval_coefs(zloc.data(), Kloc, fz);
+    for (int kk = 0; kk < Kloc; ++kk) {
+        double nrm = 0;
+        for (int t = 0; t < nterms; ++t) {
+            zc f = node_coef_.empty() ? fz[(size_t)kk * nterms + t] : node_coef_[(size_t)local_[kk] * nterms + t];
+            coef[(size_t)kk * nterms + t] = terms_[t].scale * f;
+            nrm += std::abs(coef[(size_t)kk * nterms + t]) * terms_[t].maxabs;
+        }
+        tiny[kk] = std::max(nrm * 2.2e-19, 1e-300);
+    }
+    HIPCHK(hipMemcpyAsync(d_coef_.p, coef.data(), coef.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(d_tiny_.p, tiny.data(), tiny.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemsetAsync(d_nperturb_.p, 0, Kloc * sizeof(int), stream_));
+    HIPCHK(hipStreamSynchronize(stream_));   // coef/tiny are stack-owned host buffers
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int64_t fs = S.fact_size;
+    if (dense) {
+        std::vector<const cz*> ptrs(nterms);
+        for (int t = 0; t < nterms; ++t) ptrs[t] = terms_[t].identity ? nullptr : terms_[t].d_dense.p;
+        if (!d_matptr_.upload(ptrs.data(), nterms, stream_)) return fail(FEASTHIP_EHIP, "factorize: upload failed");
+        launch_dense_assemble(stream_, d_fact_.p, fs, n, d_matptr_.p, nterms, d_coef_.p, Kloc);
+    } else {
+        HIPCHK(hipMemsetAsync(d_fact_.p, 0, (size_t)Kloc * fs * sizeof(cz), stream_));
+        for (int t = 0; t < nterms; ++t)
+            launch_scatter(stream_, d_fact_.p, fs, terms_[t].d_dest.p, terms_[t].d_cscval.p, terms_[t].colptr[n], d_coef_.p, nterms, t, Kloc);
+    }
+    const Tile* tl = d_tiles_.p;
+    const int* ls = d_lists_.p;
+    bool fin_used = false;
+    // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
+    const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
+    std::vector<hipEvent_t> tev;
+    auto stamp = [&]() { if (ftrace) { hipEvent_t e4; (void)hipEventCreate(&e4); (void)hipEventRecord(e4, stream_); tev.push_back(e4); } };
+    stamp();
+    for (int d = S.maxdepth; d >= 0; --d) {
+        FactorLevel& F = fplan_[d];
+        int par = d & 1;
+        cz* cbp = d_cb_[par].p;
+        int64_t cbs = std::max<int64_t>(1, S.cb_size[par]);
+        launch_extend_add(stream_, dsym_, tl + F.extend.off, F.extend.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
+                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 0);
+        int level_ld = 0;
+        for (int s2 : S.levels[d]) level_ld = std::max(level_ld, S.p(s2) + S.u(s2));
+        const bool tall = level_ld >= 1024;      // 1024-thread panel workgroups for tall fronts (430 -> 396 ms for the 16 factorisations of C3)
+        int level_p = 0;
+        for (int s2 : S.levels[d]) level_p = std::max(level_p, S.p(s2));
+        const bool lookahead = look_ahead_ && level_p >= 256 && la_stream_ && F.steps.size() >= 4;
+        stamp();
+        if (!lookahead) {
+            for (FactorStep& st : F.steps) {
+                launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - st.k0);
+                launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
+                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
+                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
+            }
+        } else {
+            // LU with look-ahead for the big fronts at the top of the tree (few fronts x nodes: the panel factorisation runs on a
+            // handful of workgroups and would otherwise leave the GPU idle between two trailing updates).  The panels are taken
+            // in groups of group_panels_ (columns [K0_g, K0_g+1)).  The high-priority stream P factors the panels of group g,
+            // updating only the group's own columns in between, and then applies the whole group, as one product of depth
+            // K0_g+1 - K0_g, to the columns of group g+1 (W below).  The main stream applies group g to everything else (the
+            // left columns' row interchanges, the pivot-block columns from K0_g+2 on and U12) while P is busy with group g+1.
+            // Deferring a group's update is legal because all its row interchanges are applied first, to L and to C alike; the
+            // U rows then come from a blocked forward substitution (a 32-row product with the panels before it, then the
+            // triangular solve with the panel's own L11) and the rest is one product.  Against per-panel updates the product
+            // reads and writes C once per group instead of once per panel, which is what bounds it.
+            hipStream_t P = la_stream_, R = rest_stream_ ? rest_stream_ : stream_;
+            HIPCHK(hipEventRecord(ev_la_[4], stream_));
+            HIPCHK(hipStreamWaitEvent(P, ev_la_[4], 0));
+            if (R != stream_) HIPCHK(hipStreamWaitEvent(R, ev_la_[4], 0));
+            const int ns = (int)F.steps.size(), G = group_panels_, ng = (ns + G - 1) / G;
+            const int INF = 1 << 30;
+            auto K0 = [&](int g) { return g * G < ns ? F.steps[(size_t)g * G].k0 : INF; };       // first column of group g
+            // all of group g (panels already factored) applied to the columns [c_lo, c_hi) of the pivot block, and to the left
+            // columns [0, K0_g) and U12 when `others`
+            auto apply_group = [&](hipStream_t s, int g, int c_lo, int c_hi, bool others) {
+                const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
+                auto sel = [&](int origin) {          // column offsets relative to the first column right of `origin`
+                    ColSel c;
+                    c.llo = 0; c.lhi = others ? k0g : 0;
+                    c.clo = std::max(0, c_lo - origin); c.chi = c_hi >= INF ? INF : std::max(0, c_hi - origin);
+                    c.u12 = others ? 1 : 0;
+                    return c;
+                };
+                FactorStep& s0 = F.steps[j0];
+                const int gw = F.steps[j1 - 1].k0 + FACT_NB - k0g;        // group width
+                launch_swap(s, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, sel(k0g + gw), gw);
+                for (int j = j0; j < j1; ++j) {
+                    FactorStep& sj = F.steps[j];
+                    const int bw = sj.k0 - k0g;
+                    if (bw > 0) {
+                        ColSel c = sel(sj.k0); c.llo = c.lhi = 0;
+                        launch_gemm_nn(s, dsym_, tl + s0.gemm0.off, s0.gemm0.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, c, bw, FACT_NB);
+                    }
+                    ColSel c = sel(sj.k0 + FACT_NB);
+                    launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                }
+                launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0);
+            };
+            for (int g = 0; g < ng; ++g) {
+                const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
+                const int kend = K0(g + 1);                     // first column after the group (INF for the last group)
+                if (g > 0) {
+                    if (g > 1) HIPCHK(hipStreamWaitEvent(P, ev_la_[2 + (g & 1)], 0));      // rest of group g-2 reaches these columns
+                    apply_group(P, g - 1, k0g, kend, false);
+                }
+                for (int j = j0; j < j1; ++j) {
+                    FactorStep& sj = F.steps[j];
+                    launch_panel(P, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall,
+                                 level_ld - sj.k0);
+                    // inside the group: interchanges on the group's earlier L columns and its remaining columns, U rows and update
+                    // of the remaining columns
+                    ColSel c;
+                    c.llo = k0g; c.lhi = sj.k0; c.clo = 0; c.chi = kend >= INF ? INF : std::max(0, kend - sj.k0 - FACT_NB); c.u12 = 0;
+                    launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
+                    if (c.chi > 0) {
+                        c.llo = c.lhi = 0;
+                        launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                        launch_gemm_nn(P, dsym_, tl + sj.gemm.off, sj.gemm.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
+                    }
+                }
+                HIPCHK(hipEventRecord(ev_la_[g & 1], P));
+                HIPCHK(hipStreamWaitEvent(R, ev_la_[g & 1], 0));
+                apply_group(R, g, K0(g + 2), INF, true);
+                HIPCHK(hipEventRecord(ev_la_[2 + (g & 1)], R));
+            }
+            HIPCHK(hipEventRecord(ev_la_[5], P));
+            HIPCHK(hipStreamWaitEvent(stream_, ev_la_[5], 0));
+            if (R != stream_) { HIPCHK(hipEventRecord(ev_la_[6], R)); HIPCHK(hipStreamWaitEvent(stream_, ev_la_[6], 0)); }
+        }
+        stamp();
+        launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
+        stamp();
+        // The solve-ready conversion of this level (row permutations, block inverses, panel scaling) only touches this
+        // level's own panels, which nothing above reads (parents take the contribution blocks): it runs on a side stream
+        // next to the factorisation of the levels above.  It must follow the Schur-complement product, which reads L21 / U12.
+        hipStream_t fin = (finalize_async_ && !aux_streams_.empty()) ? aux_streams_[0] : stream_;
+        if (fin != stream_) { HIPCHK(hipEventRecord(ev_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fork_, 0)); fin_used = true; }
+        launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
+        launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
+        launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
+        launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
+        launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
+                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
+    }
+    if (fin_used) { HIPCHK(hipEventRecord(ev_join_[0], aux_streams_[0])); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0)); }
+    if (ftrace) {
+        stamp();
+        HIPCHK(hipStreamSynchronize(stream_));
+        auto ms = [&](size_t a, size_t b) { float t = 0; (void)hipEventElapsedTime(&t, tev[a], tev[b]); return t; };
+        size_t q = 0;
+        for (int d = S.maxdepth; d >= 0; --d, q += 3) {
+            int mp = 0, mu = 0;
+            double fl_schur = 0, fl_steps = 0;
+            for (int s2 : S.levels[d]) {
+                double p2 = S.p(s2), u2 = S.u(s2);
+                mp = std::max(mp, S.p(s2)); mu = std::max(mu, S.u(s2));
+                fl_schur += 8.0 * u2 * u2 * p2 * Kloc;
+                fl_steps += 8.0 * (p2 * p2 * p2 / 3.0 + p2 * p2 * u2) * Kloc;      // LU of the pivot block, L21 and U12 (8 flops per complex multiply-add)
+            }
+            fprintf(stderr, "[feasthip factor] depth %2d  fronts %5zu  max p %5d  max u %5d  steps %3zu | extend-add %7.2f  panel steps %7.2f (%5.1f TF)  schur product %7.2f ms (%5.1f TF)\n",
+                    d, S.levels[d].size(), mp, mu, fplan_[d].steps.size(), ms(q, q + 1), ms(q + 1, q + 2), fl_steps / ms(q + 1, q + 2) * 1e-9, ms(q + 2, q + 3), fl_schur / ms(q + 2, q + 3) * 1e-9);
+        }
+        for (hipEvent_t e4 : tev) (void)hipEventDestroy(e4);
+    }
+    if (mixed_) {      // complex64 copy of the solve-ready factors for the mixed-precision sweeps
+        if (!d_fact32_.alloc((size_t)Kloc * fs)) return fail(FEASTHIP_EHIP, "out of device memory for the complex64 factors");
+        launch_to_f32(stream_, (int64_t)Kloc * fs, d_fact_.p, d_fact32_.p);
+    }
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    std::vector<int> np(Kloc);
+    HIPCHK(hipMemcpyAsync(np.data(), d_nperturb_.p, Kloc * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    factor_ms = ms;
+    perturbed = 0;
+    for (int v : np) perturbed += v;
+    factored_ = true;
+    return perturbed > 0 ? (int)std::min<int64_t>(perturbed, 0x7fffffff) : 0;
+}
+
+// ---------------------------------------------------------------------------
+
+}  // namespace feasthip

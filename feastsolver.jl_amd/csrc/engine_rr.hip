@@ -1,0 +1,263 @@
+// Term products, orthonormalisation and the Rayleigh-Ritz step (src/feast.jl:33-57, 108-131; src/utils.jl:69-77).
+#include "engine_impl.hpp"
+
+namespace feasthip {
+
+void Engine::apply_term(int t, const cz* V, cz* out, zc alpha, bool accumulate) { apply_term_ld(t, V, out, alpha, accumulate, ldw); }
+
+void Engine::apply_term_ld(int t, const cz* V, cz* out, zc alpha, bool accumulate, int ld) {
+    SparseTerm& T = terms_[t];
+    zc a = alpha * T.scale;
+    if (dense) {
+        if (T.identity) launch_axpby(stream_, n, ld, out, to_cz(a), V, accumulate ? 1 : 0);
+        else launch_dense_mv(stream_, n, T.d_dense.p, V, ld, out, to_cz(a), accumulate ? 1 : 0);
+    } else {
+        launch_spmm_csr(stream_, n, T.d_rowptr.p, T.d_col.p, T.d_val.p, V, ld, out, to_cz(a), accumulate ? 1 : 0);
+    }
+}
+
+int Engine::col_norms(const Tall& t, const cz* V, std::vector<double>& out) {
+    launch_colnorm2(stream_, t.rows, t.ld, V, t.nrm_scratch, t.nrm);
+    out.resize(t.ld);
+    HIPCHK(hipMemcpyAsync(out.data(), t.nrm, t.ld * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (double& v : out) v = std::sqrt(v);
+    return 0;
+}
+
+// Thin orthonormal basis of span(Q) (replaces `Q .= Matrix(qr(Q).Q)`, src/feast.jl:41,117).
+// Column-scaled CholeskyQR2: columns are normalised first (the FEAST filter scales column j by
+// rho(lambda_j), which is the dominant source of ill-conditioning), then two Cholesky passes on
+// the f64-MFMA Gram matrix.  Rtotal (optional) receives R with Q_in = Q_out * R.
+int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
+    const int m = t.m, rows = t.rows, ld = t.ld;
+    std::vector<zc> G((size_t)m * m), Rn((size_t)m * m), Rt, Tm((size_t)m * m);
+    if (Rtotal) { Rt.assign((size_t)m * m, zc(0.0)); for (int j = 0; j < m; ++j) Rt[j + (size_t)j * m] = 1.0; }
+    cz* dG = t.small;
+    cz* dM = t.small + (size_t)2 * ld * ld;
+    cz* src = Q;
+    cz* dst = tmp;
+    // two clean passes; a pass that needed a shift (numerically rank-deficient block) is followed by one more.
+    // The column scaling is folded into the first pass on the host: the Gram matrix of the scaled block is
+    // D G D with D = diag(G)^-1/2 (each G_ij carries a relative error eps in units of |q_i||q_j| either way),
+    // which saves a norm pass, a scaling pass and a host round trip over the n x m block.
+    int need = 2;
+    for (int pass = 0; pass < 6 && need > 0; ++pass) {
+        launch_gram(stream_, rows, m, ld, src, src, t.gram, dG);
+        HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (G[i + (size_t)j * m] + std::conj(G[j + (size_t)i * m])); G[i + (size_t)j * m] = a; G[j + (size_t)i * m] = std::conj(a); }
+        std::vector<double> dsc(m, 1.0);
+        if (pass == 0) {
+            for (int j = 0; j < m; ++j) {
+                double g = G[j + (size_t)j * m].real();
+                if (!(g > 0.0) || !std::isfinite(g)) return fail(FEASTHIP_ENUM, "orthonormalize: zero or non-finite column in the subspace");
+                dsc[j] = std::sqrt(g);
+            }
+            for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) G[i + (size_t)j * m] /= dsc[i] * dsc[j];
+        }
+        std::vector<zc> Gc(G);
+        int info = cholesky_upper(m, Gc.data());
+        if (info) {   // shifted CholeskyQR for a numerically rank-deficient block
+            double tr = 0;
+            for (int j = 0; j < m; ++j) tr += G[j + (size_t)j * m].real();
+            double shift = 1e-13 * tr + 1e-300;
+            for (int tries = 0; tries < 6 && info; ++tries) {
+                Gc = G;
+                for (int j = 0; j < m; ++j) Gc[j + (size_t)j * m] += shift;
+                info = cholesky_upper(m, Gc.data());
+                shift *= 100.0;
+            }
+            if (info) return fail(FEASTHIP_ENUM, "orthonormalize: Gram matrix not positive definite");
+            need = 1;
+        } else {
+            --need;
+        }
+        if (Rtotal) {   // Q_src = Q_dst (R D^-1)  ->  Rt <- (R D^-1) Rt   (only the Beyn step needs the accumulated factor)
+            std::vector<zc> Rd(Gc);
+            for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) Rd[i + (size_t)j * m] *= dsc[j];
+            matmul(m, Rd.data(), Rt.data(), Rn.data());
+            Rt.swap(Rn);
+        }
+        trtri_upper(m, Gc.data());
+        for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) Tm[i + (size_t)j * m] = Gc[i + (size_t)j * m] / dsc[i];     // T = D^-1 R^-1
+        HIPCHK(hipMemcpyAsync(dM, Tm.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        launch_ts_gemm(stream_, rows, m, ld, src, dM, dst);
+        std::swap(src, dst);
+    }
+    if (src != Q) HIPCHK(hipMemcpyAsync(Q, src, (size_t)rows * ld * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+    if (Rtotal) *Rtotal = Rt;
+    return 0;
+}
+
+// Rank-revealing variant for numerically rank-deficient blocks (the block-Hankel matrix of nlfeast_moments! has
+// rank = #eigenvalues inside as soon as the iteration converges).  Iterated pivoted block Gram-Schmidt built from
+// the same two device operations as above (MFMA Gram, tall-skinny GEMM): per pass a pivoted partial Cholesky of the
+// Gram matrix on the host accepts the columns that kept at least 1e-8 of their squared norm (the rest would be
+// decided on cancellation noise), orthonormalises them and projects them out of the others explicitly; columns
+// whose explicitly formed remainder is below 1e-13 of their original norm are dropped (zeroed).  On return
+// Q_in = Q_out * Rtot, kept columns of Q_out are orthonormal, dropped ones (keep[j] = 0) are zero.
+int Engine::orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rtot, std::vector<uint8_t>& keep) {
+    const int m = t.m, rows = t.rows, ld = t.ld;
+    std::vector<double> nr;
+    int r = col_norms(t, Q, nr);
+    if (r) return r;
+    std::vector<zc> sc(ld, zc(0.0));
+    Rtot.assign((size_t)m * m, zc(0.0));
+    keep.assign(m, 1);
+    for (int j = 0; j < m; ++j) {
+        if (!std::isfinite(nr[j])) return fail(FEASTHIP_ENUM, "orthonormalize: non-finite column in the subspace");
+        if (nr[j] > 0.0) { sc[j] = 1.0 / nr[j]; Rtot[j + (size_t)j * m] = nr[j]; } else keep[j] = 0;
+    }
+    HIPCHK(hipMemcpyAsync(t.lam, sc.data(), ld * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_scale_cols(stream_, rows, ld, Q, t.lam);
+    HIPCHK(hipStreamSynchronize(stream_));
+    const double tol_keep = 1e-8, tol_drop2 = 1e-26;       // squared-norm thresholds (columns are scaled to unit norm)
+    std::vector<zc> G((size_t)m * m), W((size_t)m * m), T((size_t)m * m), Ti((size_t)m * m), Rn((size_t)m * m), R11, R11i;
+    cz* dG = t.small;
+    cz* dM = t.small + (size_t)2 * ld * ld;
+    for (int pass = 0; pass < 10; ++pass) {
+        launch_gram(stream_, rows, m, ld, Q, Q, t.gram, dG);
+        HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (G[i + (size_t)j * m] + std::conj(G[j + (size_t)i * m])); G[i + (size_t)j * m] = a; G[j + (size_t)i * m] = std::conj(a); }
+        W = G;
+        std::vector<double> d0(m);
+        std::vector<int> state(m, 0), acc;                   // 0 undecided, 1 accepted, 2 dropped
+        double defect = 0;
+        for (int j = 0; j < m; ++j) {
+            d0[j] = G[j + (size_t)j * m].real();
+            if (!keep[j] || !(d0[j] >= tol_drop2)) { state[j] = 2; keep[j] = 0; }
+        }
+        for (int j = 0; j < m; ++j) if (state[j] == 0) for (int i = 0; i < m; ++i) if (state[i] == 0) defect = std::max(defect, std::abs(G[i + (size_t)j * m] - (i == j ? 1.0 : 0.0)));
+        std::vector<std::vector<zc>> rowsR;                  // row t of [R11 R12] over all columns
+        for (;;) {
+            int bj = -1; double bd = 0;
+            for (int j = 0; j < m; ++j) if (state[j] == 0) { double d = W[j + (size_t)j * m].real(); if (d >= tol_keep * d0[j] && d > bd) { bd = d; bj = j; } }
+            if (bj < 0) break;
+            double piv = std::sqrt(bd);
+            std::vector<zc> row(m, zc(0.0));
+            for (int i = 0; i < m; ++i) if (state[i] == 0) row[i] = W[bj + (size_t)i * m] / piv;
+            row[bj] = piv;
+            state[bj] = 1;
+            for (int b = 0; b < m; ++b) if (state[b] == 0) for (int a = 0; a < m; ++a) if (state[a] == 0) W[a + (size_t)b * m] -= std::conj(row[a]) * row[b];
+            acc.push_back(bj);
+            rowsR.push_back(row);
+        }
+        int ra = (int)acc.size(), ndef = 0;
+        for (int j = 0; j < m; ++j) if (state[j] == 0) ++ndef;   // deferred: projected now, decided on the next pass
+        // R11 (ra x ra, upper triangular in acceptance order) and its inverse
+        R11.assign((size_t)ra * ra, zc(0.0));
+        for (int tt = 0; tt < ra; ++tt) for (int s2 = tt; s2 < ra; ++s2) R11[tt + (size_t)s2 * ra] = rowsR[tt][acc[s2]];
+        R11i = R11;
+        if (ra > 0) trtri_upper(ra, R11i.data());
+        std::fill(T.begin(), T.end(), zc(0.0));
+        std::fill(Ti.begin(), Ti.end(), zc(0.0));
+        for (int s2 = 0; s2 < ra; ++s2) for (int tt = 0; tt <= s2; ++tt) T[acc[tt] + (size_t)acc[s2] * m] = R11i[tt + (size_t)s2 * ra];
+        for (int tt = 0; tt < ra; ++tt) for (int i = 0; i < m; ++i) if (state[i] != 2) Ti[acc[tt] + (size_t)i * m] = rowsR[tt][i];
+        for (int b = 0; b < m; ++b) if (state[b] == 0) {
+            T[b + (size_t)b * m] = 1.0; Ti[b + (size_t)b * m] = 1.0;
+            for (int tt = 0; tt < ra; ++tt) { zc v = 0; for (int s2 = tt; s2 < ra; ++s2) v += R11i[tt + (size_t)s2 * ra] * rowsR[s2][b]; T[acc[tt] + (size_t)b * m] = -v; }
+        }
+        matmul(m, Ti.data(), Rtot.data(), Rn.data());        // Q_orig = Q_cur Rtot = (Q_cur T)(T^-1 Rtot)
+        Rtot.swap(Rn);
+        HIPCHK(hipMemcpyAsync(dM, T.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        launch_ts_gemm(stream_, rows, m, ld, Q, dM, tmp);
+        HIPCHK(hipMemcpyAsync(Q, tmp, (size_t)rows * ld * sizeof(cz), hipMemcpyDeviceToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        // done once a pass started from an orthonormal kept set (Gram = I to 1e-10) and deferred nothing
+        if (ndef == 0 && defect < 1e-10) break;
+    }
+    return 0;
+}
+
+void Engine::inside_test(const zc* lam, uint8_t* inside) const {
+    for (int j = 0; j < m0; ++j) {
+        if (region_kind_ == FEASTHIP_REGION_RECT)
+            inside[j] = (region_[0] < lam[j].real() && lam[j].real() < region_[2] && region_[1] < lam[j].imag() && lam[j].imag() < region_[3]) ? 1 : 0;
+        else
+            inside[j] = (std::abs(lam[j] - zc(region_[0], region_[1])) <= region_[2]) ? 1 : 0;
+    }
+}
+
+int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "rr_step: call set_x first");
+    if (nterms != 2) return fail(FEASTHIP_ESTATE, "rr_step: linear pencil (2 terms) required");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int m = m0;
+    int r = orthonormalize(Qp(), d_T1_.p, nullptr);                     // src/feast.jl:41
+    if (r) return r;
+    cz* dA = d_small_.p;
+    cz* dB = d_small_.p + (size_t)ldw * ldw;
+    cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
+    std::vector<zc> Aq((size_t)m * m), Bq((size_t)m * m), lam(m), Xq((size_t)m * m);
+    apply_term(0, Qp(), d_R_.p, 1.0, false);                            // R = A Q          :42
+    launch_gram(stream_, n, m, ldw, Qp(), d_R_.p, d_gram_scratch_.p, dA);   // Aq = Q' R   :43
+    // B = -scale_1 * M_1
+    bool b_is_identity = terms_[1].identity && std::abs(terms_[1].scale + 1.0) == 0.0;
+    if (!b_is_identity) {
+        apply_term(1, Qp(), d_T1_.p, -1.0, false);                      // R = B Q          :120
+        launch_gram(stream_, n, m, ldw, Qp(), d_T1_.p, d_gram_scratch_.p, dB);   // Bq    :121
+        HIPCHK(hipMemcpyAsync(Bq.data(), dB, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    }
+    HIPCHK(hipMemcpyAsync(Aq.data(), dA, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    // Julia's eigen! takes the Hermitian(-definite) LAPACK path for exactly Hermitian input; here the projected
+    // matrices are Hermitian up to rounding whenever A, B are, and the same path is taken below 1e-13.
+    auto th0 = std::chrono::steady_clock::now();
+    int info = 1;
+    bool herm = hermitian_defect(m, Aq.data()) <= 1e-13 && (b_is_identity || hermitian_defect(m, Bq.data()) <= 1e-13);
+    if (herm) {
+        std::vector<zc> a2(Aq), b2(Bq);
+        info = eig_hermitian(m, a2.data(), b_is_identity ? nullptr : b2.data(), lam.data(), Xq.data());
+    }
+    if (info) info = b_is_identity ? eig_general(m, Aq.data(), lam.data(), Xq.data())     // :45
+                                   : eig_generalized(m, Aq.data(), Bq.data(), lam.data(), Xq.data());   // :122
+    if (info) return fail(FEASTHIP_ENUM, "rr_step: reduced eigenproblem failed to converge");
+    if (getenv("FEASTHIP_RR_TRACE"))
+        fprintf(stderr, "[feasthip] reduced eigenproblem (m=%d, %s): %.3f ms host\n", m, herm ? "hermitian" : "general",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
+    // update_R! normalises the columns of X = Q Xq (src/utils.jl:113); Q is orthonormal, so ||X_j|| = ||Xq_j||
+    // and the normalisation is applied to the m x m Xq on the host (no extra pass over the n x m block)
+    for (int j = 0; j < m; ++j) {
+        double nq = 0;
+        for (int i = 0; i < m; ++i) nq += std::norm(Xq[i + (size_t)j * m]);
+        nq = std::sqrt(nq);
+        if (nq > 0) for (int i = 0; i < m; ++i) Xq[i + (size_t)j * m] /= nq;
+    }
+    std::vector<zc> lamp(ldw, zc(0.0));
+    for (int j = 0; j < m; ++j) lamp[j] = lam[j];
+    HIPCHK(hipMemcpyAsync(dM, Xq.data(), (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(d_lam_.p, lamp.data(), ldw * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_ts_gemm(stream_, n, m, ldw, Qp(), dM, d_X_.p);              // X = Q Xq         :48
+    std::vector<double> nr;
+    const cz* BX = d_X_.p;
+    if (dense) {
+        // A X = (A Q) Xq, B X = (B Q) Xq: reuse the products of the projection instead of two more n x n passes
+        launch_ts_gemm(stream_, n, m, ldw, d_R_.p, dM, d_T2_.p);                       // A X
+        if (!b_is_identity) { launch_ts_gemm(stream_, n, m, ldw, d_T1_.p, dM, d_MX_.p); BX = d_MX_.p; }
+        launch_residual_combine(stream_, n, ldw, d_T2_.p, BX, d_lam_.p, d_R_.p);
+    } else {
+        // A X = (A Q) Xq: one tall-skinny GEMM on the product the projection already formed instead of a second
+        // SpMM with A (the gather of 19 block-vector rows per row costs twice as much); B X is a cheap SpMM
+        launch_ts_gemm(stream_, n, m, ldw, d_R_.p, dM, d_T1_.p);        // A X
+        if (!b_is_identity) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
+        launch_residual_combine(stream_, n, ldw, d_T1_.p, BX, d_lam_.p, d_R_.p);
+    }
+    r = col_norms(d_R_.p, nr);                                           // residuals! :166-171
+    if (r) return r;
+    lambda_ = lam;
+    for (int j = 0; j < m; ++j) { lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag(); res[j] = nr[j]; }
+    inside_test(lam.data(), inside);
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    rr_ms = ms;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+
+}  // namespace feasthip

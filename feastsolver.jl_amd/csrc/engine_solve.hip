@@ -1,0 +1,216 @@
+// Block substitution over all local nodes, moment accumulation, contour step (src/feast.jl:59-71), stochastic count estimate.
+#include "engine_impl.hpp"
+
+namespace feasthip {
+
+int Engine::solve_all(const cz* rhs) { return solve_all_impl(rhs, nullptr); }
+
+int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof) {
+    if (mixed_) return solve_range_t<cf>(st, kb, kc, rhs, prof, d_fact32_.p, d_W32_.p, d_Y32_.p, d_crow32_[0].p, d_crow32_[1].p, d_sk32_.p);
+    return solve_range_t<cz>(st, kb, kc, rhs, prof, d_fact_.p, d_W_.p, d_Y_.p, d_crow_[0].p, d_crow_[1].p, d_sk_.p);
+}
+
+template <typename T>
+int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall) {
+    int64_t fs = S.fact_size, ws = (int64_t)n * ldw;
+    T* crowb[2] = {crow0, crow1};
+    T* Fp = fact + (int64_t)kb * fs;
+    T* Wp = Wall + (int64_t)kb * ws;
+    T* Yp = Yall + (int64_t)kb * ws;
+    const int* rperm = d_rowperm_.p + (int64_t)kb * n;
+    const int* rinv = d_rowinv_.p + (int64_t)kb * n;
+    const Tile* tl = d_tiles_.p;
+    hipEvent_t pa = nullptr, pb = nullptr;
+    if (prof) { HIPCHK(hipEventCreate(&pa)); HIPCHK(hipEventCreate(&pb)); }
+    if (prof) prof_detail.clear();
+    int cur_tiles = 0;
+    auto begin = [&]() { if (prof) (void)hipEventRecord(pa, st); };
+    auto end = [&](int row, double bytes, double flops) {
+        if (!prof) return;
+        (void)hipEventRecord(pb, st);
+        (void)hipEventSynchronize(pb);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, pa, pb);
+        prof[row].ms += ms; prof[row].bytes += bytes; prof[row].flops += flops; prof[row].launches++;
+        prof_detail.insert(prof_detail.end(), {(double)row, (double)ms, bytes, flops, (double)cur_tiles});
+    };
+    double rowb = (double)ldw * sizeof(T);
+    begin();
+    launch_gather_rhs(st, dsym_, rhs, ldw, Wp, ws, rperm, kc);
+    end(0, 2.0 * n * rowb * kc, 0);
+    // Launch::bytes counts factor bytes, Launch::flops complex multiply-adds per block-vector column (one node)
+    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes * (sizeof(T) / 16.0) + vec_rows * rowb) * kc; };
+    auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * kc; };
+    for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
+        SolveLevel& V = splan_[d];
+        int par = d & 1;
+        int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
+        begin();
+        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs,
+                            (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, rinv, kc, 0);
+        if (V.assemble.count) end(1, 3.0 * V.asm_rows * rowb * kc, 0);
+        double lvl_rows = 0;
+        for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
+        for (Launch& L : V.f1) {
+            begin();
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc);
+            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
+        }
+        begin();
+        // contribution rows of the children that pass through to this level's contribution rows are pulled in the
+        // epilogue of the F2a tiles (kind 1), so there is no second assembly pass
+        launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
+                     nullptr, 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc);
+        if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows + V.pull_rows), stat_flops(V.f2)); }
+    }
+    for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
+        SolveLevel& V = splan_[d];
+        double lvl_p = 0, lvl_u = 0;
+        for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
+        begin();
+        int64_t sks = std::max<int64_t>(1, sk_rows_) * ldw;
+        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, skall + (int64_t)kb * sks, sks);
+        if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Yp, ws, ldw, skall + (int64_t)kb * sks, sks, kc);
+        if (V.b1.count) { cur_tiles = -V.b1.count; end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1)); }
+        for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
+            Launch& L = V.b2[c];
+            begin();
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
+            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
+        }
+        begin();
+        launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
+        if (V.b3.count) { cur_tiles = V.b3.count; end(3, stat_bytes(V.b3, 2.0 * lvl_p), stat_flops(V.b3)); }
+    }
+    if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Node groups that run on their own streams.  Two groups overlap the launch tails and the latency-bound small
+// launches of one group with the large launches of the other when there are many nodes; with few local nodes
+// (multi-GPU shards) one fuller launch per step is faster (measured: 16 nodes 2 groups, <= 8 nodes 1 group).
+// Q0 (Q1) = sum_k T_k .* e0[k,:] (e1[k,:]) over the solution blocks of the last sweep (fp64 accumulation in either precision)
+void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
+    if (mixed_) launch_accumulate(stream_, dsym_, d_X_.p, d_W32_.p, (int64_t)n * ldw, ldw, K_, e0, e1, mode, Q0, Q1);
+    else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, K_, e0, e1, mode, Q0, Q1);
+}
+
+int Engine::stream_groups() const {
+    int ns = std::min<int>((int)aux_streams_.size(), Kloc);
+    if (!streams_forced_ && Kloc < 12) ns = 1;
+    return std::max(1, ns);
+}
+
+int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
+    if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
+    int ns = stream_groups();
+    if (prof || ns <= 1) return solve_range(stream_, 0, Kloc, rhs, prof);
+    // The nodes are independent: split them over a few streams so that the tails and the latency-bound small
+    // launches of one group overlap with the large launches of another.
+    HIPCHK(hipEventRecord(ev_fork_, stream_));
+    int per = (Kloc + ns - 1) / ns;
+    for (int g = 0; g < ns; ++g) {
+        int kb = g * per, kc = std::min(per, Kloc - kb);
+        if (kc <= 0) break;
+        HIPCHK(hipStreamWaitEvent(aux_streams_[g], ev_fork_, 0));
+        int r = solve_range(aux_streams_[g], kb, kc, rhs, nullptr);
+        if (r) return r;
+        HIPCHK(hipEventRecord(ev_join_[g], aux_streams_[g]));
+        HIPCHK(hipStreamWaitEvent(stream_, ev_join_[g], 0));
+    }
+    return 0;
+}
+
+double Engine::solve_bytes() const {
+    // factor entries streamed once per node and sweep pair + block-vector traffic
+    double rowb = (double)ldw * 16.0;
+    // contribution rows: written once by their front; then either pulled by the parent's F2a epilogue (1 read) or
+    // assembled into the parent's pivot block (read + read-modify-write)
+    double asm_rows = 0, pull_rows = 0;
+    for (const SolveLevel& V : splan_) { asm_rows += V.asm_rows; pull_rows += V.pull_rows; }
+    double es = mixed_ ? 0.5 : 1.0;     // complex64 factors and block vectors in the mixed-precision sweeps
+    double per_node = (double)S.fact_size * 16.0 * es + (double)S.sum_u * 4.0 + (4.0 * n + (double)S.sum_u + pull_rows + 3.0 * asm_rows) * rowb * es;
+    return per_node * Kloc + 3.0 * n * rowb;
+}
+
+double Engine::solve_flops() const {
+    return ((double)(S.nnz_l + S.nnz_u) * 8.0 * ldw) * Kloc + 16.0 * n * (double)ldw * Kloc;
+}
+
+int Engine::contour_step(int refactor) {
+    if (!have_x_) return fail(FEASTHIP_ESTATE, "contour_step: call set_x and rr_step first");
+    HIPCHK(hipSetDevice(device_));
+    if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; }
+    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
+    for (int kk = 0; kk < Kloc; ++kk) {
+        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
+        for (int j = 0; j < m0; ++j) e0[(size_t)kk * ldw + j] = w / (z - lambda_[j]);      // src/feast.jl:60,69
+    }
+    HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    int r = solve_all(d_R_.p);                                                                // :61-66
+    if (r) return r;
+    accumulate_solutions(Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);                                // :68-70
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    solve_ms = ms;
+    return 0;
+}
+
+// contour_estimate_eig (src/stochastic.jl:2-33): est = real( sum_k w_k tr(X^H (z_k B - A)^-1 X) ) / samples.
+// The engine factorises T(z) = A - z B, so (z_k B - A)^-1 X = -Y_k; the node sum is the usual accumulation
+// kernel with weights -w_k and the trace comes from the MFMA Gram kernel.  Local nodes only (partial sum).
+int Engine::estimate_count(const void* X, int64_t n_, int m0_, double* est) {
+    if (!est) return fail(FEASTHIP_EARG, "estimate_count: null output");
+    int r = set_x(X, n_, m0_);
+    if (r) return r;
+    if (!factored_) { r = factorize(); if (r < 0) return r; }
+    HIPCHK(hipSetDevice(device_));
+    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
+    for (int kk = 0; kk < Kloc; ++kk) for (int j = 0; j < m0; ++j) e0[(size_t)kk * ldw + j] = -weights_[local_[kk]];
+    HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    r = solve_all(d_X_.p);
+    if (r) return r;
+    accumulate_solutions(Kloc, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    cz* dG = d_small_.p;
+    launch_gram(stream_, n, m0, ldw, d_X_.p, d_T1_.p, d_gram_scratch_.p, dG);
+    std::vector<zc> G((size_t)m0 * m0);
+    HIPCHK(hipMemcpyAsync(G.data(), dG, G.size() * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    zc tr = 0;
+    for (int j = 0; j < m0; ++j) tr += G[j + (size_t)j * m0];
+    *est = tr.real() / (double)m0;
+    return 0;
+}
+
+int Engine::profile_solve(ProfileRow* rows) {
+    if (!have_x_ || !factored_) return fail(FEASTHIP_ESTATE, "profile_solve: needs a factorised problem and iteration state");
+    HIPCHK(hipSetDevice(device_));
+    for (int i = 0; i < 8; ++i) rows[i] = ProfileRow();
+    int r = solve_all_impl(d_R_.p, rows);
+    if (r) return r;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, stream_));
+    accumulate_solutions(Kloc, d_e0_.p, nullptr, 1, d_T2_.p, nullptr);
+    HIPCHK(hipEventRecord(b, stream_));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    rows[4].ms = ms; rows[4].launches = 1; rows[4].bytes = ((double)Kloc + 2.0) * n * ldw * 16.0;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// NLFEAST  (src/nlfeast.jl:2-84)
+// ---------------------------------------------------------------------------
+
+}  // namespace feasthip
