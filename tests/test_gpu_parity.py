@@ -484,6 +484,43 @@ def test_c3_g24_converges_with_right_count(gpu, pkg, wl):
     assert np.abs(lam.imag).max() < 1e-10      # Hermitian-definite pencil
 
 
+def test_c3_full_size_g46(gpu, pkg, wl):
+    """BASELINE configs[2] at its full size (n = 97,336, 16 nodes, m0 = 64): right count, true residuals, real spectrum,
+    and the moment of the first contour step is linear in X (contour_step on 2 X == 2 contour_step on X)."""
+    w = wl.c3_sparse_generalized(46, 19, 64)
+    info = {}
+    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10,
+                                store=True, info=info)
+    assert len(lam) == w["n_inside"] == 35
+    assert info["nit"] <= 5
+    BV = w["B"] @ V
+    r_true = np.linalg.norm(w["A"] @ V - BV * lam[None, :], axis=0) / np.linalg.norm(BV, axis=0)
+    assert r_true.max() < 1e-9
+    assert np.abs(lam.imag).max() < 1e-10 and np.all(np.abs(lam - w["c"]) < w["r"])
+    G = V.conj().T @ BV                                  # B-orthogonality of eigenvectors of distinct eigenvalues
+    d = np.sqrt(np.abs(np.diag(G)))
+    G = G / d[:, None] / d[None, :]
+    sep = np.abs(lam[:, None] - lam[None, :]) > 1e-6 * w["r"]
+    assert np.abs(G[sep]).max() < 1e-6
+
+
+def test_c2_full_size_dense4096(gpu, pkg, wl):
+    """BASELINE configs[1] at its full size (dense generalized 4096 x 4096, 16 nodes, m0 = 64; the radius is the circular-law
+    estimate of tools/bench_c2.py, so the count is only bounded): every returned pair is a true eigenpair inside the contour."""
+    n, m0 = 4096, 64
+    w = wl.c2_dense_generalized(n, m0, radius=float(np.sqrt(32.0 / n)) * 1.03)
+    info = {}
+    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10, store=True, info=info)
+    assert 16 <= len(lam) <= m0 and info["nit"] < 20
+    assert np.all(np.abs(lam - w["c"]) < w["r"])
+    BV = w["B"] @ V
+    r_true = np.linalg.norm(w["A"] @ V - BV * lam[None, :], axis=0) / np.linalg.norm(BV, axis=0)
+    assert r_true.max() < 1e-8
+    # no inside eigenvalue was missed: the stochastic count estimate of the same contour agrees with the count
+    est = pkg.contour_estimate_eig(w["A"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), B=w["B"], samples=64, seed=7)
+    assert abs(est - len(lam)) <= 0.35 * len(lam) + 3
+
+
 @pytest.mark.parametrize("m0", [100, 128])
 def test_wide_blocks_sparse(gpu, pkg, wl, m0):
     """m0 > 64: two 64-column groups per tile"""
