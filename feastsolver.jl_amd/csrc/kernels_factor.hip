@@ -5,6 +5,7 @@
 // src/nlfeast.jl:17-28; dense zgetrf / UMFPACK in the reference).
 #include "kernels.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace feasthip {
 
@@ -613,8 +614,13 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
     d4 cr[4], ci[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+    // The read-modify-write loads of the epilogue are issued in front of the MFMAs of the last K chunk (the B staging registers
+    // are dead by then): at the depths of the panel-group updates (32..128) their latency is otherwise a tenth of the tile.
+    // The contribution block (kind 2) is written, not updated: CB = -L21 U12, the children's blocks are added afterwards.
+    cz old[4][4];
+    const bool rmw = (t.a != 2);
     // loads are unconditional (clamped addresses) and masked with selects, so they all stay in flight
-    for (int kc = 0; kc < Kd; kc += GEMM_KC) {
+    auto chunk = [&](int kc, auto is_last) {
         cz bvals[GEMM_KC * 64 / 256];
 #pragma unroll
         for (int q = 0; q < GEMM_KC * 64 / 256; ++q) {
@@ -640,6 +646,12 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
             av[ks].y = keep ? av[ks].y : 0.0;
         }
         __syncthreads();
+        if constexpr (decltype(is_last)::value) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[nt][r] = rmw ? C[mrow_c + (int64_t)min(n0 + nt * 16 + lk + 4 * r, N - 1) * ldc] : cz_make(0, 0);
+        }
 #pragma unroll
         for (int ks = 0; ks < GEMM_KC / 4; ++ks) {
             int kk = ks * 4 + lk;
@@ -657,15 +669,10 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].y, ar, ci[nt], 0, 0, 0);
         }
-    }
-    // epilogue: all 16 read-modify-write loads issued together, then stored.  The contribution block
-    // (kind 2) is written, not updated: CB = -L21 U12, the children's blocks are added afterwards.
-    cz old[4][4];
-    const bool rmw = (t.a != 2);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) old[nt][r] = rmw ? C[mrow_c + (int64_t)min(n0 + nt * 16 + lk + 4 * r, N - 1) * ldc] : cz_make(0, 0);
+    };
+    int kc0 = 0;
+    for (; kc0 + GEMM_KC < Kd; kc0 += GEMM_KC) chunk(kc0, std::false_type{});
+    chunk(kc0, std::true_type{});
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
