@@ -45,6 +45,7 @@ Engine::Engine(int device) : device_(device) {
     (void)hipEventCreate(&ev1_);
     if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_GROUP")) group_panels_ = std::max(1, std::min(8, atoi(v)));
+    if (const char* v = getenv("FEASTHIP_FUSED_UTRSM")) fused_utrsm_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_FIN_ASYNC")) finalize_async_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     int nst = 2;
@@ -284,6 +285,13 @@ bool Engine::build_plans() {
                 if (N0 > 0) for (int c = 0; c < cdiv(u, 64); ++c) tiles.push_back({s, 1, 0, c});
             }
             st.gemm0.count = (int)(tiles.size() - st.gemm0.off);
+            st.grp.off = (int64_t)tiles.size();          // 32-column tiles right of the panel group that starts here (k_group_utrsm)
+            if ((int)F.steps.size() % group_panels_ == 0 && group_panels_ * FACT_NB <= 128)
+                for (int s : lv) if (S.p(s) > k0) {
+                    int p = S.p(s), u = S.u(s), b = std::min(group_panels_ * FACT_NB, p - k0);
+                    for (int a = 0; a < cdiv(p - k0 - b + u, 32); ++a) tiles.push_back({s, a, 0, 0});
+                }
+            st.grp.count = (int)(tiles.size() - st.grp.off);
             F.steps.push_back(st);
         }
         F.cbgemm.off = (int64_t)tiles.size();

@@ -36,7 +36,7 @@ struct Launch {        // a slice of the tile / list buffers
     double bytes = 0, flops = 0;   // algorithmic bytes / real flops of this launch for ONE contour node
 };
 
-struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0; };
+struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, grp; };
 struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale; };
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     double asm_rows = 0, pull_rows = 0; };   // children's contribution rows landing in pivot blocks / in contribution rows of this level
@@ -210,7 +210,7 @@ private:
     hipStream_t rest_stream_ = nullptr;  // trailing updates of the look-ahead levels: a CU mask keeps reserve_cus_ CUs per XCD free for la_stream_
     int reserve_cus_ = 2;
     std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join, [6] rest stream join
-    bool look_ahead_ = true, finalize_async_ = true;
+    bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true;
     int group_panels_ = 4;            // panels per deferred trailing update in the look-ahead factorisation
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;

@@ -120,15 +120,19 @@ int Engine::factorize() {
                 FactorStep& s0 = F.steps[j0];
                 const int gw = F.steps[j1 - 1].k0 + FACT_NB - k0g;        // group width
                 launch_swap(s, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, sel(k0g + gw), gw);
-                for (int j = j0; j < j1; ++j) {
-                    FactorStep& sj = F.steps[j];
-                    const int bw = sj.k0 - k0g;
-                    if (bw > 0) {
-                        ColSel c = sel(sj.k0); c.llo = c.lhi = 0;
-                        launch_gemm_nn(s, dsym_, tl + s0.gemm0.off, s0.gemm0.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, c, bw, FACT_NB);
+                if (s0.grp.count > 0 && fused_utrsm_) {       // U rows of the whole group in one launch
+                    launch_group_utrsm(s, dsym_, tl + s0.grp.off, s0.grp.count, k0g, gw, d_fact_.p, fs, Kloc, sel(k0g + gw));
+                } else {
+                    for (int j = j0; j < j1; ++j) {
+                        FactorStep& sj = F.steps[j];
+                        const int bw = sj.k0 - k0g;
+                        if (bw > 0) {
+                            ColSel c = sel(sj.k0); c.llo = c.lhi = 0;
+                            launch_gemm_nn(s, dsym_, tl + s0.gemm0.off, s0.gemm0.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, c, bw, FACT_NB);
+                        }
+                        ColSel c = sel(sj.k0 + FACT_NB);
+                        launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
                     }
-                    ColSel c = sel(sj.k0 + FACT_NB);
-                    launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
                 }
                 launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0);
             };

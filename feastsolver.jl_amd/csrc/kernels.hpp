@@ -38,6 +38,8 @@ inline ColSel col_right(int clo, int chi) { ColSel c; c.llo = 0; c.lhi = 0; c.cl
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                  const int* piv, int K, ColSel cs = ColSel(), int bw = FACT_NB);
 void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs = ColSel());
+// U rows of a group of panels (gw <= 128 rows) for 32-column tiles of the columns right of the group
+void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int gw, cz* fact, int64_t fs, int K, ColSel cs);
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                     cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0);
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled

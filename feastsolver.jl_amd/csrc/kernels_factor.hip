@@ -554,6 +554,85 @@ void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntile
 }
 
 // ---------------------------------------------------------------------------
+// U rows of a whole panel group: X <- inv(L11) X for the gw <= GROUP_ROWS rows [k0, k0 + gw) of the columns right of the
+// group (pivot-block columns by offset from column k0 + gw, then the U12 columns), L11 the group's unit lower triangle.
+// One workgroup per 32-column tile.  Eight consecutive lanes share a column and hold its rows r = (lane & 7) + 8 m
+// (m < 16) in registers, so a column's row k reaches the seven other lanes with one shuffle and the workgroup needs no
+// barrier inside the 32 elimination steps of a phase; the phase's 32 columns of L11 are staged in LDS (zeros on and above
+// the diagonal, so every row below the phase's first is updated unconditionally).  Replaces, per group, four k_trsm_u
+// launches and the three 32-row products between them (7 dependent launches, 0.55 ms on the 2200-column rest of C3's
+// root front) by one launch.
+// ---------------------------------------------------------------------------
+constexpr int GROUP_ROWS = 128, GROUP_TILE = 32;
+
+template <int JB>
+__device__ __forceinline__ void group_phase(cz (&x)[GROUP_ROWS / 8], const cz (*sL)[GROUP_ROWS + 1], int rsub, int lane) {
+#pragma unroll 1
+    for (int s = 0; s < 32; ++s) {
+        // row k = 32 JB + s lives in register m = 4 JB + (s >> 3) of the lane with rsub == (s & 7); bit masks instead of a
+        // select chain keep x[] in registers (see k_trsm_u)
+        long long xr = 0, xi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            long long msk = -(long long)((s >> 3) == j);
+            xr |= msk & __double_as_longlong(x[4 * JB + j].x);
+            xi |= msk & __double_as_longlong(x[4 * JB + j].y);
+        }
+        int src = (lane & ~7) | (s & 7);
+        cz xk = cz_make(__shfl(__longlong_as_double(xr), src), __shfl(__longlong_as_double(xi), src));
+#pragma unroll
+        for (int m = 4 * JB; m < GROUP_ROWS / 8; ++m) cz_msub(x[m], sL[s][rsub + 8 * m], xk);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_group_utrsm(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, int gw,
+                                                      cz* fact, int64_t fs, ColSel cs) {
+    __shared__ cz sL[32][GROUP_ROWS + 1];
+    Tile t = tiles[blockIdx.x];
+    int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    int p = f.p, u = f.u, ld = p + u;
+    int b = min(gw, p - k0);                 // rows of the group this front has
+    int nin = p - k0 - b, ncol = nin + u;
+    int v0 = t.a * GROUP_TILE, v1 = v0 + GROUP_TILE;
+    {   // column tile without a selected column
+        bool any = (v0 < nin && v0 < cs.chi && min(v1, nin) > cs.clo) || (cs.u12 && v1 > nin && v0 < ncol);
+        if (!any) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, rsub = tid & 7;
+    const int v = v0 + (tid >> 3);
+    const bool mine = v < ncol && (v < nin ? (v >= cs.clo && v < cs.chi) : (cs.u12 != 0));
+    const cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* col = (v < nin) ? fact + (int64_t)k * fs + f.lp + (int64_t)(k0 + b + v) * ld + k0
+                        : fact + (int64_t)k * fs + f.f12 + (int64_t)(v - nin) * p + k0;
+    cz x[GROUP_ROWS / 8];
+#pragma unroll
+    for (int m = 0; m < GROUP_ROWS / 8; ++m) x[m] = (mine && rsub + 8 * m < b) ? col[rsub + 8 * m] : cz_make(0, 0);
+    auto stage = [&](int jb) {               // columns 32 jb .. 32 jb + 31 of L11, strictly below the diagonal
+        __syncthreads();
+        for (int idx = tid; idx < 32 * GROUP_ROWS; idx += 256) {
+            int r = idx % GROUP_ROWS, s2 = idx / GROUP_ROWS, c = 32 * jb + s2;
+            sL[s2][r] = (r > c && r < b) ? Lp[(k0 + r) + (int64_t)(k0 + c) * ld] : cz_make(0, 0);
+        }
+        __syncthreads();
+    };
+    stage(0); group_phase<0>(x, sL, rsub, lane);
+    if (b > 32) { stage(1); group_phase<1>(x, sL, rsub, lane); }
+    if (b > 64) { stage(2); group_phase<2>(x, sL, rsub, lane); }
+    if (b > 96) { stage(3); group_phase<3>(x, sL, rsub, lane); }
+    if (mine) {
+#pragma unroll
+        for (int m = 0; m < GROUP_ROWS / 8; ++m)
+            if (rsub + 8 * m < b) col[rsub + 8 * m] = x[m];
+    }
+}
+
+void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int gw, cz* fact, int64_t fs, int K, ColSel cs) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_group_utrsm, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, gw, fact, fs, cs);
+}
+
+// ---------------------------------------------------------------------------
 // grouped complex GEMM  C -= A * B  (all column-major) on v_mfma_f64_16x16x4_f64.
 // Workgroup tile 64 (m) x 64 (n); wave w owns rows [16w, 16w+16) and streams its
 // A rows straight from global memory (each A element is used once per n tile);
