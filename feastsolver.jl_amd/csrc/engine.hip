@@ -285,6 +285,13 @@ bool Engine::build_plans() {
                 if (N0 > 0) for (int c = 0; c < cdiv(u, 64); ++c) tiles.push_back({s, 1, 0, c});
             }
             st.gemm0.count = (int)(tiles.size() - st.gemm0.off);
+            st.gemm_in.off = (int64_t)tiles.size();      // product tiles of the first two tile columns: updates inside a panel group and of the next group's columns
+            for (int s : lv) if (S.p(s) > k0) {
+                int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0), ld = p + u;
+                int M0 = ld - k0 - b, N0 = p - k0 - b;
+                if (M0 > 0 && N0 > 0) for (int a = 0; a < cdiv(M0, 64); ++a) for (int c = 0; c < std::min(2, cdiv(N0, 64)); ++c) tiles.push_back({s, 0, a, c});
+            }
+            st.gemm_in.count = (int)(tiles.size() - st.gemm_in.off);
             st.grp.off = (int64_t)tiles.size();          // 32-column tiles right of the panel group that starts here (k_group_utrsm)
             if ((int)F.steps.size() % group_panels_ == 0 && group_panels_ * FACT_NB <= 128)
                 for (int s : lv) if (S.p(s) > k0) {

@@ -36,7 +36,7 @@ struct Launch {        // a slice of the tile / list buffers
     double bytes = 0, flops = 0;   // algorithmic bytes / real flops of this launch for ONE contour node
 };
 
-struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, grp; };
+struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp; };
 struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale; };
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     double asm_rows = 0, pull_rows = 0; };   // children's contribution rows landing in pivot blocks / in contribution rows of this level

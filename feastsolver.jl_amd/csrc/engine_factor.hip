@@ -134,7 +134,10 @@ int Engine::factorize() {
                         launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
                     }
                 }
-                launch_gemm_nn(s, dsym_, tl + s0.gemm.off, s0.gemm.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0);
+                // the next group's columns are the first two tile columns right of this group: the short list does
+                const bool narrow = !others && c_hi - (k0g + gw) <= 128 && c_lo == k0g + gw;
+                const Launch& gl = narrow ? s0.gemm_in : s0.gemm;
+                launch_gemm_nn(s, dsym_, tl + gl.off, gl.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0);
             };
             for (int g = 0; g < ng; ++g) {
                 const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
@@ -155,7 +158,7 @@ int Engine::factorize() {
                     if (c.chi > 0) {
                         c.llo = c.lhi = 0;
                         launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
-                        launch_gemm_nn(P, dsym_, tl + sj.gemm.off, sj.gemm.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
+                        launch_gemm_nn(P, dsym_, tl + sj.gemm_in.off, sj.gemm_in.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
                     }
                 }
                 HIPCHK(hipEventRecord(ev_la_[g & 1], P));
