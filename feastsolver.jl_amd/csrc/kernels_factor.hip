@@ -431,10 +431,23 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
                   int* piv, const double* tiny, int* nperturb, int K, bool tall, int max_rows) {
     if (nlist <= 0) return;
     static const bool generic = getenv("FEASTHIP_PANEL_GENERIC") != nullptr;
-    if (!generic && max_rows <= PANEL_RPT * (tall ? PANEL_NT_TALL : PANEL_NT_SMALL)) {     // max_rows: tallest panel (ld - k0) of the launch
-        if (tall) hipLaunchKernelGGL(k_panel_reg<PANEL_NT_TALL>, dim3(nlist, K), dim3(PANEL_NT_TALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
-        else hipLaunchKernelGGL(k_panel_reg<PANEL_NT_SMALL>, dim3(nlist, K), dim3(PANEL_NT_SMALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
-        return;
+    // max_rows: tallest panel (ld - k0) of the launch.  The smallest workgroup whose threads hold PANEL_RPT rows each: a
+    // 1024-thread workgroup occupies a whole CU, so levels with many mid-sized fronts (81 fronts x 16 nodes of 1000-1500 rows)
+    // otherwise run their panels five CU-rounds deep.
+    if (!generic && max_rows <= PANEL_RPT * 1024) {
+        // few workgroups (every one gets a CU of its own anyway): the widest workgroup has the shortest pivot step
+        const int floor_nt = (int64_t)nlist * K <= 256 ? (tall ? 1024 : 256) : 64;
+#define FEASTHIP_PANEL_CASE(NT) \
+        if (max_rows <= PANEL_RPT * NT && NT >= floor_nt) { \
+            hipLaunchKernelGGL(k_panel_reg<NT>, dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
+            return; \
+        }
+        FEASTHIP_PANEL_CASE(64)
+        FEASTHIP_PANEL_CASE(128)
+        FEASTHIP_PANEL_CASE(256)
+        FEASTHIP_PANEL_CASE(512)
+        FEASTHIP_PANEL_CASE(1024)
+#undef FEASTHIP_PANEL_CASE
     }
     if (tall) hipLaunchKernelGGL(k_panel<PANEL_NT_TALL>, dim3(nlist, K), dim3(PANEL_NT_TALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
     else hipLaunchKernelGGL(k_panel<PANEL_NT_SMALL>, dim3(nlist, K), dim3(PANEL_NT_SMALL), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb);
