@@ -158,7 +158,11 @@ int Engine::factorize() {
                     if (c.chi > 0) {
                         c.llo = c.lhi = 0;
                         launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
-                        launch_gemm_nn(P, dsym_, tl + sj.gemm_in.off, sj.gemm_in.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
+                        {
+                            // columns left in the group fit the first two tile columns unless the groups are wider than 160
+                            const Launch& gl = (G - 1) * FACT_NB <= 128 ? sj.gemm_in : sj.gemm;
+                            launch_gemm_nn(P, dsym_, tl + gl.off, gl.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
+                        }
                     }
                 }
                 HIPCHK(hipEventRecord(ev_la_[g & 1], P));
