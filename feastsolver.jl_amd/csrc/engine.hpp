@@ -206,6 +206,7 @@ private:
     int stream_groups() const;
     void accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
     bool streams_forced_ = false;
+    DevBuf<cz> d_mvpart_;                // split-K partial sums of the dense term products (k_dense_mv)
     hipStream_t la_stream_ = nullptr;    // high-priority stream of the look-ahead panels
     hipStream_t rest_stream_ = nullptr;  // trailing updates of the look-ahead levels: a CU mask keeps reserve_cus_ CUs per XCD free for la_stream_
     int reserve_cus_ = 2;

@@ -10,7 +10,12 @@ void Engine::apply_term_ld(int t, const cz* V, cz* out, zc alpha, bool accumulat
     zc a = alpha * T.scale;
     if (dense) {
         if (T.identity) launch_axpby(stream_, n, ld, out, to_cz(a), V, accumulate ? 1 : 0);
-        else launch_dense_mv(stream_, n, T.d_dense.p, V, ld, out, to_cz(a), accumulate ? 1 : 0);
+        else {
+            const int parts = dense_mv_parts(n, ld);
+            if (parts > 1 && d_mvpart_.n < (size_t)parts * n * ld && !d_mvpart_.alloc((size_t)parts * n * ld)) { (void)hipGetLastError(); }
+            launch_dense_mv(stream_, n, T.d_dense.p, V, ld, out, to_cz(a), accumulate ? 1 : 0,
+                            parts > 1 && d_mvpart_.n >= (size_t)parts * n * ld ? d_mvpart_.p : nullptr);
+        }
     } else {
         launch_spmm_csr(stream_, n, T.d_rowptr.p, T.d_col.p, T.d_val.p, V, ld, out, to_cz(a), accumulate ? 1 : 0);
     }

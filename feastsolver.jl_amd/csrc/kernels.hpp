@@ -94,7 +94,9 @@ void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W
 void launch_spmm_csr(hipStream_t st, int n, const int64_t* rowptr, const int* col, const cz* val, const cz* V, int ldw,
                      cz* out, cz alpha, int accumulate);
 // out(row-major n x ldw) (+)= alpha * A(col-major n x n) * V
-void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate);
+// part: scratch of dense_mv_parts(n, ldw) * n * ldw elements for the split-K partial sums (nullptr: no split)
+int dense_mv_parts(int n, int ldw);
+void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate, cz* part = nullptr);
 // G(m x m, column-major, ld m) = V^H W  (row-major n x ldw blocks); scratch >= gram_scratch_elems()
 size_t gram_scratch_elems(int n, int m);
 void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G);

@@ -37,27 +37,32 @@ void launch_spmm_csr(hipStream_t st, int n, const int64_t* rowptr, const int* co
 }
 
 // Dense product out = alpha * A * V (+ out): same streaming structure as the solve's panel kernel.
+// kparts > 1: blockIdx.z takes the z-th slice of the K range and writes its raw partial sums to part + z n ldw (summed, scaled
+// and accumulated by k_dense_mv_reduce in a fixed order): a 4096 x 4096 term has only 64 row slabs, a quarter of the CUs.
 __global__ __launch_bounds__(256) void k_dense_mv(int n, const cz* __restrict__ A, const cz* __restrict__ V, int ldw,
-                                                   cz* out, cz alpha, int accumulate) {
+                                                   cz* out, cz alpha, int accumulate, int kparts, cz* part) {
     __shared__ cz Vs[64][LDS_COLS];
     int rbase = blockIdx.x * 64, cg = blockIdx.y * LDS_COLS;
+    const int kchunks = (n + 63) / 64, kper = (kchunks + kparts - 1) / kparts;
+    const int kbeg = blockIdx.z * kper * 64, kend = min(n, kbeg + kper * 64);
+    if (kparts > 1) { out = part + (int64_t)blockIdx.z * n * ldw; alpha = cz_make(1, 0); accumulate = 0; }
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     int arow = rbase + wave * 16 + li;
     bool aok = arow < n;
     d4 cr[4], ci[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
-    for (int kc = 0; kc < n; kc += 64) {
+    for (int kc = kbeg; kc < kend; kc += 64) {
         __syncthreads();
         for (int r = wave; r < 64; r += 4) {
             int gk = kc + r;
-            Vs[r][lane] = (gk < n && cg + lane < ldw) ? V[(int64_t)gk * ldw + cg + lane] : cz_make(0, 0);
+            Vs[r][lane] = (gk < kend && cg + lane < ldw) ? V[(int64_t)gk * ldw + cg + lane] : cz_make(0, 0);
         }
         cz av[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             int gk = kc + ks * 4 + lk;
-            av[ks] = (aok && gk < n) ? A[arow + (int64_t)gk * n] : cz_make(0, 0);
+            av[ks] = (aok && gk < kend) ? A[arow + (int64_t)gk * n] : cz_make(0, 0);
         }
         __syncthreads();
 #pragma unroll
@@ -85,8 +90,31 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const cz* __restrict__ 
     }
 }
 
-void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate) {
-    hipLaunchKernelGGL(k_dense_mv, dim3((n + 63) / 64, (ldw + LDS_COLS - 1) / LDS_COLS), dim3(256), 0, st, n, A, V, ldw, out, alpha, accumulate);
+__global__ void k_dense_mv_reduce(int64_t total, int kparts, const cz* __restrict__ part, cz* out, cz alpha, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    cz s = part[i];
+    for (int z = 1; z < kparts; ++z) s = cz_add(s, part[i + (int64_t)z * total]);
+    s = cz_mul(alpha, s);
+    if (accumulate) s = cz_add(s, out[i]);
+    out[i] = s;
+}
+
+int dense_mv_parts(int n, int ldw) {
+    int wgs = ((n + 63) / 64) * ((ldw + LDS_COLS - 1) / LDS_COLS);
+    int parts = 1;
+    while (parts < 8 && wgs * parts * 2 <= 256 && (n + 63) / 64 >= parts * 8) parts *= 2;     // every slice keeps at least 8 K chunks
+    return parts;
+}
+
+void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate, cz* part) {
+    const int parts = part ? dense_mv_parts(n, ldw) : 1;
+    hipLaunchKernelGGL(k_dense_mv, dim3((n + 63) / 64, (ldw + LDS_COLS - 1) / LDS_COLS, parts), dim3(256), 0, st, n, A, V, ldw, out, alpha, accumulate,
+                       parts, part);
+    if (parts > 1) {
+        const int64_t total = (int64_t)n * ldw;
+        hipLaunchKernelGGL(k_dense_mv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, parts, part, out, alpha, accumulate);
+    }
 }
 
 // Tall-skinny projection G = V^H W on the f64 matrix cores.  Stage 1: each

@@ -18,101 +18,153 @@ inline double pythag(double a, double b) {
     return a * std::sqrt(1.0 + r * r);
 }
 
-// Householder reduction to upper Hessenberg form, H = Z^H A Z.
-void hessenberg(int m, zc* H, zc* Z) {
-    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Z[i + (size_t)j * m] = (i == j) ? 1.0 : 0.0;
-    std::vector<zc> v(m);
+// Split storage (separate real and imaginary planes, column-major) keeps every inner loop a stride-1 real loop
+// the compiler vectorises; these routines sit on the critical path of every FEAST iteration (GPU idle meanwhile).
+struct Planes {
+    int m;
+    std::vector<double> re, im;
+    explicit Planes(int m_) : m(m_), re((size_t)m_ * m_, 0.0), im((size_t)m_ * m_, 0.0) {}
+    double* r(int j) { return re.data() + (size_t)j * m; }
+    double* i(int j) { return im.data() + (size_t)j * m; }
+    void load(const zc* A) { for (size_t q = 0; q < (size_t)m * m; ++q) { re[q] = A[q].real(); im[q] = A[q].imag(); } }
+    void store(zc* A) const { for (size_t q = 0; q < (size_t)m * m; ++q) A[q] = zc(re[q], im[q]); }
+    zc at(int i2, int j) const { return zc(re[i2 + (size_t)j * m], im[i2 + (size_t)j * m]); }
+    void set(int i2, int j, zc v) { re[i2 + (size_t)j * m] = v.real(); im[i2 + (size_t)j * m] = v.imag(); }
+};
+
+// y[lo, hi) -= a * x[lo, hi)
+inline void caxpy_sub(int lo, int hi, double ar, double ai, const double* __restrict xr, const double* __restrict xi,
+                      double* __restrict yr, double* __restrict yi) {
+    for (int i = lo; i < hi; ++i) {
+        yr[i] -= ar * xr[i] - ai * xi[i];
+        yi[i] -= ar * xi[i] + ai * xr[i];
+    }
+}
+
+// Householder reduction to upper Hessenberg form, H = Z^H A Z.  Both one-sided updates run over columns (stride 1):
+// the right-hand one as w = H v (a sum of columns) followed by H[:, j] -= 2 w conj(v_j).
+void hessenberg(Planes& H, Planes& Z) {
+    const int m = H.m;
+    std::fill(Z.re.begin(), Z.re.end(), 0.0);
+    std::fill(Z.im.begin(), Z.im.end(), 0.0);
+    for (int i = 0; i < m; ++i) Z.re[i + (size_t)i * m] = 1.0;
+    std::vector<double> vr(m), vi(m), wr(m), wi(m), zr(m), zi(m);
     for (int k = 0; k + 2 < m; ++k) {
+        double* hk_r = H.r(k);
+        double* hk_i = H.i(k);
         double nrm = 0;
-        for (int i = k + 1; i < m; ++i) nrm += std::norm(H[i + (size_t)k * m]);
+        for (int i = k + 1; i < m; ++i) nrm += hk_r[i] * hk_r[i] + hk_i[i] * hk_i[i];
         nrm = std::sqrt(nrm);
         if (nrm == 0.0) continue;
-        zc x0 = H[k + 1 + (size_t)k * m];
-        zc ph = (std::abs(x0) == 0.0) ? zc(1.0) : x0 / std::abs(x0);
+        zc x0(hk_r[k + 1], hk_i[k + 1]);
+        double ax0 = std::abs(x0);
+        zc ph = (ax0 == 0.0) ? zc(1.0) : x0 / ax0;
         zc alpha = -ph * nrm;
         double vn = 0;
-        for (int i = k + 1; i < m; ++i) { v[i] = H[i + (size_t)k * m]; if (i == k + 1) v[i] -= alpha; vn += std::norm(v[i]); }
+        for (int i = k + 1; i < m; ++i) { vr[i] = hk_r[i]; vi[i] = hk_i[i]; }
+        vr[k + 1] -= alpha.real(); vi[k + 1] -= alpha.imag();
+        for (int i = k + 1; i < m; ++i) vn += vr[i] * vr[i] + vi[i] * vi[i];
         vn = std::sqrt(vn);
         if (vn == 0.0) continue;
-        for (int i = k + 1; i < m; ++i) v[i] /= vn;
+        const double inv = 1.0 / vn;
+        for (int i = k + 1; i < m; ++i) { vr[i] *= inv; vi[i] *= inv; }
         // H <- (I - 2 v v^H) H
         for (int j = k; j < m; ++j) {
-            zc s = 0;
-            for (int i = k + 1; i < m; ++i) s += std::conj(v[i]) * H[i + (size_t)j * m];
-            s *= 2.0;
-            for (int i = k + 1; i < m; ++i) H[i + (size_t)j * m] -= v[i] * s;
+            double* cr = H.r(j);
+            double* ci = H.i(j);
+            double sr = 0, si = 0;
+            for (int i = k + 1; i < m; ++i) { sr += vr[i] * cr[i] + vi[i] * ci[i]; si += vr[i] * ci[i] - vi[i] * cr[i]; }
+            caxpy_sub(k + 1, m, 2.0 * sr, 2.0 * si, vr.data(), vi.data(), cr, ci);
         }
         // H <- H (I - 2 v v^H),  Z <- Z (I - 2 v v^H)
-        for (int i = 0; i < m; ++i) {
-            zc s = 0, t = 0;
-            for (int j = k + 1; j < m; ++j) { s += H[i + (size_t)j * m] * v[j]; t += Z[i + (size_t)j * m] * v[j]; }
-            s *= 2.0; t *= 2.0;
-            for (int j = k + 1; j < m; ++j) { H[i + (size_t)j * m] -= s * std::conj(v[j]); Z[i + (size_t)j * m] -= t * std::conj(v[j]); }
+        std::fill(wr.begin(), wr.end(), 0.0); std::fill(wi.begin(), wi.end(), 0.0);
+        std::fill(zr.begin(), zr.end(), 0.0); std::fill(zi.begin(), zi.end(), 0.0);
+        for (int j = k + 1; j < m; ++j) {
+            caxpy_sub(0, m, -vr[j], -vi[j], H.r(j), H.i(j), wr.data(), wi.data());      // w += H[:, j] v_j
+            caxpy_sub(0, m, -vr[j], -vi[j], Z.r(j), Z.i(j), zr.data(), zi.data());
         }
-        H[k + 1 + (size_t)k * m] = alpha;
-        for (int i = k + 2; i < m; ++i) H[i + (size_t)k * m] = 0.0;
+        for (int j = k + 1; j < m; ++j) {
+            caxpy_sub(0, m, 2.0 * vr[j], -2.0 * vi[j], wr.data(), wi.data(), H.r(j), H.i(j));    // H[:, j] -= 2 w conj(v_j)
+            caxpy_sub(0, m, 2.0 * vr[j], -2.0 * vi[j], zr.data(), zi.data(), Z.r(j), Z.i(j));
+        }
+        hk_r[k + 1] = alpha.real(); hk_i[k + 1] = alpha.imag();
+        for (int i = k + 2; i < m; ++i) { hk_r[i] = 0.0; hk_i[i] = 0.0; }
+    }
+}
+
+// [p; q] <- [c p + conj(s) q; -s p + c q] element-wise over [lo, hi): a Givens rotation applied to two columns
+inline void rot_cols(int lo, int hi, double c, double sr, double si, double* __restrict pr, double* __restrict pi,
+                     double* __restrict qr, double* __restrict qi) {
+    for (int i = lo; i < hi; ++i) {
+        double ar = pr[i], ai = pi[i], br = qr[i], bi = qi[i];
+        pr[i] = c * ar + (sr * br + si * bi);
+        pi[i] = c * ai + (sr * bi - si * br);
+        qr[i] = c * br - (sr * ar - si * ai);
+        qi[i] = c * bi - (sr * ai + si * ar);
     }
 }
 
 // Single-shift complex QR on an upper Hessenberg matrix; H becomes the Schur form T, Z the Schur vectors.
-int hqr_schur(int m, zc* H, zc* Z) {
+// H is kept TRANSPOSED (Ht(j, i) = H(i, j)) so that the row rotations, the longer of the two updates of H, run over
+// contiguous memory like the rotations of Z; only the short column part (rows 0..k+2) is strided.
+int hqr_schur(Planes& H, Planes& Z) {
+    const int m = H.m;
+    Planes T(m);
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { T.re[j + (size_t)i * m] = H.re[i + (size_t)j * m]; T.im[j + (size_t)i * m] = H.im[i + (size_t)j * m]; }
+    auto h = [&](int i, int j) { return zc(T.re[j + (size_t)i * m], T.im[j + (size_t)i * m]); };
+    auto hset = [&](int i, int j, zc v) { T.re[j + (size_t)i * m] = v.real(); T.im[j + (size_t)i * m] = v.imag(); };
     int ihi = m - 1, its = 0, total = 0;
     double hn = 0;
-    for (size_t i = 0; i < (size_t)m * m; ++i) hn = std::max(hn, cabs1(H[i]));
+    for (size_t q = 0; q < (size_t)m * m; ++q) hn = std::max(hn, std::fabs(T.re[q]) + std::fabs(T.im[q]));
     if (hn == 0.0) return 0;
+    int info = 0;
     while (ihi >= 0) {
         int l = ihi;
         for (; l > 0; --l) {
-            double sub = cabs1(H[l + (size_t)(l - 1) * m]);
-            double dd = cabs1(H[l - 1 + (size_t)(l - 1) * m]) + cabs1(H[l + (size_t)l * m]);
+            double sub = cabs1(h(l, l - 1));
+            double dd = cabs1(h(l - 1, l - 1)) + cabs1(h(l, l));
             if (dd == 0.0) dd = hn;
             if (sub <= EPS * dd) break;
         }
-        if (l > 0) H[l + (size_t)(l - 1) * m] = 0.0;
+        if (l > 0) hset(l, l - 1, 0.0);
         if (l == ihi) { --ihi; its = 0; continue; }
-        if (++total > 60 * m + 200) return 2;
+        if (++total > 60 * m + 200) { info = 2; break; }
         zc s;
         if (its == 10 || its == 20) {
-            s = zc(std::fabs(H[ihi + (size_t)(ihi - 1) * m].real()) + (ihi >= 2 ? std::fabs(H[ihi - 1 + (size_t)(ihi - 2) * m].real()) : 0.0), 0.0) + H[ihi + (size_t)ihi * m];
+            s = zc(std::fabs(h(ihi, ihi - 1).real()) + (ihi >= 2 ? std::fabs(h(ihi - 1, ihi - 2).real()) : 0.0), 0.0) + h(ihi, ihi);
         } else {   // Wilkinson shift: eigenvalue of the trailing 2x2 closer to H[ihi][ihi]
-            zc a = H[ihi - 1 + (size_t)(ihi - 1) * m], b = H[ihi - 1 + (size_t)ihi * m];
-            zc c = H[ihi + (size_t)(ihi - 1) * m], d = H[ihi + (size_t)ihi * m];
+            zc a = h(ihi - 1, ihi - 1), b = h(ihi - 1, ihi);
+            zc c = h(ihi, ihi - 1), d = h(ihi, ihi);
             zc tr2 = 0.5 * (a + d), det = a * d - b * c;
             zc disc = std::sqrt(tr2 * tr2 - det);
             zc e1 = tr2 + disc, e2 = tr2 - disc;
             s = (std::abs(e1 - d) < std::abs(e2 - d)) ? e1 : e2;
         }
         ++its;
-        zc x = H[l + (size_t)l * m] - s, y = H[l + 1 + (size_t)l * m];
+        zc x = h(l, l) - s, y = h(l + 1, l);
         for (int k = l; k < ihi; ++k) {
             // Givens G = [c sn; -conj(sn) c] with G [x;y] = [r;0]
             double ax = std::abs(x), ay = std::abs(y), c;
             zc sn;
             if (ay == 0.0) { c = 1.0; sn = 0.0; }
             else if (ax == 0.0) { c = 0.0; sn = std::conj(y) / ay; }
-            else { double nr = std::hypot(ax, ay); c = ax / nr; sn = (x / ax) * std::conj(y) / nr; }
+            else { double nr = pythag(ax, ay); c = ax / nr; sn = (x / ax) * std::conj(y) / nr; }
             int j0 = std::max(l, k - 1);
-            for (int j = j0; j < m; ++j) {
-                zc h0 = H[k + (size_t)j * m], h1 = H[k + 1 + (size_t)j * m];
-                H[k + (size_t)j * m] = c * h0 + sn * h1;
-                H[k + 1 + (size_t)j * m] = -std::conj(sn) * h0 + c * h1;
-            }
-            if (k > l) H[k + 1 + (size_t)(k - 1) * m] = 0.0;
+            // rows k, k+1 of H = columns k, k+1 of T:  [h0; h1] <- [c h0 + sn h1; -conj(sn) h0 + c h1]
+            rot_cols(j0, m, c, sn.real(), -sn.imag(), T.r(k), T.i(k), T.r(k + 1), T.i(k + 1));
+            if (k > l) hset(k + 1, k - 1, 0.0);
             int i1 = std::min(k + 2, ihi);
-            for (int i = 0; i <= i1; ++i) {
-                zc h0 = H[i + (size_t)k * m], h1 = H[i + (size_t)(k + 1) * m];
-                H[i + (size_t)k * m] = c * h0 + std::conj(sn) * h1;
-                H[i + (size_t)(k + 1) * m] = -sn * h0 + c * h1;
+            for (int i = 0; i <= i1; ++i) {         // columns k, k+1 of H (rows of T, strided)
+                zc h0 = h(i, k), h1 = h(i, k + 1);
+                hset(i, k, c * h0 + std::conj(sn) * h1);
+                hset(i, k + 1, -sn * h0 + c * h1);
             }
-            for (int i = 0; i < m; ++i) {
-                zc z0 = Z[i + (size_t)k * m], z1 = Z[i + (size_t)(k + 1) * m];
-                Z[i + (size_t)k * m] = c * z0 + std::conj(sn) * z1;
-                Z[i + (size_t)(k + 1) * m] = -sn * z0 + c * z1;
-            }
-            if (k + 1 < ihi) { x = H[k + 1 + (size_t)k * m]; y = H[k + 2 + (size_t)k * m]; }
+            rot_cols(0, m, c, sn.real(), sn.imag(), Z.r(k), Z.i(k), Z.r(k + 1), Z.i(k + 1));
+            if (k + 1 < ihi) { x = h(k + 1, k); y = h(k + 2, k); }
         }
     }
-    return 0;
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { H.re[i + (size_t)j * m] = T.re[j + (size_t)i * m]; H.im[i + (size_t)j * m] = T.im[j + (size_t)i * m]; }
+    return info;
 }
 }  // namespace
 
@@ -129,9 +181,15 @@ void matmul(int m, const zc* A, const zc* B, zc* C) {
 int eig_general(int m, zc* A, zc* lam, zc* V) {
     if (m <= 0) return 0;
     std::vector<zc> Z((size_t)m * m);
-    hessenberg(m, A, Z.data());
-    int info = hqr_schur(m, A, Z.data());
-    if (info) return info;
+    {
+        Planes Hp(m), Zp(m);
+        Hp.load(A);
+        hessenberg(Hp, Zp);
+        int info = hqr_schur(Hp, Zp);
+        if (info) return info;
+        Hp.store(A);
+        Zp.store(Z.data());
+    }
     double tn = 0;
     for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) tn = std::max(tn, cabs1(A[i + (size_t)j * m]));
     double small = std::max(EPS * tn, 1e-300);
@@ -176,30 +234,39 @@ int eig_general(int m, zc* A, zc* lam, zc* V) {
 }
 
 int eig_generalized(int m, zc* A, zc* B, zc* lam, zc* V) {
-    // C = B^-1 A by LU with partial pivoting on B applied to A
+    // C = B^-1 A: LU of B with partial pivoting (right-looking, column updates), then L and U solves column by column
+    // of A in axpy form -- every inner loop is stride 1 on the split planes.
     int info = 0;
+    Planes Bp(m), Ap(m);
+    Bp.load(B);
+    Ap.load(A);
+    std::vector<int> piv(m);
     for (int k = 0; k < m; ++k) {
+        double* bk_r = Bp.r(k);
+        double* bk_i = Bp.i(k);
         int pr = k;
-        double best = cabs1(B[k + (size_t)k * m]);
-        for (int i = k + 1; i < m; ++i) { double a = cabs1(B[i + (size_t)k * m]); if (a > best) { best = a; pr = i; } }
-        if (best == 0.0) { info = 1; B[k + (size_t)k * m] = 1e-300; }
-        if (pr != k) {
-            for (int j = 0; j < m; ++j) { std::swap(B[k + (size_t)j * m], B[pr + (size_t)j * m]); std::swap(A[k + (size_t)j * m], A[pr + (size_t)j * m]); }
-        }
-        zc piv = B[k + (size_t)k * m];
-        for (int i = k + 1; i < m; ++i) {
-            zc l = B[i + (size_t)k * m] / piv;
-            if (l == zc(0.0)) continue;
-            for (int j = k + 1; j < m; ++j) B[i + (size_t)j * m] -= l * B[k + (size_t)j * m];
-            for (int j = 0; j < m; ++j) A[i + (size_t)j * m] -= l * A[k + (size_t)j * m];
+        double best = std::fabs(bk_r[k]) + std::fabs(bk_i[k]);
+        for (int i = k + 1; i < m; ++i) { double a = std::fabs(bk_r[i]) + std::fabs(bk_i[i]); if (a > best) { best = a; pr = i; } }
+        piv[k] = pr;
+        if (best == 0.0) { info = 1; bk_r[pr] = 1e-300; }
+        if (pr != k)
+            for (int j = 0; j < m; ++j) { std::swap(Bp.r(j)[k], Bp.r(j)[pr]); std::swap(Bp.i(j)[k], Bp.i(j)[pr]); }
+        zc inv = 1.0 / zc(bk_r[k], bk_i[k]);
+        for (int i = k + 1; i < m; ++i) { zc l = zc(bk_r[i], bk_i[i]) * inv; bk_r[i] = l.real(); bk_i[i] = l.imag(); }
+        for (int j = k + 1; j < m; ++j) caxpy_sub(k + 1, m, Bp.r(j)[k], Bp.i(j)[k], bk_r, bk_i, Bp.r(j), Bp.i(j));
+    }
+    for (int j = 0; j < m; ++j) {
+        double* xr = Ap.r(j);
+        double* xi = Ap.i(j);
+        for (int k = 0; k < m; ++k) if (piv[k] != k) { std::swap(xr[k], xr[piv[k]]); std::swap(xi[k], xi[piv[k]]); }
+        for (int k = 0; k < m; ++k) caxpy_sub(k + 1, m, xr[k], xi[k], Bp.r(k), Bp.i(k), xr, xi);          // L y = P a
+        for (int k = m - 1; k >= 0; --k) {                                                                 // U x = y
+            zc x = zc(xr[k], xi[k]) / zc(Bp.r(k)[k], Bp.i(k)[k]);
+            xr[k] = x.real(); xi[k] = x.imag();
+            caxpy_sub(0, k, x.real(), x.imag(), Bp.r(k), Bp.i(k), xr, xi);
         }
     }
-    for (int j = 0; j < m; ++j)
-        for (int i = m - 1; i >= 0; --i) {
-            zc s = A[i + (size_t)j * m];
-            for (int k = i + 1; k < m; ++k) s -= B[i + (size_t)k * m] * A[k + (size_t)j * m];
-            A[i + (size_t)j * m] = s / B[i + (size_t)i * m];
-        }
+    Ap.store(A);
     int e = eig_general(m, A, lam, V);
     return e ? e : info;
 }
@@ -214,17 +281,7 @@ double hermitian_defect(int m, const zc* M) {
     return mx > 0 ? df / mx : 0.0;
 }
 
-// Split storage (separate real and imaginary planes, column-major) keeps every inner loop a stride-1 real loop
-// the compiler vectorises; this routine sits on the critical path of every FEAST iteration (GPU idle meanwhile).
 namespace {
-struct Planes {
-    int m;
-    std::vector<double> re, im;
-    explicit Planes(int m_) : m(m_), re((size_t)m_ * m_, 0.0), im((size_t)m_ * m_, 0.0) {}
-    double* r(int j) { return re.data() + (size_t)j * m; }
-    double* i(int j) { return im.data() + (size_t)j * m; }
-};
-
 // M <- R^-H M, column by column (R upper triangular with real positive diagonal): forward substitution with R^H
 void solve_rh_cols(int m, Planes& R, Planes& M) {
     for (int j = 0; j < m; ++j) {
