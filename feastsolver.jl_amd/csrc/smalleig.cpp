@@ -180,45 +180,41 @@ void matmul(int m, const zc* A, const zc* B, zc* C) {
 
 int eig_general(int m, zc* A, zc* lam, zc* V) {
     if (m <= 0) return 0;
-    std::vector<zc> Z((size_t)m * m);
-    {
-        Planes Hp(m), Zp(m);
-        Hp.load(A);
-        hessenberg(Hp, Zp);
-        int info = hqr_schur(Hp, Zp);
-        if (info) return info;
-        Hp.store(A);
-        Zp.store(Z.data());
-    }
+    Planes T(m), Z(m);
+    T.load(A);
+    hessenberg(T, Z);
+    int info = hqr_schur(T, Z);
+    if (info) return info;
     double tn = 0;
-    for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) tn = std::max(tn, cabs1(A[i + (size_t)j * m]));
+    for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) tn = std::max(tn, std::fabs(T.r(j)[i]) + std::fabs(T.i(j)[i]));
     double small = std::max(EPS * tn, 1e-300);
-    std::vector<zc> x(m), w(m);
+    std::vector<double> xr(m), xi(m), wr(m), wi(m);
     std::vector<zc> vals(m), vecs((size_t)m * m);
     for (int k = 0; k < m; ++k) {
-        zc t = A[k + (size_t)k * m];
+        // eigenvector of the triangular T for t = T_kk: back substitution in column (axpy) form, x_k = 1
+        zc t = T.at(k, k);
         vals[k] = t;
-        std::fill(x.begin(), x.end(), zc(0.0));
-        x[k] = 1.0;
-        for (int j = k - 1; j >= 0; --j) {
-            zc s = 0;
-            for (int i = j + 1; i <= k; ++i) s += A[j + (size_t)i * m] * x[i];
-            zc d = A[j + (size_t)j * m] - t;
+        for (int j = 0; j < k; ++j) { xr[j] = -T.r(k)[j]; xi[j] = -T.i(k)[j]; }     // right-hand side: -T[0:k, k]
+        xr[k] = 1.0; xi[k] = 0.0;
+        double scale_guard = 1.0;
+        for (int i = k - 1; i >= 0; --i) {
+            zc d = T.at(i, i) - t;
             if (cabs1(d) < small) d = small;
-            x[j] = -s / d;
-            if (cabs1(x[j]) > 1e100) {   // rescale to avoid overflow
-                for (int i = j; i <= k; ++i) x[i] *= 1e-100;
+            zc x = zc(xr[i], xi[i]) / d;
+            if (cabs1(x) > 1e100) {          // rescale to avoid overflow
+                for (int j = 0; j <= k; ++j) { xr[j] *= 1e-100; xi[j] *= 1e-100; }
+                x *= 1e-100; scale_guard *= 1e-100;
             }
+            xr[i] = x.real(); xi[i] = x.imag();
+            caxpy_sub(0, i, x.real(), x.imag(), T.r(i), T.i(i), xr.data(), xi.data());     // x[0:i] -= T[0:i, i] x_i
         }
+        (void)scale_guard;
+        std::fill(wr.begin(), wr.end(), 0.0); std::fill(wi.begin(), wi.end(), 0.0);
+        for (int j = 0; j <= k; ++j) caxpy_sub(0, m, -xr[j], -xi[j], Z.r(j), Z.i(j), wr.data(), wi.data());      // w = Z[:, 0:k+1] x
         double nr = 0;
-        for (int i = 0; i < m; ++i) {
-            zc s = 0;
-            for (int j = 0; j <= k; ++j) s += Z[i + (size_t)j * m] * x[j];
-            w[i] = s;
-            nr += std::norm(s);
-        }
-        nr = std::sqrt(nr);
-        for (int i = 0; i < m; ++i) vecs[i + (size_t)k * m] = w[i] / nr;
+        for (int i = 0; i < m; ++i) nr += wr[i] * wr[i] + wi[i] * wi[i];
+        nr = 1.0 / std::sqrt(nr);
+        for (int i = 0; i < m; ++i) vecs[i + (size_t)k * m] = zc(wr[i] * nr, wi[i] * nr);
     }
     std::vector<int> order(m);
     std::iota(order.begin(), order.end(), 0);
