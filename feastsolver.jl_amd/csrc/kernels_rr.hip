@@ -281,18 +281,36 @@ __global__ __launch_bounds__(256) void k_colnorm_partial(int n, int ldw, const c
     }
 }
 
-__global__ void k_colnorm_reduce(int nchunks, int ldw, const double* __restrict__ scratch, double* nrm2) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ldw) return;
-    double s = 0;
-    for (int c = 0; c < nchunks; ++c) s += scratch[(size_t)c * ldw + j];
-    nrm2[j] = s;
+// 64 columns per workgroup; wave w sums the chunks c = w, w + 16, ... (four loads in flight), the 16 partial sums are added in a
+// fixed order.  (One thread per column walking all 760 chunks of C3 took 181 us.)
+__global__ __launch_bounds__(1024) void k_colnorm_reduce(int nchunks, int ldw, const double* __restrict__ scratch, double* nrm2) {
+    __shared__ double red[16][64];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int j = blockIdx.x * 64 + lane;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (j < ldw) {
+        int c = wave;
+        for (; c + 48 < nchunks; c += 64) {
+            s0 += scratch[(size_t)c * ldw + j];
+            s1 += scratch[(size_t)(c + 16) * ldw + j];
+            s2 += scratch[(size_t)(c + 32) * ldw + j];
+            s3 += scratch[(size_t)(c + 48) * ldw + j];
+        }
+        for (; c < nchunks; c += 16) s0 += scratch[(size_t)c * ldw + j];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && j < ldw) {
+        double s = 0;
+        for (int w = 0; w < 16; ++w) s += red[w][lane];
+        nrm2[j] = s;
+    }
 }
 
 void launch_colnorm2(hipStream_t st, int n, int ldw, const cz* V, double* scratch, double* nrm2) {
     int chunks = (n + CN_ROWS - 1) / CN_ROWS;
     hipLaunchKernelGGL(k_colnorm_partial, dim3(chunks), dim3(256), 0, st, n, ldw, V, scratch);
-    hipLaunchKernelGGL(k_colnorm_reduce, dim3((ldw + 63) / 64), dim3(64), 0, st, chunks, ldw, scratch, nrm2);
+    hipLaunchKernelGGL(k_colnorm_reduce, dim3((ldw + 63) / 64), dim3(1024), 0, st, chunks, ldw, scratch, nrm2);
 }
 
 __global__ void k_scale_cols(int64_t total, int ldw, cz* V, const cz* __restrict__ s) {
