@@ -23,7 +23,10 @@ def match_sets(a, b):
 # ---------------------------------------------------------------------------------------
 # factorizer / left_divider seam
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,m0", [(1, 1), (5, 3), (33, 16), (64, 64), (100, 20), (257, 64), (300, 100), (700, 37)])
+# 257..700: look-ahead with whole and partial panel groups; 1100 / 2100: 512- and 1024-thread register panels;
+# 4200: the first panels are taller than 4 x 1024 rows (generic panel kernel), the later ones are not
+@pytest.mark.parametrize("n,m0", [(1, 1), (5, 3), (33, 16), (64, 64), (100, 20), (257, 64), (300, 100), (700, 37), (1100, 8), (2100, 4),
+                                  (4200, 3)])
 def test_seam_dense_lu_ldiv(gpu, pkg, n, m0):
     rng = np.random.default_rng(n * 1000 + m0)
     Cm = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))      # needs real pivoting
