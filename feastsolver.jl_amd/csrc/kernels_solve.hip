@@ -473,9 +473,10 @@ __device__ __forceinline__ void apply32_body(const ApplyGeomT<cf>& g, cf (*Vs)[A
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(&Vs[buf][vr + 8 * q][2 * (tid & 31)]) = vn[q];
     };
-    f4 cr[NS], ci[NS];
+    // 3M complex product as in apply_body: T1 = ar*br, T2 = ai*bi, T3 = (ar+ai)*(br+bi);  re = T1 - T2, im = T3 - T1 - T2
+    f4 t1[NS], t2[NS], t3[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { cr[q] = (f4){0, 0, 0, 0}; ci[q] = (f4){0, 0, 0, 0}; }
+    for (int q = 0; q < NS; ++q) { t1[q] = (f4){0, 0, 0, 0}; t2[q] = (f4){0, 0, 0, 0}; t3[q] = (f4){0, 0, 0, 0}; }
     cf* dptr[4];
     bool rok[4];
 #pragma unroll
@@ -491,14 +492,13 @@ __device__ __forceinline__ void apply32_body(const ApplyGeomT<cf>& g, cf (*Vs)[A
             for (int ks = 0; ks < A32_KC / 4; ++ks) {
                 if (ks < nks) {
                     const int kk = ks * 4 + lk;
-                    const float ar = av[ks].x, ai = av[ks].y;
+                    const float ar = av[ks].x, ai = av[ks].y, as = ar + ai;
 #pragma unroll
                     for (int q = 0; q < NS; ++q) {
                         cf b = Vs[buf][kk][(ct0 + q) * 16 + li];
-                        cr[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, b.x, cr[q], 0, 0, 0);
-                        cr[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(-ai, b.y, cr[q], 0, 0, 0);
-                        ci[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, b.y, ci[q], 0, 0, 0);
-                        ci[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.x, ci[q], 0, 0, 0);
+                        t1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, b.x, t1[q], 0, 0, 0);
+                        t2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.y, t2[q], 0, 0, 0);
+                        t3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, b.x + b.y, t3[q], 0, 0, 0);
                     }
                 }
             }
@@ -556,8 +556,9 @@ __device__ __forceinline__ void apply32_body(const ApplyGeomT<cf>& g, cf (*Vs)[A
         for (int q = 0; q < NS; ++q) {
             int col = cg + (ct0 + q) * 16 + li;
             cf v;
-            if (g.mode == 1 || g.mode == 2) { v.x = sgn * cr[q][r]; v.y = sgn * ci[q][r]; }
-            else { v.x = old[r][q].x - cr[q][r]; v.y = old[r][q].y - ci[q][r]; }
+            const float re = t1[q][r] - t2[q][r], im = t3[q][r] - t1[q][r] - t2[q][r];
+            if (g.mode == 1 || g.mode == 2) { v.x = sgn * re; v.y = sgn * im; }
+            else { v.x = old[r][q].x - re; v.y = old[r][q].y - im; }
             if (rok[r] && col < ldw) dptr[r][col] = v;
         }
 }
