@@ -656,7 +656,7 @@ void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int 
 constexpr int GEMM_KC = 32;
 constexpr int GEMM_CHUNK = 64;     // work items per XCD chunk (one 8 x 8 super-tile)
 
-__global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
+__global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
                                                   cz* fact, int64_t fs, cz* cb, int64_t cbs, ColSel cs, int bw, int mrows, int ntiles, int K) {
     // cs: the columns updated by this launch (pivot-block columns by offset from column k0 + bw; the U12 tiles when cs.u12).
     // bw: width of the eliminated block, FACT_NB or the width of a group of panels that is applied in one product.
@@ -703,9 +703,11 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
     int mrow = m0 + wave * 16 + li;
     bool mok = mrow < M;
     int mrow_c = min(mrow, M - 1);
-    d4 cr[4], ci[4];
+    // 3M complex product (T1 = br ar, T2 = bi ai, T3 = (br+bi)(ar+ai); re = T1 - T2, im = T3 - T1 - T2): three MFMAs per complex
+    // multiply-add instead of four; the third accumulator fits at two waves per SIMD (138 VGPRs + 96 AGPRs)
+    d4 t1[4], t2[4], t3[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
+    for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
     // The read-modify-write loads of the epilogue are issued in front of the MFMAs of the last K chunk (the B staging registers
     // are dead by then): at the depths of the panel-group updates (32..128) their latency is otherwise a tenth of the tile.
     // The contribution block (kind 2) is written, not updated: CB = -L21 U12, the children's blocks are added afterwards.
@@ -750,16 +752,14 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
             cz bv[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) bv[nt] = Bs[kk][nt * 16 + li];
-            double ar = av[ks].x, ai = av[ks].y, nai = -av[ks].y;
+            double ar = av[ks].x, ai = av[ks].y, as = av[ks].x + av[ks].y;
             // D[n][m] += B^T[n][k] A^T[k][m]   (MFMA "A" operand = B tile from LDS, "B" operand = A slab)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].x, ar, cr[nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) t1[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].x, ar, t1[nt], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].x, ai, ci[nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].y, ai, t2[nt], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cr[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].y, nai, cr[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) ci[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].y, ar, ci[nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[nt].x + bv[nt].y, as, t3[nt], 0, 0, 0);
         }
     };
     int kc0 = 0;
@@ -770,7 +770,8 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const FrontD* __restrict__ fr, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int gn = n0 + nt * 16 + lk + 4 * r;
-            if (mok && gn < N && gn >= nlo) C[mrow + (int64_t)gn * ldc] = cz_make(old[nt][r].x - cr[nt][r], old[nt][r].y - ci[nt][r]);
+            if (mok && gn < N && gn >= nlo)
+                C[mrow + (int64_t)gn * ldc] = cz_make(old[nt][r].x - (t1[nt][r] - t2[nt][r]), old[nt][r].y - (t3[nt][r] - t1[nt][r] - t2[nt][r]));
         }
 }
 
