@@ -20,6 +20,8 @@ struct FrontD {
     int nchild, depth;
     int64_t sk_off;           // row offset of this front's split-K partial sums in the scratch (backward U12 product), or -1
     int64_t cmap;             // offset into the contribution-row pull map (u x nchild ints), or -1 without children
+    int64_t ebp;              // as a child: offset into the extend-add break points (first contribution row that lands at or
+                              // beyond parent row 64 b, b = 0 .. ceil(ld_parent / 64)), or -1 for a root
 };
 
 struct Tile { int f, a, b, c; };

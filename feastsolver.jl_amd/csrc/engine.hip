@@ -531,6 +531,7 @@ int Engine::analyze() {
         f.child_ptr = S.child_ptr[s]; f.nchild = (int)(S.child_ptr[s + 1] - S.child_ptr[s]); f.depth = S.depth[s];
         f.sk_off = -1;
         f.cmap = -1;
+        f.ebp = -1;
     }
     // pull map of the forward sweep: for every contribution row of a front and every child slot, the row of the child's
     // contribution block that is added to it (rel >= p), as an absolute row of the children's arena; -1 if none
@@ -551,6 +552,22 @@ int Engine::analyze() {
         }
     }
     if (cmap.empty()) cmap.push_back(-1);
+    // extend-add break points: for a child g of parent s, ebp[b] = number of contribution rows of g that land before parent
+    // row 64 b (rel is ascending), so a 64 x 64 parent tile finds its slice of the child's block without searching
+    std::vector<int> ebp;
+    for (int g2 = 0; g2 < S.nsuper; ++g2) {
+        int par = S.sn_parent[g2];
+        if (par < 0 || S.u(g2) == 0) continue;
+        int nb = (S.p(par) + S.u(par) + 63) / 64, ug = S.u(g2);
+        fr[g2].ebp = (int64_t)ebp.size();
+        const int* rc = S.rel.data() + S.struct_ptr[g2];
+        int i = 0;
+        for (int b = 0; b <= nb; ++b) {
+            while (i < ug && rc[i] < 64 * b) ++i;
+            ebp.push_back(i);
+        }
+    }
+    if (ebp.empty()) ebp.push_back(0);
     std::vector<int> c0row(n);
     for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
     std::vector<int> one(1, 0);
@@ -559,12 +576,12 @@ int Engine::analyze() {
               d_rel_.upload(S.rel.empty() ? one.data() : S.rel.data(), std::max<size_t>(1, S.rel.size()), stream_) &&
               d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
               d_perm_.upload(S.perm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
-              d_cmap_.upload(cmap.data(), cmap.size(), stream_);
+              d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_);
     if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
     for (int s = 0; s < S.nsuper; ++s) fr[s].sk_off = sk_off_[s];
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
-    dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.n = n;
+    dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.n = n;
     // numeric arenas
     analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto t_alloc = std::chrono::steady_clock::now();

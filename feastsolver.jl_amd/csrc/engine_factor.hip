@@ -197,15 +197,19 @@ int Engine::factorize() {
         size_t q = 0;
         for (int d = S.maxdepth; d >= 0; --d, q += 3) {
             int mp = 0, mu = 0;
-            double fl_schur = 0, fl_steps = 0;
+            double fl_schur = 0, fl_steps = 0, by_ext = 0;
+            // extend-add into this level (both phases): every child contribution entry is read once and added into the parent
+            // (read-modify-write): 48 bytes per entry
+            for (int s2 : S.levels[d])
+                for (int64_t c = S.child_ptr[s2]; c < S.child_ptr[s2 + 1]; ++c) { double uc = S.u(S.child_idx[c]); by_ext += 48.0 * uc * uc * Kloc; }
             for (int s2 : S.levels[d]) {
                 double p2 = S.p(s2), u2 = S.u(s2);
                 mp = std::max(mp, S.p(s2)); mu = std::max(mu, S.u(s2));
                 fl_schur += 8.0 * u2 * u2 * p2 * Kloc;
                 fl_steps += 8.0 * (p2 * p2 * p2 / 3.0 + p2 * p2 * u2) * Kloc;      // LU of the pivot block, L21 and U12 (8 flops per complex multiply-add)
             }
-            fprintf(stderr, "[feasthip factor] depth %2d  fronts %5zu  max p %5d  max u %5d  steps %3zu | extend-add %7.2f  panel steps %7.2f (%5.1f TF)  schur product %7.2f ms (%5.1f TF)\n",
-                    d, S.levels[d].size(), mp, mu, fplan_[d].steps.size(), ms(q, q + 1), ms(q + 1, q + 2), fl_steps / ms(q + 1, q + 2) * 1e-9, ms(q + 2, q + 3), fl_schur / ms(q + 2, q + 3) * 1e-9);
+            fprintf(stderr, "[feasthip factor] depth %2d  fronts %5zu  max p %5d  max u %5d  steps %3zu | extend-add %7.2f (%4.1f TB/s)  panel steps %7.2f (%5.1f TF)  schur product %7.2f ms (%5.1f TF)\n",
+                    d, S.levels[d].size(), mp, mu, fplan_[d].steps.size(), ms(q, q + 1), by_ext / ms(q, q + 1) * 1e-9, ms(q + 1, q + 2), fl_steps / ms(q + 1, q + 2) * 1e-9, ms(q + 2, q + 3), fl_schur / ms(q + 2, q + 3) * 1e-9);
         }
         for (hipEvent_t e4 : tev) (void)hipEventDestroy(e4);
     }

@@ -19,6 +19,7 @@ struct DevSym {          // device copies of the symbolic structure
     const int* perm;     // new -> old
     const int* c0_of_row;  // first column of the supernode owning (new) row i
     const int* cmap;       // per front with children: [contribution row][child slot] -> row in the children's arena, or -1
+    const int* ebp;        // extend-add break points, see FrontD::ebp
     int n;
 };
 

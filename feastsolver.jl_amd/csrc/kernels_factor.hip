@@ -78,8 +78,8 @@ void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                     const int* __restrict__ rel, const int* __restrict__ child_idx,
-                                                    cz* fact, int64_t fs, cz* cbp, int64_t cbsp, const cz* __restrict__ cbc,
-                                                    int64_t cbsc, int phase) {
+                                                    const int* __restrict__ ebp, cz* fact, int64_t fs, cz* cbp, int64_t cbsp,
+                                                    const cz* __restrict__ cbc, int64_t cbsc, int phase) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ f
         FrontD g = fr[child_idx[f.child_ptr + ci]];
         const int* rc = rel + g.sptr;
         int uc = g.u;
-        int ia = lower_bound_dev(rc, uc, r0), ib = lower_bound_dev(rc, uc, r0 + 64);
-        int ja = lower_bound_dev(rc, uc, q0), jb = lower_bound_dev(rc, uc, q0 + 64);
+        // the child's rows / columns that land in this tile (host-made break points instead of four binary searches over rel)
+        const int* bp = ebp + g.ebp;
+        int ia = bp[t.a], ib = bp[t.a + 1], ja = bp[t.b], jb = bp[t.b + 1];
         int nr = ib - ia, nc = jb - ja;
         if (nr > 0 && nc > 0) {
             const cz* src = cbc + (int64_t)k * cbsc + g.cb;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ f
 void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,
                        cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K, int phase) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_extend_add, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, fact, fs,
+    hipLaunchKernelGGL(k_extend_add, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, S.ebp, fact, fs,
                        cb_parent, cbs_parent, cb_child, cbs_child, phase);
 }
 

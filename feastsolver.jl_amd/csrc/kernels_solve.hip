@@ -61,7 +61,7 @@ void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, 
 template <typename T>
 __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                       const int* __restrict__ rel, const int* __restrict__ child_idx,
-                                                      T* W, int64_t ws, int ldw, T* crp, int64_t crsp,
+                                                      const int* __restrict__ ebp, T* W, int64_t ws, int ldw, T* crp, int64_t crsp,
                                                       const T* __restrict__ crc, int64_t crsc,
                                                       const int* __restrict__ rowinv, int n, int phase) {
     Tile t = tiles[blockIdx.x];
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
     for (int ci = 0; ci < f.nchild; ++ci) {
         FrontD g = fr[child_idx[f.child_ptr + ci]];
         const int* rc = rel + g.sptr;
-        int ia = lower_bound_dev2(rc, g.u, r0), ib = lower_bound_dev2(rc, g.u, r0 + 64);
+        int ia = ebp[g.ebp + t.a], ib = ebp[g.ebp + t.a + 1];        // the child's rows that land in parent rows [r0, r0 + 64)
         for (int i = ia + wave; i < ib; i += 4) {
             int dst = rc[i];
             if ((dst < p) != (phase == 0)) continue;
@@ -93,14 +93,14 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
                          const int* rowinv, int K, int phase) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, W, ws, ldw,
+    hipLaunchKernelGGL(k_fwd_assemble<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, S.ebp, W, ws, ldw,
                        crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
                          cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
                          const int* rowinv, int K, int phase) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, W, ws, ldw,
+    hipLaunchKernelGGL(k_fwd_assemble<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, S.ebp, W, ws, ldw,
                        crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase);
 }
 
