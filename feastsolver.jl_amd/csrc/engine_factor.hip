@@ -76,7 +76,7 @@ int Engine::factorize() {
                           std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 0);
         int level_ld = 0;
         for (int s2 : S.levels[d]) level_ld = std::max(level_ld, S.p(s2) + S.u(s2));
-        const bool tall = level_ld >= 1024;      // 1024-thread panel workgroups for tall fronts (430 -> 396 ms for the 16 factorisations of C3)
+        const bool tall = level_ld >= 1024;      // wide panel workgroups for tall fronts (launch_panel picks the width)
         int level_p = 0;
         for (int s2 : S.levels[d]) level_p = std::max(level_p, S.p(s2));
         const bool lookahead = look_ahead_ && level_p >= 256 && la_stream_ && F.steps.size() >= 4;
@@ -93,12 +93,14 @@ int Engine::factorize() {
             // handful of workgroups and would otherwise leave the GPU idle between two trailing updates).  The panels are taken
             // in groups of group_panels_ (columns [K0_g, K0_g+1)).  The high-priority stream P factors the panels of group g,
             // updating only the group's own columns in between, and then applies the whole group, as one product of depth
-            // K0_g+1 - K0_g, to the columns of group g+1 (W below).  The main stream applies group g to everything else (the
-            // left columns' row interchanges, the pivot-block columns from K0_g+2 on and U12) while P is busy with group g+1.
+            // K0_g+1 - K0_g, to the columns of group g+1.  Stream R (CU-masked so that the panel workgroups of P always find an
+            // empty CU, see the constructor) applies group g to everything else (the left columns' row interchanges, the
+            // pivot-block columns from K0_g+2 on and U12) while P is busy with group g+1.
             // Deferring a group's update is legal because all its row interchanges are applied first, to L and to C alike; the
-            // U rows then come from a blocked forward substitution (a 32-row product with the panels before it, then the
-            // triangular solve with the panel's own L11) and the rest is one product.  Against per-panel updates the product
-            // reads and writes C once per group instead of once per panel, which is what bounds it.
+            // U rows then come from one k_group_utrsm launch (or, for groups wider than 128 columns, from a blocked forward
+            // substitution: a 32-row product with the panels before it, then the triangular solve with the panel's own L11) and
+            // the rest is one product.  Against per-panel updates the product reads and writes C once per group instead of once
+            // per panel, which is what bounds it.
             hipStream_t P = la_stream_, R = rest_stream_ ? rest_stream_ : stream_;
             HIPCHK(hipEventRecord(ev_la_[4], stream_));
             HIPCHK(hipStreamWaitEvent(P, ev_la_[4], 0));
