@@ -46,6 +46,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_GROUP")) group_panels_ = std::max(1, std::min(8, atoi(v)));
     if (const char* v = getenv("FEASTHIP_FUSED_UTRSM")) fused_utrsm_ = atoi(v) != 0;
+    if (const char* v = getenv("FEASTHIP_FUSE_EXTEND")) { fuse_extend_ = atoi(v) != 0; if (atoi(v) > 0) fuse_min_p_ = atoi(v); }
     if (const char* v = getenv("FEASTHIP_FIN_ASYNC")) finalize_async_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     int nst = 2;

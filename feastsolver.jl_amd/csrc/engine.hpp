@@ -211,7 +211,8 @@ private:
     hipStream_t rest_stream_ = nullptr;  // trailing updates of the look-ahead levels: a CU mask keeps reserve_cus_ CUs per XCD free for la_stream_
     int reserve_cus_ = 2;
     std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join, [6] rest stream join
-    bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true;
+    bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true, fuse_extend_ = true;
+    int fuse_min_p_ = 128;            // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself
     int group_panels_ = 4;            // panels per deferred trailing update in the look-ahead factorisation
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;

@@ -177,7 +177,12 @@ int Engine::factorize() {
             if (R != stream_) { HIPCHK(hipEventRecord(ev_la_[6], R)); HIPCHK(hipStreamWaitEvent(stream_, ev_la_[6], 0)); }
         }
         stamp();
-        launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc);
+        // The children's contributions to the contribution block are pulled in by the product's epilogue where the product is long
+        // enough to carry the extra dependent loads (pivot blocks of 128 columns and more: extend-add 39 -> 17 ms for +9 ms of
+        // products on C3); the levels of small fronts keep the separate second extend-add pass.
+        const bool fuse = fuse_extend_ && level_p >= fuse_min_p_;
+        launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc, ColSel(), FACT_NB, 0,
+                       fuse ? d_cb_[par ^ 1].p : nullptr, std::max<int64_t>(1, S.cb_size[par ^ 1]));
         stamp();
         // The solve-ready conversion of this level (row permutations, block inverses, panel scaling) only touches this
         // level's own panels, which nothing above reads (parents take the contribution blocks): it runs on a side stream
@@ -188,8 +193,9 @@ int Engine::factorize() {
         launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
-        launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
-                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
+        if (!fuse)
+            launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
+                              std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
     }
     if (fin_used) { HIPCHK(hipEventRecord(ev_join_[0], aux_streams_[0])); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0)); }
     if (ftrace) {

@@ -658,7 +658,9 @@ constexpr int GEMM_KC = 32;
 constexpr int GEMM_CHUNK = 64;     // work items per XCD chunk (one 8 x 8 super-tile)
 
 __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
-                                                  cz* fact, int64_t fs, cz* cb, int64_t cbs, ColSel cs, int bw, int mrows, int ntiles, int K) {
+                                                  cz* fact, int64_t fs, cz* cb, int64_t cbs, ColSel cs, int bw, int mrows, int ntiles, int K,
+                                                  const int* __restrict__ child_idx, const int* __restrict__ cmap,
+                                                  const cz* __restrict__ cbc, int64_t cbsc) {
     // cs: the columns updated by this launch (pivot-block columns by offset from column k0 + bw; the U12 tiles when cs.u12).
     // bw: width of the eliminated block, FACT_NB or the width of a group of panels that is applied in one product.
     // mrows > 0: only the first mrows rows below the block (the U rows of the next panel of the group).
@@ -766,6 +768,33 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
     int kc0 = 0;
     for (; kc0 + GEMM_KC < Kd; kc0 += GEMM_KC) chunk(kc0, std::false_type{});
     chunk(kc0, std::true_type{});
+    // Contribution block with children (cbc given): the children's contribution entries that land in this tile are pulled in
+    // here, in child order, instead of in a second pass (k_extend_add phase 1) that would read and rewrite the whole block:
+    // cmap[row][child] is the child's contribution row behind a parent contribution row (as in the forward sweep).
+    if (t.a == 2 && cbc != nullptr && f.cmap >= 0 && mok) {
+        const int nch = f.nchild;
+        for (int c = 0; c < nch; ++c) {
+            const FrontD* g = fr + child_idx[f.child_ptr + c];
+            const int64_t gcrow = g->crow;
+            const int rm = cmap[f.cmap + (int64_t)mrow * nch + c];
+            if (rm < 0) continue;
+            const int gu = g->u;
+            const cz* src = cbc + (int64_t)k * cbsc + g->cb + (rm - gcrow);
+            int cn[4][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cn[nt][r] = cmap[f.cmap + (int64_t)min(n0 + nt * 16 + lk + 4 * r, N - 1) * nch + c];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (cn[nt][r] >= 0) {
+                        cz v = src[(int64_t)(cn[nt][r] - gcrow) * gu];
+                        old[nt][r].x += v.x; old[nt][r].y += v.y;
+                    }
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -777,11 +806,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
 }
 
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                    cz* cb, int64_t cbs, int K, ColSel cs, int bw, int mrows) {
+                    cz* cb, int64_t cbs, int K, ColSel cs, int bw, int mrows, const cz* cbc, int64_t cbsc) {
     if (ntiles <= 0) return;
     const int64_t items = (int64_t)ntiles * K, per = 8 * GEMM_CHUNK;
     hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((items + per - 1) / per * per)), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, cb, cbs, cs, bw, mrows,
-                       ntiles, K);
+                       ntiles, K, S.child_idx, S.cmap, cbc, cbsc);
 }
 
 // ---------------------------------------------------------------------------
