@@ -487,6 +487,34 @@ def test_c3_g24_converges_with_right_count(gpu, pkg, wl):
     assert np.abs(lam.imag).max() < 1e-10      # Hermitian-definite pencil
 
 
+@pytest.mark.parametrize("shape,extra", [((48, 24, 14), 300), ((90, 70, 3), 0), ((30, 30, 30), 2000)])
+def test_irregular_trees_sparse_lu(gpu, pkg, shape, extra):
+    """Elimination trees whose levels mix fronts of very different pivot-block widths (non-cubic grids, random long-range
+    couplings): the grouped look-ahead schedule sees panel groups that end inside a front's pivot block."""
+    rng = np.random.default_rng(sum(shape) + extra)
+    def lap1(g):
+        return sp.diags([-np.ones(g - 1), 2.0 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
+    gx, gy, gz = shape
+    A = (sp.kron(sp.kron(lap1(gx), sp.identity(gy)), sp.identity(gz)) + sp.kron(sp.kron(sp.identity(gx), lap1(gy)), sp.identity(gz))
+         + sp.kron(sp.kron(sp.identity(gx), sp.identity(gy)), lap1(gz))).tocsc()
+    n = A.shape[0]
+    if extra:
+        i = rng.integers(0, n, extra)
+        j = rng.integers(0, n, extra)
+        E = sp.coo_matrix((rng.standard_normal(extra) * 0.3, (i, j)), shape=(n, n))
+        A = (A + E + 0.5 * E.T).tocsc()            # structurally symmetric, numerically not
+    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.31 + 0.23j) * sp.identity(n))
+    R = np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8)))
+    F = pkg.lu(Cm)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    pkg.finalize(F)
+    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * spla.norm(Cm) * np.linalg.norm(Y)
+    if extra == 0:          # (the host reference LU of the cases with long-range couplings takes minutes; the residual is the check)
+        ref = spla.splu(Cm).solve(np.ascontiguousarray(R))
+        assert np.abs(Y - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
 def test_c3_full_size_g46(gpu, pkg, wl):
     """BASELINE configs[2] at its full size (n = 97,336, 16 nodes, m0 = 64): right count, true residuals, real spectrum,
     and the moment of the first contour step is linear in X (contour_step on 2 X == 2 contour_step on X)."""
