@@ -24,7 +24,14 @@ __global__ void k_spmm_csr(int n, const int64_t* __restrict__ rowptr, const int*
     int64_t a = rowptr[i], b = rowptr[i + 1];
     for (int j = lane; j < ldw; j += 64) {
         cz acc = cz_make(0, 0);
-        for (int64_t t = a; t < b; ++t) cz_madd(acc, val[t], V[(int64_t)col[t] * ldw + j]);
+        int64_t t = a;
+        for (; t + 4 <= b; t += 4) {          // four gathered rows of V in flight (the plain loop is one dependent chain per entry)
+            int c0 = col[t], c1 = col[t + 1], c2 = col[t + 2], c3 = col[t + 3];
+            cz a0 = val[t], a1 = val[t + 1], a2 = val[t + 2], a3 = val[t + 3];
+            cz v0 = V[(int64_t)c0 * ldw + j], v1 = V[(int64_t)c1 * ldw + j], v2 = V[(int64_t)c2 * ldw + j], v3 = V[(int64_t)c3 * ldw + j];
+            cz_madd(acc, a0, v0); cz_madd(acc, a1, v1); cz_madd(acc, a2, v2); cz_madd(acc, a3, v3);
+        }
+        for (; t < b; ++t) cz_madd(acc, val[t], V[(int64_t)col[t] * ldw + j]);
         cz r = cz_mul(alpha, acc);
         if (accumulate) r = cz_add(r, out[(int64_t)i * ldw + j]);
         out[(int64_t)i * ldw + j] = r;
