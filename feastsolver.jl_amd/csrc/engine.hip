@@ -64,6 +64,10 @@ Engine::Engine(int device) : device_(device) {
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
         if (hipStreamCreateWithPriority(&la_stream_, hipStreamNonBlocking, phi) != hipSuccess) la_stream_ = nullptr;
+        // the solve-ready conversion of a finished level fills the gaps of the levels above: lowest priority
+        if (hipStreamCreateWithPriority(&fin_stream_, hipStreamNonBlocking, plo) != hipSuccess) fin_stream_ = nullptr;
+        (void)hipEventCreateWithFlags(&ev_fin_, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ev_fin_fork_, hipEventDisableTiming);
         for (int i = 0; i < 7; ++i) { hipEvent_t e3 = nullptr; (void)hipEventCreateWithFlags(&e3, hipEventDisableTiming); ev_la_.push_back(e3); }
         // A panel workgroup (1024 threads, 126 registers) needs an empty CU: behind a trailing update that fills every CU it
         // would only start when that update drains.  The trailing updates of the look-ahead levels therefore run on a stream
@@ -91,6 +95,9 @@ Engine::~Engine() {
     for (hipEvent_t e3 : ev_la_) if (e3) (void)hipEventDestroy(e3);
     if (la_stream_) { (void)hipStreamSynchronize(la_stream_); (void)hipStreamDestroy(la_stream_); }
     if (rest_stream_) { (void)hipStreamSynchronize(rest_stream_); (void)hipStreamDestroy(rest_stream_); }
+    if (fin_stream_) { (void)hipStreamSynchronize(fin_stream_); (void)hipStreamDestroy(fin_stream_); }
+    if (ev_fin_) (void)hipEventDestroy(ev_fin_);
+    if (ev_fin_fork_) (void)hipEventDestroy(ev_fin_fork_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);

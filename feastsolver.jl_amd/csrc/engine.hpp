@@ -208,6 +208,8 @@ private:
     bool streams_forced_ = false;
     DevBuf<cz> d_mvpart_;                // split-K partial sums of the dense term products (k_dense_mv)
     hipStream_t la_stream_ = nullptr;    // high-priority stream of the look-ahead panels
+    hipStream_t fin_stream_ = nullptr;   // low-priority stream of the solve-ready conversion
+    hipEvent_t ev_fin_ = nullptr, ev_fin_fork_ = nullptr;
     hipStream_t rest_stream_ = nullptr;  // trailing updates of the look-ahead levels: a CU mask keeps reserve_cus_ CUs per XCD free for la_stream_
     int reserve_cus_ = 2;
     std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join, [6] rest stream join

@@ -187,8 +187,8 @@ int Engine::factorize() {
         // The solve-ready conversion of this level (row permutations, block inverses, panel scaling) only touches this
         // level's own panels, which nothing above reads (parents take the contribution blocks): it runs on a side stream
         // next to the factorisation of the levels above.  It must follow the Schur-complement product, which reads L21 / U12.
-        hipStream_t fin = (finalize_async_ && !aux_streams_.empty()) ? aux_streams_[0] : stream_;
-        if (fin != stream_) { HIPCHK(hipEventRecord(ev_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fork_, 0)); fin_used = true; }
+        hipStream_t fin = (finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_) ? fin_stream_ : stream_;
+        if (fin != stream_) { HIPCHK(hipEventRecord(ev_fin_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fin_fork_, 0)); fin_used = true; }
         launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
         launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
@@ -197,7 +197,7 @@ int Engine::factorize() {
             launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
                               std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
     }
-    if (fin_used) { HIPCHK(hipEventRecord(ev_join_[0], aux_streams_[0])); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0)); }
+    if (fin_used) { HIPCHK(hipEventRecord(ev_fin_, fin_stream_)); HIPCHK(hipStreamWaitEvent(stream_, ev_fin_, 0)); }
     if (ftrace) {
         stamp();
         HIPCHK(hipStreamSynchronize(stream_));
