@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=16)
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--cpu-grid", type=int, default=24)
+    ap.add_argument("--no-fold", action="store_true",
+                    help="factorise every contour node separately (the conjugate fold of real pencils off): the reference's literal schedule")
     ap.add_argument("--mixed-prec", action="store_true",
                     help="secondary measurement: complex64 shifted solves with complex128 accumulation (feast!'s mixed_prec); not the headline number")
     args = ap.parse_args()
@@ -127,6 +129,8 @@ def main():
     h.set_terms([w["A"], w["B"]], [1.0, -1.0])
     h.set_contour(con)
     h.set_node_shard(rank, world)
+    if args.no_fold:
+        h.set_conjugate_fold(False)
     if args.mixed_prec:
         h.set_precision(True)
     ldw = ((args.m0 + 15) // 16) * 16
@@ -201,6 +205,7 @@ def main():
                 "workload": f"C3 sparse generalized: {args.stencil}-point 3-D Laplacian {args.grid}^3, B=diag(U(0.5,1.5)), "
                             f"circular contour {args.nodes} trapezoid nodes, m0={args.m0}, store=true",
                 "n": n, "nnz_A": int(w["A"].nnz), "nodes": args.nodes, "m0": args.m0, "nodes_per_gpu": st["local_nodes"],
+                "conjugate_fold": bool(st["folded"]), "factorisations_per_gpu": st["factor_units"],
                 "nnz_L": st["nnz_l"], "nnz_U": st["nnz_u"], "supernodes": st["nsuper"], "max_front": st["max_front"],
             },
             "roofline": {
@@ -210,7 +215,7 @@ def main():
                 "launches_per_step": pa["launches"], "avg_launch_ms": pa["ms"] / max(1, pa["launches"]),
                 "f64_mfma": {"achieved": dom_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom_tf / F64_MFMA_PEAK_TF,
                              "note": "m0=64 complex f64 is 32 flop/B (24 with the 3M product): the f64 matrix cores bind before HBM (ceiling 3.2 TB/s of factor bytes); achieved counts 8 flops per complex multiply-add"},
-                "contour_step": {"ms": st2["solve_ms"], "algorithmic_GB": st2["solve_bytes"] / 1e9,
+                "contour_step": {"ms": st2["solve_ms"], "algorithmic_GB": st2["solve_bytes"] / 1e9, "streamed_GB_model": st2["solve_bytes_streamed"] / 1e9,
                                  "GBps": st2["solve_bytes"] / (st2["solve_ms"] * 1e-3) / 1e9,
                                  "TFLOPs": st2["solve_flops"] / (st2["solve_ms"] * 1e-3) / 1e12},
                 "kernel_classes_ms": {k: v["ms"] for k, v in prof.items()},
@@ -218,7 +223,7 @@ def main():
             "breakdown_ms_per_step": {k: 1e3 * v / args.steps for k, v in phase.items()},      # rank 0; rr is replicated, contour is this rank's node shard
             # analyze_s: ordering + symbolic analysis + plan upload; alloc_s: hipMalloc of the arenas (0.03 .. 2 s for the same
             # request depending on what the previous process left to scrub) -- reported separately, both count in time_to_solution_s
-            "setup": {"analyze_s": st["analyze_seconds"], "alloc_s": st["alloc_seconds"], "analyze_call_s": t_analyze, "factor_ms": st["factor_ms"], "factor_TFLOPs": st["flops_factor"] * st["local_nodes"] / (st["factor_ms"] * 1e-3) / 1e12,
+            "setup": {"analyze_s": st["analyze_seconds"], "alloc_s": st["alloc_seconds"], "analyze_call_s": t_analyze, "factor_ms": st["factor_ms"], "factor_TFLOPs": st["flops_factor"] * st["factor_units"] / (st["factor_ms"] * 1e-3) / 1e12,
                       "perturbed_pivots": int(warn), "store_false_iterations_per_s": 1.0 / (dt / args.steps + st["factor_ms"] * 1e-3)},
             "result": {"inside": int(ins.sum()), "expected_inside": w["n_inside"], "max_res_inside": float(res[ins].max()) if ins.any() else None,
                        "rr_ms": st2["rr_ms"],

@@ -22,6 +22,7 @@ class Stats(C.Structure):
         ("solve_ms", C.c_double), ("rr_ms", C.c_double), ("solve_bytes", C.c_double), ("solve_flops", C.c_double),
         ("perturbed_pivots", C.c_int64), ("local_nodes", C.c_int32), ("m0", C.c_int32), ("ldw", C.c_int32),
         ("dense", C.c_int32), ("alloc_seconds", C.c_double),
+        ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double),
     ]
 
 
@@ -57,6 +58,7 @@ PROTOTYPES = {
     "feasthip_dual_feast_run": (I, [VP, VP, VP, I64, I, I, D, I, VP, VP, VP, VP, C.POINTER(I)]),
     "feasthip_nlfeast_run": (I, [VP, VP, I64, I, I, D, D, VP, VP, VP, C.POINTER(I)]),
     "feasthip_set_precision": (I, [VP, I]),
+    "feasthip_set_conjugate_fold": (I, [VP, I]),
     "feasthip_set_coef_functions": (I, [VP, VP, VP]),
     "feasthip_set_node_coefficients": (I, [VP, VP, I, I]),
     "feasthip_nl_beyn_step": (I, [VP, VP, VP]),

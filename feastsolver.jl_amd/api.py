@@ -187,6 +187,11 @@ class FeastHandle:
         """mixed_prec of feast! (src/feast.jl:19-25): complex64 shifted solves, complex128 accumulation."""
         self._ck(self.lib.feasthip_set_precision(self.h, 1 if mixed else 0))
 
+    def set_conjugate_fold(self, on):
+        """Conjugate fold (default on): real coefficient matrices + mirror-symmetric contour => one factorisation per
+        conjugate node pair, the mirror system as m0 more right-hand-side columns (feasthip_set_conjugate_fold)."""
+        self._ck(self.lib.feasthip_set_conjugate_fold(self.h, 1 if on else 0))
+
     def set_coef_functions(self, funcs):
         """f_t(z) of a split-form NEP (None restores the polynomial default z^t)."""
         if funcs is None:
@@ -342,8 +347,10 @@ def _writeback(X_in, Xw):
 
 
 def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=False, store=False, eps=1e-12,
-              factorizer=None, left_divider=None, device=0, info=None, _mixed_prec=False):
+              factorizer=None, left_divider=None, device=0, info=None, _mixed_prec=False, conjugate_fold=True):
     """gen_feast!(X, A, B[, contour]; ...)  src/feast.jl:82-156.  B=None gives feast!.
+    ``conjugate_fold=False`` factorises every contour node separately like the reference even when the matrices are real
+    and the contour is mirror-symmetric (FeastHandle.set_conjugate_fold).
 
     ``factorizer``/``left_divider`` are accepted for signature parity; the built-in
     GPU LU (the ``lu``/``ldiv`` of this module) is what runs.  ``info`` (a dict) receives
@@ -359,6 +366,8 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     try:
         h.set_terms([A, B], scales=[1.0, -1.0])          # T(z) = A - z B
         h.set_contour(contour)
+        if not conjugate_fold:
+            h.set_conjugate_fold(False)
         if _mixed_prec:
             h.set_precision(True)
         if debug:

@@ -113,6 +113,10 @@ int feasthip_set_precision(feasthip_handle_t h, int mixed) {
     GUARD(h) return h->e->set_precision(mixed); ENDGUARD(h)
 }
 
+int feasthip_set_conjugate_fold(feasthip_handle_t h, int on) {
+    GUARD(h) return h->e->set_fold(on); ENDGUARD(h)
+}
+
 int feasthip_set_coef_functions(feasthip_handle_t h, feasthip_coef_fn fn, void* user) {
     GUARD(h) return h->e->set_coef_functions(fn, user); ENDGUARD(h)
 }
@@ -169,7 +173,8 @@ int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     o->flops_factor = e->S.flops_factor; o->analyze_seconds = e->analyze_seconds; o->factor_ms = e->factor_ms;
     o->solve_ms = e->solve_ms; o->rr_ms = e->rr_ms; o->alloc_seconds = e->alloc_seconds;
     o->solve_bytes = e->ldw ? e->solve_bytes() : 0; o->solve_flops = e->ldw ? e->solve_flops() : 0;
-    o->perturbed_pivots = e->perturbed; o->local_nodes = e->Kloc; o->m0 = e->m0; o->ldw = e->ldw; o->dense = e->dense ? 1 : 0;
+    o->perturbed_pivots = e->perturbed; o->local_nodes = e->nodes_local(); o->m0 = e->m0; o->ldw = e->ldw; o->dense = e->dense ? 1 : 0;
+    o->factor_units = e->Kloc; o->folded = e->folded() ? 1 : 0; o->solve_bytes_streamed = e->ldw ? e->solve_bytes_streamed() : 0;
     return 0;
     ENDGUARD(h)
 }
@@ -292,8 +297,7 @@ static int build_pattern(int64_t n, const int64_t* colptr, const int64_t* rowval
 }
 
 int feasthip_symbolic_probe(int64_t n, const int64_t* colptr, const int64_t* rowval, int index_base, int ordering,
-                            int64_t* stats, int32_t* perm_out, int32_t* sn_of_out, int32_t* unused) {
-    (void)unused;
+                            int64_t* stats, int32_t* perm_out, int32_t* sn_of_out, int32_t* fronts_out) {
     try {
         std::vector<int64_t> cp, ri;
         int r = build_pattern(n, colptr, rowval, index_base, cp, ri);
@@ -309,6 +313,7 @@ int feasthip_symbolic_probe(int64_t n, const int64_t* colptr, const int64_t* row
         }
         if (perm_out) for (int64_t i = 0; i < n; ++i) perm_out[i] = S.perm[i];
         if (sn_of_out) for (int64_t i = 0; i < n; ++i) sn_of_out[i] = S.sn_of[i];
+        if (fronts_out) for (int s = 0; s < S.nsuper; ++s) { fronts_out[4 * s] = S.p(s); fronts_out[4 * s + 1] = S.u(s); fronts_out[4 * s + 2] = S.depth[s]; fronts_out[4 * s + 3] = S.sn_parent[s]; }
         return 0;
     } catch (...) { return FEASTHIP_EARG; }
 }

@@ -49,6 +49,8 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FUSE_EXTEND")) { fuse_extend_ = atoi(v) != 0; if (atoi(v) > 0) fuse_min_p_ = atoi(v); }
     if (const char* v = getenv("FEASTHIP_FIN_ASYNC")) finalize_async_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
+    if (const char* v = getenv("FEASTHIP_NB256_MINP")) nb256_min_p_ = std::max(129, atoi(v));      // tuning knobs: 1 << 30 keeps the 128-column blocks
+    if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
     if (nst > 1) {
@@ -130,6 +132,8 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
     analyzed_ = factored_ = have_x_ = false;
     terms_.clear();
     terms_.resize(nterms);
+    terms_real_ = false;
+    bool real = true;
     std::vector<zc> tmp;
     for (int t = 0; t < nterms; ++t) {
         SparseTerm& T = terms_[t];
@@ -142,8 +146,12 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
         double mx = 0;
         for (size_t e = 0; e < nn; ++e) { tmp[e] = read_val(mats[t], ty, (int64_t)e); mx = std::max(mx, std::abs(tmp[e])); }
         T.maxabs = mx;
+        for (size_t e = 0; e < nn && real; ++e) if (tmp[e].imag() != 0.0) real = false;
         if (!T.d_dense.upload((const cz*)tmp.data(), nn, stream_)) return fail(FEASTHIP_EHIP, "set_dense: device allocation/upload failed");
     }
+    for (auto& T : terms_) if (T.scale.imag() != 0.0) real = false;
+    terms_real_ = real;
+    rebuild_shard();
     return 0;
 }
 
@@ -156,9 +164,12 @@ int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const
     analyzed_ = factored_ = have_x_ = false;
     terms_.clear();
     terms_.resize(nterms);
+    terms_real_ = false;
+    bool real = true;
     for (int t = 0; t < nterms; ++t) {
         SparseTerm& T = terms_[t];
         T.scale = scale ? zc(scale[2 * t], scale[2 * t + 1]) : zc(1.0);
+        if (T.scale.imag() != 0.0) real = false;
         T.colptr.resize(n + 1);
         if (!colptr[t]) {   // identity, stored as an explicit diagonal
             T.identity = true;
@@ -184,11 +195,14 @@ int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const
                 if (r < 0 || r >= n) return fail(FEASTHIP_EDIM_A, "Incorrect dimensions of A, must be square");
                 T.rowval[e] = (int)r;
                 T.val[e] = read_val(nzval[t], ty, e);
+                if (T.val[e].imag() != 0.0) real = false;
                 mx = std::max(mx, std::abs(T.val[e]));
             }
         }
         T.maxabs = mx;
     }
+    terms_real_ = real;
+    rebuild_shard();
     return 0;
 }
 
@@ -213,12 +227,51 @@ int Engine::set_contour(int K_, const double* nodes, const double* weights, int 
 int Engine::set_shard(int first, int stride) {
     if (first < 0 || stride < 1) return fail(FEASTHIP_EARG, "set_node_shard: bad shard");
     shard_first_ = first; shard_stride_ = stride;
-    local_.clear();
-    for (int k = first; k < K; k += stride) local_.push_back(k);
-    if ((int)local_.size() != Kloc) { factored_ = false; analyzed_ = false; have_x_ = false; }
+    rebuild_shard();
     factored_ = false;
-    Kloc = (int)local_.size();
     return 0;
+}
+
+int Engine::set_fold(int on) {
+    fold_enabled_ = on != 0;
+    rebuild_shard();
+    return 0;
+}
+
+// Which contour nodes this handle factorises.  Without the conjugate fold: nodes first, first + stride, ...  With it
+// (real coefficient matrices, every node has its mirror image on the contour, no per-node coefficient overrides) the
+// units that are dealt out are conjugate PAIRS, represented by their member in the upper half plane.
+void Engine::rebuild_shard() {
+    std::vector<int> loc, par;
+    bool can = fold_enabled_ && terms_real_ && !terms_.empty() && node_coef_.empty() && coef_fn_ == nullptr && K >= 2 && K % 2 == 0;
+    std::vector<int> mate(K, -1);
+    const double eps8 = 8.0 * std::numeric_limits<double>::epsilon();
+    for (int k = 0; k < K && can; ++k) {
+        if (mate[k] >= 0) continue;
+        const zc zk = nodes_[k];
+        if (std::abs(zk.imag()) <= eps8 * std::abs(zk)) { can = false; break; }        // a node on the real axis is its own mirror image
+        for (int k2 = k + 1; k2 < K; ++k2)
+            if (mate[k2] < 0 && std::abs(nodes_[k2] - std::conj(zk)) <= eps8 * std::max(1.0, std::abs(zk))) { mate[k] = k2; mate[k2] = k; break; }
+        if (mate[k] < 0) can = false;
+    }
+    if (can && K / 2 < shard_stride_) can = false;          // fewer pairs than ranks: deal out single nodes instead (same decision on every rank)
+    if (can) {
+        int u = 0;
+        for (int k = 0; k < K; ++k) {
+            if (mate[k] < k) continue;                      // second member of its pair
+            if (u >= shard_first_ && (u - shard_first_) % shard_stride_ == 0) {
+                const int rep = nodes_[k].imag() > 0 ? k : mate[k];
+                loc.push_back(rep); par.push_back(rep == k ? mate[k] : k);
+            }
+            ++u;
+        }
+    } else {
+        for (int k = shard_first_; k < K; k += shard_stride_) { loc.push_back(k); par.push_back(-1); }
+    }
+    if (loc.size() != local_.size() || can != fold_) { analyzed_ = false; have_x_ = false; }
+    if (loc != local_ || par != partner_ || can != fold_) factored_ = false;
+    local_.swap(loc); partner_.swap(par); fold_ = can;
+    Kloc = (int)local_.size();
 }
 
 // ---------------------------------------------------------------------------
@@ -329,27 +382,53 @@ bool Engine::build_plans() {
             for (int a = 0; a < cdiv(ld - k0 - b, 64 * SCALE_ROWTILES); ++a) tiles.push_back({s, t, a, 1});
         }
         F.scale.count = (int)(tiles.size() - F.scale.off);
+        // coupling into 256- and 512-column super blocks (kernels.hpp: launch_couple_outer / launch_couple_level)
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            const int half = SOLVE_NB << lvl;
+            F.outer[lvl].off = (int64_t)tiles.size();
+            for (int s : lv) if (solve_nb(s) >= 2 * half) {
+                int p = S.p(s), ld = p + S.u(s);
+                for (int pr = 0; pr * 2 * half + half < p; ++pr) {
+                    int kp = pr * 2 * half, bb = std::min(half, p - kp - half);
+                    int mb = ld - (kp + half + bb);
+                    if (mb > 0) push_supertiles(s, 3 | (pr << 8), cdiv(mb, 64), cdiv(half, 64));
+                    if (kp > 0) push_supertiles(s, 4 | (pr << 8), cdiv(kp, 64), cdiv(bb, 64));
+                }
+            }
+            F.outer[lvl].count = (int)(tiles.size() - F.outer[lvl].off);
+            F.inner[lvl].off = (int64_t)tiles.size();
+            for (int s : lv) if (solve_nb(s) >= 2 * half) {
+                int p = S.p(s);
+                for (int pr = 0; pr * 2 * half + half < p; ++pr) {
+                    int bb = std::min(half, p - pr * 2 * half - half);
+                    for (int c = 0; c < cdiv(half, 16); ++c) tiles.push_back({s, pr, 0, c});       // Pc: bb x half
+                    for (int c = 0; c < cdiv(bb, 16); ++c) tiles.push_back({s, pr, 1, c});         // Qd: half x bb
+                }
+            }
+            F.inner[lvl].count = (int)(tiles.size() - F.inner[lvl].off);
+        }
         // block substitution launches (kernels.hpp: launch_apply).  Tile height (64/32/16 rows) is chosen per
         // launch so that even the top of the tree (few fronts, long K) spreads over the whole chip.
         auto pick_slabs = [&](auto&& rows_of) {     // rows_of(callback(rows)) enumerates the row extents of the launch
             int64_t wgs = 0;
             rows_of([&](int rows) { wgs += cdiv(rows, 64); });
-            if (wgs * Kloc < 128) return 1;      // latency-bound launch (few nodes left on this GPU): 16-row tiles, four waves share the columns
-            return (wgs * Kloc >= 1024) ? 4 : 2;
+            if (wgs * nodes_local() < 128) return 1;      // latency-bound launch (few nodes left on this GPU): 16-row tiles, four waves share the columns
+            return (wgs * nodes_local() >= 1024) ? 4 : 2;
         };
         double rowb = 1.0;   // bytes are scaled by 16*ldw at run time: count block-vector ROWS here
         (void)rowb;
-        int nsteps = cdiv(pmax, SOLVE_NB);
+        int nsteps = 0;
+        for (int s : lv) nsteps = std::max(nsteps, cdiv(S.p(s), solve_nb(s)));
         for (int c = 0; c + 1 < nsteps; ++c) {
             Launch L;
             L.off = (int64_t)tiles.size();
-            int sl = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.p(s) > c * SOLVE_NB + SOLVE_NB) cb(S.p(s) - c * SOLVE_NB - SOLVE_NB); });
+            int sl = pick_slabs([&](auto&& cb) { for (int s : lv) { int NB = solve_nb(s); if (S.p(s) > c * NB + NB) cb(S.p(s) - c * NB - NB); } });
             for (int s : lv) {
-                int p = S.p(s), k0 = c * SOLVE_NB;
-                if (p <= k0 + SOLVE_NB) continue;
-                int rows = p - k0 - SOLVE_NB;
+                int NB = solve_nb(s), p = S.p(s), k0 = c * NB;
+                if (p <= k0 + NB) continue;
+                int rows = p - k0 - NB;
                 for (int a = 0; a < cdiv(rows, 16 * sl); ++a) tiles.push_back({s, 0 | (sl << 8), a, c});
-                L.bytes += (double)rows * SOLVE_NB * 16.0; L.flops += (double)rows * SOLVE_NB;
+                L.bytes += (double)rows * NB * 16.0; L.flops += (double)rows * NB; L.vrows += 2.0 * rows + NB;
             }
             L.count = (int)(tiles.size() - L.off);
             V.f1.push_back(L);
@@ -357,16 +436,16 @@ bool Engine::build_plans() {
         V.f2.off = (int64_t)tiles.size();
         int sl2 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.u(s)); });
         for (int s : lv) {
-            int p = S.p(s), u = S.u(s);
+            int p = S.p(s), u = S.u(s), NB = solve_nb(s);
             for (int a = 0; a < cdiv(u, 16 * sl2); ++a) tiles.push_back({s, 1 | (sl2 << 8), a, 0});
-            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t)
-                for (int rt = 0; rt < cdiv(std::min(SOLVE_NB, p - t * SOLVE_NB), 64); ++rt) tiles.push_back({s, 2, t, rt});
-            V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, SOLVE_NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, SOLVE_NB);
+            for (int t = 0; t < cdiv(p, NB); ++t)
+                for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 64); ++rt) tiles.push_back({s, 2, t, rt});
+            V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, NB);
         }
         V.f2.count = (int)(tiles.size() - V.f2.off);
-        // longest tiles first (LPT): the K loop of a tile is p (kind 1) or at most SOLVE_NB (kind 2); fronts stay together
+        // longest tiles first (LPT): the K loop of a tile is p (kind 1) or at most the super-block size (kind 2); fronts stay together
         std::stable_sort(tiles.begin() + V.f2.off, tiles.end(), [&](const Tile& a, const Tile& b) {
-            int ka = (a.a & 0xff) == 1 ? S.p(a.f) : std::min(SOLVE_NB, S.p(a.f)), kb2 = (b.a & 0xff) == 1 ? S.p(b.f) : std::min(SOLVE_NB, S.p(b.f));
+            int ka = (a.a & 0xff) == 1 ? S.p(a.f) : std::min(solve_nb(a.f), S.p(a.f)), kb2 = (b.a & 0xff) == 1 ? S.p(b.f) : std::min(solve_nb(b.f), S.p(b.f));
             return ka > kb2;
         });
         V.b1.off = (int64_t)tiles.size();
@@ -375,7 +454,7 @@ bool Engine::build_plans() {
             int64_t wgs = 0; int umax = 0;
             for (int s : lv) if (S.u(s) > 0) { wgs += cdiv(S.p(s), 64); umax = std::max(umax, S.u(s)); }
             int ns = 0;
-            int keff = std::max(1, Kloc / stream_groups());     // nodes per launch
+            int keff = std::max(1, nodes_local() / stream_groups());     // nodes per launch
             if (wgs > 0 && wgs * keff < 1024 && umax >= 512) ns = (int)std::min<int64_t>(8, std::min<int64_t>(umax / 256, cdiv(2048, (int)(wgs * keff))));
             V.b1split = ns >= 2 ? ns : 0;
             if (V.b1split) sl3 = 4;
@@ -402,22 +481,22 @@ bool Engine::build_plans() {
         for (int c = 1; c < nsteps; ++c) {
             Launch& L = V.b2[c];
             L.off = (int64_t)tiles.size();
-            int sl = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.p(s) > c * SOLVE_NB) cb(c * SOLVE_NB); });
+            int sl = pick_slabs([&](auto&& cb) { for (int s : lv) { int NB = solve_nb(s); if (S.p(s) > c * NB) cb(c * NB); } });
             for (int s : lv) {
-                int p = S.p(s), k0 = c * SOLVE_NB;
+                int NB = solve_nb(s), p = S.p(s), k0 = c * NB;
                 if (p <= k0) continue;
-                int b = std::min(SOLVE_NB, p - k0);
+                int b = std::min(NB, p - k0);
                 for (int a = 0; a < cdiv(k0, 16 * sl); ++a) tiles.push_back({s, 4 | (sl << 8), a, c});
-                L.bytes += (double)k0 * b * 16.0; L.flops += (double)k0 * b;
+                L.bytes += (double)k0 * b * 16.0; L.flops += (double)k0 * b; L.vrows += 2.0 * k0 + b;
             }
             L.count = (int)(tiles.size() - L.off);
         }
         V.b3.off = (int64_t)tiles.size();
         for (int s : lv) {
-            int p = S.p(s);
-            for (int t = 0; t < cdiv(p, SOLVE_NB); ++t)
-                for (int rt = 0; rt < cdiv(std::min(SOLVE_NB, p - t * SOLVE_NB), 64); ++rt) tiles.push_back({s, 5, t, rt});
-            V.b3.bytes += 0.5 * p * std::min(p, SOLVE_NB) * 16.0; V.b3.flops += 0.5 * p * std::min(p, SOLVE_NB);
+            int p = S.p(s), NB = solve_nb(s);
+            for (int t = 0; t < cdiv(p, NB); ++t)
+                for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 64); ++rt) tiles.push_back({s, 5, t, rt});
+            V.b3.bytes += 0.5 * p * std::min(p, NB) * 16.0; V.b3.flops += 0.5 * p * std::min(p, NB);
         }
         V.b3.count = (int)(tiles.size() - V.b3.off);
     }
@@ -540,6 +619,7 @@ int Engine::analyze() {
         f.sk_off = -1;
         f.cmap = -1;
         f.ebp = -1;
+        f.nb = solve_nb(s); f.pad_ = 0;
     }
     // pull map of the forward sweep: for every contribution row of a front and every child slot, the row of the child's
     // contribution block that is added to it (rel >= p), as an absolute row of the children's arena; -1 if none
@@ -609,17 +689,18 @@ int Engine::analyze() {
 // or the caller's functions (split form, feasthip_set_coef_functions).  out is point-major: out[i*nterms + t].
 int Engine::alloc_iteration_buffers() {
     size_t blk = (size_t)n * ldw;
+    const size_t lw = (size_t)solve_width(), sblk = (size_t)n * lw;      // per-unit solve blocks (twice as wide with the conjugate fold)
     bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && (q_ext_ ? (q_ext_bytes_ >= 2 * blk * sizeof(cz)) : d_Q_.alloc(2 * blk)) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
-              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * blk) && d_Y_.alloc((size_t)Kloc * blk) && d_sk_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * ldw) &&
-              d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * ldw) &&
-              d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * ldw) &&
-              d_e0_.alloc((size_t)Kloc * ldw) && d_e1_.alloc((size_t)Kloc * ldw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
+              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * sblk) && d_Y_.alloc((size_t)Kloc * sblk) && d_sk_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * lw) &&
+              d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * lw) &&
+              d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * lw) &&
+              d_e0_.alloc((size_t)Kloc * lw) && d_e1_.alloc((size_t)Kloc * lw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
               d_lam_.alloc(ldw) && d_gram_scratch_.alloc(gram_scratch_elems(n, ldw)) && d_io_.alloc((size_t)n * std::max(1, m0)) &&
               d_nrm_.alloc(ldw) && d_nrm_scratch_.alloc(colnorm_scratch_elems(n, ldw));
     if (ok && mixed_)
-        ok = d_W32_.alloc((size_t)Kloc * blk) && d_Y32_.alloc((size_t)Kloc * blk) && d_sk32_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * ldw) &&
-             d_crow32_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * ldw) &&
-             d_crow32_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * ldw);
+        ok = d_W32_.alloc((size_t)Kloc * sblk) && d_Y32_.alloc((size_t)Kloc * sblk) && d_sk32_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * lw) &&
+             d_crow32_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * lw) &&
+             d_crow32_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * lw);
     if (!ok) return fail(FEASTHIP_EHIP, "out of device memory for the iteration buffers");
     return 0;
 }
@@ -708,7 +789,7 @@ int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
     launch_cm_to_rm(stream_, n, m0, ldw, d_io_.p, n, d_R_.p);
     int r = solve_all(d_R_.p);
     if (r) return r;
-    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
+    std::vector<zc> e0((size_t)Kloc * solve_width(), zc(0.0));
     for (int j = 0; j < ldw; ++j) e0[j] = 1.0;        // node 0 only
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     accumulate_solutions(1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);

@@ -34,10 +34,12 @@ struct Launch {        // a slice of the tile / list buffers
     int64_t off = 0;
     int count = 0;
     double bytes = 0, flops = 0;   // algorithmic bytes / real flops of this launch for ONE contour node
+    double vrows = 0;              // block-vector rows read or written by the in-block steps (one node)
 };
 
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp; };
-struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale; };
+struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale;
+                     Launch outer[2], inner[2]; };      // coupling of 128 -> 256 ([0]) and 256 -> 512 ([1]) super blocks (launch_couple_outer / _level)
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     double asm_rows = 0, pull_rows = 0; };   // children's contribution rows landing in pivot blocks / in contribution rows of this level
 
@@ -75,6 +77,12 @@ public:
     int set_q_buffer(void* dptr, size_t bytes);
     int set_precision(int mixed);
     bool mixed() const { return mixed_; }
+    // Conjugate fold: a pencil / polynomial with REAL coefficient matrices satisfies T(conj z) = conj(T(z)), so a contour node
+    // and its mirror image share ONE factorisation; the mirror system rides along as m0 more right-hand-side columns conj(R)
+    // (T(conj z)^-1 R = conj(T(z)^-1 conj(R))).  On by default whenever every node of the contour has its mirror node.
+    int set_fold(int on);
+    bool folded() const { return fold_; }
+    int solve_width() const { return fold_ ? 2 * ldw : ldw; }    // leading dimension of the per-unit solve blocks
     int set_coef_functions(feasthip_coef_fn fn, void* user);
     int set_node_coefficients(const double* coef, int K, int nterms);
     int nl_set_r(const void* R);
@@ -116,8 +124,10 @@ public:
     Symbolic S;
     int n = 0, nterms = 0, K = 0, Kloc = 0, m0 = 0, ldw = 0;
     bool dense = false;
-    double solve_bytes() const;
+    double solve_bytes() const;           // algorithmic bytes of one contour step (per contour NODE)
+    double solve_bytes_streamed() const;  // what the sweeps actually stream (folded pairs read their factor once)
     double solve_flops() const;
+    int nodes_local() const { return Kloc * (fold_ ? 2 : 1); }
 
 private:
     int device_;
@@ -126,7 +136,11 @@ private:
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     std::vector<SparseTerm> terms_;
     std::vector<zc> nodes_, weights_;      // all K
-    std::vector<int> local_;               // indices of local nodes
+    std::vector<int> local_;               // indices of local nodes (conjugate fold: the member of each local pair that is factorised)
+    std::vector<int> partner_;             // conjugate fold: index of the mirror node of local_[kk], else -1
+    bool fold_ = false, fold_enabled_ = true, terms_real_ = false;
+    void rebuild_shard();                  // local_ / partner_ / fold_ / Kloc from contour, shard, terms and overrides
+    template <class F> std::vector<zc> node_table(F f, int nq = 1) const;   // [q][unit][solve_width] table of f(node, column, q) for the accumulation kernel
     int shard_first_ = 0, shard_stride_ = 1;
     int region_kind_ = 0;
     double region_[4] = {0, 0, 1, 0};
@@ -216,6 +230,8 @@ private:
     bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true, fuse_extend_ = true;
     int fuse_min_p_ = 128;            // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself
     int group_panels_ = 4;            // panels per deferred trailing update in the look-ahead factorisation
+    int nb256_min_p_ = 193, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
+    int solve_nb(int s) const { int p = S.p(s); return p >= nb512_min_p_ ? 512 : p >= nb256_min_p_ ? 256 : 128; }
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;
     hipEvent_t ev_fork_ = nullptr;

@@ -15,14 +15,16 @@ void Engine::eval_coefs(const zc* pts, int count, std::vector<zc>& out) {
 int Engine::set_coef_functions(feasthip_coef_fn fn, void* user) {
     coef_fn_ = fn; coef_user_ = user;
     factored_ = false;
+    rebuild_shard();
     return 0;
 }
 
 int Engine::set_node_coefficients(const double* coef, int K_, int nterms_) {
-    if (!coef) { node_coef_.clear(); factored_ = false; return 0; }
+    if (!coef) { node_coef_.clear(); factored_ = false; rebuild_shard(); return 0; }
     if (K_ != K || nterms_ != nterms) return fail(FEASTHIP_EARG, "set_node_coefficients: table must be K x nterms (set the contour and the terms first)");
     node_coef_.assign(reinterpret_cast<const zc*>(coef), reinterpret_cast<const zc*>(coef) + (size_t)K * nterms);
     factored_ = false;
+    rebuild_shard();
     return 0;
 }
 
@@ -193,6 +195,10 @@ int Engine::factorize() {
         launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
+        for (int lvl = 0; lvl < 2; ++lvl) {       // 256- and 512-column super blocks of the fronts with many pivot columns
+            launch_couple_outer(fin, dsym_, tl + F.outer[lvl].off, F.outer[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
+            launch_couple_level(fin, dsym_, tl + F.inner[lvl].off, F.inner[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
+        }
         if (!fuse)
             launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
                               std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);

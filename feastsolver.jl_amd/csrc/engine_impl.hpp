@@ -21,4 +21,19 @@ namespace feasthip {
 
 static inline cz to_cz(zc v) { return cz_make(v.real(), v.imag()); }
 
+// Coefficient table of the accumulation kernel: entry [q][unit kk][column] = f(contour node, column j < m0, q); with the
+// conjugate fold a unit carries two nodes and the mirror node's coefficients occupy columns [ldw, 2 ldw).
+template <class F>
+std::vector<zc> Engine::node_table(F f, int nq) const {
+    const int lw = solve_width();
+    std::vector<zc> e((size_t)nq * Kloc * lw, zc(0.0));
+    for (int q = 0; q < nq; ++q)
+        for (int kk = 0; kk < Kloc; ++kk)
+            for (int j = 0; j < m0; ++j) {
+                e[((size_t)q * Kloc + kk) * lw + j] = f(local_[kk], j, q);
+                if (fold_) e[((size_t)q * Kloc + kk) * lw + ldw + j] = f(partner_[kk], j, q);
+            }
+    return e;
+}
+
 }  // namespace feasthip

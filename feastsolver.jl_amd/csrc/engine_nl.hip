@@ -13,15 +13,8 @@ int Engine::nl_contour_step(int first) {
     if (!have_x_) return fail(FEASTHIP_ESTATE, "nl_contour_step: call set_x first");
     HIPCHK(hipSetDevice(device_));
     if (!factored_) { int r = factorize(); if (r < 0) return r; }
-    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0)), e1((size_t)Kloc * ldw, zc(0.0));
-    for (int kk = 0; kk < Kloc; ++kk) {
-        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
-        for (int j = 0; j < m0; ++j) {
-            zc e = first ? w : w / (z - lambda_[j]);           // src/nlfeast.jl:42 / :47
-            e0[(size_t)kk * ldw + j] = e;
-            e1[(size_t)kk * ldw + j] = e * z;                  // :58
-        }
-    }
+    auto ef = [&](int k, int j, int q) { zc e = first ? weights_[k] : weights_[k] / (nodes_[k] - lambda_[j]); return q ? e * nodes_[k] : e; };   // src/nlfeast.jl:42 / :47, :58
+    std::vector<zc> e0 = node_table([&](int k, int j, int) { return ef(k, j, 0); }), e1 = node_table([&](int k, int j, int) { return ef(k, j, 1); });
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(d_e1_.p, e1.data(), e1.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -200,7 +193,7 @@ int Engine::nlm_alloc(int moments) {
     ldM_ = ((M + 15) / 16) * 16;
     size_t blk = (size_t)n * ldw, hrows = (size_t)mm_ * n, tall = hrows * ldM_, wide = (size_t)n * ldM_;
     bool ok = d_Qm_.alloc(2 * (size_t)mm_ * blk) && d_H0_.alloc(tall) && d_H1_.alloc(tall) && d_Ht_.alloc(tall) && d_Ym_.alloc(wide) &&
-              d_Rm_.alloc(wide) && d_MXm_.alloc(wide * std::max(2, nterms)) && d_em_.alloc(2 * (size_t)mm_ * Kloc * ldw) &&
+              d_Rm_.alloc(wide) && d_MXm_.alloc(wide * std::max(2, nterms)) && d_em_.alloc(2 * (size_t)mm_ * Kloc * solve_width()) &&
               d_smallM_.alloc((size_t)8 * ldM_ * ldM_) && d_lamM_.alloc(ldM_) && d_gramM_.alloc(gram_scratch_elems((int)hrows, ldM_)) &&
               d_nrmM_.alloc(ldM_) && d_nrmMs_.alloc(colnorm_scratch_elems((int)hrows, ldM_)) && d_colidx_.alloc(ldM_);
     if (!ok) return fail(FEASTHIP_EHIP, "out of device memory for the moment buffers");
@@ -211,20 +204,16 @@ int Engine::nlm_alloc(int moments) {
 int Engine::nlm_contour_step(int first) {
     HIPCHK(hipSetDevice(device_));
     const int L = 2 * mm_;
-    std::vector<zc> e((size_t)L * Kloc * ldw, zc(0.0));
-    for (int kk = 0; kk < Kloc; ++kk) {
-        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
-        for (int j = 0; j < m0; ++j) {
-            zc v = first ? w : w / (z - lambda_[j]);
-            for (int q = 0; q < L; ++q) { e[((size_t)q * Kloc + kk) * ldw + j] = v; v *= z; }
-        }
-    }
+    std::vector<zc> e = node_table([&](int k, int j, int q) {
+        zc v = first ? weights_[k] : weights_[k] / (nodes_[k] - lambda_[j]);
+        for (int t = 0; t < q; ++t) v *= nodes_[k];
+        return v; }, L);
     HIPCHK(hipMemcpyAsync(d_em_.p, e.data(), e.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(first ? d_X_.p : d_R_.p);
     if (r) return r;
-    size_t blk = (size_t)n * ldw, eb = (size_t)Kloc * ldw;
+    size_t blk = (size_t)n * ldw, eb = (size_t)Kloc * solve_width();
     for (int q = 0; q < L; q += 2)      // two moments per pass over the K solution blocks
         accumulate_solutions(Kloc, d_em_.p + q * eb, d_em_.p + (q + 1) * eb, first ? 0 : 1, d_Qm_.p + q * blk, d_Qm_.p + (q + 1) * blk);
     HIPCHK(hipEventRecord(ev1_, stream_));
@@ -495,8 +484,8 @@ int Engine::dual_contour_step() {
         if (r == 0) r = solve_range(stream_, Kh, Kh, d_Rl_.p, nullptr);
         if (r) return r;
     }
-    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)blk, ldw, Kh, d_e0_.p, nullptr, 1, Qp(), nullptr);                          // :232-234
-    launch_accumulate(stream_, dsym_, d_Xl_.p, d_W_.p + (size_t)Kh * blk, (int64_t)blk, ldw, Kh, d_e0_.p + (size_t)Kh * ldw, nullptr, 1,
+    launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)blk, ldw, ldw, Kh, d_e0_.p, nullptr, 1, Qp(), nullptr);                          // :232-234
+    launch_accumulate(stream_, dsym_, d_Xl_.p, d_W_.p + (size_t)Kh * blk, (int64_t)blk, ldw, ldw, Kh, d_e0_.p + (size_t)Kh * ldw, nullptr, 1,
                       Qp() + blk, nullptr);                                                                                             // :242-244
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));

@@ -12,6 +12,8 @@ int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRo
 
 template <typename T>
 int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall) {
+    const int ldw = solve_width();       // from here on the block vectors are the per-unit solve blocks (2 x Engine::ldw columns with the conjugate fold)
+    const int ldrhs = this->ldw;
     int64_t fs = S.fact_size, ws = (int64_t)n * ldw;
     T* crowb[2] = {crow0, crow1};
     T* Fp = fact + (int64_t)kb * fs;
@@ -36,10 +38,11 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     };
     double rowb = (double)ldw * sizeof(T);
     begin();
-    launch_gather_rhs(st, dsym_, rhs, ldw, Wp, ws, rperm, kc);
+    launch_gather_rhs(st, dsym_, rhs, ldrhs, ldw, Wp, ws, rperm, kc);
     end(0, 2.0 * n * rowb * kc, 0);
     // Launch::bytes counts factor bytes, Launch::flops complex multiply-adds per block-vector column (one node)
-    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes * (sizeof(T) / 16.0) + vec_rows * rowb) * kc; };
+    const double npu = fold_ ? 2.0 : 1.0;      // contour nodes per unit: algorithmic bytes count the factor once per NODE
+    auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes * (sizeof(T) / 16.0) * npu + vec_rows * rowb) * kc; };
     auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * kc; };
     for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
         SolveLevel& V = splan_[d];
@@ -54,7 +57,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         for (Launch& L : V.f1) {
             begin();
             launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc);
-            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
+            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, L.vrows), stat_flops(L)); }
         }
         begin();
         // contribution rows of the children that pass through to this level's contribution rows are pulled in the
@@ -76,7 +79,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
             Launch& L = V.b2[c];
             begin();
             launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
-            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, 2.0 * L.flops / SOLVE_NB), stat_flops(L)); }
+            if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, L.vrows), stat_flops(L)); }
         }
         begin();
         launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
@@ -92,13 +95,14 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
 // (multi-GPU shards) one fuller launch per step is faster (measured: 16 nodes 2 groups, <= 8 nodes 1 group).
 // Q0 (Q1) = sum_k T_k .* e0[k,:] (e1[k,:]) over the solution blocks of the last sweep (fp64 accumulation in either precision)
 void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
-    if (mixed_) launch_accumulate(stream_, dsym_, d_X_.p, d_W32_.p, (int64_t)n * ldw, ldw, K_, e0, e1, mode, Q0, Q1);
-    else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * ldw, ldw, K_, e0, e1, mode, Q0, Q1);
+    const int lw = solve_width();
+    if (mixed_) launch_accumulate(stream_, dsym_, d_X_.p, d_W32_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1);
+    else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1);
 }
 
 int Engine::stream_groups() const {
     int ns = std::min<int>((int)aux_streams_.size(), Kloc);
-    if (!streams_forced_ && Kloc < 12) ns = 1;
+    if (!streams_forced_ && nodes_local() < 12) ns = 1;
     return std::max(1, ns);
 }
 
@@ -123,7 +127,7 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
 }
 
 double Engine::solve_bytes() const {
-    // factor entries streamed once per node and sweep pair + block-vector traffic
+    // SURVEY 8d, per contour NODE: factor entries streamed once per node and sweep pair + block-vector traffic
     double rowb = (double)ldw * 16.0;
     // contribution rows: written once by their front; then either pulled by the parent's F2a epilogue (1 read) or
     // assembled into the parent's pivot block (read + read-modify-write)
@@ -131,22 +135,24 @@ double Engine::solve_bytes() const {
     for (const SolveLevel& V : splan_) { asm_rows += V.asm_rows; pull_rows += V.pull_rows; }
     double es = mixed_ ? 0.5 : 1.0;     // complex64 factors and block vectors in the mixed-precision sweeps
     double per_node = (double)S.fact_size * 16.0 * es + (double)S.sum_u * 4.0 + (4.0 * n + (double)S.sum_u + pull_rows + 3.0 * asm_rows) * rowb * es;
-    return per_node * Kloc + 3.0 * n * rowb;
+    return per_node * nodes_local() + 3.0 * n * rowb;
+}
+
+double Engine::solve_bytes_streamed() const {
+    // what the sweeps move: with the conjugate fold the factor (and the index arrays) of a pair is read once for both nodes
+    double es = mixed_ ? 0.5 : 1.0;
+    return solve_bytes() - (fold_ ? ((double)S.fact_size * 16.0 * es + (double)S.sum_u * 4.0) * Kloc : 0.0);
 }
 
 double Engine::solve_flops() const {
-    return ((double)(S.nnz_l + S.nnz_u) * 8.0 * ldw) * Kloc + 16.0 * n * (double)ldw * Kloc;
+    return ((double)(S.nnz_l + S.nnz_u) * 8.0 * ldw) * nodes_local() + 16.0 * n * (double)ldw * nodes_local();
 }
 
 int Engine::contour_step(int refactor) {
     if (!have_x_) return fail(FEASTHIP_ESTATE, "contour_step: call set_x and rr_step first");
     HIPCHK(hipSetDevice(device_));
     if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; }
-    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
-    for (int kk = 0; kk < Kloc; ++kk) {
-        zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
-        for (int j = 0; j < m0; ++j) e0[(size_t)kk * ldw + j] = w / (z - lambda_[j]);      // src/feast.jl:60,69
-    }
+    std::vector<zc> e0 = node_table([&](int k, int j, int) { return weights_[k] / (nodes_[k] - lambda_[j]); });      // src/feast.jl:60,69
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipEventRecord(ev0_, stream_));
@@ -171,8 +177,7 @@ int Engine::estimate_count(const void* X, int64_t n_, int m0_, double* est) {
     if (r) return r;
     if (!factored_) { r = factorize(); if (r < 0) return r; }
     HIPCHK(hipSetDevice(device_));
-    std::vector<zc> e0((size_t)Kloc * ldw, zc(0.0));
-    for (int kk = 0; kk < Kloc; ++kk) for (int j = 0; j < m0; ++j) e0[(size_t)kk * ldw + j] = -weights_[local_[kk]];
+    std::vector<zc> e0 = node_table([&](int k, int, int) { return -weights_[k]; });
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     r = solve_all(d_X_.p);
@@ -204,7 +209,7 @@ int Engine::profile_solve(ProfileRow* rows) {
     HIPCHK(hipEventSynchronize(b));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, a, b));
-    rows[4].ms = ms; rows[4].launches = 1; rows[4].bytes = ((double)Kloc + 2.0) * n * ldw * 16.0;
+    rows[4].ms = ms; rows[4].launches = 1; rows[4].bytes = ((double)nodes_local() + 2.0) * n * ldw * 16.0;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return 0;
 }

@@ -5,7 +5,8 @@
 namespace feasthip {
 
 constexpr int FACT_NB = 32;     // panel width of the blocked front factorisation
-constexpr int SOLVE_NB = 128;   // diagonal (super)block of the inverse-based block substitution
+constexpr int SOLVE_NB = 128;   // base diagonal (super)block of the inverse-based block substitution; fronts with many pivot columns
+                                // couple these further into 256- / 512-column super blocks (FrontD::nb, launch_couple_level)
 constexpr int INV_NB = 64;      // size of the directly inverted triangular blocks (two are coupled into a super block)
 constexpr int TRSM_COLS = 64;       // columns per workgroup of the U-row triangular solves
 constexpr int SCALE_ROWTILES = 4;  // 64-row tiles per workgroup of the panel-scaling pass (they share one staged inverse block)
@@ -48,11 +49,19 @@ void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntil
 void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
+// Coupling of two solve-ready super blocks of `half` columns (a = [k0, k0+half), b = [k0+half, ...)) into one of 2*half, k0 = pair * 2*half:
+//   launch_couple_outer (Tile {front, 3 | pair << 8, m tile, n tile}: rows below the pair, P_a -= P_b Pc;
+//                              {front, 4 | pair << 8, m tile, n tile}: rows above the pair, Q_b -= Q_a Qd)       -- k_gemm_nn
+//   launch_couple_level (Tile {front, pair, side (0 lower / 1 upper), 16-column strip}): Pc <- -inv(L_bb) Pc, Qd <- -inv(U_aa) Qd, in place
+// (inv([L_a 0; C L_b]) = [I_a 0; -I_b C I_a, I_b], and the mirrored identity for the upper factor); run outer first, it reads Pc / Qd.
+void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K);
+void launch_couple_level(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K);
 void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* piv, int* rowperm,
                     int* rowinv, int K);
 
 // ---- block triangular solves ------------------------------------------------
-void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cz* W, int64_t ws,
+// lds = leading dimension of W: ldw, or 2 ldw for the conjugate fold (columns ldw.. receive conj(src))
+void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cz* W, int64_t ws,
                        const int* rowperm, int K);
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
@@ -73,14 +82,14 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather = false,
                   cf* skbuf = nullptr, int64_t sks = 0, const cf* crow_child = nullptr, int64_t crs_child = 0);
-void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cf* W, int64_t ws,
+void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cf* W, int64_t ws,
                        const int* rowperm, int K);
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
                          cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
                          const int* rowinv, int K, int phase);
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* Y, int64_t ws, int ldw,
                           const cf* skbuf, int64_t sks, int K);
-void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int K,
+void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
 void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out);
 // Kind-3 tiles may be split along K (Tile.a bits 16.. = number of parts, Tile.c = part): each part writes
@@ -88,8 +97,9 @@ void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out);
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,
                           const cz* skbuf, int64_t sks, int K);
 // (gather = true for launches made only of kind-3 tiles: V rows are gathered through struct_idx)
-// Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order
-void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int K,
+// Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order;
+// lds = leading dimension of W and of the coefficient tables (2 ldw: conjugate fold, see k_accumulate)
+void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int lds, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
 
 // ---- Rayleigh-Ritz block ------------------------------------------------------

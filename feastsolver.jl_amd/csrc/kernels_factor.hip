@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
     if (t.a == 1 && !cs.u12) return;
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
-    int b = min(bw, p - k0);
+    int b = max(1, min(bw, p - k0));
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* F12 = fact + (int64_t)k * fs + f.f12;
     const cz *A, *B;
@@ -692,12 +692,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
         A = Lp + (k0 + b) + (int64_t)k0 * ld; lda = ld; M = p - k0 - b; Kd = b;
         B = F12 + k0; ldb = p; N = u;
         C = F12 + (k0 + b); ldc = p;
-    } else {
+    } else if (t.a == 2) {
         A = Lp + p; lda = ld; M = u; Kd = p;
         B = F12; ldb = p; N = u;
         C = cb + (int64_t)k * cbs + f.cb; ldc = u;
+    } else {
+        // coupling of two solve-ready super blocks of bw columns (launch_couple_outer): pair index in t.a >> 8
+        const int half = bw, kp = (t.a >> 8) * 2 * half, bb = min(half, p - kp - half);
+        lda = ldb = ldc = ld;
+        if ((t.a & 0xff) == 3) {      // rows below the pair:  P_a -= P_b * Pc
+            A = Lp + (kp + half + bb) + (int64_t)(kp + half) * ld; M = ld - (kp + half + bb); Kd = bb;
+            B = Lp + (kp + half) + (int64_t)kp * ld; N = half;
+            C = Lp + (kp + half + bb) + (int64_t)kp * ld;
+        } else {                      // rows above the pair:  Q_b -= Q_a * Qd
+            A = Lp + (int64_t)kp * ld; M = kp; Kd = half;
+            B = Lp + kp + (int64_t)(kp + half) * ld; N = bb;
+            C = Lp + (int64_t)(kp + half) * ld;
+        }
     }
-    if (mrows > 0 && t.a != 2) M = min(M, min(mrows, p - k0 - b));     // pivot-block rows only
+    const int kind = t.a & 0xff;
+    if (mrows > 0 && kind < 2) M = min(M, min(mrows, p - k0 - b));     // pivot-block rows only
     int nlo = 0;
     if (t.a == 0) { N = min(N, cs.chi); nlo = cs.clo; }
     int m0 = t.b * 64, n0 = t.c * 64;
@@ -715,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
     // are dead by then): at the depths of the panel-group updates (32..128) their latency is otherwise a tenth of the tile.
     // The contribution block (kind 2) is written, not updated: CB = -L21 U12, the children's blocks are added afterwards.
     cz old[4][4];
-    const bool rmw = (t.a != 2);
+    const bool rmw = (kind != 2);
     // loads are unconditional (clamped addresses) and masked with selects, so they all stay in flight
     auto chunk = [&](int kc, auto is_last) {
         cz bvals[GEMM_KC * 64 / 256];
@@ -1006,6 +1020,52 @@ __global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__
 void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K) {
     if (ntiles <= 0) return;
     hipLaunchKernelGGL(k_scale_panels, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, fact, fs);
+}
+
+void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K) {
+    launch_gemm_nn(st, S, tiles, ntiles, 0, fact, fs, nullptr, 0, K, ColSel(), half, 0, nullptr, 0);
+}
+
+// Second half of the coupling of two solve-ready super blocks (kernels.hpp: launch_couple_level): one workgroup owns 16 whole
+// columns of the coupling block, so the product can be formed in place: the strip goes to LDS, thread i then owns row i of the
+// result, out[i,:] = -sum_k T[i,k] S[k,:], with T the unit lower inverse inv(L_bb) (side 0, rows/columns of block b) or the upper
+// inverse inv(U_aa) (side 1, block a), both read from the diagonal super blocks they live in.  m x m x 16 multiply-adds on the
+// vector units: a few hundred workgroups of < 20 us per tree level.
+__global__ __launch_bounds__(256) void k_couple_level(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int half,
+                                                      cz* fact, int64_t fs) {
+    __shared__ cz Ss[256][16];          // half <= 256
+    Tile t = tiles[blockIdx.x];
+    const int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    const int ld = f.p + f.u, kp = t.a * 2 * half, bb = min(half, f.p - kp - half);
+    const bool upper = t.b != 0;
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    // lower: strip of Pc (rows of b, columns of a), triangle = diagonal block b;  upper: strip of Qd (rows of a, columns of b), triangle = block a
+    const int m = upper ? half : bb, ncols = upper ? bb : half, c0 = t.c * 16;
+    if (c0 >= ncols) return;
+    const int nc = min(16, ncols - c0);
+    cz* Cb = upper ? Lp + kp + (int64_t)(kp + half + c0) * ld : Lp + (kp + half) + (int64_t)(kp + c0) * ld;
+    const cz* Tb = upper ? Lp + kp + (int64_t)kp * ld : Lp + (kp + half) + (int64_t)(kp + half) * ld;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < m * 16; idx += 256) { int i = idx % m, j = idx / m; Ss[i][j] = j < nc ? Cb[i + (int64_t)j * ld] : cz_make(0, 0); }
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) {
+        cz acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = upper ? cz_make(0, 0) : Ss[i][j];           // unit diagonal of inv(L_bb)
+        const int klo = upper ? i : 0, khi = upper ? m : i;                                   // upper incl. diagonal / strictly lower
+        for (int kk = klo; kk < khi; ++kk) {
+            const cz a = Tb[i + (int64_t)kk * ld];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cz_madd(acc[j], a, Ss[kk][j]);
+        }
+        for (int j = 0; j < nc; ++j) Cb[i + (int64_t)j * ld] = cz_make(-acc[j].x, -acc[j].y);
+    }
+}
+
+void launch_couple_level(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_couple_level, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, half, fact, fs);
 }
 
 // ---------------------------------------------------------------------------

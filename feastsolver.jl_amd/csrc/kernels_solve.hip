@@ -32,26 +32,31 @@ template <> __device__ inline cz el_make<cz>(double x, double y) { return cz_mak
 template <> __device__ inline cf el_make<cf>(double x, double y) { cf r; r.x = (float)x; r.y = (float)y; return r; }
 
 // W_k[i,:] = src[perm[c0 + rowperm_k[i]], :]   (fill-reducing + pivot permutation folded into one gather)
+// Conjugate fold (lds > ldw): a real pencil gives T(conj z) = conj(T(z)), so the system of the conjugate node,
+// T(conj z)^-1 R = conj(T(z)^-1 conj(R)), rides along as ldw more right-hand-side columns conj(R) of the SAME factor.
 template <typename T>
 __global__ void k_gather_rhs(const int* __restrict__ perm, const int* __restrict__ c0_of_row, int n,
-                             const cz* __restrict__ src, int ldw, T* W, int64_t ws, const int* __restrict__ rowperm) {
+                             const cz* __restrict__ src, int ldw, int lds, T* W, int64_t ws, const int* __restrict__ rowperm) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     int k = blockIdx.y, lane = threadIdx.x & 63;
     if (i >= n) return;
     int c0 = c0_of_row[i];
     int srow = perm[c0 + rowperm[(int64_t)k * n + i]];
     const cz* s = src + (int64_t)srow * ldw;
-    T* d = W + (int64_t)k * ws + (int64_t)i * ldw;
-    for (int j = lane; j < ldw; j += 64) d[j] = el_make<T>(s[j].x, s[j].y);
+    T* d = W + (int64_t)k * ws + (int64_t)i * lds;
+    for (int j = lane; j < lds; j += 64) {
+        cz v = s[j < ldw ? j : j - ldw];
+        d[j] = el_make<T>(v.x, j < ldw ? v.y : -v.y);
+    }
 }
 
-void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cz* W, int64_t ws,
+void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cz* W, int64_t ws,
                        const int* rowperm, int K) {
-    hipLaunchKernelGGL(k_gather_rhs<cz>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, W, ws, rowperm);
+    hipLaunchKernelGGL(k_gather_rhs<cz>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm);
 }
-void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, cf* W, int64_t ws,
+void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cf* W, int64_t ws,
                        const int* rowperm, int K) {
-    hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, W, ws, rowperm);
+    hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm);
 }
 
 // Forward sweep, assembly of the children's contribution rows into the parent:
@@ -119,7 +124,7 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // ---------------------------------------------------------------------------
 constexpr int APPLY_KC = 32;
 #ifndef FEASTHIP_ABLATE
-#define FEASTHIP_ABLATE 0      // timing experiments only (tools/ablate.sh): 1 no factor loads, 2 no LDS-DMA, 3 no epilogue, 4 no MFMA
+#define FEASTHIP_ABLATE 0      // timing experiments only (tools/ablate.sh), bit mask: 1 no factor loads, 2 no LDS-DMA, 4 no epilogue, 8 no MFMA, 16 no barrier, 32 no LDS reads
 #endif
 
 // LDS reads of the staged block-vector rows are issued as inline asm: the compiler cannot tell the two
@@ -179,12 +184,15 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
     g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0; g.pull = nullptr; g.npull = 0; g.pullbase = nullptr;
     g.sidx = struct_idx + f.sptr;
     g.out = Yk; g.orow_shift = f.c0;
-    if (kind == 0) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
+    const int NB = f.nb;         // diagonal super-block size of this front's solve-ready form (128, 256 or 512)
+    if (kind == 0) { g.k0 = t.c * NB; int b = min(NB, p - g.k0); g.rbase = g.k0 + b + t.b * th; g.rend = p; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.out = Wk; }
     else if (kind == 1) {
         g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2;
         if (f.cmap >= 0) { g.mode = 3; g.pull = cmap + f.cmap; g.npull = f.nchild; g.pullbase = crow_child + (int64_t)k * crs_child; }
     }
-    else if (kind == 2) { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1; }
+    else if (kind == 2) {   // unit lower inverse: row tile c only needs the columns left of its last row
+        g.k0 = t.b * NB; int b = min(NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = min(b, t.c * 64 + 64); g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1;
+    }
     else if (kind == 3) {
         g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk;
         if (nsplit > 0) {   // split-K part t.c: partial product into the scratch slab (part, row), reduced afterwards
@@ -194,8 +202,11 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
             g.out = skbuf + (int64_t)k * sks + (f.sk_off + (int64_t)t.c * p) * ldw; g.orow_shift = 0; g.mode = 2;
         }
     }
-    else if (kind == 4) { g.k0 = t.c * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
-    else { g.k0 = t.b * SOLVE_NB; int b = min(SOLVE_NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk; }
+    else if (kind == 4) { g.k0 = t.c * NB; int b = min(NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
+    else {                  // upper inverse: row tile c only needs the columns from its first row on
+        int kb = t.b * NB, b = min(NB, p - kb), ks = t.c * 64;
+        g.rbase = kb + ks; g.rend = kb + b; g.k0 = kb + ks; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b - ks; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk;
+    }
     return min(th, g.rend - g.rbase);
 }
 
@@ -240,7 +251,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
             int gk = kc + ks * 4 + lk;
-#if FEASTHIP_ABLATE != 1
+#if !(FEASTHIP_ABLATE & 1)
             an[ks] = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];
 #else
             an[ks] = cz_make(gk, lane);
@@ -251,7 +262,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
             int r = wave + 4 * q;
             int vrow = GATHER ? __builtin_amdgcn_readlane(idxv, q) : g.vrow0 + min(kc + r, Kd - 1);
             const cz* src = g.Vk + (int64_t)vrow * ldw + vcol_c;
-#if FEASTHIP_ABLATE != 2
+#if !(FEASTHIP_ABLATE & 2)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)&Vs[buf][r][0], 16, 0, 0);
 #else
@@ -281,7 +292,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
     }
     auto mf = [&](const cz& a, dv2 (&bv)[NS]) {
         const double ar = a.x, ai = a.y, as = a.x + a.y;
-#if FEASTHIP_ABLATE == 4
+#if FEASTHIP_ABLATE & 8
 #pragma unroll
         for (int q = 0; q < NS; ++q) { t1[q][0] += ar * bv[q][0]; t2[q][0] += ai * bv[q][1]; t3[q][0] += as; }
         return;
@@ -294,12 +305,16 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
         for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv[q][0] + bv[q][1], t3[q], 0, 0, 0);
     };
     // k-step KS runs on the matrix cores while the LDS reads of k-step KS+1 are in flight
+#if FEASTHIP_ABLATE & 32
+#define FEASTHIP_KSTEP(KS, CUR, NXT) if (KS < nks) { mf(av[KS], b0); }
+#else
 #define FEASTHIP_KSTEP(KS, CUR, NXT)                                                  \
     if (KS < nks) {                                                                   \
         if (KS + 1 < APPLY_KC / 4) lds_ld_step<(KS + 1) % (APPLY_KC / 4), NS>(NXT, la); \
         mf(av[KS], CUR);                                                              \
         if (KS + 1 < APPLY_KC / 4) lds_wait<NS>(NXT);                                 \
     }
+#endif
     auto mfma_chunk = [&](int kc, int buf) {
         const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;    // k-steps that carry data (uniform)
         if (wave_active) {
@@ -322,7 +337,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's A registers and V rows have landed
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
-        __syncthreads();                                      // everyone's rows landed; buffer buf^1 is free again
+        if (!(FEASTHIP_ABLATE & 16)) __syncthreads();         // everyone's rows landed; buffer buf^1 is free again
         load_chunk(kc + APPLY_KC, buf ^ 1);
         load_idx(kc + 2 * APPLY_KC);
         mfma_chunk(kc, buf);
@@ -335,8 +350,8 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
-        __syncthreads();
-        if (g.mode == 0 && wave_active && FEASTHIP_ABLATE != 3) {
+        if (!(FEASTHIP_ABLATE & 16)) __syncthreads();
+        if (g.mode == 0 && wave_active && !(FEASTHIP_ABLATE & 4)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -382,7 +397,7 @@ __device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC
             cz v;
             if (g.mode == 1 || g.mode == 2) v = cz_make(sgn * cr[q][r], sgn * ci[q][r]);
             else v = cz_make(old[r][q].x - cr[q][r], old[r][q].y - ci[q][r]);
-#if FEASTHIP_ABLATE == 3
+#if FEASTHIP_ABLATE & 4
             if (v.x == 123.456)
 #endif
             if (rok[r] && col < ldw) dptr[r][col] = v;
@@ -393,14 +408,16 @@ template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
                                                cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks,
-                                               int ntiles, const int* __restrict__ cmap, const cz* __restrict__ crow_child, int64_t crs_child) {
+                                               int ntiles, int ncg, const int* __restrict__ cmap, const cz* __restrict__ crow_child, int64_t crs_child) {
     __shared__ cz Vs[2][APPLY_KC][LDS_COLS];      // double buffered, filled by LDS-DMA
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the
     // (node, tile) items are handed out in node-major order with a contiguous range per XCD: the tiles of
     // one front of one node then run on ONE XCD and re-read their block-vector rows from that L2.
-    const int item = xcd_item();
+    // the column groups of one (node, tile) are consecutive items: they run on the same XCD at about the same time, so the
+    // factor slab they share comes from HBM once
+    const int item0 = xcd_item(), item = item0 / ncg;
     Tile t = tiles[item % ntiles];
-    int k = item / ntiles, cg = blockIdx.z * LDS_COLS;
+    int k = item / ntiles, cg = (item0 % ncg) * LDS_COLS;
     FrontD f = fr[t.f];
     ApplyGeom g;
     int trows = decode_tile<cz>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
@@ -413,9 +430,10 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
                   const cz* crow_child, int64_t crs_child) {
     if (ntiles <= 0) return;
-    dim3 g(ntiles * K, 1, (ldw + LDS_COLS - 1) / LDS_COLS);
-    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
-    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
+    const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
+    dim3 g(ntiles * K * ncg);
+    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
+    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
 }
 
 // ---------------------------------------------------------------------------
@@ -567,11 +585,11 @@ template <bool GATHER>
 __global__ __launch_bounds__(256) void k_apply32(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                  const int* __restrict__ struct_idx, const cf* __restrict__ fact, int64_t fs,
                                                  cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, cf* skbuf, int64_t sks,
-                                                 int ntiles, const int* __restrict__ cmap, const cf* __restrict__ crow_child, int64_t crs_child) {
+                                                 int ntiles, int ncg, const int* __restrict__ cmap, const cf* __restrict__ crow_child, int64_t crs_child) {
     __shared__ cf Vs[2][A32_KC][A32_LD];
-    const int item = xcd_item();
+    const int item0 = xcd_item(), item = item0 / ncg;
     Tile t = tiles[item % ntiles];
-    int k = item / ntiles, cg = blockIdx.z * LDS_COLS;
+    int k = item / ntiles, cg = (item0 % ncg) * LDS_COLS;
     FrontD f = fr[t.f];
     ApplyGeomT<cf> g;
     int trows = decode_tile<cf>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
@@ -584,9 +602,10 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather, cf* skbuf, int64_t sks,
                   const cf* crow_child, int64_t crs_child) {
     if (ntiles <= 0) return;
-    dim3 g(ntiles * K, 1, (ldw + LDS_COLS - 1) / LDS_COLS);
-    if (gather) hipLaunchKernelGGL(k_apply32<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
-    else hipLaunchKernelGGL(k_apply32<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, S.cmap, crow_child, crs_child);
+    const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
+    dim3 g(ntiles * K * ncg);
+    if (gather) hipLaunchKernelGGL(k_apply32<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
+    else hipLaunchKernelGGL(k_apply32<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
 }
 
 __global__ void k_to_f32(int64_t total, const cz* __restrict__ in, cf* out) {
@@ -637,36 +656,46 @@ void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, in
 
 // Q0[old,:] = sum_k T_k[i,:] .* e0[k,:]  (and Q1 with e1), T_k = mode ? X[old,:] - W_k[i,:] : W_k[i,:].
 // Fixed summation order over k: run-to-run reproducible (src/feast.jl:68-70, src/nlfeast.jl:56-59).
+// Conjugate fold (lds = 2 ldw): unit k carries two contour nodes; columns [ldw, 2 ldw) of W_k hold T(z_k)^-1 conj(R),
+// whose conjugate is the solution of the node conj(z_k); its coefficients are columns [ldw, 2 ldw) of e0 / e1.
 template <typename T>
 __global__ void k_accumulate(const int* __restrict__ perm, int n, const cz* __restrict__ X, const T* __restrict__ W,
-                             int64_t ws, int ldw, int K, const cz* __restrict__ e0, const cz* __restrict__ e1, int mode,
+                             int64_t ws, int ldw, int lds, int K, const cz* __restrict__ e0, const cz* __restrict__ e1, int mode,
                              cz* Q0, cz* Q1) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (i >= n) return;
     int64_t old = perm[i];
+    const bool fold = lds > ldw;
     for (int j = lane; j < ldw; j += 64) {
         cz x = mode ? X[old * ldw + j] : cz_make(0, 0);
         cz q0 = cz_make(0, 0), q1 = cz_make(0, 0);
         for (int k = 0; k < K; ++k) {
-            T wt = W[(int64_t)k * ws + (int64_t)i * ldw + j];
+            T wt = W[(int64_t)k * ws + (int64_t)i * lds + j];
             cz w = cz_make(wt.x, wt.y);                 // accumulation is always fp64 (src/feast.jl:68-70)
             cz tv = mode ? cz_sub(x, w) : w;
-            cz_madd(q0, tv, e0[(int64_t)k * ldw + j]);
-            if (Q1) cz_madd(q1, tv, e1[(int64_t)k * ldw + j]);
+            cz_madd(q0, tv, e0[(int64_t)k * lds + j]);
+            if (Q1) cz_madd(q1, tv, e1[(int64_t)k * lds + j]);
+            if (fold) {
+                T wc = W[(int64_t)k * ws + (int64_t)i * lds + ldw + j];
+                cz w2 = cz_make(wc.x, -(double)wc.y);
+                cz tv2 = mode ? cz_sub(x, w2) : w2;
+                cz_madd(q0, tv2, e0[(int64_t)k * lds + ldw + j]);
+                if (Q1) cz_madd(q1, tv2, e1[(int64_t)k * lds + ldw + j]);
+            }
         }
         Q0[old * ldw + j] = q0;
         if (Q1) Q1[old * ldw + j] = q1;
     }
 }
 
-void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int K,
+void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int lds, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
-    hipLaunchKernelGGL(k_accumulate<cz>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, K, e0, e1, mode, Q0, Q1);
+    hipLaunchKernelGGL(k_accumulate<cz>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
 }
-void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int K,
+void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
-    hipLaunchKernelGGL(k_accumulate<cf>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, K, e0, e1, mode, Q0, Q1);
+    hipLaunchKernelGGL(k_accumulate<cf>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
 }
 
 }  // namespace feasthip

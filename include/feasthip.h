@@ -130,6 +130,15 @@ int feasthip_nlfeast_run(feasthip_handle_t h, void* X, int64_t n, int m0, int it
  * accumulation Q += (X - temp) diag(w/(z-lambda)) stays complex128 (src/feast.jl:68-70).  Call before feasthip_set_x /
  * feasthip_factorize; default 0. */
 int feasthip_set_precision(feasthip_handle_t h, int mixed);
+/* Conjugate fold (default on).  When every coefficient matrix and scale is real, T(conj z) = conj(T(z)); if in addition every
+ * contour node z_k has its mirror image conj(z_k) on the contour (circles and rectangles centred on the real axis), the pair
+ * shares ONE factorisation: T(conj z_k)^-1 R = conj(T(z_k)^-1 conj(R)) is obtained as m0 more right-hand-side columns of the
+ * sweep over the factors of T(z_k).  The moment Q = sum_k w_k ... (src/feast.jl:57-72) is the same sum over all K nodes with
+ * each node's own weight; only the number of factorisations (src/feast.jl:28-38) and the factor bytes streamed per iteration
+ * halve.  Applies to feast!/gen_feast!/nlfeast!/nlfeast_moments! on real matrices; never to per-node coefficient overrides
+ * (feasthip_set_coef_functions, feasthip_set_node_coefficients, dual_gen_feast).  Node shards (feasthip_set_node_shard) then
+ * deal out pairs instead of nodes.  on = 0 factorises every node separately, exactly like the reference. */
+int feasthip_set_conjugate_fold(feasthip_handle_t h, int on);
 
 /* ---- NEPs that are not polynomials (SURVEY 8b "generic-T NLFEAST"; the reference takes any closure z -> matrix,
  * src/nlfeast.jl:2,21, src/utils.jl:107; test/gun2.jl:30-37, test/hadeler.jl:27-59).
@@ -210,9 +219,12 @@ typedef struct {
     double solve_bytes;         /* algorithmic bytes of one contour step */
     double solve_flops;         /* real flops of one contour step                   */
     int64_t perturbed_pivots;
-    int32_t local_nodes, m0, ldw, dense;
+    int32_t local_nodes, m0, ldw, dense;     /* local_nodes: contour nodes this handle integrates over */
     double alloc_seconds;       /* hipMalloc of the factor / contribution arenas at the end of feasthip_analyze (the driver may
                                  * have to scrub tens of GB freed by a previous process: 0.03 .. 2 s for the same request) */
+    int32_t factor_units;       /* factorisations held: local_nodes, or local_nodes / 2 with the conjugate fold */
+    int32_t folded;             /* 1 if the conjugate fold is active (feasthip_set_conjugate_fold) */
+    double solve_bytes_streamed;/* bytes the sweeps of one contour step move (a folded pair reads its factor once) */
 } feasthip_stats_t;
 int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* out);
 /* One instrumented contour sweep: HIP-event time per kernel class.  out = 8 rows x
@@ -236,10 +248,11 @@ int feasthip_mm_write_csc(const char* path, int64_t rows, int64_t cols, const in
 
 /* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------- */
 /* symbolic analysis of a pattern: stats[0..7] = nsuper, nnz_l, nnz_u, fact_elems,
- * max_front, max_p, depth, flops(as int64).  perm_out (n ints, new->old) optional. */
+ * max_front, max_p, depth, flops(as int64).  perm_out (n ints, new->old) optional;
+ * fronts_out (4 ints per supernode, at most 4 n: pivot columns, update rows, depth, parent) optional. */
 int feasthip_symbolic_probe(int64_t n, const int64_t* colptr, const int64_t* rowval, int index_base,
                             int ordering, int64_t* stats, int32_t* perm_out,
-                            int32_t* sn_of_out, int32_t* front_rows_ptr_out /* unused: NULL */);
+                            int32_t* sn_of_out, int32_t* fronts_out);
 /* structural check: returns 0 if every (i,j) of the pattern and of its LU fill (given as a
  * dense n x n 0/1 byte mask, column-major, in ORIGINAL ordering after the caller applied
  * perm) lies inside the predicted supernodal structure. */

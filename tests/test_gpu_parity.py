@@ -780,6 +780,78 @@ def test_node_shards_sum_to_full_moment(gpu, pkg, wl):
     assert np.abs(even + odd - full).max() <= 1e-13 * np.abs(full).max()
 
 
+def _moment(pkg, w, con, fold, shard=(0, 1), nl=False):
+    h = pkg.FeastHandle(0)
+    h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+    h.set_contour(con)
+    h.set_conjugate_fold(fold)
+    h.set_node_shard(*shard)
+    h.factorize()
+    h.set_x(w["X0"])
+    h.rr_step()
+    h.contour_step()
+    q = h.get_block(2).copy()
+    st = h.stats()
+    h.close()
+    return q, st
+
+
+def test_conjugate_fold_matches_one_factorisation_per_node(gpu, pkg, wl):
+    """Real pencil + mirror-symmetric contour: a conjugate node pair shares one factorisation, the mirror system rides along
+    as m0 more right-hand-side columns conj(R).  The moment must equal the one from 16 separate factorisations to rounding,
+    with half the factorisations; shards deal out pairs and still add up to the full moment."""
+    w = wl.c3_sparse_generalized(12, 19, 64)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    q1, s1 = _moment(pkg, w, con, True)
+    q0, s0 = _moment(pkg, w, con, False)
+    assert s1["folded"] == 1 and s1["factor_units"] == 8 and s1["local_nodes"] == 16
+    assert s0["folded"] == 0 and s0["factor_units"] == 16 and s0["local_nodes"] == 16
+    assert s1["solve_bytes"] == s0["solve_bytes"] and s1["solve_bytes_streamed"] < 0.9 * s0["solve_bytes_streamed"]
+    assert np.abs(q1 - q0).max() <= 1e-12 * np.abs(q0).max()
+    parts = [_moment(pkg, w, con, True, (r, 4)) for r in range(4)]
+    assert all(p[1]["factor_units"] == 2 and p[1]["local_nodes"] == 4 for p in parts)
+    assert np.abs(sum(p[0] for p in parts) - q1).max() <= 1e-13 * np.abs(q1).max()
+    # more ranks than pairs: every rank falls back to single nodes, consistently
+    parts = [_moment(pkg, w, con, True, (r, 16)) for r in (0, 5, 15)]
+    assert all(p[1]["folded"] == 0 and p[1]["local_nodes"] == 1 for p in parts)
+
+
+def test_conjugate_fold_only_where_it_is_exact(gpu, pkg, wl):
+    """No fold for complex matrices, for a contour that is not mirror-symmetric, or with a node on the real axis."""
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    A, B = w["A"], w["B"]
+
+    def folded(A_, B_, con):
+        h = pkg.FeastHandle(0)
+        h.set_terms([A_, B_], [1.0, -1.0])
+        h.set_contour(con)
+        f = h.stats()["folded"]
+        h.close()
+        return f
+
+    assert folded(A, B, pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)) == 1
+    assert folded(A.astype(np.complex128) * (1.0 + 0.0j) + 1e-3j * B, B, pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)) == 0
+    assert folded(A, B, pkg.circular_contour_trapezoidal(w["c"] + 0.01j, w["r"], 16)) == 0
+    import copy
+    con2 = copy.copy(pkg.circular_contour_trapezoidal(w["c"], w["r"], 16))
+    con2.nodes = con2.nodes.copy()
+    con2.nodes[0], con2.nodes[-1] = con2.nodes[0].real, con2.nodes[-1].real        # two nodes on the real axis: their own mirror images
+    assert folded(A, B, con2) == 0
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_c3_sparse_g12_fold_switch(gpu, pkg, wl, golden, fold):
+    """the whole gen_feast loop with and without the conjugate fold against the same oracle fixture"""
+    w = wl.c3_sparse_generalized(12, 19, 64)
+    g = golden["c3_g12_s19"]
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
+    info = {}
+    lam, X, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, info=info, conjugate_fold=fold)
+    assert info["folded"] == (1 if fold else 0)
+    assert len(lam) == len(g["lam"]) and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
+    assert abs(info["nit"] - g["history"][-1][0]) <= 1
+
+
 def test_contour_estimate_eig(gpu, pkg, fo, wl):
     """adjacent caller of the same seam (src/stochastic.jl): same random block -> same estimate as the oracle,
     and the estimate is close to the true count"""

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Node groups on separate streams (FEASTHIP_STREAMS): 16 local nodes, C3 46^3.
-for st in 1 2 3 4; do
-FEASTHIP_STREAMS=$st timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --cpu-baseline off 2>/dev/null | python3 -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('streams',$st,'ms/step %.2f contour %.2f'%(d['ms_per_step'], d['breakdown_ms_per_step']['contour']))"
-done
+# contour-step time for 1 / 2 node groups (streams), with and without the conjugate fold, for the super-block thresholds given in the environment
+for f in "" "--no-fold"; do for s in 1 2; do
+  echo "== streams $s $f NB256_MINP=${FEASTHIP_NB256_MINP:-default} NB512_MINP=${FEASTHIP_NB512_MINP:-default}"
+  FEASTHIP_STREAMS=$s python bench.py --cpu-baseline off --steps 6 $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],2), d['breakdown_ms_per_step'], d['setup']['factor_ms'])"
+done; done
