@@ -59,6 +59,7 @@ PROTOTYPES = {
     "feasthip_nlfeast_run": (I, [VP, VP, I64, I, I, D, D, VP, VP, VP, C.POINTER(I)]),
     "feasthip_set_precision": (I, [VP, I]),
     "feasthip_set_conjugate_fold": (I, [VP, I]),
+    "feasthip_select_apply_kernel": (I, [I]),
     "feasthip_set_coef_functions": (I, [VP, VP, VP]),
     "feasthip_set_node_coefficients": (I, [VP, VP, I, I]),
     "feasthip_nl_beyn_step": (I, [VP, VP, VP]),

@@ -9,6 +9,8 @@
 // lines.  The factor panels are streamed from HBM exactly once per sweep and go
 // straight into the f64 matrix cores; the right-hand-side tile is staged in LDS.
 #include "kernels.hpp"
+#include <cstdlib>
+#include <type_traits>
 
 namespace feasthip {
 
@@ -426,14 +428,194 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
     else apply_body<GATHER, 4>(g, Vs, cg, ldw);
 }
 
+static int apply2_enabled();
+static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
+                          cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
+                          const cz* crow_child, int64_t crs_child);
+
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
                   const cz* crow_child, int64_t crs_child) {
     if (ntiles <= 0) return;
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
     dim3 g(ntiles * K * ncg);
+    if (apply2_enabled()) { launch_apply2(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child); return; }
     if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
     else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
+}
+
+// ---------------------------------------------------------------------------
+// k_apply2 -- the same tiles without LDS and without workgroup barriers (the default; FEASTHIP_APPLY2=0 selects k_apply).
+// Every wave owns 16 output rows x 16*NS block-vector columns and streams BOTH operands straight from global memory into the
+// matrix-core operand registers: the factor slab (HBM) A2_DA - 1 k-steps ahead, the block-vector rows (they are shared by
+// the waves and tiles of a front, so they come from L1 / L2) A2_DV - 1 k-steps ahead -- a 16 B load per lane IS the MFMA
+// fragment layout for both (A: 16 consecutive rows of one factor column, V: 16 consecutive columns of one block-vector row).
+// The loop body is straight-line code (8 k-steps, uniform exits every second step), so the compiler's s_waitcnt vmcnt(N) waits
+// for exactly the loads a k-step consumes while 15-20 younger ones stay in flight; waves never wait for each other.
+// Measured on random operands (tools/probes/apply2_bench.hip): +21 % on matrix-core-bound tiles (K = 1024: 60.7 -> 73.8 TFLOP/s),
+// +12 % on short-K tiles; bit-identical results (same summation order).
+// ---------------------------------------------------------------------------
+constexpr int A2_DA = 8, A2_DV = 4, A2_DI = 2;
+
+template <bool GATHER, int NS>
+__device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw) {
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wave = tid >> 6;
+    const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
+    if (g.rbase + slab * 16 >= g.rend || cg + ct0 * 16 >= ldw) return;   // nothing to do for this wave (no barriers: it may leave)
+    const int arow = g.rbase + slab * 16 + li;
+    const bool aok = arow < g.rend;
+    const int adiag = arow - g.k0;
+    const int Kd = g.Kd, nks = (Kd + 3) >> 2;
+    const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
+    const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
+    const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
+    const cz* Ap = g.A + min(arow, g.rend - 1);
+    const int64_t lda = g.lda;
+    int vcol[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) vcol[q] = min(cg + (ct0 + q) * 16 + li, ldw - 1);
+    cz ar[A2_DA], vr[A2_DV][NS];
+    int ir[8];
+    auto kof = [&](int s) { return min(4 * s + lk, Kd - 1); };        // clamped: steps beyond the end re-read the last column (masked)
+    auto loadA = [&](int s, int slot) { ar[slot] = Ap[(int64_t)kof(s) * lda]; };
+    auto loadI = [&](int s, int slot) { if (GATHER) ir[slot] = g.sidx[kof(s)]; };
+    auto loadV = [&](int s, int slot, int islot) {
+        const int vrow = GATHER ? ir[islot] : g.vrow0 + kof(s);
+        const cz* vp = g.Vk + (int64_t)vrow * ldw;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) vr[slot][q] = vp[vcol[q]];
+    };
+    d4 t1[NS], t2[NS], t3[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { t1[q] = (d4){0, 0, 0, 0}; t2[q] = (d4){0, 0, 0, 0}; t3[q] = (d4){0, 0, 0, 0}; }
+    // prologue: fill the rings
+#pragma unroll
+    for (int s = 0; s < A2_DV - 1 + A2_DI; ++s) loadI(s, s % 8);
+#pragma unroll
+    for (int s = 0; s < A2_DA - 1; ++s) loadA(s, s);
+#pragma unroll
+    for (int s = 0; s < A2_DV - 1; ++s) loadV(s, s, s % 8);
+    auto step = [&](int s, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(s + A2_DA - 1, (j + A2_DA - 1) % A2_DA);
+        loadI(s + A2_DV - 1 + A2_DI, (j + A2_DV - 1 + A2_DI) % 8);
+        loadV(s + A2_DV - 1, (j + A2_DV - 1) % A2_DV, (j + A2_DV - 1) % 8);
+        __builtin_amdgcn_sched_barrier(0);
+        const int gk = 4 * s + lk;
+        cz a = ar[j % A2_DA];
+        const bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
+        a.x = keep ? a.x : (gk == unit_at ? 1.0 : 0.0);
+        a.y = keep ? a.y : 0.0;
+        const double as = a.x + a.y;
+        // 3M complex product, see apply_body
+#pragma unroll
+        for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vr[j % A2_DV][q].x, t1[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, vr[j % A2_DV][q].y, t2[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q], 0, 0, 0);
+    };
+#define FEASTHIP_STEP2(S0, J) step((S0) + (J), std::integral_constant<int, (J)>{}); step((S0) + (J) + 1, std::integral_constant<int, (J) + 1>{});
+    int s0 = 0;
+    for (; s0 + 8 <= nks; s0 += 8) { FEASTHIP_STEP2(s0, 0) FEASTHIP_STEP2(s0, 2) FEASTHIP_STEP2(s0, 4) FEASTHIP_STEP2(s0, 6) }
+    const int rem = nks - s0;       // 0 .. 7 k-steps left: pairs of steps (a step beyond the end multiplies masked zeros)
+    if (rem > 0) {
+        FEASTHIP_STEP2(s0, 0)
+        if (rem > 2) {
+            FEASTHIP_STEP2(s0, 2)
+            if (rem > 4) {
+                FEASTHIP_STEP2(s0, 4)
+                if (rem > 6) { FEASTHIP_STEP2(s0, 6) }
+            }
+        }
+    }
+#undef FEASTHIP_STEP2
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue: output rows of this lane (D layout: row (l >> 4) + 4 r, columns (ct0 + q) * 16 + li)
+    cz* dptr[4];
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int orow = g.rbase + slab * 16 + lk + 4 * r;
+        rok[r] = orow < g.rend;
+        dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
+    }
+    cz old[4][NS];
+    if (g.mode == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][vcol[q]];
+    } else if (g.mode == 3) {
+        // extend-add of the forward sweep fused into the producer (fixed child order: deterministic)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) old[r][q] = cz_make(0, 0);
+        for (int c = 0; c < g.npull; ++c) {
+            int src[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int orow = g.rbase + slab * 16 + lk + 4 * r;
+                src[r] = rok[r] ? g.pull[(int64_t)(orow + g.orow_shift) * g.npull + c] : -1;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (src[r] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        cz v = g.pullbase[(int64_t)src[r] * ldw + vcol[q]];
+                        old[r][q].x += v.x; old[r][q].y += v.y;
+                    }
+                }
+        }
+    }
+    const double sgn = (g.mode == 2) ? -1.0 : 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int col = cg + (ct0 + q) * 16 + li;
+            const double cr = t1[q][r] - t2[q][r], ci = t3[q][r] - t1[q][r] - t2[q][r];
+            cz v;
+            if (g.mode == 1 || g.mode == 2) v = cz_make(sgn * cr, sgn * ci);
+            else v = cz_make(old[r][q].x - cr, old[r][q].y - ci);
+            if (rok[r] && col < ldw) dptr[r][col] = v;
+        }
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
+                                                cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks,
+                                                int ntiles, int ncg, const int* __restrict__ cmap, const cz* __restrict__ crow_child, int64_t crs_child) {
+    const int item0 = xcd_item(), item = item0 / ncg;      // same work mapping as k_apply
+    Tile t = tiles[item % ntiles];
+    int k = item / ntiles, cg = (item0 % ncg) * LDS_COLS;
+    FrontD f = fr[t.f];
+    ApplyGeom g;
+    int trows = decode_tile<cz>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
+    if (trows <= 16) apply2_body<GATHER, 1>(g, cg, ldw);
+    else if (trows <= 32) apply2_body<GATHER, 2>(g, cg, ldw);
+    else apply2_body<GATHER, 4>(g, cg, ldw);
+}
+
+static int g_apply2 = -1;
+static int apply2_enabled() {
+    if (g_apply2 < 0) { const char* e = getenv("FEASTHIP_APPLY2"); g_apply2 = e ? (atoi(e) != 0) : 1; }
+    return g_apply2;
+}
+void select_apply_kernel(int barrier_free) { g_apply2 = barrier_free ? 1 : 0; }
+
+static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
+                          cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
+                          const cz* crow_child, int64_t crs_child) {
+    const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
+    dim3 g(ntiles * K * ncg);
+    if (gather) hipLaunchKernelGGL(k_apply2<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
+    else hipLaunchKernelGGL(k_apply2<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
 }
 
 // ---------------------------------------------------------------------------

@@ -852,6 +852,33 @@ def test_c3_sparse_g12_fold_switch(gpu, pkg, wl, golden, fold):
     assert abs(info["nit"] - g["history"][-1][0]) <= 1
 
 
+@pytest.mark.parametrize("m0,fold", [(64, True), (64, False), (24, True), (100, False)])
+def test_apply_kernels_bit_identical(gpu, pkg, wl, m0, fold):
+    """k_apply2 (operands streamed from global memory, no LDS, no barriers) and k_apply (LDS-staged) run the same tiles in the
+    same summation order: the moment Q must be bit-identical (all tile kinds, row-tile heights, masks, split-K, gathers)."""
+    w = wl.c3_sparse_generalized(14, 19, m0)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    lib = pkg.load_library()
+    outs = []
+    try:
+        for sel in (1, 0):
+            lib.feasthip_select_apply_kernel(sel)
+            h = pkg.FeastHandle(0)
+            h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+            h.set_contour(con)
+            h.set_conjugate_fold(fold)
+            h.factorize()
+            h.set_x(w["X0"])
+            h.rr_step()
+            h.contour_step()
+            outs.append(h.get_block(2).copy())
+            h.close()
+    finally:
+        lib.feasthip_select_apply_kernel(1)
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_contour_estimate_eig(gpu, pkg, fo, wl):
     """adjacent caller of the same seam (src/stochastic.jl): same random block -> same estimate as the oracle,
     and the estimate is close to the true count"""

@@ -12,7 +12,7 @@ using namespace feasthip;
 constexpr int DA = 8, DV = 4;      // ring sizes (k-steps): A loads are issued DA - 1 steps ahead, V loads DV - 1 steps ahead
 
 // out[r, :] = -sum_k A[r, k] V[k, :]   r in [rbase, rend), k < Kd;  A column-major (lda), V/out row-major (ldw = 64)
-__global__ __launch_bounds__(256, 2) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, const cz* __restrict__ fact, int64_t fs,
+__global__ __launch_bounds__(256, 2) void k_apply2p(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, const cz* __restrict__ fact, int64_t fs,
                                                    const cz* __restrict__ W, int64_t ws, cz* crow, int64_t crs, int ntiles) {
     const int item = xcd_item();
     Tile t = tiles[item % ntiles];
@@ -110,10 +110,11 @@ static void run_case(const Case& c, bool check) {
     CK(hipMalloc(&crow2, (size_t)K * crs * 16)); CK(hipMemset(crow2, 0, (size_t)K * crs * 16));
     DevSym S{}; S.fr = dfr; S.n = (int)n;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
+        select_apply_kernel(variant == 1);
         auto go = [&]() {
-            if (variant == 0) launch_apply(0, S, dt1, (int)t1.size(), fact, fs, W, Y, ws, ldw, crow, crs, K);
-            else hipLaunchKernelGGL(k_apply2, dim3((unsigned)(t1.size() * K)), dim3(256), 0, 0, dfr, dt1, fact, fs, W, ws, crow2, crs, (int)t1.size());
+            if (variant < 2) launch_apply(0, S, dt1, (int)t1.size(), fact, fs, W, Y, ws, ldw, crow, crs, K);
+            else hipLaunchKernelGGL(k_apply2p, dim3((unsigned)(t1.size() * K)), dim3(256), 0, 0, dfr, dt1, fact, fs, W, ws, crow2, crs, (int)t1.size());
         };
         go(); CK(hipDeviceSynchronize());
         int reps = 10;
@@ -122,7 +123,7 @@ static void run_case(const Case& c, bool check) {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
         double fb = (double)F * p * u * 16.0 * K, vb = ((double)F * (p + u)) * ldw * 16.0 * K, fl = (double)F * p * u * 8.0 * ldw * K;
-        printf("%-10s %s: tiles %6zu x %2d nodes  %.3f ms  factor %.2f TB/s  (+vec %.2f TB/s)  %.1f TFLOP/s (8/cmadd)\n", c.name, variant ? "k_apply2" : "k_apply ",
+        printf("%-10s %s: tiles %6zu x %2d nodes  %.3f ms  factor %.2f TB/s  (+vec %.2f TB/s)  %.1f TFLOP/s (8/cmadd)\n", c.name, variant == 0 ? "k_apply  (LDS)" : variant == 1 ? "k_apply2 (lib)" : "prototype     ",
                t1.size(), K, ms, fb / ms / 1e9, (fb + vb) / ms / 1e9, fl / ms / 1e9);
     }
     if (check) {
@@ -138,8 +139,8 @@ static void run_case(const Case& c, bool check) {
 
 int main() {
     int occ = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_apply2, 256, 0));
-    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)k_apply2));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_apply2p, 256, 0));
+    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)k_apply2p));
     printf("k_apply2: %d workgroups / CU, regs %d, LDS %zu\n", occ, fa.numRegs, fa.sharedSizeBytes);
     Case cases[] = { {"tiny", 2, 40, 100, 2}, {"top", 3, 1024, 2048, 16}, {"mid", 48, 128, 1024, 16}, {"mid2", 24, 256, 1536, 16}, {"low", 600, 40, 400, 16}, {"low2", 400, 64, 600, 16} };
     run_case(cases[0], true);

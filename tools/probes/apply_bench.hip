@@ -12,6 +12,14 @@ using namespace feasthip;
 
 struct Case { const char* name; int F, p, u, K; };
 
+static void fill_random(cz* d, size_t n) {
+    size_t m = std::min<size_t>(n, (size_t)4 << 20);
+    std::vector<cz> h(m);
+    unsigned long long s = 88172645463325252ull;
+    for (size_t i = 0; i < m; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].x = ((double)(s >> 11) / 9007199254740992.0 - 0.5) * 1e-3; s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].y = ((double)(s >> 11) / 9007199254740992.0 - 0.5) * 1e-3; }
+    for (size_t off = 0; off < n; off += m) CK(hipMemcpy(d + off, h.data(), std::min(m, n - off) * 16, hipMemcpyHostToDevice));
+}
+
 static void run_case(const Case& c, int ldw, int sl) {
     int F = c.F, p = c.p, u = c.u, K = c.K;
     int64_t n = (int64_t)F * p + u + 64;               // update rows of every front live after all pivot rows
@@ -38,8 +46,8 @@ static void run_case(const Case& c, int ldw, int sl) {
     CK(hipMalloc(&dsidx, sidx.size() * 4)); CK(hipMemcpy(dsidx, sidx.data(), sidx.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dt1, t1.size() * sizeof(Tile))); CK(hipMemcpy(dt1, t1.data(), t1.size() * sizeof(Tile), hipMemcpyHostToDevice));
     CK(hipMalloc(&dt3, t3.size() * sizeof(Tile))); CK(hipMemcpy(dt3, t3.data(), t3.size() * sizeof(Tile), hipMemcpyHostToDevice));
-    CK(hipMalloc(&fact, (size_t)K * fs * 16)); CK(hipMemset(fact, 0x3f, (size_t)K * fs * 16));
-    CK(hipMalloc(&W, (size_t)K * ws * 16)); CK(hipMemset(W, 0x3f, (size_t)K * ws * 16));
+    CK(hipMalloc(&fact, (size_t)K * fs * 16)); fill_random(fact, (size_t)K * fs);      // random operands: the clock under load depends on the data
+    CK(hipMalloc(&W, (size_t)K * ws * 16)); fill_random(W, (size_t)K * ws);
     CK(hipMalloc(&Y, (size_t)K * ws * 16)); CK(hipMemset(Y, 0, (size_t)K * ws * 16));
     CK(hipMalloc(&crow, (size_t)K * crs * 16)); CK(hipMemset(crow, 0, (size_t)K * crs * 16));
     DevSym S{}; S.fr = dfr; S.struct_idx = dsidx; S.rel = nullptr; S.child_idx = nullptr; S.perm = nullptr; S.c0_of_row = nullptr; S.cmap = nullptr; S.ebp = nullptr; S.n = (int)n;
@@ -76,7 +84,11 @@ int main(int argc, char** argv) {
         {"top", 3, 1024, 2048, 16}, {"top8", 3, 1024, 2048, 8}, {"root-ish", 1, 3072, 3072, 16},
         {"mid", 48, 128, 1024, 16}, {"mid2", 24, 256, 1536, 16}, {"low", 600, 40, 400, 16}, {"low2", 400, 64, 600, 16},
     };
-    for (const Case& c : cases) run_case(c, 64, 4);
-    run_case(cases[0], 128, 4);
+    for (int variant = 0; variant < 2; ++variant) {
+        select_apply_kernel(variant);
+        printf("=== %s\n", variant ? "k_apply2 (no LDS, no barriers)" : "k_apply (LDS-staged)");
+        for (const Case& c : cases) run_case(c, 64, 4);
+        run_case(cases[0], 128, 4);
+    }
     return 0;
 }
