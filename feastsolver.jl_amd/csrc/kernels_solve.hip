@@ -471,7 +471,7 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
     const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
     const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
     const cz* Ap = g.A + min(arow, g.rend - 1);
-    const int64_t lda = g.lda;
+    const int lda = (int)g.lda;       // a panel's leading dimension fits 31 bits: one v_mad_i64_i32 per address
     int vcol[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) vcol[q] = min(cg + (ct0 + q) * 16 + li, ldw - 1);

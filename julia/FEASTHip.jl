@@ -72,7 +72,7 @@ eltag(::Type{ComplexF64}) = C128
 eltag(::Type{Int64}) = I64
 
 function gen_feast!(X::Matrix{ComplexF64}, A::SparseMatrixCSC{TA,Int64}, B::SparseMatrixCSC{TB,Int64}, contour;
-                    iter::Integer=10, debug=false, store=false, ϵ=1e-12, device::Integer=0) where {TA,TB}
+                    iter::Integer=10, debug=false, store=false, ϵ=1e-12, device::Integer=0, conjugate_fold::Bool=true) where {TA,TB}
     N, m₀ = size(X)
     size(A, 1) != size(A, 2) && error("Incorrect dimensions of A, must be square")
     size(A, 1) != N && error("Incorrect dimensions of X, must match A")
@@ -95,6 +95,8 @@ function gen_feast!(X::Matrix{ComplexF64}, A::SparseMatrixCSC{TA,Int64}, B::Spar
             check(h[], ccall((:feasthip_set_contour, lib), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{ComplexF64}, Ptr{ComplexF64}, Cint, Ptr{Float64}),
                 h[], length(nodes), nodes, weights, kind, region))
+            # real A, B + mirror-symmetric contour: one factorisation per conjugate node pair (default); false = one per node
+            conjugate_fold || check(h[], ccall((:feasthip_set_conjugate_fold, lib), Cint, (Ptr{Cvoid}, Cint), h[], 0))
             check(h[], ccall((:feasthip_feast_run, lib), Cint,
                 (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Cint, Float64, Cint, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}),
                 h[], X, N, m₀, iter, ϵ, store ? 1 : 0, Λ, res, inside, nit))
