@@ -51,6 +51,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     if (const char* v = getenv("FEASTHIP_NB256_MINP")) nb256_min_p_ = std::max(129, atoi(v));      // tuning knobs: 1 << 30 keeps the 128-column blocks
     if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
+    if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
     if (nst > 1) {
@@ -413,6 +414,7 @@ bool Engine::build_plans() {
             int64_t wgs = 0;
             rows_of([&](int rows) { wgs += cdiv(rows, 64); });
             if (wgs * nodes_local() < 128) return 1;      // latency-bound launch (few nodes left on this GPU): 16-row tiles, four waves share the columns
+            if (pmax <= short_k_max_p_) return 2;         // levels of small fronts (short K loops): 32-row tiles run the k_apply2 instance with three workgroups per CU
             return (wgs * nodes_local() >= 1024) ? 4 : 2;
         };
         double rowb = 1.0;   // bytes are scaled by 16*ldw at run time: count block-vector ROWS here
@@ -431,6 +433,7 @@ bool Engine::build_plans() {
                 L.bytes += (double)rows * NB * 16.0; L.flops += (double)rows * NB; L.vrows += 2.0 * rows + NB;
             }
             L.count = (int)(tiles.size() - L.off);
+            L.sl = sl;
             V.f1.push_back(L);
         }
         V.f2.off = (int64_t)tiles.size();
@@ -439,10 +442,11 @@ bool Engine::build_plans() {
             int p = S.p(s), u = S.u(s), NB = solve_nb(s);
             for (int a = 0; a < cdiv(u, 16 * sl2); ++a) tiles.push_back({s, 1 | (sl2 << 8), a, 0});
             for (int t = 0; t < cdiv(p, NB); ++t)
-                for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 64); ++rt) tiles.push_back({s, 2, t, rt});
+                for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * sl2); ++rt) tiles.push_back({s, 2 | (sl2 << 8), t, rt});
             V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, NB);
         }
         V.f2.count = (int)(tiles.size() - V.f2.off);
+        V.f2.sl = sl2;
         // longest tiles first (LPT): the K loop of a tile is p (kind 1) or at most the super-block size (kind 2); fronts stay together
         std::stable_sort(tiles.begin() + V.f2.off, tiles.end(), [&](const Tile& a, const Tile& b) {
             int ka = (a.a & 0xff) == 1 ? S.p(a.f) : std::min(solve_nb(a.f), S.p(a.f)), kb2 = (b.a & 0xff) == 1 ? S.p(b.f) : std::min(solve_nb(b.f), S.p(b.f));
@@ -472,6 +476,7 @@ bool Engine::build_plans() {
             V.b1.bytes += (double)u * p * 16.0; V.b1.flops += (double)u * p;
         }
         V.b1.count = (int)(tiles.size() - V.b1.off);
+        V.b1.sl = sl3;
         std::stable_sort(tiles.begin() + V.b1.off, tiles.end(), [&](const Tile& a, const Tile& b) { return S.u(a.f) > S.u(b.f); });   // K = u
         sk_rows_ = std::max(sk_rows_, sk_level);
         V.b1red.off = (int64_t)tiles.size();
@@ -490,12 +495,15 @@ bool Engine::build_plans() {
                 L.bytes += (double)k0 * b * 16.0; L.flops += (double)k0 * b; L.vrows += 2.0 * k0 + b;
             }
             L.count = (int)(tiles.size() - L.off);
+            L.sl = sl;
         }
         V.b3.off = (int64_t)tiles.size();
+        const int sl5 = std::max(2, pick_slabs([&](auto&& cb) { for (int s : lv) cb(S.p(s)); }));
+        V.b3.sl = sl5;
         for (int s : lv) {
             int p = S.p(s), NB = solve_nb(s);
             for (int t = 0; t < cdiv(p, NB); ++t)
-                for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 64); ++rt) tiles.push_back({s, 5, t, rt});
+                for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * sl5); ++rt) tiles.push_back({s, 5 | (sl5 << 8), t, rt});
             V.b3.bytes += 0.5 * p * std::min(p, NB) * 16.0; V.b3.flops += 0.5 * p * std::min(p, NB);
         }
         V.b3.count = (int)(tiles.size() - V.b3.off);

@@ -35,6 +35,7 @@ struct Launch {        // a slice of the tile / list buffers
     int count = 0;
     double bytes = 0, flops = 0;   // algorithmic bytes / real flops of this launch for ONE contour node
     double vrows = 0;              // block-vector rows read or written by the in-block steps (one node)
+    int sl = 4;                    // tile height of the launch in 16-row slabs (launch_apply: max_slabs)
 };
 
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp; };
@@ -230,6 +231,7 @@ private:
     bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true, fuse_extend_ = true;
     int fuse_min_p_ = 128;            // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself
     int group_panels_ = 4;            // panels per deferred trailing update in the look-ahead factorisation
+    int short_k_max_p_ = 96;          // levels whose fronts have at most this many pivot columns use 32-row substitution tiles
     int nb256_min_p_ = 193, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
     int solve_nb(int s) const { int p = S.p(s); return p >= nb512_min_p_ ? 512 : p >= nb256_min_p_ ? 256 : 128; }
     std::vector<hipStream_t> aux_streams_;

@@ -56,14 +56,14 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
         for (Launch& L : V.f1) {
             begin();
-            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false, nullptr, 0, nullptr, 0, L.sl);
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, L.vrows), stat_flops(L)); }
         }
         begin();
         // contribution rows of the children that pass through to this level's contribution rows are pulled in the
         // epilogue of the F2a tiles (kind 1), so there is no second assembly pass
         launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
-                     nullptr, 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc);
+                     nullptr, 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2.sl);
         if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows + V.pull_rows), stat_flops(V.f2)); }
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
@@ -72,17 +72,17 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
         int64_t sks = std::max<int64_t>(1, sk_rows_) * ldw;
-        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, skall + (int64_t)kb * sks, sks);
+        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, skall + (int64_t)kb * sks, sks, nullptr, 0, V.b1.sl);
         if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Yp, ws, ldw, skall + (int64_t)kb * sks, sks, kc);
         if (V.b1.count) { cur_tiles = -V.b1.count; end(3, stat_bytes(V.b1, lvl_u + 2.0 * lvl_p), stat_flops(V.b1)); }
         for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
             Launch& L = V.b2[c];
             begin();
-            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, L.sl);
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, L.vrows), stat_flops(L)); }
         }
         begin();
-        launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc);
+        launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, V.b3.sl);
         if (V.b3.count) { cur_tiles = V.b3.count; end(3, stat_bytes(V.b3, 2.0 * lvl_p), stat_flops(V.b3)); }
     }
     if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }

@@ -75,15 +75,17 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 //   3 B1  backward, pivot rows:                                        Y_J -= U12 W[struct]    (K = u, gathered; final x lives in W)
 //   4 B2  backward, rows above diagonal block c:                       Y_r -= PU_rc Y_c
 //   5 B3  backward, diagonal super block b, row tile c:                W_b  = inv(U_bb) Y_b
+// max_slabs: an upper bound of the tile heights of this launch in 16-row slabs (4, 2 or 1).  Launches whose tiles all have
+// at most 32 rows run a k_apply2 instance that needs fewer registers and keeps three workgroups per CU instead of two.
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false,
-                  cz* skbuf = nullptr, int64_t sks = 0, const cz* crow_child = nullptr, int64_t crs_child = 0);
+                  cz* skbuf = nullptr, int64_t sks = 0, const cz* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4);
 // complex128 tiles run on k_apply2 (no LDS, no barriers) unless FEASTHIP_APPLY2=0 / select_apply_kernel(0) picks k_apply (LDS-staged)
 void select_apply_kernel(int barrier_free);
 // complex64 twins for the mixed-precision solve path (same tiles, same plans)
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather = false,
-                  cf* skbuf = nullptr, int64_t sks = 0, const cf* crow_child = nullptr, int64_t crs_child = 0);
+                  cf* skbuf = nullptr, int64_t sks = 0, const cf* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4);
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cf* W, int64_t ws,
                        const int* rowperm, int K);
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,

@@ -193,7 +193,7 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
         if (f.cmap >= 0) { g.mode = 3; g.pull = cmap + f.cmap; g.npull = f.nchild; g.pullbase = crow_child + (int64_t)k * crs_child; }
     }
     else if (kind == 2) {   // unit lower inverse: row tile c only needs the columns left of its last row
-        g.k0 = t.b * NB; int b = min(NB, p - g.k0); g.rbase = g.k0 + t.c * 64; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = min(b, t.c * 64 + 64); g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1;
+        g.k0 = t.b * NB; int b = min(NB, p - g.k0); g.rbase = g.k0 + t.c * th; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = min(b, t.c * th + th); g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1;
     }
     else if (kind == 3) {
         g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk;
@@ -206,7 +206,7 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
     }
     else if (kind == 4) { g.k0 = t.c * NB; int b = min(NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
     else {                  // upper inverse: row tile c only needs the columns from its first row on
-        int kb = t.b * NB, b = min(NB, p - kb), ks = t.c * 64;
+        int kb = t.b * NB, b = min(NB, p - kb), ks = t.c * th;
         g.rbase = kb + ks; g.rend = kb + b; g.k0 = kb + ks; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b - ks; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk;
     }
     return min(th, g.rend - g.rbase);
@@ -431,15 +431,15 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
 static int apply2_enabled();
 static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                           cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
-                          const cz* crow_child, int64_t crs_child);
+                          const cz* crow_child, int64_t crs_child, int max_slabs);
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
-                  const cz* crow_child, int64_t crs_child) {
+                  const cz* crow_child, int64_t crs_child, int max_slabs) {
     if (ntiles <= 0) return;
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
     dim3 g(ntiles * K * ncg);
-    if (apply2_enabled()) { launch_apply2(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child); return; }
+    if (apply2_enabled()) { launch_apply2(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs); return; }
     if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
     else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
 }
@@ -586,8 +586,8 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
         }
 }
 
-template <bool GATHER>
-__global__ __launch_bounds__(256, 2) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+template <bool GATHER, int NSMAX>
+__global__ __launch_bounds__(256, NSMAX == 4 ? 2 : 3) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                 const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
                                                 cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks,
                                                 int ntiles, int ncg, const int* __restrict__ cmap, const cz* __restrict__ crow_child, int64_t crs_child) {
@@ -598,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void k_apply2(const FrontD* __restrict__ fr
     ApplyGeom g;
     int trows = decode_tile<cz>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
     if (trows <= 16) apply2_body<GATHER, 1>(g, cg, ldw);
-    else if (trows <= 32) apply2_body<GATHER, 2>(g, cg, ldw);
-    else apply2_body<GATHER, 4>(g, cg, ldw);
+    else if (NSMAX == 2 || trows <= 32) apply2_body<GATHER, 2>(g, cg, ldw);
+    else if (NSMAX == 4) apply2_body<GATHER, 4>(g, cg, ldw);
 }
 
 static int g_apply2 = -1;
@@ -611,11 +611,13 @@ void select_apply_kernel(int barrier_free) { g_apply2 = barrier_free ? 1 : 0; }
 
 static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                           cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
-                          const cz* crow_child, int64_t crs_child) {
+                          const cz* crow_child, int64_t crs_child, int max_slabs) {
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
     dim3 g(ntiles * K * ncg);
-    if (gather) hipLaunchKernelGGL(k_apply2<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
-    else hipLaunchKernelGGL(k_apply2<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
+#define FEASTHIP_A2(G, N) hipLaunchKernelGGL((k_apply2<G, N>), g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child)
+    if (max_slabs <= 2) { if (gather) FEASTHIP_A2(true, 2); else FEASTHIP_A2(false, 2); }
+    else { if (gather) FEASTHIP_A2(true, 4); else FEASTHIP_A2(false, 4); }
+#undef FEASTHIP_A2
 }
 
 // ---------------------------------------------------------------------------
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(256) void k_apply32(const FrontD* __restrict__ fr, 
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather, cf* skbuf, int64_t sks,
-                  const cf* crow_child, int64_t crs_child) {
+                  const cf* crow_child, int64_t crs_child, int /*max_slabs*/) {
     if (ntiles <= 0) return;
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
     dim3 g(ntiles * K * ncg);
