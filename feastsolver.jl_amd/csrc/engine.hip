@@ -43,6 +43,7 @@ Engine::Engine(int device) : device_(device) {
     own_stream_ = true;
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
+    { void* q = nullptr; if (hipHostMalloc(&q, PIN_SLOTS * PIN_SLOT_BYTES, hipHostMallocDefault) == hipSuccess) pin_ = (char*)q; else (void)hipGetLastError(); }
     if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_GROUP")) group_panels_ = std::max(1, std::min(8, atoi(v)));
     if (const char* v = getenv("FEASTHIP_FUSED_UTRSM")) fused_utrsm_ = atoi(v) != 0;
@@ -104,6 +105,23 @@ Engine::~Engine() {
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+    if (pin_) (void)hipHostFree(pin_);
+}
+
+// device -> host through a pinned slot: the bytes land in *landed (the slot, or host_dst itself when no slot fits);
+// after the stream synchronisation the caller copies them out if landed != host_dst
+hipError_t Engine::d2h_async(int slot, void* host_dst, const void* dev, size_t bytes, void** landed) {
+    void* q = pin_slot(slot, bytes);
+    *landed = q ? q : host_dst;
+    return hipMemcpyAsync(*landed, dev, bytes, hipMemcpyDeviceToHost, stream_);
+}
+
+// host -> device through a pinned slot (the slot must not be rewritten before the stream has passed the copy: every user
+// synchronises the stream before its next use of the same slot)
+hipError_t Engine::h2d_async(int slot, void* dev, const void* host_src, size_t bytes) {
+    void* q = pin_slot(slot, bytes);
+    if (q) std::memcpy(q, host_src, bytes);
+    return hipMemcpyAsync(dev, q ? q : host_src, bytes, hipMemcpyHostToDevice, stream_);
 }
 
 int Engine::hip_fail(hipError_t e, const char* what) {

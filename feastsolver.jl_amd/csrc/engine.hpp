@@ -169,6 +169,14 @@ private:
     DevBuf<cz> d_e0_, d_e1_, d_small_, d_lam_, d_gram_scratch_, d_io_;
     DevBuf<double> d_nrm_, d_nrm_scratch_;
 
+    // pinned staging slots for the small host <-> device hand-offs of the Rayleigh-Ritz step (Gram matrices, reduced eigenvectors,
+    // coefficient tables): pageable memory costs an extra runtime staging copy and 10-20 us per transfer
+    static constexpr int PIN_SLOTS = 8;
+    static constexpr size_t PIN_SLOT_BYTES = (size_t)1 << 20;
+    char* pin_ = nullptr;
+    void* pin_slot(int slot, size_t bytes) { return (pin_ && bytes <= PIN_SLOT_BYTES) ? (void*)(pin_ + (size_t)slot * PIN_SLOT_BYTES) : nullptr; }
+    hipError_t d2h_async(int slot, void* host_dst, const void* dev, size_t bytes, void** landed);      // *landed: where the bytes arrive (copy out after the sync if != host_dst)
+    hipError_t h2d_async(int slot, void* dev, const void* host_src, size_t bytes);
     cz* q_ext_ = nullptr;
     size_t q_ext_bytes_ = 0;
     cz* Qp() const { return q_ext_ ? q_ext_ : d_Q_.p; }

@@ -153,7 +153,7 @@ int Engine::contour_step(int refactor) {
     HIPCHK(hipSetDevice(device_));
     if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; }
     std::vector<zc> e0 = node_table([&](int k, int j, int) { return weights_[k] / (nodes_[k] - lambda_[j]); });      // src/feast.jl:60,69
-    HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(h2d_async(5, d_e0_.p, e0.data(), e0.size() * sizeof(zc)));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66

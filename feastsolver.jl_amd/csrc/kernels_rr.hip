@@ -129,7 +129,7 @@ void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, c
 // operands are read straight from the row-major blocks (16 consecutive columns of a
 // row per lane group = 256 B segments), two k-steps (8 rows, ten 16-byte loads per lane)
 // in flight per iteration.  Stage 2 sums the partials in a fixed order.
-constexpr int GRAM_ROWS = 256;
+constexpr int GRAM_ROWS = 128;
 
 size_t gram_scratch_elems(int n, int m) {
     size_t chunks = ((size_t)n + GRAM_ROWS - 1) / GRAM_ROWS;
@@ -152,15 +152,20 @@ __global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, co
         int colb[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) colb[nt] = min(jg * 64 + nt * 16 + li, mp - 1);      // clamped: the extra columns are not stored
-        for (int r = r0; r < r1; r += 8) {
-            cz a[2], b[2][4];
+        // software pipelined: the 8 rows of the next step are in flight while this step runs on the matrix cores
+        cz a[2], b[2][4], an[2], bn[2][4];
+        auto load8 = [&](int r, cz (&aa)[2], cz (&bb)[2][4]) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int row = min(r + 4 * h + lk, n - 1);
-                a[h] = V[(int64_t)row * ldw + it * 16 + li];
+                aa[h] = V[(int64_t)row * ldw + it * 16 + li];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) b[h][nt] = W[(int64_t)row * ldw + colb[nt]];
+                for (int nt = 0; nt < 4; ++nt) bb[h][nt] = W[(int64_t)row * ldw + colb[nt]];
             }
+        };
+        load8(r0, a, b);
+        for (int r = r0; r < r1; r += 8) {
+            load8(min(r + 8, r1 - 1), an, bn);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 bool ok = r + 4 * h + lk < r1;
@@ -171,6 +176,12 @@ __global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, co
                     t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b[h][nt].y, t2[nt], 0, 0, 0);
                     t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b[h][nt].x + b[h][nt].y, t3[nt], 0, 0, 0);
                 }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[h] = an[h];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b[h][nt] = bn[h][nt];
             }
         }
 #pragma unroll
