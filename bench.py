@@ -189,7 +189,7 @@ def main():
     if rank == 0:
         pa = prof["panel_apply"]
         traffic = None          # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/)
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(tpath) and args.grid == 46 and args.stencil == 19 and world == 1:
             # the PMC run uses two streams (twice the launches of the single-stream profiling sweep): normalise per step
             per_step = json.load(open(tpath)).get("traffic_bytes_per_contour_step")
