@@ -60,6 +60,7 @@ PROTOTYPES = {
     "feasthip_set_precision": (I, [VP, I]),
     "feasthip_set_conjugate_fold": (I, [VP, I]),
     "feasthip_select_apply_kernel": (I, [I]),
+    "feasthip_shard_plan": (I, [I, VP, I, I, I, VP, VP, VP, VP]),
     "feasthip_set_coef_functions": (I, [VP, VP, VP]),
     "feasthip_set_node_coefficients": (I, [VP, VP, I, I]),
     "feasthip_nl_beyn_step": (I, [VP, VP, VP]),

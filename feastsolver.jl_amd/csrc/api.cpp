@@ -343,6 +343,20 @@ int feasthip_symbolic_contains(int64_t n, const int64_t* colptr, const int64_t* 
     } catch (...) { return FEASTHIP_EARG; }
 }
 
+int feasthip_shard_plan(int K, const double* nodes, int fold_allowed, int first, int stride, int32_t* local, int32_t* partner,
+                        int* count, int* folded) {
+    if (K <= 0 || !nodes || first < 0 || stride < 1 || !local || !partner || !count || !folded) return FEASTHIP_EARG;
+    try {
+        std::vector<zc> z(K);
+        for (int k = 0; k < K; ++k) z[k] = zc(nodes[2 * k], nodes[2 * k + 1]);
+        std::vector<int> loc, par;
+        *folded = plan_node_shard(z, first, stride, fold_allowed != 0, loc, par) ? 1 : 0;
+        *count = (int)loc.size();
+        for (size_t i = 0; i < loc.size(); ++i) { local[i] = loc[i]; partner[i] = par[i]; }
+        return 0;
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
 int feasthip_small_eig(int m, const double* A, const double* B, double* lambda, double* V) {
     if (m <= 0 || !A || !lambda || !V) return FEASTHIP_EARG;
     try {

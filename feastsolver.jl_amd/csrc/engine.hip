@@ -257,36 +257,45 @@ int Engine::set_fold(int on) {
     return 0;
 }
 
-// Which contour nodes this handle factorises.  Without the conjugate fold: nodes first, first + stride, ...  With it
-// (real coefficient matrices, every node has its mirror image on the contour, no per-node coefficient overrides) the
-// units that are dealt out are conjugate PAIRS, represented by their member in the upper half plane.
-void Engine::rebuild_shard() {
-    std::vector<int> loc, par;
-    bool can = fold_enabled_ && terms_real_ && !terms_.empty() && node_coef_.empty() && coef_fn_ == nullptr && K >= 2 && K % 2 == 0;
+bool plan_node_shard(const std::vector<zc>& nodes, int first, int stride, bool fold_allowed, std::vector<int>& loc, std::vector<int>& par) {
+    const int K = (int)nodes.size();
+    loc.clear(); par.clear();
+    bool can = fold_allowed && K >= 2 && K % 2 == 0;
     std::vector<int> mate(K, -1);
-    const double eps8 = 8.0 * std::numeric_limits<double>::epsilon();
+    // mirror images agree to the rounding of the contour constructors (z = c + r e^{i theta}: a few ulps of the contour's size)
+    double zmax = 0;
+    for (const zc& z : nodes) zmax = std::max(zmax, std::abs(z));
+    const double tol = 16.0 * std::numeric_limits<double>::epsilon() * zmax;
     for (int k = 0; k < K && can; ++k) {
         if (mate[k] >= 0) continue;
-        const zc zk = nodes_[k];
-        if (std::abs(zk.imag()) <= eps8 * std::abs(zk)) { can = false; break; }        // a node on the real axis is its own mirror image
+        const zc zk = nodes[k];
+        if (std::abs(zk.imag()) <= tol) { can = false; break; }        // a node on the real axis is its own mirror image
         for (int k2 = k + 1; k2 < K; ++k2)
-            if (mate[k2] < 0 && std::abs(nodes_[k2] - std::conj(zk)) <= eps8 * std::max(1.0, std::abs(zk))) { mate[k] = k2; mate[k2] = k; break; }
+            if (mate[k2] < 0 && std::abs(nodes[k2] - std::conj(zk)) <= tol) { mate[k] = k2; mate[k2] = k; break; }
         if (mate[k] < 0) can = false;
     }
-    if (can && K / 2 < shard_stride_) can = false;          // fewer pairs than ranks: deal out single nodes instead (same decision on every rank)
+    if (can && K / 2 < stride) can = false;          // fewer pairs than ranks: deal out single nodes instead (same decision on every rank)
     if (can) {
         int u = 0;
         for (int k = 0; k < K; ++k) {
             if (mate[k] < k) continue;                      // second member of its pair
-            if (u >= shard_first_ && (u - shard_first_) % shard_stride_ == 0) {
-                const int rep = nodes_[k].imag() > 0 ? k : mate[k];
+            if (u >= first && (u - first) % stride == 0) {
+                const int rep = nodes[k].imag() > 0 ? k : mate[k];
                 loc.push_back(rep); par.push_back(rep == k ? mate[k] : k);
             }
             ++u;
         }
     } else {
-        for (int k = shard_first_; k < K; k += shard_stride_) { loc.push_back(k); par.push_back(-1); }
+        for (int k = first; k < K; k += stride) { loc.push_back(k); par.push_back(-1); }
     }
+    return can;
+}
+
+// local_ / partner_ / fold_ / Kloc from the contour, the shard, the terms and the per-node overrides (plan_node_shard, engine.hpp)
+void Engine::rebuild_shard() {
+    std::vector<int> loc, par;
+    const bool allowed = fold_enabled_ && terms_real_ && !terms_.empty() && node_coef_.empty() && coef_fn_ == nullptr;
+    const bool can = plan_node_shard(nodes_, shard_first_, shard_stride_, allowed, loc, par);
     if (loc.size() != local_.size() || can != fold_) { analyzed_ = false; have_x_ = false; }
     if (loc != local_ || par != partner_ || can != fold_) factored_ = false;
     local_.swap(loc); partner_.swap(par); fold_ = can;

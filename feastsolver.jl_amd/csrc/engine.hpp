@@ -62,6 +62,13 @@ struct SparseTerm {
 
 struct ProfileRow { double ms = 0, bytes = 0, flops = 0; int launches = 0; };
 
+// Which contour nodes a shard (first, stride) integrates over, and which of them are factorised.  fold_allowed: real coefficient
+// matrices and no per-node overrides.  When every node has its mirror image conj(z) among the nodes (and there are at least
+// `stride` pairs) the units dealt out are conjugate pairs: local[i] is the member in the upper half plane (the one that is
+// factorised), partner[i] its mirror node; otherwise single nodes first, first + stride, ... with partner[i] = -1.
+// Host-only (also behind feasthip_shard_plan for the CPU test-suite); returns whether the conjugate fold is active.
+bool plan_node_shard(const std::vector<zc>& nodes, int first, int stride, bool fold_allowed, std::vector<int>& local, std::vector<int>& partner);
+
 class Engine {
 public:
     explicit Engine(int device);

@@ -1,7 +1,8 @@
 """Multi-GPU driver: contour nodes sharded over ranks, one RCCL sum of Q per iteration.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank g owns
-the nodes {k : k mod G = g} including their factorisations -- the memory-heavy
+the nodes {k : k mod G = g} -- or, for real matrices on a mirror-symmetric contour, every G-th conjugate
+node PAIR (shard_plan) -- including their factorisations -- the memory-heavy
 state is what gets sharded; A, B, X, R are replicated.  After the all-reduce every rank
 runs the small Rayleigh-Ritz step redundantly, so no broadcast is needed.  The reference has
 no distributed path (Distributed/SharedArrays are imported but unused,
@@ -13,10 +14,31 @@ import numpy as np
 
 
 def shard_nodes(K, world_size, rank):
-    """Indices of the contour nodes owned by `rank` (round robin, matches feasthip_set_node_shard)."""
+    """Indices of the contour nodes owned by `rank` when single nodes are dealt out (round robin: what
+    feasthip_set_node_shard does without the conjugate fold)."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
     return list(range(rank, K, world_size))
+
+
+def shard_plan(nodes, world_size, rank, fold_allowed=True):
+    """What feasthip_set_node_shard(rank, world_size) makes of a contour (host-only query of the library's own logic,
+    feasthip_shard_plan): (local, partner, folded).  With the conjugate fold (real matrices, every node has its mirror
+    image on the contour, at least world_size pairs) the units dealt out are conjugate PAIRS: local[i] is factorised,
+    partner[i] rides along as extra right-hand-side columns; this rank integrates over local + partner."""
+    import ctypes as C
+    from . import _lib
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    z = np.ascontiguousarray(nodes, dtype=np.complex128)
+    K = len(z)
+    loc = np.zeros(K, dtype=np.int32); par = np.zeros(K, dtype=np.int32)
+    cnt, fol = C.c_int(0), C.c_int(0)
+    rc = _lib.load_library().feasthip_shard_plan(K, z.ctypes.data, 1 if fold_allowed else 0, int(rank), int(world_size),
+                                                 loc.ctypes.data, par.ctypes.data, C.byref(cnt), C.byref(fol))
+    if rc != 0:
+        raise ValueError("feasthip_shard_plan failed")
+    return loc[:cnt.value].tolist(), par[:cnt.value].tolist(), bool(fol.value)
 
 
 def allreduce_moment(q, group=None):

@@ -264,6 +264,12 @@ int feasthip_symbolic_probe(int64_t n, const int64_t* colptr, const int64_t* row
  * perm) lies inside the predicted supernodal structure. */
 int feasthip_symbolic_contains(int64_t n, const int64_t* colptr, const int64_t* rowval, int index_base,
                                int ordering, const int32_t* ii, const int32_t* jj, int64_t count);
+/* node sharding of feasthip_set_node_shard / the conjugate fold, without a device: for K contour nodes (complex pairs) and the shard
+ * (first, stride), local[i] (count entries, caller-allocated K ints) are the nodes whose matrices this shard factorises and
+ * partner[i] the mirror node that rides along (-1 without the fold); *folded = 1 if pairs were dealt out.  fold_allowed = the
+ * matrices are real and there are no per-node coefficient overrides. */
+int feasthip_shard_plan(int K, const double* nodes, int fold_allowed, int first, int stride, int32_t* local, int32_t* partner,
+                        int* count, int* folded);
 /* small dense complex eigensolver used for the reduced problem (replaces Julia's
  * eigen!(Aq) / eigen!(Aq,Bq), src/feast.jl:45,122): m x m column-major; B may be NULL.
  * Outputs sorted by (re, im), unit 2-norm vectors. */

@@ -62,6 +62,64 @@ def test_shard_nodes_partition(pkg):
         dm.shard_nodes(8, 2, 2)
 
 
+def test_shard_plan_deals_out_conjugate_pairs(pkg):
+    """feasthip_set_node_shard with the conjugate fold (host-only query of the library's logic): every rank gets whole
+    conjugate pairs, the ranks together cover every node exactly once, and the fold is dropped consistently on all ranks
+    when it does not apply (complex centre, more ranks than pairs, fold not allowed)."""
+    import importlib
+    import __graft_entry__ as graft
+    dm = importlib.import_module(graft.PKG_NAME + ".distributed")
+    for K in (8, 16, 32):
+        con = pkg.circular_contour_trapezoidal(0.3, 0.7, K)
+        z = np.asarray(con.nodes)
+        for G in (1, 2, 3, 4, 8, 16):
+            plans = [dm.shard_plan(z, G, r) for r in range(G)]
+            folded = {p[2] for p in plans}
+            assert len(folded) == 1                                   # the same decision on every rank
+            covered = sorted(sum((p[0] + [q for q in p[1] if q >= 0] for p in plans), []))
+            assert covered == list(range(K))
+            if K // 2 >= G:
+                assert folded == {True}
+                for loc, par, _ in plans:
+                    assert all(z[a].imag > 0 and abs(z[b] - np.conj(z[a])) <= 1e-14 for a, b in zip(loc, par))
+                assert max(len(p[0]) for p in plans) - min(len(p[0]) for p in plans) <= 1
+            else:
+                assert folded == {False} and all(p[0] == dm.shard_nodes(K, G, r) for r, p in enumerate(plans))
+        # not allowed (complex matrices / per-node overrides) or no mirror symmetry: single nodes, round robin
+        assert dm.shard_plan(z, 2, 1, fold_allowed=False) == (dm.shard_nodes(K, 2, 1), [-1] * (K // 2), False)
+        zc = np.asarray(pkg.circular_contour_trapezoidal(0.3 + 0.1j, 0.7, K).nodes)
+        assert dm.shard_plan(zc, 2, 0)[2] is False
+    zr = np.asarray(pkg.circular_contour_trapezoidal(0.0, 1.0, 8).nodes).copy()
+    zr[0] = zr[0].real                                               # a node on the real axis has no partner
+    assert dm.shard_plan(zr, 1, 0)[2] is False
+
+
+def test_conjugate_fold_identity_with_the_oracle(pkg, fo, wl):
+    """The identity behind the fold, checked on the CPU with the oracle's LU: for real A, B
+    T(conj z)^-1 R = conj(T(z)^-1 conj(R)), so a pair's contribution to the moment needs one factorisation."""
+    w = wl.c3_sparse_generalized(6, 19, 8)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    A, B = w["A"].astype(np.complex128), w["B"].astype(np.complex128)
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal(w["X0"].shape) + 1j * rng.standard_normal(w["X0"].shape)
+    lam = np.linspace(0.1, 1.2, X.shape[1]).astype(np.complex128)
+    R = A @ X - (B @ X) * lam[None, :]
+    import importlib
+    import __graft_entry__ as graft
+    dm = importlib.import_module(graft.PKG_NAME + ".distributed")
+    loc, par, folded = dm.shard_plan(con.nodes, 1, 0)
+    assert folded and len(loc) == 4
+    Qf = np.zeros_like(X)
+    for a, b in zip(loc, par):
+        F = fo.lu(A - B * con.nodes[a])
+        Y, Y2 = F.solve(R), F.solve(R.conj())
+        Qf += (X - Y) * (con.weights[a] / (con.nodes[a] - lam))[None, :] + (X - Y2.conj()) * (con.weights[b] / (con.nodes[b] - lam))[None, :]
+    Q = np.zeros_like(X)
+    for k in range(8):                                                 # src/feast.jl:59-71
+        Q += (X - fo.lu(A - B * con.nodes[k]).solve(R)) * (con.weights[k] / (con.nodes[k] - lam))[None, :]
+    assert np.abs(Qf - Q).max() <= 1e-12 * np.abs(Q).max()
+
+
 def test_two_rank_moment_allreduce_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
