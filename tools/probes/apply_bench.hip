@@ -54,8 +54,8 @@ static void run_case(const Case& c, int ldw, int sl) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int kind = 1; kind <= 3; kind += 2) {
         auto go = [&]() {
-            if (kind == 1) launch_apply(0, S, dt1, (int)t1.size(), fact, fs, W, Y, ws, ldw, crow, crs, K);
-            else launch_apply(0, S, dt3, (int)t3.size(), fact, fs, W, Y, ws, ldw, nullptr, 0, K, true, nullptr, 0);
+            if (kind == 1) launch_apply(0, S, dt1, (int)t1.size(), fact, fs, W, Y, ws, ldw, crow, crs, K, false, nullptr, 0, nullptr, 0, sl);
+            else launch_apply(0, S, dt3, (int)t3.size(), fact, fs, W, Y, ws, ldw, nullptr, 0, K, true, nullptr, 0, nullptr, 0, sl);
         };
         go(); CK(hipDeviceSynchronize());
         int reps = 5;
@@ -84,6 +84,12 @@ int main(int argc, char** argv) {
         {"top", 3, 1024, 2048, 16}, {"top8", 3, 1024, 2048, 8}, {"root-ish", 1, 3072, 3072, 16},
         {"mid", 48, 128, 1024, 16}, {"mid2", 24, 256, 1536, 16}, {"low", 600, 40, 400, 16}, {"low2", 400, 64, 600, 16},
     };
+    if (argc > 1) {     // few-node study: one factorised unit of 128 columns, tile heights 64 / 32 / 16
+        select_apply_kernel(1);
+        Case one[] = { {"top-1unit", 3, 1024, 2048, 1}, {"mid-1unit", 48, 128, 1024, 1}, {"top-2unit", 3, 1024, 2048, 2}, {"top-8unit", 3, 1024, 2048, 8} };
+        for (const Case& c : one) for (int sl : {4, 2, 1}) run_case(c, 128, sl);
+        return 0;
+    }
     for (int variant = 0; variant < 2; ++variant) {
         select_apply_kernel(variant);
         printf("=== %s\n", variant ? "k_apply2 (no LDS, no barriers)" : "k_apply (LDS-staged)");
