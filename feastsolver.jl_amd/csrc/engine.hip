@@ -53,6 +53,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_NB256_MINP")) nb256_min_p_ = std::max(129, atoi(v));      // tuning knobs: 1 << 30 keeps the 128-column blocks
     if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
+    if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
     if (nst > 1) {
