@@ -109,6 +109,108 @@ function gen_feast!(X::Matrix{ComplexF64}, A::SparseMatrixCSC{TA,Int64}, B::Spar
     Λ[in_c], X[:, in_c], res[in_c]
 end
 
+# ---- the other drivers of the hot path, same pattern: create -> terms -> contour -> *_run -> destroy ----------------
+function with_handle(f::Function, device::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(C_NULL, ccall((:feasthip_create, lib), Cint, (Ref{Ptr{Cvoid}}, Cint), h, device))
+    try
+        return f(h[])
+    finally
+        ccall((:feasthip_destroy, lib), Cint, (Ptr{Cvoid},), h[])
+    end
+end
+
+# T(z) = Σ_j scales[j] z^(j-1) mats[j]; `nothing` stands for the identity (feasthip_set_csc: NULL pointer)
+function set_terms!(h::Ptr{Cvoid}, N::Integer, mats::Vector, scales::Vector{ComplexF64})
+    nt = length(mats)
+    if all(M -> M === nothing || M isa SparseMatrixCSC, mats)
+        colptr = [M === nothing ? Ptr{Int64}(C_NULL) : pointer(M.colptr) for M in mats]
+        rowval = [M === nothing ? Ptr{Int64}(C_NULL) : pointer(M.rowval) for M in mats]
+        nzval = [M === nothing ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(M.nzval)) for M in mats]
+        types = Cint[M === nothing ? C128 : eltag(eltype(M)) for M in mats]
+        check(h, ccall((:feasthip_set_csc, lib), Cint,
+            (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Cvoid}}, Ptr{Cint}, Ptr{ComplexF64}, Cint),
+            h, N, nt, colptr, rowval, nzval, types, scales, 1))
+    else                                                  # dense column-major matrices (src/feast.jl with Matrix arguments)
+        ptrs = [M === nothing ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(M)) for M in mats]
+        types = Cint[M === nothing ? C128 : eltag(eltype(M)) for M in mats]
+        check(h, ccall((:feasthip_set_dense, lib), Cint,
+            (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cint}, Ptr{ComplexF64}),
+            h, N, nt, ptrs, types, scales))
+    end
+end
+
+function set_contour!(h::Ptr{Cvoid}, nodes::Vector{ComplexF64}, weights::Vector{ComplexF64}, kind::Cint, region::Vector{Float64})
+    check(h, ccall((:feasthip_set_contour, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{ComplexF64}, Ptr{ComplexF64}, Cint, Ptr{Float64}),
+        h, length(nodes), nodes, weights, kind, region))
+end
+
+function circle(c, r, nodes::Integer)                     # circular_contour_trapezoidal, src/contour.jl:26-31
+    θ = LinRange(π / nodes, 2π - π / nodes, nodes)
+    ComplexF64.(r .* exp.(θ .* im) .+ c), ComplexF64.(r .* exp.(θ .* im) ./ nodes), Cint(0), Float64[real(c), imag(c), r, 0.0]
+end
+
+"feast!(X, A; nodes, iter, c, r, ϵ, store, mixed_prec)   src/feast.jl:3-80 (T(z) = A - z I), dense or sparse A"
+function feast!(X::Matrix{ComplexF64}, A::AbstractMatrix; nodes::Integer=8, iter::Integer=10, c=complex(0.0, 0.0), r=1.0,
+                ϵ=1e-12, debug=false, store=false, mixed_prec=false, device::Integer=0)
+    N, m₀ = size(X)
+    size(A, 1) != size(A, 2) && error("Incorrect dimensions of A, must be square")
+    size(A, 1) != N && error("Incorrect dimensions of X, must match A")
+    Λ, res, inside, nit = zeros(ComplexF64, m₀), zeros(m₀), zeros(UInt8, m₀), Ref{Cint}(0)
+    with_handle(device) do h
+        GC.@preserve A X begin
+            set_terms!(h, N, Any[A, nothing], ComplexF64[1.0, -1.0])
+            set_contour!(h, circle(c, r, nodes)...)
+            mixed_prec && check(h, ccall((:feasthip_set_precision, lib), Cint, (Ptr{Cvoid}, Cint), h, 1))   # src/feast.jl:19-25
+            check(h, ccall((:feasthip_feast_run, lib), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Cint, Float64, Cint, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}),
+                h, X, N, m₀, iter, ϵ, store ? 1 : 0, Λ, res, inside, nit))
+        end
+    end
+    in_c = inside .!= 0
+    any(in_c) || println("no eigenvalues found in contour!")           # src/feast.jl:78
+    Λ[in_c], X[:, in_c], res[in_c]
+end
+
+"gen_feast!(X, A, B; nodes, iter, c, r, ...) for dense A, B   src/feast.jl:82-156"
+function gen_feast!(X::Matrix{ComplexF64}, A::Matrix, B::Matrix; nodes::Integer=8, iter::Integer=10, c=complex(0.0, 0.0), r=1.0,
+                    ϵ=1e-12, debug=false, store=false, device::Integer=0)
+    N, m₀ = size(X)
+    size(A, 1) != size(A, 2) && error("Incorrect dimensions of A, must be square")
+    size(A, 1) != N && error("Incorrect dimensions of X, must match A")
+    Λ, res, inside, nit = zeros(ComplexF64, m₀), zeros(m₀), zeros(UInt8, m₀), Ref{Cint}(0)
+    with_handle(device) do h
+        GC.@preserve A B X begin
+            set_terms!(h, N, Any[A, B], ComplexF64[1.0, -1.0])
+            set_contour!(h, circle(c, r, nodes)...)
+            check(h, ccall((:feasthip_feast_run, lib), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Cint, Float64, Cint, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}),
+                h, X, N, m₀, iter, ϵ, store ? 1 : 0, Λ, res, inside, nit))
+        end
+    end
+    in_c = inside .!= 0
+    any(in_c) || println("no eigenvalues found in contour!")
+    Λ[in_c], X[:, in_c], res[in_c]
+end
+
+"nlfeast!(T, X, nodes, iter; c, r, ϵ, spurious) for a polynomial T(z) = Σ_j z^j coeffs[j+1]   src/nlfeast.jl:2-84: all m₀ pairs are returned"
+function nlfeast!(coeffs::Vector{<:AbstractMatrix}, X::Matrix{ComplexF64}, nodes::Integer, iter::Integer;
+                  c=complex(0.0, 0.0), r=1.0, debug=false, ϵ=10e-12, store=true, spurious=1e-5, device::Integer=0)
+    N, m₀ = size(X)
+    Λ, res, inside, nit = zeros(ComplexF64, m₀), zeros(m₀), zeros(UInt8, m₀), Ref{Cint}(0)
+    with_handle(device) do h
+        GC.@preserve coeffs X begin
+            set_terms!(h, N, Any[M for M in coeffs], ones(ComplexF64, length(coeffs)))
+            set_contour!(h, circle(c, r, nodes)...)
+            check(h, ccall((:feasthip_nlfeast_run, lib), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Cint, Float64, Float64, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}),
+                h, X, N, m₀, iter, ϵ, spurious, Λ, res, inside, nit))
+        end
+    end
+    Λ, X, res
+end
+
 # nlfeast_moments!(T, X, nodes, iter; c, r, ϵ, moments, spurious)  (src/nlfeast.jl:173-318) for a polynomial
 # T(z) = Σ_j z^j coeffs[j+1] with sparse coefficients (test/polynomial.jl:5-20): returns (Λ, Y, res) for all
 # moments*m₀ candidates sorted by residual, X overwritten with the m₀ best (normalised).
