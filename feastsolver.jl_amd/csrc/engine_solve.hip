@@ -90,9 +90,6 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     return 0;
 }
 
-// Node groups that run on their own streams.  Two groups overlap the launch tails and the latency-bound small
-// launches of one group with the large launches of the other when there are many nodes; with few local nodes
-// (multi-GPU shards) one fuller launch per step is faster (measured: 16 nodes 2 groups, <= 8 nodes 1 group).
 // Q0 (Q1) = sum_k T_k .* e0[k,:] (e1[k,:]) over the solution blocks of the last sweep (fp64 accumulation in either precision)
 void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
     const int lw = solve_width();
@@ -100,6 +97,10 @@ void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, 
     else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1);
 }
 
+// Node groups that run on their own streams.  Two groups overlap the launch tails and the latency-bound small
+// launches of one group with the large launches of the other when there are many nodes; with few local nodes
+// (multi-GPU shards) or with the 128-column units of the conjugate fold one fuller launch per step is faster
+// (measured: 16 unfolded nodes 2 groups; <= 8 nodes, or folded units, 1 group).
 int Engine::stream_groups() const {
     int ns = std::min<int>((int)aux_streams_.size(), Kloc);
     if (!streams_forced_ && (nodes_local() < 12 || fold_)) ns = 1;      // folded units are already 128 columns wide: one node group (measured 17.9 vs 18.2 ms)

@@ -7,7 +7,10 @@
 // Block vectors are ROW-major n x ldw (one row = ldw contiguous complex128), so a
 // supernode's rows are one contiguous slab and update rows gather as whole 1 KiB
 // lines.  The factor panels are streamed from HBM exactly once per sweep and go
-// straight into the f64 matrix cores; the right-hand-side tile is staged in LDS.
+// straight into the f64 matrix cores; the block-vector rows either come the same way,
+// per k-step, into the other operand registers (k_apply2, the default) or are staged
+// in LDS per 32-column chunk (k_apply).  With the conjugate fold of real pencils a
+// unit's block vectors are 2 m0 columns wide: [R, conj(R)].
 #include "kernels.hpp"
 #include <cstdlib>
 #include <type_traits>
