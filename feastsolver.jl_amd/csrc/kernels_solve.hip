@@ -468,6 +468,7 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
     if (g.rbase + slab * 16 >= g.rend || cg + ct0 * 16 >= ldw) return;   // nothing to do for this wave (no barriers: it may leave)
     const int arow = g.rbase + slab * 16 + li;
     const bool aok = arow < g.rend;
+    const bool aok_all = g.rbase + slab * 16 + 16 <= g.rend;        // wave-uniform: the whole slab has rows
     const int adiag = arow - g.k0;
     const int Kd = g.Kd, nks = (Kd + 3) >> 2;
     const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
@@ -502,9 +503,11 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
     auto step = [&](int s, auto jc) {
         constexpr int j = decltype(jc)::value;
         __builtin_amdgcn_sched_barrier(0);
-        loadA(s + A2_DA - 1, (j + A2_DA - 1) % A2_DA);
+        // order matters: vmcnt counts in order, so the wait for a block-vector row covers every load issued before it.  With the
+        // factor load LAST in its step, the row loads of step s + 3 only wait for factor loads of earlier steps.
         loadI(s + A2_DV - 1 + A2_DI, (j + A2_DV - 1 + A2_DI) % 8);
         loadV(s + A2_DV - 1, (j + A2_DV - 1) % A2_DV, (j + A2_DV - 1) % 8);
+        loadA(s + A2_DA - 1, (j + A2_DA - 1) % A2_DA);
         __builtin_amdgcn_sched_barrier(0);
         const int gk = 4 * s + lk;
         cz a = ar[j % A2_DA];
@@ -520,8 +523,47 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
 #pragma unroll
         for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q], 0, 0, 0);
     };
-#define FEASTHIP_STEP2(S0, J) step((S0) + (J), std::integral_constant<int, (J)>{}); step((S0) + (J) + 1, std::integral_constant<int, (J) + 1>{});
+    // Bulk of a long K loop: every k-step it touches (the one it computes and the ones it prefetches) is complete and unmasked, so the
+    // addresses advance by running pointers, the column tiles sit at immediate offsets of one row pointer and nothing is clamped or
+    // masked: about half the vector instructions of the generic step (which matters for the waves that own few columns).
     int s0 = 0;
+    const bool fast_ok = g.mask == 0 && aok_all && cg + (ct0 + NS) * 16 <= ldw;
+    if (fast_ok) {
+        const int nfull = Kd >> 2;                                   // complete k-steps
+        const cz* pAi = Ap + (int64_t)(4 * (A2_DA - 1) + lk) * lda;  // next factor load to issue: step DA - 1
+        const int64_t stepA = 4 * (int64_t)lda;
+        const cz* pVi = g.Vk + (int64_t)(g.vrow0 + 4 * (A2_DV - 1) + lk) * ldw + vcol[0];    // contiguous kinds: step DV - 1
+        const int64_t stepV = 4 * (int64_t)ldw;
+        const int* pIi = g.sidx + 4 * (A2_DV - 1 + A2_DI) + lk;       // gathered kinds: next index to load
+        const cz* vbase = g.Vk + vcol[0];
+        auto fstep = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (GATHER) { ir[(j + A2_DV - 1 + A2_DI) % 8] = *pIi; pIi += 4; }
+            {
+                const cz* vp = GATHER ? vbase + (int64_t)ir[(j + A2_DV - 1) % 8] * ldw : pVi;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) vr[(j + A2_DV - 1) % A2_DV][q] = vp[q * 16];
+                pVi += stepV;
+            }
+            ar[(j + A2_DA - 1) % A2_DA] = *pAi; pAi += stepA;
+            __builtin_amdgcn_sched_barrier(0);
+            const cz a = ar[j % A2_DA];
+            const double as = a.x + a.y;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vr[j % A2_DV][q].x, t1[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, vr[j % A2_DV][q].y, t2[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q], 0, 0, 0);
+        };
+        // a pass computes steps s0 .. s0 + 7 and prefetches up to step s0 + 7 + DA - 1 (factor) / + DV - 1 + DI (indices): all < nfull
+        for (; s0 + 8 + A2_DA - 1 <= nfull; s0 += 8) {
+            fstep(std::integral_constant<int, 0>{}); fstep(std::integral_constant<int, 1>{}); fstep(std::integral_constant<int, 2>{}); fstep(std::integral_constant<int, 3>{});
+            fstep(std::integral_constant<int, 4>{}); fstep(std::integral_constant<int, 5>{}); fstep(std::integral_constant<int, 6>{}); fstep(std::integral_constant<int, 7>{});
+        }
+    }
+#define FEASTHIP_STEP2(S0, J) step((S0) + (J), std::integral_constant<int, (J)>{}); step((S0) + (J) + 1, std::integral_constant<int, (J) + 1>{});
     for (; s0 + 8 <= nks; s0 += 8) { FEASTHIP_STEP2(s0, 0) FEASTHIP_STEP2(s0, 2) FEASTHIP_STEP2(s0, 4) FEASTHIP_STEP2(s0, 6) }
     const int rem = nks - s0;       // 0 .. 7 k-steps left: pairs of steps (a step beyond the end multiplies masked zeros)
     if (rem > 0) {
