@@ -482,13 +482,28 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
     cz ar[A2_DA], vr[A2_DV][NS];
     int ir[8];
     auto kof = [&](int s) { return min(4 * s + lk, Kd - 1); };        // clamped: steps beyond the end re-read the last column (masked)
-    auto loadA = [&](int s, int slot) { ar[slot] = Ap[(int64_t)kof(s) * lda]; };
+#ifndef FEASTHIP_A2_ABLATE
+#define FEASTHIP_A2_ABLATE 0      // timing experiments (tools/probes/ablate2_bench.sh), bit mask: 1 no factor loads, 2 no block-vector loads, 4 no MFMA
+#endif
+    auto loadA = [&](int s, int slot) {
+#if FEASTHIP_A2_ABLATE & 1
+        ar[slot] = cz_make(1.0 + s, lane);
+#else
+        ar[slot] = Ap[(int64_t)kof(s) * lda];
+#endif
+    };
     auto loadI = [&](int s, int slot) { if (GATHER) ir[slot] = g.sidx[kof(s)]; };
     auto loadV = [&](int s, int slot, int islot) {
         const int vrow = GATHER ? ir[islot] : g.vrow0 + kof(s);
         const cz* vp = g.Vk + (int64_t)vrow * ldw;
 #pragma unroll
-        for (int q = 0; q < NS; ++q) vr[slot][q] = vp[vcol[q]];
+        for (int q = 0; q < NS; ++q) {
+#if FEASTHIP_A2_ABLATE & 2
+            vr[slot][q] = cz_make(0.5 + q, (double)(size_t)vp * 1e-30);
+#else
+            vr[slot][q] = vp[vcol[q]];
+#endif
+        }
     };
     d4 t1[NS], t2[NS], t3[NS];
 #pragma unroll
@@ -516,6 +531,11 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
         a.y = keep ? a.y : 0.0;
         const double as = a.x + a.y;
         // 3M complex product, see apply_body
+#if FEASTHIP_A2_ABLATE & 4
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { t1[q][0] += a.x * vr[j % A2_DV][q].x; t2[q][0] += a.y * vr[j % A2_DV][q].y; t3[q][0] += as; }
+        return;
+#endif
 #pragma unroll
         for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vr[j % A2_DV][q].x, t1[q], 0, 0, 0);
 #pragma unroll
@@ -543,13 +563,28 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
             {
                 const cz* vp = GATHER ? vbase + (int64_t)ir[(j + A2_DV - 1) % 8] * ldw : pVi;
 #pragma unroll
-                for (int q = 0; q < NS; ++q) vr[(j + A2_DV - 1) % A2_DV][q] = vp[q * 16];
+                for (int q = 0; q < NS; ++q) {
+#if FEASTHIP_A2_ABLATE & 2
+                    vr[(j + A2_DV - 1) % A2_DV][q] = cz_make(0.5 + q, (double)(size_t)vp * 1e-30);
+#else
+                    vr[(j + A2_DV - 1) % A2_DV][q] = vp[q * 16];
+#endif
+                }
                 pVi += stepV;
             }
+#if FEASTHIP_A2_ABLATE & 1
+            ar[(j + A2_DA - 1) % A2_DA] = cz_make(1.0 + j, lane); pAi += stepA;
+#else
             ar[(j + A2_DA - 1) % A2_DA] = *pAi; pAi += stepA;
+#endif
             __builtin_amdgcn_sched_barrier(0);
             const cz a = ar[j % A2_DA];
             const double as = a.x + a.y;
+#if FEASTHIP_A2_ABLATE & 4
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { t1[q][0] += a.x * vr[j % A2_DV][q].x; t2[q][0] += a.y * vr[j % A2_DV][q].y; t3[q][0] += as; }
+            return;
+#endif
 #pragma unroll
             for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vr[j % A2_DV][q].x, t1[q], 0, 0, 0);
 #pragma unroll

@@ -86,7 +86,8 @@ int main(int argc, char** argv) {
     };
     if (argc > 1) {     // few-node study: one factorised unit of 128 columns, tile heights 64 / 32 / 16
         select_apply_kernel(1);
-        Case one[] = { {"top-1unit", 3, 1024, 2048, 1}, {"mid-1unit", 48, 128, 1024, 1}, {"top-2unit", 3, 1024, 2048, 2}, {"top-8unit", 3, 1024, 2048, 8} };
+        Case one[] = { {"top-1unit", 3, 1024, 2048, 1}, {"mid-1unit", 48, 128, 1024, 1}, {"top-2unit", 3, 1024, 2048, 2}, {"top-8unit", 3, 1024, 2048, 8},
+                       {"low-8unit", 600, 40, 400, 8}, {"low2-8unit", 400, 64, 600, 8} };
         for (const Case& c : one) for (int sl : {4, 2, 1}) run_case(c, 128, sl);
         return 0;
     }
