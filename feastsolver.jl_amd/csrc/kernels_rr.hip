@@ -3,6 +3,7 @@
 // projection Q^H (A Q) on the f64 matrix cores, Ritz back-transform, residual
 // vectors and column norms.  Block vectors are row-major n x ldw complex128.
 #include "kernels.hpp"
+#include <algorithm>
 
 namespace feasthip {
 
@@ -226,33 +227,31 @@ void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W
     hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 63) / 64), dim3(256), 0, st, chunks, mp, m, scratch, G);
 }
 
-// out = V * M  (V n x ldw row-major, M m x m column-major) on the f64 matrix cores.  A workgroup owns 64 rows
-// (one 16-row slab per wave) and 64 output columns; M^T^T = M is staged in LDS row-major [k][64 cols] in chunks of
-// TS_KC rows; the V fragment (row = lane & 15, k = lane >> 4) comes straight from global memory: the four lane
-// groups read 64 consecutive bytes of a row, consecutive k-steps walk along the same lines.
-constexpr int TS_KC = 64;
+// out = V * M  (V n x ldw row-major, M m x m column-major) on the f64 matrix cores.  Persistent workgroups: a workgroup
+// stages its 64 output columns of M ONCE in LDS (row-major [k][64 cols], all m <= TS_KMAX rows) and then walks over 64-row
+// tiles of V (one 16-row slab per wave; V fragment: row = lane & 15, k = lane >> 4, the four lane groups read 64 consecutive
+// bytes of a row); the waves never synchronise after the staging, and the second workgroup of the CU computes while this
+// one loads.  (One tile per workgroup with M re-staged every time: 86 us for n = 97,336, m = 64.)
+constexpr int TS_KMAX = 64;       // rows of M held in LDS (64 KB: two workgroups per CU; 16 k-steps of V fragments per tile in registers, twice); larger m runs in K chunks
 
-__global__ __launch_bounds__(256) void k_ts_gemm(int n, int m, int ldw, const cz* __restrict__ V, const cz* __restrict__ M, cz* out) {
-    __shared__ cz Ms[TS_KC][64];
+template <int KS>     // k-steps per pass (m rounded up to 4 KS, at most TS_KMAX / 4)
+__device__ __forceinline__ void ts_tile_loop(int n, int m, int ldw, const cz* __restrict__ V, cz* out, const cz (*Ms)[64], int kc, int klen,
+                                             int cg, bool accumulate, int tile0, int tstride, int ntiles) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int r0 = blockIdx.x * 64 + wave * 16, cg = blockIdx.y * 64;
-    const int64_t arow = min(r0 + li, n - 1);
-    d4 t1[4], t2[4], t3[4];
+    for (int tile = tile0; tile < ntiles; tile += tstride) {
+        asm volatile("" ::: "memory");     // M is the same for every tile: without this the compiler hoists all of its LDS reads (256 registers)
+        cz av[KS];
+        {
+            const int64_t arow = min(tile * 64 + wave * 16 + li, n - 1);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
-    for (int kc = 0; kc < m; kc += TS_KC) {
-        __syncthreads();
-        for (int idx = tid; idx < TS_KC * 64; idx += 256) {
-            int k = idx >> 6, c = idx & 63;
-            Ms[k][c] = (kc + k < m && cg + c < m) ? M[(kc + k) + (size_t)(cg + c) * m] : cz_make(0, 0);
+            for (int ks = 0; ks < KS; ++ks) av[ks] = V[arow * ldw + min(kc + ks * 4 + lk, ldw - 1)];
         }
-        cz av[TS_KC / 4];
+        d4 t1[4], t2[4], t3[4];
 #pragma unroll
-        for (int ks = 0; ks < TS_KC / 4; ++ks) av[ks] = V[arow * ldw + min(kc + ks * 4 + lk, ldw - 1)];
-        __syncthreads();
+        for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
 #pragma unroll
-        for (int ks = 0; ks < TS_KC / 4; ++ks) {
-            const bool kok = kc + ks * 4 + lk < m;                // padding columns of V never enter the product
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool kok = ks * 4 + lk < klen;                  // padding columns of V never enter the product
             const double ar = kok ? av[ks].x : 0.0, ai = kok ? av[ks].y : 0.0, as = ar + ai;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -262,21 +261,53 @@ __global__ __launch_bounds__(256) void k_ts_gemm(int n, int m, int ldw, const cz
                 t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv.x + bv.y, t3[nt], 0, 0, 0);
             }
         }
-    }
+        const int r0 = tile * 64 + wave * 16;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int orow = r0 + lk + 4 * r;
-        if (orow >= n) continue;
+        for (int r = 0; r < 4; ++r) {
+            int orow = r0 + lk + 4 * r;
+            if (orow >= n) continue;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            int col = cg + nt * 16 + li;
-            if (col < ldw) out[(int64_t)orow * ldw + col] = cz_make(t1[nt][r] - t2[nt][r], t3[nt][r] - t1[nt][r] - t2[nt][r]);
+            for (int nt = 0; nt < 4; ++nt) {
+                int col = cg + nt * 16 + li;
+                if (col < ldw) {
+                    cz v = cz_make(t1[nt][r] - t2[nt][r], t3[nt][r] - t1[nt][r] - t2[nt][r]);
+                    if (accumulate) { cz o = out[(int64_t)orow * ldw + col]; v.x += o.x; v.y += o.y; }
+                    out[(int64_t)orow * ldw + col] = v;
+                }
+            }
         }
     }
 }
 
+__global__ __launch_bounds__(256, 2) void k_ts_gemm(int n, int m, int ldw, const cz* __restrict__ V, const cz* __restrict__ M, cz* out) {
+    extern __shared__ cz ts_lds[];
+    cz (*Ms)[64] = reinterpret_cast<cz (*)[64]>(ts_lds);
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.y * 64, ntiles = (n + 63) / 64;
+    for (int kc = 0; kc < m; kc += TS_KMAX) {
+        const int klen = min(TS_KMAX, m - kc), krows = (klen + 3) & ~3;
+        __syncthreads();
+        for (int idx = tid; idx < krows * 64; idx += 256) {
+            int k = idx >> 6, c = idx & 63;
+            Ms[k][c] = (k < klen && cg + c < m) ? M[(kc + k) + (size_t)(cg + c) * m] : cz_make(0, 0);
+        }
+        __syncthreads();
+        const bool acc = kc > 0;
+        if (krows <= 16) ts_tile_loop<4>(n, m, ldw, V, out, Ms, kc, klen, cg, acc, blockIdx.x, gridDim.x, ntiles);
+        else if (krows <= 32) ts_tile_loop<8>(n, m, ldw, V, out, Ms, kc, klen, cg, acc, blockIdx.x, gridDim.x, ntiles);
+        else ts_tile_loop<16>(n, m, ldw, V, out, Ms, kc, klen, cg, acc, blockIdx.x, gridDim.x, ntiles);
+    }
+}
+
 void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* M, cz* out) {
-    hipLaunchKernelGGL(k_ts_gemm, dim3((n + 63) / 64, (ldw + 63) / 64), dim3(256), 0, st, n, m, ldw, V, M, out);
+    const int ntiles = (n + 63) / 64, ncg = (ldw + 63) / 64;
+    const int krows = (std::min(m, TS_KMAX) + 3) & ~3;
+    const size_t lds = (size_t)krows * 64 * sizeof(cz);                 // 64 KB for m = 64: two workgroups per CU
+    const int per_cu = 2;
+    const int wgs = std::max(1, std::min(ntiles, 256 * per_cu / std::max(1, ncg) ));
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ts_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, TS_KMAX * 64 * (int)sizeof(cz)); attr_set = true; }
+    hipLaunchKernelGGL(k_ts_gemm, dim3(wgs, ncg), dim3(256), lds, st, n, m, ldw, V, M, out);
 }
 
 // column sums of |V|^2, two deterministic stages
