@@ -881,6 +881,53 @@ def test_apply_kernels_bit_identical(gpu, pkg, wl, m0, fold):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("kind", ["circular", "rect_trap", "rect_gauss"])
+def test_conjugate_fold_on_the_reference_contours(gpu, pkg, wl, kind):
+    """The three contour constructors of test/runtests.jl:33-49 on a real matrix: where the nodes come in mirror pairs the fold
+    halves the factorisations, and the moment equals the unfolded one either way."""
+    A = sp.diags([-np.ones(399), 2 * np.ones(400), -np.ones(399)], [-1, 0, 1], format="csc")
+    R = 0.05
+    con = {"circular": pkg.circular_contour_trapezoidal(complex(0.05, 0.0), R, 8),
+           "rect_trap": pkg.rectangular_contour_trapezoidal(0.0 - R * 1j, 2 * R + R * 1j, 8),
+           "rect_gauss": pkg.rectangular_contour_gauss(0.0 - R * 1j, 2 * R + R * 1j, 8)}[kind]
+    z = np.asarray(con.nodes)
+    mirrored = all(np.abs(z - np.conj(zk)).min() <= 1e-13 for zk in z) and np.abs(z.imag).min() > 1e-13
+    w = {"A": A, "B": sp.identity(400, format="csc"), "X0": wl.rand_x0(400, 24, 5)}
+    q1, s1 = _moment(pkg, w, con, True)
+    q0, s0 = _moment(pkg, w, con, False)
+    assert s1["folded"] == (1 if mirrored else 0) and s0["folded"] == 0
+    assert s1["factor_units"] == (len(z) // 2 if mirrored else len(z))
+    assert np.abs(q1 - q0).max() <= 1e-12 * np.abs(q0).max()
+
+
+def test_conjugate_fold_nlfeast_polynomial(gpu, pkg, fo, wl):
+    """nlfeast! on a real polynomial with a real centre (test/polynomial.jl: system5, c = -1.55): the fold applies to T(z) = sum z^j M_j
+    as well; eigenvalues and residuals must not depend on it."""
+    import os
+    Ms = wl.system5_coeffs(sparse=True)
+    assert all(np.abs(M.data.imag).max() == 0 for M in Ms)
+    n, m0 = Ms[0].shape[0], 40          # fewer columns than eigenvalues inside (50): the Beyn step has no tiny singular values to amplify rounding
+    X0 = wl.rand_x0(n, m0, 77)
+    outs = []
+    for fold in (True, False):
+        os.environ["FEASTHIP_FOLD"] = "1" if fold else "0"
+        try:
+            info = {}
+            lam, X, res = pkg.nlfeast(pkg.PolynomialNEP(Ms), X0.copy(), 16, 2, c=-1.55, r=0.05, eps=1e-14, info=info)
+        finally:
+            os.environ.pop("FEASTHIP_FOLD", None)
+        assert info["folded"] == (1 if fold else 0) and info["factor_units"] == (8 if fold else 16)
+        outs.append((lam.copy(), res.copy()))
+    # the same iteration either way: after three sweeps the Ritz values inside the contour and their residuals agree
+    (l1, r1), (l0, r0) = outs
+    i1, i0 = np.abs(l1 + 1.55) <= 0.05, np.abs(l0 + 1.55) <= 0.05
+    assert i0.sum() >= 5 and i1.sum() == i0.sum()
+    # (not converged yet after two sweeps: the Ritz values still move by 1e-3 per sweep, the two schedules differ by rounding amplified once)
+    assert match_sets(l1[i1], l0[i0]) < 1e-5 and match_sets(l0[i0], l1[i1]) < 1e-5
+    o1, o0 = np.argsort(l1[i1].real + 1e-3 * l1[i1].imag), np.argsort(l0[i0].real + 1e-3 * l0[i0].imag)
+    assert np.abs(r1[i1][o1] - r0[i0][o0]).max() < 1e-3 * max(1.0, r0[i0].max())
+
+
 def test_contour_estimate_eig(gpu, pkg, fo, wl):
     """adjacent caller of the same seam (src/stochastic.jl): same random block -> same estimate as the oracle,
     and the estimate is close to the true count"""
