@@ -928,6 +928,35 @@ def test_conjugate_fold_nlfeast_polynomial(gpu, pkg, fo, wl):
     assert np.abs(r1[i1][o1] - r0[i0][o0]).max() < 1e-3 * max(1.0, r0[i0].max())
 
 
+def test_conjugate_fold_nlfeast_rii_step_against_oracle(gpu, pkg, fo, wl):
+    """nl_contour_step in residual-inverse-iteration form (src/nlfeast.jl:47-58) with the fold: from the library's own state (X, R, lambda)
+    after one iteration the two moments must equal the oracle's sums over all 16 nodes, each solved separately."""
+    coeffs = wl.system5_coeffs(sparse=True)
+    X0 = wl.rand_x0(1000, 40, 78)
+    con = pkg.circular_contour_trapezoidal(-1.55 + 0j, 0.05, 16)
+    h = pkg.FeastHandle(0)
+    h.set_terms(coeffs)
+    h.set_contour(con)
+    assert h.stats()["folded"] == 1
+    h.set_x(X0)
+    h.nl_orthonormalize_x()
+    h.factorize()
+    h.nl_contour_step(True)
+    lam, res, ins = h.nl_rr_step()
+    X, R = h.get_block(0), h.get_block(1)
+    h.nl_contour_step(False)
+    Q0, Q1 = h.get_block(2), h.get_block(3)
+    h.close()
+    T = fo.poly_T(coeffs)
+    R0 = np.zeros_like(Q0); R1 = np.zeros_like(Q1)
+    for z, wgt in zip(con.nodes, con.weights):
+        Y = (X - fo.lu(T(z)).solve(R)) * (wgt / (z - lam))[None, :]
+        R0 += Y; R1 += Y * z
+    # (1e-9 with or without the fold: the columns of spurious Ritz values far outside the contour lose digits in X - T^-1 R)
+    assert np.abs(Q0 - R0).max() < 1e-8 * np.abs(R0).max()
+    assert np.abs(Q1 - R1).max() < 1e-8 * np.abs(R1).max()
+
+
 def test_contour_estimate_eig(gpu, pkg, fo, wl):
     """adjacent caller of the same seam (src/stochastic.jl): same random block -> same estimate as the oracle,
     and the estimate is close to the true count"""
