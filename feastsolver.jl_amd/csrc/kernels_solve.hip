@@ -432,9 +432,10 @@ __global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr,
 }
 
 static int apply2_enabled();
-static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
-                          cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
-                          const cz* crow_child, int64_t crs_child, int max_slabs);
+template <typename T>
+static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const T* fact, int64_t fs,
+                          T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, int K, bool gather, T* skbuf, int64_t sks,
+                          const T* crow_child, int64_t crs_child, int max_slabs);
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
@@ -442,7 +443,7 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
     if (ntiles <= 0) return;
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
     dim3 g(ntiles * K * ncg);
-    if (apply2_enabled()) { launch_apply2(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs); return; }
+    if (apply2_enabled()) { launch_apply2<cz>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs); return; }
     if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
     else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
 }
@@ -460,8 +461,26 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
 // ---------------------------------------------------------------------------
 constexpr int A2_DA = 8, A2_DV = 4, A2_DI = 2;
 
-template <bool GATHER, int NS>
-__device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw) {
+// element type of a sweep: complex128 on the f64 matrix cores, or complex64 (feast!'s mixed_prec) on the f32 ones
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <typename T> struct A2;
+template <> struct A2<cz> {
+    typedef double real;
+    typedef d4 acc;
+    static __device__ __forceinline__ acc mfma(real a, real b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int drow(int lk, int r) { return lk + 4 * r; }     // D layout: register r of lane l holds row (l >> 4) + 4 r
+};
+template <> struct A2<cf> {
+    typedef float real;
+    typedef f4 acc;
+    static __device__ __forceinline__ acc mfma(real a, real b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int drow(int lk, int r) { return 4 * lk + r; }     // row 4 (l >> 4) + r
+};
+
+template <typename T, bool GATHER, int NS>
+__device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int ldw) {
+    typedef typename A2<T>::real real;
+    typedef typename A2<T>::acc acc;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wave = tid >> 6;
     const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
@@ -474,12 +493,30 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
     const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
     const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
     const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
-    const cz* Ap = g.A + min(arow, g.rend - 1);
+    const T* Ap = g.A + min(arow, g.rend - 1);
     const int lda = (int)g.lda;       // a panel's leading dimension fits 31 bits: one v_mad_i64_i32 per address
+    // Column of lane li in column tile q.  complex128: 16 consecutive columns per tile, one 16-byte load per lane and tile.
+    // complex64: two tiles share a 32-column span, lane li owning the columns 2 li (even tile) and 2 li + 1 (odd tile), so that one
+    // 16-byte load (store) per lane serves both -- the complex64 sweeps are bound by the number of vector memory instructions,
+    // not by bytes or matrix-core time.  (ldw is a multiple of 16, so a pair never straddles the end of a row.)
+    constexpr bool PAIR = sizeof(T) == 8 && NS >= 2;
     int vcol[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) vcol[q] = min(cg + (ct0 + q) * 16 + li, ldw - 1);
-    cz ar[A2_DA], vr[A2_DV][NS];
+    for (int q = 0; q < NS; ++q)
+        vcol[q] = PAIR ? min(cg + (ct0 + (q & ~1)) * 16 + 2 * li, ldw - 2) + (q & 1) : min(cg + (ct0 + q) * 16 + li, ldw - 1);
+    auto ld_cols = [&](T (&dst)[NS], const T* rowp, bool imm) {      // the lane's NS block-vector entries of one row (imm: rowp points at vcol[0])
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int q = 0; q < NS; q += 2) {
+                const float4 w = *reinterpret_cast<const float4*>(imm ? rowp + q * 16 : rowp + vcol[q]);
+                dst[q].x = w.x; dst[q].y = w.y; dst[q + 1].x = w.z; dst[q + 1].y = w.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) dst[q] = imm ? rowp[q * 16] : rowp[vcol[q]];
+        }
+    };
+    T ar[A2_DA], vr[A2_DV][NS];
     int ir[8];
     auto kof = [&](int s) { return min(4 * s + lk, Kd - 1); };        // clamped: steps beyond the end re-read the last column (masked)
 #ifndef FEASTHIP_A2_ABLATE
@@ -495,19 +532,17 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
     auto loadI = [&](int s, int slot) { if (GATHER) ir[slot] = g.sidx[kof(s)]; };
     auto loadV = [&](int s, int slot, int islot) {
         const int vrow = GATHER ? ir[islot] : g.vrow0 + kof(s);
-        const cz* vp = g.Vk + (int64_t)vrow * ldw;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
+        const T* vp = g.Vk + (int64_t)vrow * ldw;
 #if FEASTHIP_A2_ABLATE & 2
-            vr[slot][q] = cz_make(0.5 + q, (double)(size_t)vp * 1e-30);
-#else
-            vr[slot][q] = vp[vcol[q]];
-#endif
-        }
-    };
-    d4 t1[NS], t2[NS], t3[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { t1[q] = (d4){0, 0, 0, 0}; t2[q] = (d4){0, 0, 0, 0}; t3[q] = (d4){0, 0, 0, 0}; }
+        for (int q = 0; q < NS; ++q) { vr[slot][q].x = 0.5 + q; vr[slot][q].y = (double)(size_t)vp * 1e-30; }
+#else
+        ld_cols(vr[slot], vp, false);
+#endif
+    };
+    acc t1[NS], t2[NS], t3[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { t1[q] = (acc){0, 0, 0, 0}; t2[q] = (acc){0, 0, 0, 0}; t3[q] = (acc){0, 0, 0, 0}; }
     // prologue: fill the rings
 #pragma unroll
     for (int s = 0; s < A2_DV - 1 + A2_DI; ++s) loadI(s, s % 8);
@@ -525,11 +560,11 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
         loadA(s + A2_DA - 1, (j + A2_DA - 1) % A2_DA);
         __builtin_amdgcn_sched_barrier(0);
         const int gk = 4 * s + lk;
-        cz a = ar[j % A2_DA];
+        T a = ar[j % A2_DA];
         const bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
-        a.x = keep ? a.x : (gk == unit_at ? 1.0 : 0.0);
-        a.y = keep ? a.y : 0.0;
-        const double as = a.x + a.y;
+        a.x = keep ? a.x : (gk == unit_at ? (real)1 : (real)0);
+        a.y = keep ? a.y : (real)0;
+        const real as = a.x + a.y;
         // 3M complex product, see apply_body
 #if FEASTHIP_A2_ABLATE & 4
 #pragma unroll
@@ -537,39 +572,37 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
         return;
 #endif
 #pragma unroll
-        for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vr[j % A2_DV][q].x, t1[q], 0, 0, 0);
+        for (int q = 0; q < NS; ++q) t1[q] = A2<T>::mfma(a.x, vr[j % A2_DV][q].x, t1[q]);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, vr[j % A2_DV][q].y, t2[q], 0, 0, 0);
+        for (int q = 0; q < NS; ++q) t2[q] = A2<T>::mfma(a.y, vr[j % A2_DV][q].y, t2[q]);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q], 0, 0, 0);
+        for (int q = 0; q < NS; ++q) t3[q] = A2<T>::mfma(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q]);
     };
     // Bulk of a long K loop: every k-step it touches (the one it computes and the ones it prefetches) is complete and unmasked, so the
     // addresses advance by running pointers, the column tiles sit at immediate offsets of one row pointer and nothing is clamped or
     // masked: about half the vector instructions of the generic step (which matters for the waves that own few columns).
     int s0 = 0;
-    const bool fast_ok = g.mask == 0 && aok_all && cg + (ct0 + NS) * 16 <= ldw;
+    const bool fast_ok = g.mask == 0 && aok_all && cg + (ct0 + NS) * 16 <= ldw;      // (then no column is clamped: the pairs sit 32 entries apart)
     if (fast_ok) {
         const int nfull = Kd >> 2;                                   // complete k-steps
-        const cz* pAi = Ap + (int64_t)(4 * (A2_DA - 1) + lk) * lda;  // next factor load to issue: step DA - 1
+        const T* pAi = Ap + (int64_t)(4 * (A2_DA - 1) + lk) * lda;  // next factor load to issue: step DA - 1
         const int64_t stepA = 4 * (int64_t)lda;
-        const cz* pVi = g.Vk + (int64_t)(g.vrow0 + 4 * (A2_DV - 1) + lk) * ldw + vcol[0];    // contiguous kinds: step DV - 1
+        const T* pVi = g.Vk + (int64_t)(g.vrow0 + 4 * (A2_DV - 1) + lk) * ldw + vcol[0];    // contiguous kinds: step DV - 1
         const int64_t stepV = 4 * (int64_t)ldw;
         const int* pIi = g.sidx + 4 * (A2_DV - 1 + A2_DI) + lk;       // gathered kinds: next index to load
-        const cz* vbase = g.Vk + vcol[0];
+        const T* vbase = g.Vk + vcol[0];
         auto fstep = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             __builtin_amdgcn_sched_barrier(0);
             if (GATHER) { ir[(j + A2_DV - 1 + A2_DI) % 8] = *pIi; pIi += 4; }
             {
-                const cz* vp = GATHER ? vbase + (int64_t)ir[(j + A2_DV - 1) % 8] * ldw : pVi;
-#pragma unroll
-                for (int q = 0; q < NS; ++q) {
+                const T* vp = GATHER ? vbase + (int64_t)ir[(j + A2_DV - 1) % 8] * ldw : pVi;
 #if FEASTHIP_A2_ABLATE & 2
-                    vr[(j + A2_DV - 1) % A2_DV][q] = cz_make(0.5 + q, (double)(size_t)vp * 1e-30);
+#pragma unroll
+                for (int q = 0; q < NS; ++q) { vr[(j + A2_DV - 1) % A2_DV][q].x = 0.5 + q; vr[(j + A2_DV - 1) % A2_DV][q].y = (double)(size_t)vp * 1e-30; }
 #else
-                    vr[(j + A2_DV - 1) % A2_DV][q] = vp[q * 16];
+                ld_cols(vr[(j + A2_DV - 1) % A2_DV], vp, true);
 #endif
-                }
                 pVi += stepV;
             }
 #if FEASTHIP_A2_ABLATE & 1
@@ -578,19 +611,19 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
             ar[(j + A2_DA - 1) % A2_DA] = *pAi; pAi += stepA;
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            const cz a = ar[j % A2_DA];
-            const double as = a.x + a.y;
+            const T a = ar[j % A2_DA];
+            const real as = a.x + a.y;
 #if FEASTHIP_A2_ABLATE & 4
 #pragma unroll
             for (int q = 0; q < NS; ++q) { t1[q][0] += a.x * vr[j % A2_DV][q].x; t2[q][0] += a.y * vr[j % A2_DV][q].y; t3[q][0] += as; }
             return;
 #endif
 #pragma unroll
-            for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vr[j % A2_DV][q].x, t1[q], 0, 0, 0);
+            for (int q = 0; q < NS; ++q) t1[q] = A2<T>::mfma(a.x, vr[j % A2_DV][q].x, t1[q]);
 #pragma unroll
-            for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, vr[j % A2_DV][q].y, t2[q], 0, 0, 0);
+            for (int q = 0; q < NS; ++q) t2[q] = A2<T>::mfma(a.y, vr[j % A2_DV][q].y, t2[q]);
 #pragma unroll
-            for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q], 0, 0, 0);
+            for (int q = 0; q < NS; ++q) t3[q] = A2<T>::mfma(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q]);
         };
         // a pass computes steps s0 .. s0 + 7 and prefetches up to step s0 + 7 + DA - 1 (factor) / + DV - 1 + DI (indices): all < nfull
         for (; s0 + 8 + A2_DA - 1 <= nfull; s0 += 8) {
@@ -614,72 +647,81 @@ __device__ __forceinline__ void apply2_body(const ApplyGeom& g, int cg, int ldw)
 #undef FEASTHIP_STEP2
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue: output rows of this lane (D layout: row (l >> 4) + 4 r, columns (ct0 + q) * 16 + li)
-    cz* dptr[4];
+    T* dptr[4];
     bool rok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        int orow = g.rbase + slab * 16 + lk + 4 * r;
+        int orow = g.rbase + slab * 16 + A2<T>::drow(lk, r);
         rok[r] = orow < g.rend;
         dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
     }
-    cz old[4][NS];
+    T old[4][NS];
     if (g.mode == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][vcol[q]];
+        for (int r = 0; r < 4; ++r) ld_cols(old[r], dptr[r], false);
     } else if (g.mode == 3) {
         // extend-add of the forward sweep fused into the producer (fixed child order: deterministic)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int q = 0; q < NS; ++q) old[r][q] = cz_make(0, 0);
+            for (int q = 0; q < NS; ++q) { old[r][q].x = 0; old[r][q].y = 0; }
         for (int c = 0; c < g.npull; ++c) {
             int src[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int orow = g.rbase + slab * 16 + lk + 4 * r;
+                int orow = g.rbase + slab * 16 + A2<T>::drow(lk, r);
                 src[r] = rok[r] ? g.pull[(int64_t)(orow + g.orow_shift) * g.npull + c] : -1;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (src[r] >= 0) {
+                    T pv[NS];
+                    ld_cols(pv, g.pullbase + (int64_t)src[r] * ldw, false);
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        cz v = g.pullbase[(int64_t)src[r] * ldw + vcol[q]];
-                        old[r][q].x += v.x; old[r][q].y += v.y;
-                    }
+                    for (int q = 0; q < NS; ++q) { old[r][q].x += pv[q].x; old[r][q].y += pv[q].y; }
                 }
         }
     }
-    const double sgn = (g.mode == 2) ? -1.0 : 1.0;
+    const real sgn = (g.mode == 2) ? (real)-1 : (real)1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+        T o[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            const int col = cg + (ct0 + q) * 16 + li;
-            const double cr = t1[q][r] - t2[q][r], ci = t3[q][r] - t1[q][r] - t2[q][r];
-            cz v;
-            if (g.mode == 1 || g.mode == 2) v = cz_make(sgn * cr, sgn * ci);
-            else v = cz_make(old[r][q].x - cr, old[r][q].y - ci);
-            if (rok[r] && col < ldw) dptr[r][col] = v;
+            const real cr = t1[q][r] - t2[q][r], ci = t3[q][r] - t1[q][r] - t2[q][r];
+            if (g.mode == 1 || g.mode == 2) { o[q].x = sgn * cr; o[q].y = sgn * ci; }
+            else { o[q].x = old[r][q].x - cr; o[q].y = old[r][q].y - ci; }
         }
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int q = 0; q < NS; q += 2) {
+                const int col = cg + (ct0 + q) * 16 + 2 * li;
+                if (rok[r] && col < ldw) *reinterpret_cast<float4*>(dptr[r] + col) = make_float4(o[q].x, o[q].y, o[q + 1].x, o[q + 1].y);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int col = cg + (ct0 + q) * 16 + li;
+                if (rok[r] && col < ldw) dptr[r][col] = o[q];
+            }
+        }
+    }
 }
 
-template <bool GATHER, int NSMAX>
+template <typename T, bool GATHER, int NSMAX>
 __global__ __launch_bounds__(256, NSMAX == 4 ? 2 : 3) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
-                                                const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
-                                                cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks,
-                                                int ntiles, int ncg, const int* __restrict__ cmap, const cz* __restrict__ crow_child, int64_t crs_child) {
+                                                const int* __restrict__ struct_idx, const T* __restrict__ fact, int64_t fs,
+                                                T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, T* skbuf, int64_t sks,
+                                                int ntiles, int ncg, const int* __restrict__ cmap, const T* __restrict__ crow_child, int64_t crs_child) {
     const int item0 = xcd_item(), item = item0 / ncg;      // same work mapping as k_apply
     Tile t = tiles[item % ntiles];
     int k = item / ntiles, cg = (item0 % ncg) * LDS_COLS;
     FrontD f = fr[t.f];
-    ApplyGeom g;
-    int trows = decode_tile<cz>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
-    if (trows <= 16) apply2_body<GATHER, 1>(g, cg, ldw);
-    else if (NSMAX == 2 || trows <= 32) apply2_body<GATHER, 2>(g, cg, ldw);
-    else if (NSMAX == 4) apply2_body<GATHER, 4>(g, cg, ldw);
+    ApplyGeomT<T> g;
+    int trows = decode_tile<T>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
+    if (trows <= 16) apply2_body<T, GATHER, 1>(g, cg, ldw);
+    else if (NSMAX == 2 || trows <= 32) apply2_body<T, GATHER, 2>(g, cg, ldw);
+    else if (NSMAX == 4) apply2_body<T, GATHER, 4>(g, cg, ldw);
 }
 
 static int g_apply2 = -1;
@@ -689,25 +731,25 @@ static int apply2_enabled() {
 }
 void select_apply_kernel(int barrier_free) { g_apply2 = barrier_free ? 1 : 0; }
 
-static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
-                          cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
-                          const cz* crow_child, int64_t crs_child, int max_slabs) {
+template <typename T>
+static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const T* fact, int64_t fs,
+                          T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, int K, bool gather, T* skbuf, int64_t sks,
+                          const T* crow_child, int64_t crs_child, int max_slabs) {
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
     dim3 g(ntiles * K * ncg);
-#define FEASTHIP_A2(G, N) hipLaunchKernelGGL((k_apply2<G, N>), g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child)
+#define FEASTHIP_A2(G, N) hipLaunchKernelGGL((k_apply2<T, G, N>), g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child)
     if (max_slabs <= 2) { if (gather) FEASTHIP_A2(true, 2); else FEASTHIP_A2(false, 2); }
     else { if (gather) FEASTHIP_A2(true, 4); else FEASTHIP_A2(false, 4); }
 #undef FEASTHIP_A2
 }
 
 // ---------------------------------------------------------------------------
-// Mixed precision (feast!'s mixed_prec, src/feast.jl:19-25): the same tiles on complex64 copies of the solve-ready
-// factors and block vectors -- half the bytes per sweep, f32 matrix cores (v_mfma_f32_16x16x4_f32, 4 real products
-// per complex one).  The kernel is HBM-bound, so the V rows go through registers (global load one chunk ahead,
-// ds_write into the other half of a padded double buffer) and 4 waves per SIMD fit.
+// Mixed precision (feast!'s mixed_prec, src/feast.jl:19-25), round-1 kernel (FEASTHIP_APPLY2=0; the default is k_apply2<cf>
+// above): the same tiles on complex64 copies of the solve-ready factors and block vectors -- half the bytes per sweep, f32
+// matrix cores (v_mfma_f32_16x16x4_f32, 3M product).  The V rows go through registers (global load one chunk ahead, ds_write
+// into the other half of a padded double buffer) and 4 waves per SIMD fit.
 // D layout of the f32 instruction: register r of lane l holds row 4 (l >> 4) + r, column l & 15.
 // ---------------------------------------------------------------------------
-typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int A32_KC = 32;
 constexpr int A32_LD = 80;     // LDS row stride in complex64 (640 B): rows k and k+1 fall on disjoint halves of the banks
 
@@ -864,8 +906,9 @@ __global__ __launch_bounds__(256) void k_apply32(const FrontD* __restrict__ fr, 
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather, cf* skbuf, int64_t sks,
-                  const cf* crow_child, int64_t crs_child, int /*max_slabs*/) {
+                  const cf* crow_child, int64_t crs_child, int max_slabs) {
     if (ntiles <= 0) return;
+    if (apply2_enabled()) { launch_apply2<cf>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs); return; }
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
     dim3 g(ntiles * K * ncg);
     if (gather) hipLaunchKernelGGL(k_apply32<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
