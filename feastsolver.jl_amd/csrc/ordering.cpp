@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <numeric>
 #include <queue>
+#include <thread>
 
 namespace feasthip {
 namespace {
@@ -28,42 +29,87 @@ struct XorShift {
 // one coarsening step; returns false if the graph hardly shrinks
 bool coarsen(const WGraph& g, WGraph& c, std::vector<int>& cmap, XorShift& rng) {
     int n = g.n;
-    std::vector<int> match(n, -1), order(n);
-    std::iota(order.begin(), order.end(), 0);
-    for (int i = n - 1; i > 0; --i) std::swap(order[i], order[rng.next() % (i + 1)]);
-    int nc = 0;
+    // Heavy-edge matching.  Vertices are visited in index order (the adjacency arrays stream through the cache; a random visiting
+    // order costs a cache miss per vertex on the fine levels) and ties between equally heavy edges are broken at random, which is
+    // what keeps the matching isotropic on stencil graphs whose edges all weigh the same.
     cmap.assign(n, -1);
-    for (int v : order) {
-        if (match[v] >= 0) continue;
-        int best = -1, bw = -1;
+    std::vector<int> mate(n);          // second member of the coarse vertex whose first member is v (or -1), indexed by coarse id
+    int nc = 0;
+    std::vector<int> first(n);
+    for (int v = 0; v < n; ++v) {
+        if (cmap[v] >= 0) continue;
+        int best = -1, bw = -1, ties = 0;
         for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
             int w = g.adj[t];
-            if (match[w] < 0 && w != v && g.ewgt[t] > bw) { bw = g.ewgt[t]; best = w; }
+            if (cmap[w] >= 0 || w == v) continue;
+            int e = g.ewgt[t];
+            if (e > bw) { bw = e; best = w; ties = 1; }
+            else if (e == bw && rng.next() % (uint32_t)(++ties) == 0) best = w;
         }
-        if (best >= 0) { match[v] = best; match[best] = v; cmap[v] = cmap[best] = nc++; }
-        else { match[v] = v; cmap[v] = nc++; }
+        cmap[v] = nc;
+        if (best >= 0) cmap[best] = nc;
+        first[nc] = v; mate[nc] = best;
+        ++nc;
     }
     if (nc > 0.92 * n) return false;
     c.n = nc;
-    c.vwgt.assign(nc, 0);
-    c.xadj.assign(nc + 1, 0);
-    c.adj.clear(); c.ewgt.clear();
-    std::vector<int> pos(nc, -1);
-    std::vector<std::pair<int, int>> members(nc, {-1, -1});
-    for (int v = 0; v < n; ++v) { auto& m = members[cmap[v]]; if (m.first < 0) m.first = v; else m.second = v; }
-    for (int cv = 0; cv < nc; ++cv) {
-        int start = (int)c.adj.size();
-        for (int v : {members[cv].first, members[cv].second}) {
-            if (v < 0) continue;
-            c.vwgt[cv] += g.vwgt[v];
-            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
-                int cw = cmap[g.adj[t]];
-                if (cw == cv) continue;
-                if (pos[cw] >= start) c.ewgt[pos[cw]] += g.ewgt[t];
-                else { pos[cw] = (int)c.adj.size(); c.adj.push_back(cw); c.ewgt.push_back(g.ewgt[t]); }
+    c.vwgt.resize(nc);
+    c.xadj.resize(nc + 1);
+    // Contraction: coarse vertex cv gets the merged adjacency of its members.  Large graphs are cut into NPART contiguous
+    // ranges of coarse vertices that are built by separate threads into private arrays and concatenated in order, so the result
+    // does not depend on the number of threads or on their timing (NPART is fixed).
+    constexpr int NPART = 8;
+    const int nparts = n >= 16384 ? NPART : 1;
+    std::vector<std::vector<int>> padj(nparts), pew(nparts);
+    std::vector<int> cdeg(nc);
+    const int* __restrict gx = g.xadj.data(); const int* __restrict ga = g.adj.data(); const int* __restrict ge = g.ewgt.data();
+    const int* __restrict cm = cmap.data();
+    auto build = [&](int part) {
+        const int c0 = (int)((int64_t)nc * part / nparts), c1 = (int)((int64_t)nc * (part + 1) / nparts);
+        int64_t cap = 0;
+        for (int cv = c0; cv < c1; ++cv) { cap += gx[first[cv] + 1] - gx[first[cv]]; if (mate[cv] >= 0) cap += gx[mate[cv] + 1] - gx[mate[cv]]; }
+        std::vector<int>& A = padj[part]; std::vector<int>& E = pew[part];
+        A.resize(cap); E.resize(cap);
+        std::vector<int> pos(nc, -1);
+        int* __restrict ca = A.data(); int* __restrict ce = E.data(); int* __restrict ps = pos.data();
+        int len = 0;
+        for (int cv = c0; cv < c1; ++cv) {
+            const int start = len;
+            int vw = 0;
+            const int mem[2] = {first[cv], mate[cv]};
+            for (int q = 0; q < 2; ++q) {
+                const int v = mem[q];
+                if (v < 0) continue;
+                vw += g.vwgt[v];
+                for (int t = gx[v]; t < gx[v + 1]; ++t) {
+                    const int cw = cm[ga[t]];
+                    if (cw == cv) continue;
+                    const int pp = ps[cw];
+                    if (pp >= start) ce[pp] += ge[t];
+                    else { ps[cw] = len; ca[len] = cw; ce[len] = ge[t]; ++len; }
+                }
             }
+            c.vwgt[cv] = vw;
+            cdeg[cv] = len - start;
         }
-        c.xadj[cv + 1] = (int)c.adj.size();
+        A.resize(len); E.resize(len);
+    };
+    if (nparts > 1) {
+        std::vector<std::thread> th;
+        for (int part = 1; part < nparts; ++part) th.emplace_back(build, part);
+        build(0);
+        for (auto& t : th) t.join();
+    } else build(0);
+    c.xadj[0] = 0;
+    for (int cv = 0; cv < nc; ++cv) c.xadj[cv + 1] = c.xadj[cv] + cdeg[cv];
+    c.adj.resize(c.xadj[nc]); c.ewgt.resize(c.xadj[nc]);
+    {
+        int64_t off = 0;
+        for (int part = 0; part < nparts; ++part) {
+            std::copy(padj[part].begin(), padj[part].end(), c.adj.begin() + off);
+            std::copy(pew[part].begin(), pew[part].end(), c.ewgt.begin() + off);
+            off += (int64_t)padj[part].size();
+        }
     }
     return true;
 }
