@@ -35,6 +35,7 @@ PROTOTYPES = {
     "feasthip_device_count": (I, []),
     "feasthip_create": (I, [PVP, I]),
     "feasthip_destroy": (I, [VP]),
+    "feasthip_trim_memory": (I, []),
     "feasthip_last_error": (C.c_char_p, [VP]),
     "feasthip_set_stream": (I, [VP, VP]),
     "feasthip_set_dense": (I, [VP, I64, I, PVP, C.POINTER(I), C.POINTER(D)]),

@@ -400,6 +400,12 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     return lam[ins], Xw[:, ins], res[ins]
 
 
+def trim_memory():
+    """Return the library's cache of released device blocks to the driver (feasthip_trim_memory): handles that are closed
+    leave their large buffers (factor arena, block vectors) for the next handle of the process."""
+    _lib.load_library().feasthip_trim_memory()
+
+
 def mmread(path):
     """MatrixMarket coordinate file -> scipy CSC complex128 through the library's own reader (feasthip_mm_read_csc);
     what MatrixMarket.mmread does in the reference's scripts (test/butterfly.jl:57-59, test/polynomial.jl:5-11)."""

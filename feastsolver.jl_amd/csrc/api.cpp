@@ -64,6 +64,11 @@ int feasthip_destroy(feasthip_handle_t h) {
     return 0;
 }
 
+int feasthip_trim_memory(void) {
+    try { feasthip::trim_device_memory(); } catch (...) {}
+    return 0;
+}
+
 const char* feasthip_last_error(feasthip_handle_t h) {
     if (!h || !h->e) return g_create_error.c_str();
     return h->e->err.c_str();

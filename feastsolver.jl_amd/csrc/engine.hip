@@ -4,15 +4,75 @@
 
 namespace feasthip {
 
-template <class T> void DevBuf<T>::release() { if (p) { (void)hipFree((void*)p); p = nullptr; n = 0; } }
+// Large device blocks (factor arena, block vectors, contribution stacks) are kept in a small process-wide cache when a handle
+// releases them and handed to the next handle that asks for a block of about that size: FEAST is typically run several times
+// per process (other contours / spectrum slices), and a fresh multi-GB hipMalloc costs 1 ms to 0.8 s depending on what the
+// driver has to map.  feasthip_trim_memory() returns the cached blocks to the driver; so does an allocation that fails.
+namespace {
+struct CachedBlock { int dev; void* p; size_t bytes; };
+std::mutex g_pool_mu;
+std::vector<CachedBlock> g_pool;
+constexpr size_t POOL_MIN_BYTES = (size_t)64 << 20;
+size_t pool_limit_bytes() {
+    static const size_t lim = [] { const char* e = getenv("FEASTHIP_POOL_GB"); return (size_t)((e ? atof(e) : 48.0) * 1073741824.0); }();
+    return lim;
+}
+void* pool_take(size_t bytes, size_t& got) {       // smallest cached block of this device with bytes <= size <= 1.25 bytes
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+        if (g_pool[i].dev == dev && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 4 && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    if (best < 0) return nullptr;
+    void* q = g_pool[best].p;
+    got = g_pool[best].bytes;
+    g_pool.erase(g_pool.begin() + best);
+    return q;
+}
+bool pool_put(void* q, size_t bytes) {
+    if (bytes < POOL_MIN_BYTES) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t held = 0;
+    for (const CachedBlock& b : g_pool) held += b.bytes;
+    if (held + bytes > pool_limit_bytes() || g_pool.size() >= 32) return false;
+    g_pool.push_back({dev, q, bytes});
+    return true;
+}
+}  // namespace
+
+void trim_device_memory() {
+    std::vector<CachedBlock> blocks;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); blocks.swap(g_pool); }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const CachedBlock& b : blocks) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    (void)hipSetDevice(cur);
+}
+
+template <class T> void DevBuf<T>::release() {
+    if (p) { if (!pool_put((void*)p, cap_bytes)) (void)hipFree((void*)p); p = nullptr; n = 0; cap_bytes = 0; }
+}
 template <class T> bool DevBuf<T>::alloc(size_t count) {
     if (count <= n && p) return true;
     release();
     if (count == 0) count = 1;
-    void* q = nullptr;
-    if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t bytes = count * sizeof(T);
+    size_t got = bytes;
+    void* q = bytes >= POOL_MIN_BYTES ? pool_take(bytes, got) : nullptr;
+    if (!q) {
+        got = bytes;
+        if (hipMalloc(&q, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            trim_device_memory();          // give the cached blocks back and try once more
+            if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+    }
     p = (T*)q;
     n = count;
+    cap_bytes = got;
     return true;
 }
 template <class T> bool DevBuf<T>::upload(const T* h, size_t count, hipStream_t st) {

@@ -19,16 +19,19 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t cap_bytes = 0;              // size of the underlying block (a recycled block may be larger than n elements)
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), cap_bytes(o.cap_bytes) { o.p = nullptr; o.n = 0; o.cap_bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap_bytes = o.cap_bytes; o.p = nullptr; o.n = 0; o.cap_bytes = 0; } return *this; }
     ~DevBuf() { release(); }
     void release();
     bool alloc(size_t count);          // false on failure
     bool upload(const T* h, size_t count, hipStream_t st);
 };
+
+void trim_device_memory();     // frees the process-wide cache of released device blocks (engine.hip)
 
 struct Launch {        // a slice of the tile / list buffers
     int64_t off = 0;

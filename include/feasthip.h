@@ -53,6 +53,10 @@ int feasthip_version(void);
 int feasthip_device_count(void);
 int feasthip_create(feasthip_handle_t* h, int device_id);
 int feasthip_destroy(feasthip_handle_t h);
+/* Device blocks of 64 MiB and more that a destroyed (or re-analysed) handle releases stay in a process-wide cache (at most
+ * FEASTHIP_POOL_GB, default 48) for the next handle of this process; this call returns them to the driver.  The counterpart of
+ * the reference's finalize! for whole solver runs (src/utils.jl:173): memory is the library's, the caller decides when it goes. */
+int feasthip_trim_memory(void);
 const char* feasthip_last_error(feasthip_handle_t h);   /* h may be NULL: last create() error */
 /* run all work of this handle on an existing hipStream_t (e.g. the caller's) */
 int feasthip_set_stream(feasthip_handle_t h, void* hip_stream);

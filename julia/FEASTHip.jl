@@ -66,6 +66,10 @@ function finalize!(F::HipLU)
     nothing
 end
 
+"trim_memory(): hand the library's cache of released device blocks back to the driver (a destroyed handle leaves its large
+buffers for the next solver call of the process)"
+trim_memory() = (ccall((:feasthip_trim_memory, lib), Cint, ()); nothing)
+
 # ---- coarse seam: the whole loop of gen_feast! (src/feast.jl:89-156) in one call -------------
 eltag(::Type{Float64}) = F64
 eltag(::Type{ComplexF64}) = C128

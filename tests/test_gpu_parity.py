@@ -989,3 +989,18 @@ def test_error_codes(gpu, pkg, wl):
     # empty contour is not an error: empty arrays + message (src/feast.jl:78-79)
     e, v, res = pkg.feast(wl.rand_x0(25, 5, 3), np.diag(np.arange(1.0, 26)), nodes=8, iter=2, c=100.5, r=0.1)
     assert e.shape == (0,) and v.shape == (25, 0) and res.shape == (0,)
+
+def test_device_block_cache_reuse_is_invisible(gpu, pkg, wl):
+    """Large device blocks released by a handle are recycled by the next one (feasthip_trim_memory gives them back): a second
+    run on recycled, non-zeroed blocks must give bit-identical results, and so must a run after trimming."""
+    w = wl.c3_sparse_generalized(24, 19, 64)
+    contour = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    outs = []
+    for rep in range(3):
+        X = np.array(w["X0"], copy=True)
+        lam, Xo, res = pkg.gen_feast(X, w["A"], w["B"], contour, iter=4, eps=1e-13, store=True)
+        outs.append((lam.copy(), Xo.copy(), res.copy()))
+        if rep == 1:
+            pkg.trim_memory()
+    for lam, Xo, res in outs[1:]:
+        assert np.array_equal(lam, outs[0][0]) and np.array_equal(Xo, outs[0][1]) and np.array_equal(res, outs[0][2])
