@@ -854,10 +854,12 @@ def test_c3_sparse_g12_fold_switch(gpu, pkg, wl, golden, fold):
     assert abs(info["nit"] - g["history"][-1][0]) <= 1
 
 
-@pytest.mark.parametrize("m0,fold", [(64, True), (64, False), (24, True), (100, False)])
-def test_apply_kernels_bit_identical(gpu, pkg, wl, m0, fold):
+@pytest.mark.parametrize("m0,fold,mixed", [(64, True, False), (64, False, False), (24, True, False), (100, False, False),
+                                           (64, True, True), (40, False, True), (24, True, True)])
+def test_apply_kernels_bit_identical(gpu, pkg, wl, m0, fold, mixed):
     """k_apply2 (operands streamed from global memory, no LDS, no barriers) and k_apply (LDS-staged) run the same tiles in the
-    same summation order: the moment Q must be bit-identical (all tile kinds, row-tile heights, masks, split-K, gathers)."""
+    same summation order: the moment Q must be bit-identical (all tile kinds, row-tile heights, masks, split-K, gathers).
+    mixed: the complex64 instance of k_apply2 (paired 16-byte lanes) against k_apply32."""
     w = wl.c3_sparse_generalized(14, 19, m0)
     con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
     lib = pkg.load_library()
@@ -869,6 +871,8 @@ def test_apply_kernels_bit_identical(gpu, pkg, wl, m0, fold):
             h.set_terms([w["A"], w["B"]], [1.0, -1.0])
             h.set_contour(con)
             h.set_conjugate_fold(fold)
+            if mixed:
+                h.set_precision(1)
             h.factorize()
             h.set_x(w["X0"])
             h.rr_step()
