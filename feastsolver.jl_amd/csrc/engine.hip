@@ -641,6 +641,26 @@ int Engine::analyze() {
         for (int j = 0; j <= n; ++j) mix((uint64_t)cp[j]);
         for (int64_t t = 0; t < cp[n]; ++t) mix((uint64_t)ri[t]);
         mix((uint64_t)opt.leaf_size); mix((uint64_t)opt.relax_small); mix((uint64_t)opt.relax_mid); mix((uint64_t)(opt.zmid * 1e6)); mix((uint64_t)(opt.zbig * 1e6)); mix((uint64_t)opt.ordering);
+        // CSR copies of the terms for SpMM (a transpose of the caller's CSC arrays) do not depend on the ordering: one host thread
+        // per term builds them while the nested dissection leaves most cores idle at its top levels
+        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0; };
+        std::vector<TermHost> th(terms_.size());
+        std::vector<std::thread> csr_pool;
+        for (size_t ti = 0; ti < terms_.size(); ++ti)
+            csr_pool.emplace_back([&, ti]() {
+                const SparseTerm& T = terms_[ti];
+                TermHost& H = th[ti];
+                const int64_t nnz = T.colptr[n];
+                H.rp.assign(n + 1, 0);
+                for (int64_t e2 = 0; e2 < nnz; ++e2) H.rp[T.rowval[e2] + 1]++;
+                for (int i = 0; i < n; ++i) H.rp[i + 1] += H.rp[i];
+                H.col.resize(nnz);
+                H.v.resize(nnz);
+                std::vector<int64_t> pos(H.rp.begin(), H.rp.end() - 1);
+                for (int j = 0; j < n; ++j)
+                    for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; H.col[q] = j; H.v[q] = T.val[e2]; }
+            });
+        struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& t : p) if (t.joinable()) t.join(); } } csr_join{csr_pool};
         bool hit = false;
         {
             std::lock_guard<std::mutex> lk(g_sym_mu);
@@ -654,10 +674,8 @@ int Engine::analyze() {
             g_sym_cache.emplace_back(key, S);
         }
         if (trace) fprintf(stderr, "[feasthip analyze] analyze_pattern total        %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        // arena destinations + CSR copies for SpMM: host work per term on its own thread (the destination map itself
-        // fans out over the columns), uploads afterwards from this thread
-        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0; };
-        std::vector<TermHost> th(terms_.size());
+        // arena destination of every entry (a binary search in the supernode's row structure): independent per column, fanned
+        // out over host threads per term; uploads afterwards from this thread
         {
             std::vector<std::thread> tpool;
             for (size_t ti = 0; ti < terms_.size(); ++ti)
@@ -666,32 +684,26 @@ int Engine::analyze() {
                     TermHost& H = th[ti];
                     int64_t nnz = T.colptr[n];
                     H.dest.resize(nnz);
-                    // arena destination of every entry (a binary search in the supernode's row structure): independent per column
                     int nth = (int)std::min<int64_t>(std::max(1, host_cpu_budget() / 2), std::max<int64_t>(1, nnz / 100000));
                     std::vector<std::thread> pool;
                     std::vector<char> bad(nth, 0);
-                    for (int tix = 0; tix < nth; ++tix)
-                        pool.emplace_back([&, tix]() {
-                            int j0 = (int)((int64_t)n * tix / nth), j1 = (int)((int64_t)n * (tix + 1) / nth);
+                    for (int tix = 1; tix <= nth; ++tix) {
+                        auto work = [&, tix]() {
+                            int j0 = (int)((int64_t)n * (tix - 1) / nth), j1 = (int)((int64_t)n * tix / nth);
                             for (int j = j0; j < j1; ++j)
                                 for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
                                     H.dest[e2] = entry_dest(S, T.rowval[e2], j);
-                                    if (H.dest[e2] < 0) bad[tix] = 1;
+                                    if (H.dest[e2] < 0) bad[tix - 1] = 1;
                                 }
-                        });
-                    H.rp.assign(n + 1, 0);
-                    for (int64_t e2 = 0; e2 < nnz; ++e2) H.rp[T.rowval[e2] + 1]++;
-                    for (int i = 0; i < n; ++i) H.rp[i + 1] += H.rp[i];
-                    H.col.resize(nnz);
-                    H.v.resize(nnz);
-                    std::vector<int64_t> pos(H.rp.begin(), H.rp.end() - 1);
-                    for (int j = 0; j < n; ++j)
-                        for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; H.col[q] = j; H.v[q] = T.val[e2]; }
+                        };
+                        if (tix < nth) pool.emplace_back(work); else work();
+                    }
                     for (auto& t2 : pool) t2.join();
                     for (char b2 : bad) if (b2) H.bad = 1;
                 });
             for (auto& t2 : tpool) t2.join();
         }
+        for (auto& t2 : csr_pool) t2.join();
         for (size_t ti = 0; ti < terms_.size(); ++ti) {
             SparseTerm& T = terms_[ti];
             TermHost& H = th[ti];
