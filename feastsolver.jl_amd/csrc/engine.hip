@@ -643,7 +643,7 @@ int Engine::analyze() {
         mix((uint64_t)opt.leaf_size); mix((uint64_t)opt.relax_small); mix((uint64_t)opt.relax_mid); mix((uint64_t)(opt.zmid * 1e6)); mix((uint64_t)(opt.zbig * 1e6)); mix((uint64_t)opt.ordering);
         // CSR copies of the terms for SpMM (a transpose of the caller's CSC arrays) do not depend on the ordering: one host thread
         // per term builds them while the nested dissection leaves most cores idle at its top levels
-        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0; };
+        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0; };
         std::vector<TermHost> th(terms_.size());
         std::vector<std::thread> csr_pool;
         for (size_t ti = 0; ti < terms_.size(); ++ti)
@@ -659,6 +659,14 @@ int Engine::analyze() {
                 std::vector<int64_t> pos(H.rp.begin(), H.rp.end() - 1);
                 for (int j = 0; j < n; ++j)
                     for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; H.col[q] = j; H.v[q] = T.val[e2]; }
+                // ... and uploads them (and the CSC values the factorisation scatters) from this thread, on its own stream
+                SparseTerm& Tw = terms_[ti];
+                hipStream_t us = nullptr;
+                bool ok = hipSetDevice(device_) == hipSuccess && hipStreamCreateWithFlags(&us, hipStreamNonBlocking) == hipSuccess;
+                ok = ok && Tw.d_cscval.upload((const cz*)T.val.data(), nnz, us) && Tw.d_rowptr.upload(H.rp.data(), n + 1, us) &&
+                     Tw.d_col.upload(H.col.data(), nnz, us) && Tw.d_val.upload((const cz*)H.v.data(), nnz, us);
+                if (us) (void)hipStreamDestroy(us);
+                if (!ok) H.bad = 2;
             });
         struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& t : p) if (t.joinable()) t.join(); } } csr_join{csr_pool};
         bool hit = false;
@@ -699,20 +707,18 @@ int Engine::analyze() {
                         if (tix < nth) pool.emplace_back(work); else work();
                     }
                     for (auto& t2 : pool) t2.join();
-                    for (char b2 : bad) if (b2) H.bad = 1;
+                    for (char b2 : bad) if (b2) H.bad_dest = 1;
                 });
             for (auto& t2 : tpool) t2.join();
         }
         for (auto& t2 : csr_pool) t2.join();
+        for (TermHost& H : th) if (H.bad_dest) H.bad = 1;
         for (size_t ti = 0; ti < terms_.size(); ++ti) {
             SparseTerm& T = terms_[ti];
             TermHost& H = th[ti];
-            if (H.bad) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
+            if (H.bad == 1) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
             int64_t nnz = T.colptr[n];
-            bool ok = T.d_dest.upload(H.dest.data(), nnz, stream_) && T.d_cscval.upload((const cz*)T.val.data(), nnz, stream_) &&
-                      T.d_rowptr.upload(H.rp.data(), n + 1, stream_) && T.d_col.upload(H.col.data(), nnz, stream_) &&
-                      T.d_val.upload((const cz*)H.v.data(), nnz, stream_);
-            if (!ok) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+            if (H.bad == 2 || !T.d_dest.upload(H.dest.data(), nnz, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
         }
     }
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + arena destinations, CSR    %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
