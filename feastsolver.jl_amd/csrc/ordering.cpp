@@ -205,14 +205,14 @@ struct FM {
     }
 };
 
-void initial_partition(const WGraph& g, std::vector<int>& part, XorShift& rng) {
+void initial_partition(const WGraph& g, std::vector<int>& part, XorShift& rng, int trials) {
     int n = g.n;
     int64_t total = 0;
     for (int v = 0; v < n; ++v) total += g.vwgt[v];
     std::vector<int> best;
     int64_t bestcut = INT64_MAX;
     std::vector<int> p(n), q;
-    for (int trial = 0; trial < 10; ++trial) {
+    for (int trial = 0; trial < trials; ++trial) {
         std::fill(p.begin(), p.end(), 1);
         int64_t w0 = 0;
         std::vector<char> seen(n, 0);
@@ -337,7 +337,10 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
     }
     lap("coarsening");
     std::vector<int> part;
-    initial_partition(levels.back(), part, rng);
+    // greedy graph growing from random seeds: the small subgraphs deep in the dissection (most of the calls, each a few hundred
+    // vertices) get fewer tries -- their separators bound small fronts, and the tries were most of their cost
+    const int trials = getenv("FEASTHIP_IP_TRIALS") ? atoi(getenv("FEASTHIP_IP_TRIALS")) : (n >= 20000 ? 10 : n >= 2000 ? 6 : 4);
+    initial_partition(levels.back(), part, rng, trials);
     lap("initial partition");
     for (int l = (int)levels.size() - 1; l >= 0; --l) {
         if (l < (int)levels.size() - 1) {
