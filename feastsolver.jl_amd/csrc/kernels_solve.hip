@@ -81,19 +81,41 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
     // phase 0: destinations inside the pivot block (before the front is solved);
     // phase 1: destinations among the contribution rows (after F2a has written them)
     if (phase == 0 ? (r0 >= p) : (r0 + 64 <= p)) return;
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T* const Wk = W + (int64_t)k * ws;
+    T* const Ck = crp + (int64_t)k * crsp;
     for (int ci = 0; ci < f.nchild; ++ci) {
         FrontD g = fr[child_idx[f.child_ptr + ci]];
         const int* rc = rel + g.sptr;
-        int ia = ebp[g.ebp + t.a], ib = ebp[g.ebp + t.a + 1];        // the child's rows that land in parent rows [r0, r0 + 64)
-        for (int i = ia + wave; i < ib; i += 4) {
-            int dst = rc[i];
-            if ((dst < p) != (phase == 0)) continue;
-            const T* s = crc + (int64_t)k * crsc + (g.crow + i) * (int64_t)ldw;
-            T* d;
-            if (dst < p) d = W + (int64_t)k * ws + (int64_t)(f.c0 + rowinv[(int64_t)k * n + f.c0 + dst]) * ldw;
-            else d = crp + (int64_t)k * crsp + (f.crow + dst - p) * (int64_t)ldw;
-            for (int j = lane; j < ldw; j += 64) { T a = d[j], b = s[j]; a.x += b.x; a.y += b.y; d[j] = a; }
+        const int ia = ebp[g.ebp + t.a], ib = ebp[g.ebp + t.a + 1];        // the child's rows that land in parent rows [r0, r0 + 64): at most 64
+        const int cnt = ib - ia;
+        // lane l resolves the destination of the child's row ia + l (two dependent index loads, all rows at once); the waves
+        // then add four rows per step with every load of the step in flight together
+        int drow = -1;                                                       // >= 0: row of W;  <= -2: -(row of the parent's contribution arena) - 2
+        if (lane < cnt) {
+            const int dst = rc[ia + lane];
+            if ((dst < p) == (phase == 0))
+                drow = dst < p ? f.c0 + rowinv[(int64_t)k * n + f.c0 + dst] : -((int)f.crow + dst - p) - 2;
+        }
+        const T* s0 = crc + (int64_t)k * crsc + (int64_t)(g.crow + ia) * ldw;
+        for (int base = wave * 4; base < cnt; base += 16) {
+            T* d[4];
+            const T* sp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = min(base + u, cnt - 1);
+                const int dr = __builtin_amdgcn_readlane(drow, l);
+                d[u] = (base + u < cnt && dr != -1) ? (dr >= 0 ? Wk + (int64_t)dr * ldw : Ck + (int64_t)(-dr - 2) * ldw) : nullptr;
+                sp[u] = s0 + (int64_t)l * ldw;
+            }
+            for (int j = lane; j < ldw; j += 64) {
+                T a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const T* dd = d[u] ? d[u] : sp[u]; a[u] = dd[j]; b[u] = sp[u][j]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (d[u]) { a[u].x += b[u].x; a[u].y += b[u].y; d[u][j] = a[u]; }
+            }
         }
         __syncthreads();
     }
@@ -928,24 +950,37 @@ void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out) {
 }
 
 // Y[c0 + r, :] += sum_part scratch[part][r, :]   (parts in increasing order: deterministic)
+// A thread owns one (row, column) element: the row's value and all its partials (at most SPLITK_MAX, the planner's cap) are
+// loaded together -- with few nodes per GPU this kernel is a handful of workgroups and its time is its longest dependent chain.
+constexpr int SPLITK_MAX = 8;
 template <typename T>
-__global__ void k_splitk_reduce(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int nsplit, T* Y, int64_t ws,
-                                int ldw, const T* __restrict__ skbuf, int64_t sks) {
+__global__ __launch_bounds__(256) void k_splitk_reduce(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int nsplit, T* Y, int64_t ws,
+                                                       int ldw, const T* __restrict__ skbuf, int64_t sks) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int Kp = (((f.u + nsplit - 1) / nsplit) + 31) & ~31;
-    int nparts = (f.u + Kp - 1) / Kp;
-    for (int r = t.a * 64 + wave; r < min(f.p, t.a * 64 + 64); r += 4) {
-        T* y = Y + (int64_t)k * ws + (int64_t)(f.c0 + r) * ldw;
-        for (int j = lane; j < ldw; j += 64) {
-            T v = y[j];
-            for (int q = 0; q < nparts; ++q) {
-                T a = skbuf[(int64_t)k * sks + (f.sk_off + (int64_t)q * f.p + r) * ldw + j];
-                v.x += a.x; v.y += a.y;
-            }
-            y[j] = v;
+    const int Kp = (((f.u + nsplit - 1) / nsplit) + 31) & ~31;
+    const int nparts = (f.u + Kp - 1) / Kp;
+    const int r0 = t.a * 64, nr = min(f.p, r0 + 64) - r0;
+    const int total = nr * ldw;
+    T* y0 = Y + (int64_t)k * ws + (int64_t)(f.c0 + r0) * ldw;                       // the tile's rows are contiguous
+    const T* p0 = skbuf + (int64_t)k * sks + (f.sk_off + (int64_t)r0) * ldw;        // part q of row r0 + i: p0 + (q p + i) ldw
+    const int64_t pstride = (int64_t)f.p * ldw;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * 256) {
+        T v[4], a[4][SPLITK_MAX];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + u * 256, total - 1);
+            v[u] = y0[e];
+#pragma unroll
+            for (int q = 0; q < SPLITK_MAX; ++q) a[u][q] = p0[(int64_t)min(q, nparts - 1) * pstride + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = 0; q < SPLITK_MAX; ++q)
+                if (q < nparts) { v[u].x += a[u][q].x; v[u].y += a[u][q].y; }
+            if (e0 + u * 256 < total) y0[e0 + u * 256] = v[u];
         }
     }
 }
