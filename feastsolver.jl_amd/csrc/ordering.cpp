@@ -131,14 +131,45 @@ struct FM {
         cut /= 2;
         total = w[0] + w[1];
     }
-    // one FM pass with hill climbing and rollback; returns true if the cut (or balance) improved
+    // one FM pass with hill climbing and rollback; returns true if the cut (or balance) improved.
+    // Gains are bounded integers (at most the largest weighted degree), so the candidates of each side sit in gain buckets
+    // (doubly linked lists, the classic Fiduccia-Mattheyses structure): selecting and re-ranking a vertex is O(1), where the
+    // binary heaps with lazy deletion of the first version pushed a new entry per touched neighbour.
+    std::vector<int> bnext, bprev, bgain, bhead[2];
+    std::vector<char> inb;
+    int gmax = 0, top[2] = {-1, -1};
+    void bucket_insert(int v, int side, int gain) {
+        const int b = gain + gmax;
+        bgain[v] = gain; inb[v] = 1;
+        bprev[v] = -1; bnext[v] = bhead[side][b];
+        if (bhead[side][b] >= 0) bprev[bhead[side][b]] = v;
+        bhead[side][b] = v;
+        if (b > top[side]) top[side] = b;
+    }
+    void bucket_remove(int v, int side) {
+        const int b = bgain[v] + gmax;
+        if (bprev[v] >= 0) bnext[bprev[v]] = bnext[v]; else bhead[side][b] = bnext[v];
+        if (bnext[v] >= 0) bprev[bnext[v]] = bprev[v];
+        inb[v] = 0;
+    }
+    int bucket_top(int side) {          // best candidate of a side (or -1); lowers the side's top pointer past empty buckets
+        while (top[side] >= 0 && bhead[side][top[side]] < 0) --top[side];
+        return top[side] >= 0 ? bhead[side][top[side]] : -1;
+    }
     bool pass(double maxfrac) {
         int n = g.n;
         int64_t maxw = (int64_t)(maxfrac * total) + 1;
-        typedef std::pair<int, int> PI;   // (gain, vertex)
-        std::priority_queue<PI> heap[2];
+        if (bnext.empty()) {
+            for (int v = 0; v < n; ++v) gmax = std::max(gmax, id[v] + ed[v]);
+            bnext.assign(n, -1); bprev.assign(n, -1); bgain.assign(n, 0); inb.assign(n, 0);
+            bhead[0].assign(2 * (size_t)gmax + 1, -1); bhead[1].assign(2 * (size_t)gmax + 1, -1);
+        } else {
+            std::fill(bhead[0].begin(), bhead[0].end(), -1); std::fill(bhead[1].begin(), bhead[1].end(), -1);
+            std::fill(inb.begin(), inb.end(), 0);
+        }
+        top[0] = top[1] = -1;
         std::vector<char> locked(n, 0);
-        for (int v = 0; v < n; ++v) if (ed[v] > 0 || g.xadj[v + 1] == g.xadj[v]) heap[part[v]].push({ed[v] - id[v], v});
+        for (int v = 0; v < n; ++v) if (ed[v] > 0 || g.xadj[v + 1] == g.xadj[v]) bucket_insert(v, part[v], ed[v] - id[v]);
         std::vector<int> moved;
         int64_t bestcut = cut, curcut = cut;
         int64_t bestimb = std::max(w[0], w[1]);
@@ -146,28 +177,28 @@ struct FM {
         int limit = std::max(60, std::min(n / 20, 800));
         while (true) {
             int from;
+            const int t0 = bucket_top(0), t1 = bucket_top(1);
             if (w[0] > maxw) from = 0;
             else if (w[1] > maxw) from = 1;
             else {
-                // pop stale entries to see the true tops
-                for (int s = 0; s < 2; ++s)
-                    while (!heap[s].empty()) {
-                        PI t = heap[s].top();
-                        if (locked[t.second] || part[t.second] != s || t.first != ed[t.second] - id[t.second]) heap[s].pop(); else break;
-                    }
-                if (heap[0].empty() && heap[1].empty()) break;
-                if (heap[0].empty()) from = 1;
-                else if (heap[1].empty()) from = 0;
-                else from = heap[0].top().first >= heap[1].top().first ? 0 : 1;
+                if (t0 < 0 && t1 < 0) break;
+                if (t0 < 0) from = 1;
+                else if (t1 < 0) from = 0;
+                else from = bgain[t0] >= bgain[t1] ? 0 : 1;
             }
             int v = -1;
-            while (!heap[from].empty()) {
-                PI t = heap[from].top(); heap[from].pop();
-                if (locked[t.second] || part[t.second] != from || t.first != ed[t.second] - id[t.second]) continue;
-                if (w[from ^ 1] + g.vwgt[t.second] > maxw && w[from] <= maxw) continue;   // would break balance
-                v = t.second; break;
+            while (true) {
+                const int c = bucket_top(from);
+                if (c < 0) break;
+                bucket_remove(c, from);
+                if (w[from ^ 1] + g.vwgt[c] > maxw && w[from] <= maxw) { locked[c] = 1; continue; }   // would break balance: out for this pass
+                v = c; break;
             }
-            if (v < 0) { if (w[from] > maxw) break; else { if (heap[from ^ 1].empty()) break; else { std::priority_queue<PI>().swap(heap[from]); continue; } } }
+            if (v < 0) {
+                if (w[from] > maxw) break;
+                if (bucket_top(from ^ 1) < 0) break;
+                continue;
+            }
             // move v
             int gain = ed[v] - id[v];
             curcut -= gain;
@@ -179,7 +210,10 @@ struct FM {
             for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
                 int u = g.adj[t], e = g.ewgt[t];
                 if (part[u] == part[v]) { id[u] += e; ed[u] -= e; } else { id[u] -= e; ed[u] += e; }
-                if (!locked[u]) heap[part[u]].push({ed[u] - id[u], u});
+                if (!locked[u]) {
+                    if (inb[u]) bucket_remove(u, part[u]);
+                    bucket_insert(u, part[u], ed[u] - id[u]);
+                }
             }
             int64_t imb = std::max(w[0], w[1]);
             bool better;
