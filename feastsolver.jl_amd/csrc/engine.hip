@@ -609,6 +609,24 @@ int Engine::analyze() {
     if (Kloc <= 0) return fail(FEASTHIP_ESTATE, "analyze: no contour nodes on this shard");
     HIPCHK(hipSetDevice(device_));
     auto t0 = std::chrono::steady_clock::now();
+    // A HIP stream gets its hardware queue with the first operation submitted to it (25-30 ms each, measured): every stream of
+    // the handle is touched from a helper thread now, beside the host-side analysis, instead of in the middle of the first
+    // upload / factorisation / contour step.
+    std::thread warm;
+    if (!streams_warm_) {
+        streams_warm_ = true;
+        warm = std::thread([this]() {
+            if (hipSetDevice(device_) != hipSuccess) return;
+            void* q = nullptr;
+            if (hipMalloc(&q, 256) != hipSuccess) { (void)hipGetLastError(); return; }
+            std::vector<hipStream_t> all{stream_, la_stream_, fin_stream_, rest_stream_};
+            all.insert(all.end(), aux_streams_.begin(), aux_streams_.end());
+            for (hipStream_t st : all) if (st) (void)hipMemsetAsync(q, 0, 256, st);
+            for (hipStream_t st : all) if (st) (void)hipStreamSynchronize(st);
+            (void)hipFree(q);
+        });
+    }
+    struct JoinWarm { std::thread& t; ~JoinWarm() { if (t.joinable()) t.join(); } } join_warm{warm};
     if (dense) {
         analyze_dense(n, S);
     } else {

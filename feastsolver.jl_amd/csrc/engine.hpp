@@ -143,6 +143,7 @@ public:
 private:
     int device_;
     hipStream_t stream_ = nullptr;
+    bool streams_warm_ = false;           // analyze() touches every stream once (queue creation) beside the host-side analysis
     bool own_stream_ = false;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     std::vector<SparseTerm> terms_;
