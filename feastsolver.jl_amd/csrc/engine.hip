@@ -34,6 +34,9 @@ bool pool_put(void* q, size_t bytes) {
     if (bytes < POOL_MIN_BYTES) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
+    // hipFree waits for the device before it returns the memory; a block that goes to another handle instead must not have
+    // work in flight either
+    if (hipDeviceSynchronize() != hipSuccess) return false;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     size_t held = 0;
     for (const CachedBlock& b : g_pool) held += b.bytes;
