@@ -805,6 +805,28 @@ int Engine::analyze() {
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
     dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.n = n;
+    dsym_.asmflag = nullptr; dsym_.relfirst = nullptr;
+    {
+        // fused right-hand-side gather: pivot rows that receive contributions of children, and the first contribution to each
+        // (children in the order k_fwd_assemble visits them)
+        static const bool fuse_gather = [] { const char* e = getenv("FEASTHIP_FUSE_GATHER"); return e ? atoi(e) != 0 : true; }();
+        if (fuse_gather && !dense && !S.rel.empty()) {
+            std::vector<int> asmflag(n, 0), relfirst(S.rel.size(), 0);
+            for (int s2 = 0; s2 < S.nsuper; ++s2) {
+                const int p = S.p(s2), c0 = S.sn_start[s2];
+                for (int64_t c = S.child_ptr[s2]; c < S.child_ptr[s2 + 1]; ++c) {
+                    const int g2 = S.child_idx[c], ug = S.u(g2);
+                    for (int i = 0; i < ug; ++i) {
+                        const int dst = S.rel[S.struct_ptr[g2] + i];
+                        if (dst < p && !asmflag[c0 + dst]) { asmflag[c0 + dst] = 1; relfirst[S.struct_ptr[g2] + i] = 1; }
+                    }
+                }
+            }
+            if (!d_asmflag_.upload(asmflag.data(), asmflag.size(), stream_) || !d_relfirst_.upload(relfirst.data(), relfirst.size(), stream_))
+                return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+            dsym_.asmflag = d_asmflag_.p; dsym_.relfirst = d_relfirst_.p;
+        }
+    }
     // numeric arenas
     analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto t_alloc = std::chrono::steady_clock::now();

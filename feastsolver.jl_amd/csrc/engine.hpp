@@ -163,6 +163,7 @@ private:
     // device symbolic
     DevBuf<FrontD> d_fr_;
     DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_c0row_, d_cmap_, d_ebp_;
+    DevBuf<int> d_asmflag_, d_relfirst_;  // fused right-hand-side gather (kernels.hpp: DevSym::asmflag / relfirst; FEASTHIP_FUSE_GATHER=0 turns it off)
     DevBuf<Tile> d_tiles_;
     DevBuf<int> d_lists_;
     std::vector<FactorLevel> fplan_;

@@ -50,7 +50,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
         begin();
         launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs,
-                            (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, rinv, kc, 0);
+                            (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, rinv, kc, 0, dsym_.asmflag ? rhs : nullptr, ldrhs);
         if (V.assemble.count) end(1, 3.0 * V.asm_rows * rowb * kc, 0);
         double lvl_rows = 0;
         for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);

@@ -21,6 +21,10 @@ struct DevSym {          // device copies of the symbolic structure
     const int* c0_of_row;  // first column of the supernode owning (new) row i
     const int* cmap;       // per front with children: [contribution row][child slot] -> row in the children's arena, or -1
     const int* ebp;        // extend-add break points, see FrontD::ebp
+    // fused right-hand-side gather (nullptr: off): rows of the block vectors that receive contributions of children are not
+    // written by k_gather_rhs but by the first contribution in k_fwd_assemble (W = R + contribution instead of W += contribution)
+    const int* asmflag;    // [n] by pre-pivot (new) row: 1 = some child contributes to this pivot row
+    const int* relfirst;   // parallel to rel: 1 = this child row is the first contribution to its destination
     int n;
 };
 
@@ -63,9 +67,10 @@ void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist,
 // lds = leading dimension of W: ldw, or 2 ldw for the conjugate fold (columns ldw.. receive conj(src))
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cz* W, int64_t ws,
                        const int* rowperm, int K);
+// (src, ldsrc: the right-hand side the sweep started from, for the rows k_gather_rhs left to the first contribution)
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase);
+                         const int* rowinv, int K, int phase, const cz* src = nullptr, int ldsrc = 0);
 // Block substitution on the solve-ready factors: every tile is out (-)= A * V on the f64 matrix cores.
 // Tile.a = kind, Tile.b = row tile (or diagonal block), Tile.c = step block index:
 //   0 F1  forward, rows of the pivot block below diagonal block c:   W_r -= P_rc W_c
@@ -90,7 +95,7 @@ void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, 
                        const int* rowperm, int K);
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
                          cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase);
+                         const int* rowinv, int K, int phase, const cz* src = nullptr, int ldsrc = 0);
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* Y, int64_t ws, int ldw,
                           const cf* skbuf, int64_t sks, int K);
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,

@@ -39,14 +39,20 @@ template <> __device__ inline cf el_make<cf>(double x, double y) { cf r; r.x = (
 // W_k[i,:] = src[perm[c0 + rowperm_k[i]], :]   (fill-reducing + pivot permutation folded into one gather)
 // Conjugate fold (lds > ldw): a real pencil gives T(conj z) = conj(T(z)), so the system of the conjugate node,
 // T(conj z)^-1 R = conj(T(z)^-1 conj(R)), rides along as ldw more right-hand-side columns conj(R) of the SAME factor.
+// Rows that receive contributions of children (asmflag, by pre-pivot row) are left to k_fwd_assemble, whose first
+// contribution writes src + contribution instead of reading the row back: one write here and one read there less per such row
+// (two thirds of the rows of a nested-dissection tree).
 template <typename T>
 __global__ void k_gather_rhs(const int* __restrict__ perm, const int* __restrict__ c0_of_row, int n,
-                             const cz* __restrict__ src, int ldw, int lds, T* W, int64_t ws, const int* __restrict__ rowperm) {
+                             const cz* __restrict__ src, int ldw, int lds, T* W, int64_t ws, const int* __restrict__ rowperm,
+                             const int* __restrict__ asmflag) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     int k = blockIdx.y, lane = threadIdx.x & 63;
     if (i >= n) return;
     int c0 = c0_of_row[i];
-    int srow = perm[c0 + rowperm[(int64_t)k * n + i]];
+    const int pre = c0 + rowperm[(int64_t)k * n + i];
+    if (asmflag && asmflag[pre]) return;
+    int srow = perm[pre];
     const cz* s = src + (int64_t)srow * ldw;
     T* d = W + (int64_t)k * ws + (int64_t)i * lds;
     for (int j = lane; j < lds; j += 64) {
@@ -57,11 +63,11 @@ __global__ void k_gather_rhs(const int* __restrict__ perm, const int* __restrict
 
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cz* W, int64_t ws,
                        const int* rowperm, int K) {
-    hipLaunchKernelGGL(k_gather_rhs<cz>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm);
+    hipLaunchKernelGGL(k_gather_rhs<cz>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm, S.asmflag);
 }
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cf* W, int64_t ws,
                        const int* rowperm, int K) {
-    hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm);
+    hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 3) / 4, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm, S.asmflag);
 }
 
 // Forward sweep, assembly of the children's contribution rows into the parent:
@@ -73,7 +79,9 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
                                                       const int* __restrict__ rel, const int* __restrict__ child_idx,
                                                       const int* __restrict__ ebp, T* W, int64_t ws, int ldw, T* crp, int64_t crsp,
                                                       const T* __restrict__ crc, int64_t crsc,
-                                                      const int* __restrict__ rowinv, int n, int phase) {
+                                                      const int* __restrict__ rowinv, int n, int phase,
+                                                      const int* __restrict__ relfirst, const int* __restrict__ perm,
+                                                      const cz* __restrict__ src, int ldsrc) {
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -92,26 +100,37 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
         // lane l resolves the destination of the child's row ia + l (two dependent index loads, all rows at once); the waves
         // then add four rows per step with every load of the step in flight together
         int drow = -1;                                                       // >= 0: row of W;  <= -2: -(row of the parent's contribution arena) - 2
+        int frow = -1;                                                       // >= 0: first contribution to the row, which starts from this row of src (fused gather)
         if (lane < cnt) {
             const int dst = rc[ia + lane];
-            if ((dst < p) == (phase == 0))
+            if ((dst < p) == (phase == 0)) {
                 drow = dst < p ? f.c0 + rowinv[(int64_t)k * n + f.c0 + dst] : -((int)f.crow + dst - p) - 2;
+                if (relfirst && dst < p && relfirst[g.sptr + ia + lane]) frow = perm[f.c0 + dst];
+            }
         }
         const T* s0 = crc + (int64_t)k * crsc + (int64_t)(g.crow + ia) * ldw;
         for (int base = wave * 4; base < cnt; base += 16) {
             T* d[4];
             const T* sp[4];
+            const cz* fp[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int l = min(base + u, cnt - 1);
                 const int dr = __builtin_amdgcn_readlane(drow, l);
+                const int fr2 = __builtin_amdgcn_readlane(frow, l);
                 d[u] = (base + u < cnt && dr != -1) ? (dr >= 0 ? Wk + (int64_t)dr * ldw : Ck + (int64_t)(-dr - 2) * ldw) : nullptr;
                 sp[u] = s0 + (int64_t)l * ldw;
+                fp[u] = (d[u] && fr2 >= 0) ? src + (int64_t)fr2 * ldsrc : nullptr;
             }
             for (int j = lane; j < ldw; j += 64) {
                 T a[4], b[4];
+                const int js = j < ldsrc ? j : j - ldsrc;          // columns ldsrc .. of a folded block vector: conj(src)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const T* dd = d[u] ? d[u] : sp[u]; a[u] = dd[j]; b[u] = sp[u][j]; }
+                for (int u = 0; u < 4; ++u) {
+                    b[u] = sp[u][j];
+                    if (fp[u]) { const cz v = fp[u][js]; a[u] = el_make<T>(v.x, j < ldsrc ? v.y : -v.y); }
+                    else a[u] = (d[u] ? d[u] : sp[u])[j];
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (d[u]) { a[u].x += b[u].x; a[u].y += b[u].y; d[u][j] = a[u]; }
@@ -123,17 +142,17 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__
 
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
                          cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase) {
+                         const int* rowinv, int K, int phase, const cz* src, int ldsrc) {
     if (ntiles <= 0) return;
     hipLaunchKernelGGL(k_fwd_assemble<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, S.ebp, W, ws, ldw,
-                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase);
+                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase, src ? S.relfirst : nullptr, S.perm, src, ldsrc);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
                          cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase) {
+                         const int* rowinv, int K, int phase, const cz* src, int ldsrc) {
     if (ntiles <= 0) return;
     hipLaunchKernelGGL(k_fwd_assemble<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, S.ebp, W, ws, ldw,
-                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase);
+                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase, src ? S.relfirst : nullptr, S.perm, src, ldsrc);
 }
 
 // ---------------------------------------------------------------------------
