@@ -114,6 +114,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FIN_ASYNC")) finalize_async_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_MIXED")) mixed_ = atoi(v) != 0;      // tuning / test knob; the API is feasthip_set_precision
     if (const char* v = getenv("FEASTHIP_NB256_MINP")) nb256_min_p_ = std::max(129, atoi(v));      // tuning knobs: 1 << 30 keeps the 128-column blocks
+    if (const char* v = getenv("FEASTHIP_FUSE_B3")) fuse_b3_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
@@ -378,6 +379,7 @@ bool Engine::build_plans() {
     sk_rows_ = 0;
     std::vector<int> nchild(S.nsuper);
     for (int s = 0; s < S.nsuper; ++s) nchild[s] = (int)(S.child_ptr[s + 1] - S.child_ptr[s]);
+    std::vector<char> fused_b3(S.nsuper, 0);
     // product tiles of one front in 8 x 8 super-tiles (64 consecutive tiles share 8 row panels and 8 column panels; k_gemm_nn
     // hands such runs to one XCD)
     auto push_supertiles = [&](int s, int kind, int na, int nc) {
@@ -545,6 +547,7 @@ bool Engine::build_plans() {
         });
         V.b1.off = (int64_t)tiles.size();
         int sl3 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
+        if (fuse_b3_ && sl3 == 2) sl3 = 4;      // 64-row tiles: the long K loop of the gather does not mind, and fronts of up to 64 pivot columns fuse their B3
         {   // few, long tiles (top of the tree): split the K = u loop over several workgroups
             int64_t wgs = 0; int umax = 0;
             for (int s : lv) if (S.u(s) > 0) { wgs += cdiv(S.p(s), 64); umax = std::max(umax, S.u(s)); }
@@ -562,7 +565,9 @@ bool Engine::build_plans() {
                 sk_off_[s] = sk_level; sk_level += (int64_t)nparts * p;
                 for (int q = 0; q < nparts; ++q) for (int a = 0; a < cdiv(p, 64); ++a) tiles.push_back({s, 3 | (sl3 << 8) | (V.b1split << 16), a, q});
             } else {
-                for (int a = 0; a < cdiv(p, 16 * sl3); ++a) tiles.push_back({s, 3 | (sl3 << 8), a, 0});
+                const bool fuse = fuse_b3_ && p <= 16 * sl3 && p <= solve_nb(s);     // one row tile, one diagonal block: B1 + B3 in one tile
+                fused_b3[s] = fuse ? 1 : 0;
+                for (int a = 0; a < cdiv(p, 16 * sl3); ++a) tiles.push_back({s, (fuse ? 6 : 3) | (sl3 << 8), a, 0});
             }
             V.b1.bytes += (double)u * p * 16.0; V.b1.flops += (double)u * p;
         }
@@ -588,16 +593,20 @@ bool Engine::build_plans() {
             L.count = (int)(tiles.size() - L.off);
             L.sl = sl;
         }
-        V.b3.off = (int64_t)tiles.size();
         const int sl5 = std::max(2, pick_slabs([&](auto&& cb) { for (int s : lv) cb(S.p(s)); }));
-        V.b3.sl = sl5;
-        for (int s : lv) {
-            int p = S.p(s), NB = solve_nb(s);
-            for (int t = 0; t < cdiv(p, NB); ++t)
-                for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * sl5); ++rt) tiles.push_back({s, 5 | (sl5 << 8), t, rt});
-            V.b3.bytes += 0.5 * p * std::min(p, NB) * 16.0; V.b3.flops += 0.5 * p * std::min(p, NB);
+        for (int pass = 0; pass < 2; ++pass) {       // the fronts whose B3 rides with their B1 tile (kind 6) go to their own launch
+            Launch& L = pass == 0 ? V.b3 : V.b3s;
+            L.off = (int64_t)tiles.size();
+            L.sl = sl5;
+            for (int s : lv) {
+                if ((fused_b3[s] != 0) != (pass == 1)) continue;
+                int p = S.p(s), NB = solve_nb(s);
+                for (int t = 0; t < cdiv(p, NB); ++t)
+                    for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * sl5); ++rt) tiles.push_back({s, 5 | (sl5 << 8), t, rt});
+                L.bytes += 0.5 * p * std::min(p, NB) * 16.0; L.flops += 0.5 * p * std::min(p, NB);
+            }
+            L.count = (int)(tiles.size() - L.off);
         }
-        V.b3.count = (int)(tiles.size() - V.b3.off);
     }
     if (tiles.empty()) tiles.push_back({0, 0, 0, 0});
     if (lists.empty()) lists.push_back(0);

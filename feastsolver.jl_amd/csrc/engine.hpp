@@ -45,6 +45,7 @@ struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp;
 struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale;
                      Launch outer[2], inner[2]; };      // coupling of 128 -> 256 ([0]) and 256 -> 512 ([1]) super blocks (launch_couple_outer / _level)
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
+                    Launch b3s;       // B3 tiles of the fronts whose B1 tile is kind 6 (launched only when the apply kernel does not fuse them)
                     double asm_rows = 0, pull_rows = 0; };   // children's contribution rows landing in pivot blocks / in contribution rows of this level
 
 struct SparseTerm {
@@ -143,7 +144,8 @@ public:
 private:
     int device_;
     hipStream_t stream_ = nullptr;
-    bool streams_warm_ = false;           // analyze() touches every stream once (queue creation) beside the host-side analysis
+    bool streams_warm_ = false;
+    bool fuse_b3_ = true;                 // plan kind-6 tiles (FEASTHIP_FUSE_B3=0: never)           // analyze() touches every stream once (queue creation) beside the host-side analysis
     bool own_stream_ = false;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     std::vector<SparseTerm> terms_;

@@ -212,6 +212,13 @@ struct ApplyGeomT {
     const int* pull;     // mode 3: [output row][child slot] -> row of the children's contribution arena, or -1
     int npull;           // child slots per row
     const T* pullbase;   // children's contribution arena of this node
+    // kind 6 (B1 of a front whose pivot block fits one row tile, fused with its B3): after  y' = y - U12 x_I  the tile goes
+    // through LDS and is multiplied by the upper inverse D (p x p, leading dimension dld) in the same workgroup;  x = D y'  is
+    // written to xout (row + orow_shift).  Kernels without the fusion treat the tile as kind 3 and run the B3 tiles separately.
+    int fuse;
+    const T* D;
+    int dld, dp;
+    T* xout;
 };
 typedef ApplyGeomT<cz> ApplyGeom;
 
@@ -228,6 +235,7 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
     T* Wk = W + (int64_t)k * ws;
     T* Yk = Y + (int64_t)k * ws;
     g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0; g.pull = nullptr; g.npull = 0; g.pullbase = nullptr;
+    g.fuse = 0; g.D = nullptr; g.dld = 0; g.dp = 0; g.xout = nullptr;
     g.sidx = struct_idx + f.sptr;
     g.out = Yk; g.orow_shift = f.c0;
     const int NB = f.nb;         // diagonal super-block size of this front's solve-ready form (128, 256 or 512)
@@ -239,8 +247,9 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
     else if (kind == 2) {   // unit lower inverse: row tile c only needs the columns left of its last row
         g.k0 = t.b * NB; int b = min(NB, p - g.k0); g.rbase = g.k0 + t.c * th; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = min(b, t.c * th + th); g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1;
     }
-    else if (kind == 3) {
+    else if (kind == 3 || kind == 6) {
         g.rbase = t.b * th; g.rend = p; g.A = fact + (int64_t)k * fs + f.f12; g.lda = p; g.Kd = u; g.Vk = Wk;
+        if (kind == 6) { g.fuse = 1; g.D = Lp; g.dld = ld; g.dp = p; g.xout = Wk; }
         if (nsplit > 0) {   // split-K part t.c: partial product into the scratch slab (part, row), reduced afterwards
             int Kp = (((u + nsplit - 1) / nsplit) + 31) & ~31;
             int kbeg = t.c * Kp;
@@ -519,13 +528,15 @@ template <> struct A2<cf> {
 };
 
 template <typename T, bool GATHER, int NS>
-__device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int ldw) {
+__device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int ldw, T* Ys = nullptr) {
     typedef typename A2<T>::real real;
     typedef typename A2<T>::acc acc;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wave = tid >> 6;
     const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
-    if (g.rbase + slab * 16 >= g.rend || cg + ct0 * 16 >= ldw) return;   // nothing to do for this wave (no barriers: it may leave)
+    const bool fused = GATHER && g.fuse != 0;                       // kind 6: the tile ends with a barrier, so every wave stays (its rows
+                                                                    // and columns are clamped and masked like any ragged tile's)
+    if (!fused && (g.rbase + slab * 16 >= g.rend || cg + ct0 * 16 >= ldw)) return;   // nothing to do for this wave (no barriers: it may leave)
     const int arow = g.rbase + slab * 16 + li;
     const bool aok = arow < g.rend;
     const bool aok_all = g.rbase + slab * 16 + 16 <= g.rend;        // wave-uniform: the whole slab has rows
@@ -733,6 +744,19 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
             if (g.mode == 1 || g.mode == 2) { o[q].x = sgn * cr; o[q].y = sgn * ci; }
             else { o[q].x = old[r][q].x - cr; o[q].y = old[r][q].y - ci; }
         }
+        if constexpr (GATHER) {
+            if (fused) {     // y' goes to LDS (rows beyond the pivot block as zeros: the second product runs over whole k-steps)
+                T* yr = Ys + (slab * 16 + A2<T>::drow(lk, r)) * LDS_COLS;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const int lc = PAIR ? (ct0 + (q & ~1)) * 16 + 2 * li + (q & 1) : (ct0 + q) * 16 + li;
+                    T v = o[q];
+                    if (!rok[r]) { v.x = 0; v.y = 0; }
+                    yr[lc] = v;
+                }
+                continue;
+            }
+        }
         if constexpr (PAIR) {
 #pragma unroll
             for (int q = 0; q < NS; q += 2) {
@@ -744,6 +768,55 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
             for (int q = 0; q < NS; ++q) {
                 const int col = cg + (ct0 + q) * 16 + li;
                 if (rok[r] && col < ldw) dptr[r][col] = o[q];
+            }
+        }
+    }
+    if constexpr (GATHER) {
+        if (!fused) return;
+        // ---- x = D y' : the upper inverse of the pivot block times the tile just computed (the B3 step of this front), same
+        // k order and 3M products as the kind-5 tile it replaces
+        __syncthreads();
+        const int p2 = g.dp, nk2 = (p2 + 3) >> 2;
+        const int r2 = slab * 16 + li;
+        const T* Dp = g.D + min(r2, p2 - 1);
+        acc u1[NS], u2[NS], u3[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { u1[q] = (acc){0, 0, 0, 0}; u2[q] = (acc){0, 0, 0, 0}; u3[q] = (acc){0, 0, 0, 0}; }
+        constexpr int MAXK2 = 4 * NS;                    // k-steps of a pivot block of at most 16 NS rows
+        T dreg[MAXK2];
+#pragma unroll
+        for (int s2 = 0; s2 < MAXK2; ++s2) dreg[s2] = Dp[(int64_t)min(4 * s2 + lk, p2 - 1) * g.dld];
+#pragma unroll
+        for (int s2 = 0; s2 < MAXK2; ++s2) {
+            if (s2 < nk2) {
+                const int gk = 4 * s2 + lk;
+                const bool keep = r2 < p2 && gk < p2 && gk >= r2;
+                T a = dreg[s2];
+                a.x = keep ? a.x : (real)0;
+                a.y = keep ? a.y : (real)0;
+                const real as = a.x + a.y;
+                const T* yk = Ys + gk * LDS_COLS;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const int lc = PAIR ? (ct0 + (q & ~1)) * 16 + 2 * li + (q & 1) : (ct0 + q) * 16 + li;
+                    const T v = yk[lc];
+                    u1[q] = A2<T>::mfma(a.x, v.x, u1[q]);
+                    u2[q] = A2<T>::mfma(a.y, v.y, u2[q]);
+                    u3[q] = A2<T>::mfma(as, v.x + v.y, u3[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int xr = slab * 16 + A2<T>::drow(lk, r);
+            if (xr >= p2) continue;
+            T* xrow = g.xout + (int64_t)(xr + g.orow_shift) * ldw;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int col = cg + (PAIR ? (ct0 + (q & ~1)) * 16 + 2 * li + (q & 1) : (ct0 + q) * 16 + li);
+                T v;
+                v.x = u1[q][r] - u2[q][r]; v.y = u3[q][r] - u1[q][r] - u2[q][r];
+                if (col < ldw) xrow[col] = v;
             }
         }
     }
@@ -760,9 +833,10 @@ __global__ __launch_bounds__(256, NSMAX == 4 ? 2 : 3) void k_apply2(const FrontD
     FrontD f = fr[t.f];
     ApplyGeomT<T> g;
     int trows = decode_tile<T>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
-    if (trows <= 16) apply2_body<T, GATHER, 1>(g, cg, ldw);
-    else if (NSMAX == 2 || trows <= 32) apply2_body<T, GATHER, 2>(g, cg, ldw);
-    else if (NSMAX == 4) apply2_body<T, GATHER, 4>(g, cg, ldw);
+    __shared__ T Ys[GATHER ? 16 * NSMAX * LDS_COLS : 1];     // the y' tile of a fused B1 + B3 tile (kind 6)
+    if (trows <= 16) apply2_body<T, GATHER, 1>(g, cg, ldw, Ys);
+    else if (NSMAX == 2 || trows <= 32) apply2_body<T, GATHER, 2>(g, cg, ldw, Ys);
+    else if (NSMAX == 4) apply2_body<T, GATHER, 4>(g, cg, ldw, Ys);
 }
 
 static int g_apply2 = -1;
@@ -771,6 +845,7 @@ static int apply2_enabled() {
     return g_apply2;
 }
 void select_apply_kernel(int barrier_free) { g_apply2 = barrier_free ? 1 : 0; }
+int apply_kernel_fuses_b3() { return apply2_enabled(); }      // kind-6 tiles end with their B3 product only in k_apply2
 
 template <typename T>
 static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const T* fact, int64_t fs,
