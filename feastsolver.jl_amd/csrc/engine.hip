@@ -547,7 +547,9 @@ bool Engine::build_plans() {
         });
         V.b1.off = (int64_t)tiles.size();
         int sl3 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
-        if (fuse_b3_ && sl3 == 2) sl3 = 4;      // 64-row tiles: the long K loop of the gather does not mind, and fronts of up to 64 pivot columns fuse their B3
+        // 64-row tiles where 32 rows were only chosen for the short K loops of small fronts (the gather's K loop is long): fronts of up
+        // to 64 pivot columns then fuse their B3.  With few nodes per GPU the smaller tiles' extra workgroups are worth more.
+        if (fuse_b3_ && sl3 == 2 && pmax <= short_k_max_p_ && nodes_local() >= 12) sl3 = 4;
         {   // few, long tiles (top of the tree): split the K = u loop over several workgroups
             int64_t wgs = 0; int umax = 0;
             for (int s : lv) if (S.u(s) > 0) { wgs += cdiv(S.p(s), 64); umax = std::max(umax, S.u(s)); }
