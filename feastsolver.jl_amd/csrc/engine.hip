@@ -605,7 +605,7 @@ bool Engine::build_plans() {
                 int p = S.p(s), NB = solve_nb(s);
                 for (int t = 0; t < cdiv(p, NB); ++t)
                     for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * sl5); ++rt) tiles.push_back({s, 5 | (sl5 << 8), t, rt});
-                L.bytes += 0.5 * p * std::min(p, NB) * 16.0; L.flops += 0.5 * p * std::min(p, NB);
+                L.bytes += 0.5 * p * std::min(p, NB) * 16.0; L.flops += 0.5 * p * std::min(p, NB); L.vrows += 2.0 * p;
             }
             L.count = (int)(tiles.size() - L.off);
         }
