@@ -9,40 +9,93 @@ nnz = 1,786,456), B = diag(U(0.5,1.5)), circular contour with 16 trapezoid
 nodes, m0 = 64 -- the configuration the metric is quoted on (it fits one GPU).
 One *step* = one FEAST iteration with store=true semantics (src/feast.jl:40-73):
 Rayleigh-Ritz block + 16 shifted block solves + moment accumulation (+ the RCCL
-sum of Q when N > 1).  Ordering, symbolic analysis and the 16 numeric
+sum of Q when N > 1).  Ordering, symbolic analysis and the numeric
 factorisations are setup and reported separately.  For N > 1 the contour nodes
-are sharded over ranks (one process per GPU, launched by torch.distributed.run)
-and the partial moments are summed with one all-reduce per iteration; total work
-is fixed, so scaling is "strong".
+are sharded over ranks (one process per GPU) and the partial moments are summed
+with one all-reduce per iteration; total work is fixed, so scaling is "strong".
+
+Ranks: under torch.distributed.run (RANK / WORLD_SIZE in the environment) this
+process IS one rank.  Started plainly with --gpus N > 1 it starts the N rank
+processes itself (children created before anything here touches the GPU) and
+exits non-zero unless all N joined the process group.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_STREAM_GBS = 6290.0      # same guide: measured float4 copy
 F64_MFMA_PEAK_TF = 78.6      # spec; 77.2 measured (profiles/r01_probe_gfx950.log)
 
 
-def cpu_baseline(pkg, wl, fo, args):
-    """Oracle (numpy/scipy restatement of the reference loop) timed on the host cores of
-    this box on a bounded sample: the same operator family on a 24^3 grid, ONE contour node
-    factorised and solved (the reference's per-node body, src/feast.jl:59-71), the
-    Rayleigh-Ritz block once; iteration time = 16 x node + RR."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=46)
+    ap.add_argument("--stencil", type=int, default=19)
+    ap.add_argument("--m0", type=int, default=64)
+    ap.add_argument("--nodes", type=int, default=16)
+    ap.add_argument("--cpu-baseline", choices=["auto", "off", "full"], default="auto",
+                    help="auto: bounded 24^3 sample of the same pencil family (about 20 s of host work); full: additionally the "
+                         "metric's own 46^3 configuration (minutes; writes profiles/r03_cpu_baseline_c3_g46.json when --record)")
+    ap.add_argument("--cpu-grid", type=int, default=24)
+    ap.add_argument("--record", action="store_true", help="with --cpu-baseline full: write the measured line under profiles/")
+    ap.add_argument("--no-fold", action="store_true",
+                    help="factorise every contour node separately (the conjugate fold of real pencils off): the reference's literal schedule")
+    ap.add_argument("--mixed-prec", action="store_true",
+                    help="secondary measurement: complex64 shifted solves with complex128 accumulation (feast!'s mixed_prec); not the headline number")
+    ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
+                    help="auto: nccl (= RCCL) when every rank has its own GPU, gloo when ranks have to share one (single-GPU rehearsal)")
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce of the whole moment after the contour step instead of column chunks under its tail")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks as child processes.  Nothing in this parent has touched HIP or
+    torch.cuda (torch is not even imported), so the children are ordinary fresh processes, not execs of a GPU process."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FEASTHIP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        sys.exit(1)
+    line = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != args.gpus:
+        print(f"bench.py: fewer than {args.gpus} ranks joined the process group", file=sys.stderr)
+        sys.exit(1)
+
+
+def cpu_node_body(fo, w, grid_desc):
+    """The reference's per-node body (src/feast.jl:134-148) + its Rayleigh-Ritz block (:116-127) through the oracle, timed
+    on this host: ONE node factorised (SuperLU, serial like the reference's UMFPACK) and block-solved for the m0 columns."""
+    import numpy as np
     import scipy.sparse as sp
-    g = args.cpu_grid
-    w = wl.c3_sparse_generalized(g, args.stencil, 64)
     A = sp.csc_matrix(w["A"], dtype=np.complex128)
     B = sp.csc_matrix(w["B"], dtype=np.complex128)
     con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
-    n, m0 = A.shape[0], 64
+    n, m0 = A.shape[0], w["X0"].shape[1]
     X = w["X0"].copy()
     t0 = time.perf_counter()
     Q, _ = np.linalg.qr(X, mode="reduced")
@@ -52,7 +105,7 @@ def cpu_baseline(pkg, wl, fo, args):
     lam, Xq = fo._sorted_eig(Aq, Bq)
     Xr = Q @ Xq
     fo.update_R(Xr, R, lam, A, B)
-    res = fo.residuals_linear(R)
+    fo.residuals_linear(R)
     t_rr = time.perf_counter() - t0
     t0 = time.perf_counter()
     F = fo.lu(A - B * con.nodes[0])
@@ -62,7 +115,27 @@ def cpu_baseline(pkg, wl, fo, args):
     fo.ldiv(temp, F, R)
     temp = (Xr - temp) * ((1.0 / (con.nodes[0] - lam)) * con.weights[0])[None, :]
     t_node = time.perf_counter() - t0
-    it_s = 1.0 / (16 * t_node + t_rr)
+    return {"n": n, "t_rr_s": t_rr, "t_factor_node_s": t_fact, "t_solve_node_s": t_node,
+            "iterations_per_s": 1.0 / (16 * t_node + t_rr), "store_false_iterations_per_s": 1.0 / (16 * (t_node + t_fact) + t_rr),
+            "grid": grid_desc}
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        return None
+
+
+def cpu_baseline(pkg, wl, fo, args):
+    """Oracle (numpy/scipy restatement of the reference loop) timed on the host cores of this box on a bounded sample: the
+    same operator family on a 24^3 grid, ONE contour node factorised and solved, the Rayleigh-Ritz block once; iteration
+    time = 16 x node + RR.  The metric's own 46^3 configuration takes minutes per node: it is measured once with
+    --cpu-baseline full --record and read back from profiles/ (metric_config_value)."""
+    g = args.cpu_grid
+    w = wl.c3_sparse_generalized(g, args.stencil, 64)
+    s = cpu_node_body(fo, w, f"{g}^3")
     # the HIP path on the very same sample, for an apples-to-apples ratio
     h = pkg.FeastHandle(0)
     h.set_terms([w["A"], w["B"]], [1.0, -1.0])
@@ -76,47 +149,150 @@ def cpu_baseline(pkg, wl, fo, args):
     gpu_it_s = 5.0 / (time.perf_counter() - t0)
     st = h.stats()
     h.close()
-    return {
-        "value": it_s, "unit": "iterations/s", "cores": 1, "kind": "port",
-        "sample": f"same pencil family on a {g}^3 grid (n={n}), 16 nodes, m0=64: one node factorised "
-                  f"(SuperLU, {t_fact:.2f} s, setup) and block-solved ({t_node:.3f} s), RR block once ({t_rr:.3f} s); "
-                  f"iteration = 16 x node + RR; SuperLU is serial like the reference's UMFPACK solves",
-        "host_cpus": os.cpu_count(), "store_false_value": 1.0 / (16 * (t_node + t_fact) + t_rr),
+    out = {
+        "value": s["iterations_per_s"], "unit": "iterations/s", "cores": 1, "blas_threads": blas_threads(), "kind": "port",
+        "sample": f"same pencil family on a {g}^3 grid (n={s['n']}), 16 nodes, m0=64: one node factorised "
+                  f"(SuperLU, {s['t_factor_node_s']:.2f} s, setup) and block-solved ({s['t_solve_node_s']:.3f} s), RR block once ({s['t_rr_s']:.3f} s); "
+                  f"iteration = 16 x node + RR; SuperLU is serial like the reference's UMFPACK solves (cores = 1: the node loop of "
+                  f"src/feast.jl:134-148 is serial; the dense RR products use blas_threads)",
+        "host_cpus": os.cpu_count(), "store_false_value": s["store_false_iterations_per_s"],
         "gpu_same_sample_value": gpu_it_s, "gpu_same_sample_factor_ms": st["factor_ms"],
+    }
+    rec = os.path.join(ROOT, "profiles", "r03_cpu_baseline_c3_g46.json")
+    if args.cpu_baseline == "full":
+        wf = wl.c3_sparse_generalized(args.grid, args.stencil, args.m0)
+        full = cpu_node_body(fo, wf, f"{args.grid}^3")
+        full.update(host_cpus=os.cpu_count(), blas_threads=blas_threads(), cores=1, kind="port",
+                    workload=f"C3 {args.stencil}-point {args.grid}^3, 16 nodes, m0={args.m0}: one node measured, iteration = 16 x node + RR")
+        out["metric_config_value"] = full["iterations_per_s"]
+        out["metric_config"] = full
+        out["metric_config_source"] = "measured in this run"
+        if args.record:
+            json.dump(full, open(rec, "w"), indent=1)
+    elif os.path.exists(rec) and args.grid == 46 and args.stencil == 19:
+        full = json.load(open(rec))
+        out["metric_config_value"] = full["iterations_per_s"]
+        out["metric_config_store_false_value"] = full["store_false_iterations_per_s"]
+        out["metric_config_source"] = "profiles/r03_cpu_baseline_c3_g46.json (bench.py --cpu-baseline full --record, same pool; " \
+                                      f"one node: factor {full['t_factor_node_s']:.1f} s, 64-column solve {full['t_solve_node_s']:.2f} s; {full.get('host_cpus')} host cpus)"
+    return out
+
+
+def roofline(args, st, st2, prof, detail, levels, world):
+    """SURVEY 8(d) accounting for the dominant kernel (k_apply2, every launch of one contour step):
+    bytes = sum over the nodes of this rank [(nnz_L + nnz_U) * 20 + 2 (n + 1) * 4 + 4 n m0 16],
+    flops = 8 (nnz_L + nnz_U) m0 per node, time = sum of the HIP-event durations of those launches."""
+    import numpy as np
+    n, m0 = st["n"], args.m0
+    es = 0.5 if args.mixed_prec else 1.0
+    nodes = st["local_nodes"]
+    nnz = st["nnz_l"] + st["nnz_u"]
+    node_bytes = (nnz * (16 * es + 4) + 2 * (n + 1) * 4 + 4 * n * m0 * 16 * es)
+    step_bytes = node_bytes * nodes
+    step_flops = 8.0 * nnz * m0 * nodes
+    pa = prof["panel_apply"]
+    t = pa["ms"] * 1e-3
+    peak_tf = F64_MFMA_PEAK_TF * (2.0 if args.mixed_prec else 1.0)
+    tf = step_flops / t / 1e12
+    gbs = step_bytes / t / 1e9
+    traffic = tsrc = None
+    for nm in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", nm)
+        if os.path.exists(tpath) and args.grid == 46 and args.stencil == 19 and world == 1 and not args.mixed_prec and not args.no_fold:
+            per_step = json.load(open(tpath)).get("traffic_bytes_per_contour_step")
+            if per_step:
+                traffic = per_step / max(1, pa["launches"])
+                tsrc = f"profiles/{nm}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command on an earlier run " \
+                       "(FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact), per contour step / launches_per_step; not a live counter"
+                break
+    # regimes: tree levels whose widest pivot block is at most 96 columns (32-row tiles; HBM side: block-vector rows) vs the levels above
+    ap = detail[detail[:, 0] == 3]
+    split = len(levels)
+    for d in range(len(levels)):
+        if levels[d, 4] <= 96:
+            split = d
+            break
+    reg = {}
+    for name, sel, lv in (("top_levels", ap[:, 5] < split, levels[:split]), ("small_front_levels", ap[:, 5] >= split, levels[split:])):
+        ms = float(ap[sel, 1].sum())
+        nz, sp = float(lv[:, 3].sum()), float(lv[:, 1].sum())
+        b = (nz * (16 * es + 4) + 4 * sp * m0 * 16 * es) * nodes
+        f = 8.0 * nz * m0 * nodes
+        reg[name] = {"depths": [0, split - 1] if name == "top_levels" else [split, len(levels) - 1], "launches": int(sel.sum()), "ms": ms,
+                     "algorithmic_GB": b / 1e9, "GBps": b / ms / 1e6 if ms > 0 else None, "hbm_frac": b / ms / 1e6 / HBM_PEAK_GBS if ms > 0 else None,
+                     "TFLOPs": f / ms / 1e9 if ms > 0 else None, "mfma_frac": f / ms / 1e9 / peak_tf if ms > 0 else None}
+    proj_flops = 8.0 * n * m0 * m0
+    proj = {"kernel": "k_gram_partial + k_gram_reduce (Aq = Q'(AQ), src/feast.jl:43,118)", "ms": st2["proj_ms"], "flops": proj_flops,
+            "TFLOPs": proj_flops / (st2["proj_ms"] * 1e-3) / 1e12 if st2["proj_ms"] > 0 else None,
+            "frac": proj_flops / (st2["proj_ms"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TF if st2["proj_ms"] > 0 else None,
+            "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "bytes": 2.0 * n * m0 * 16,
+            "GBps": 2.0 * n * m0 * 16 / (st2["proj_ms"] * 1e-3) / 1e9 if st2["proj_ms"] > 0 else None}
+    return {
+        "kernel": "k_apply2 (supernodal block forward/back substitution, all tile kinds; %d launches per contour step)" % pa["launches"],
+        "bound": "mfma", "mfma_dtype": "f32" if args.mixed_prec else "f64",
+        "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "frac_executed_3M": 0.75 * tf / peak_tf,
+        "flops_per_step": step_flops, "kernel_ms_per_step": pa["ms"], "launches_per_step": pa["launches"], "avg_launch_ms": pa["ms"] / max(1, pa["launches"]),
+        "traffic": traffic, "traffic_source": tsrc,
+        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_algorithmic": gbs / HBM_PEAK_GBS,
+                "frac_of_measured_stream_rate": gbs / HBM_STREAM_GBS,
+                "algorithmic_bytes_per_step": step_bytes, "algorithmic_bytes_per_launch": step_bytes / max(1, pa["launches"]),
+                "frac_counter_traffic": (traffic * pa["launches"] / t / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "traffic_over_algorithmic": (traffic * pa["launches"] / step_bytes) if traffic else None},
+        "accounting": "SURVEY 8(d): per node (nnz_L+nnz_U)*20 + 2(n+1)*4 + 4*n*m0*16 bytes and 8*(nnz_L+nnz_U)*m0 flops, times the nodes of this rank "
+                      "(config.nnz_L, nnz_U, n, m0, nodes_per_gpu), over the HIP-event time of all k_apply2 launches of one contour step; "
+                      "m0=64 complex f64 is 25.6 flop/B on those bytes, above the 78.6 TF / 8 TB/s balance of 9.8: the f64 matrix cores bind first",
+        "regimes": reg,
+        "projection": proj,
+        "contour_step": {"ms": st2["solve_ms"], "algorithmic_GB_8d_with_epilogue": (step_bytes + 3 * n * m0 * 16) / 1e9,
+                         "GBps": (step_bytes + 3 * n * m0 * 16) / (st2["solve_ms"] * 1e-3) / 1e9,
+                         "TFLOPs": (step_flops + 16.0 * n * m0 * nodes) / (st2["solve_ms"] * 1e-3) / 1e12,
+                         "builder_model_GB": st2["solve_bytes"] / 1e9, "builder_streamed_model_GB": st2["solve_bytes_streamed"] / 1e9},
+        "kernel_classes_ms": {k: v["ms"] for k, v in prof.items()},
     }
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--grid", type=int, default=46)
-    ap.add_argument("--stencil", type=int, default=19)
-    ap.add_argument("--m0", type=int, default=64)
-    ap.add_argument("--nodes", type=int, default=16)
-    ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
-    ap.add_argument("--cpu-grid", type=int, default=24)
-    ap.add_argument("--no-fold", action="store_true",
-                    help="factorise every contour node separately (the conjugate fold of real pencils off): the reference's literal schedule")
-    ap.add_argument("--mixed-prec", action="store_true",
-                    help="secondary measurement: complex64 shifted solves with complex128 accumulation (feast!'s mixed_prec); not the headline number")
-    args = ap.parse_args()
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        self_launch(args)
+        return
 
+    import numpy as np
+    import __graft_entry__ as graft
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch  # first: libfeasthip.so then shares torch's HIP runtime (same SONAME)
     dist = None
     use_dist = world > 1 or os.environ.get("FEASTHIP_FORCE_DIST") == "1"    # the flag rehearses the RCCL path on one GPU
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    backend = args.backend
+    if backend == "auto":
+        backend = "nccl" if ndev >= world else "gloo"
+    device = local_rank % ndev
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            if rank == 0:
+                print(f"bench.py: {world} ranks share {ndev} GPU(s): moments are summed through gloo on the host (rehearsal, not a scaling number)", file=sys.stderr)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        world = dist.get_world_size()
+        if world != args.gpus and os.environ.get("FEASTHIP_FORCE_DIST") != "1":
+            if rank == 0:
+                print(f"bench.py: --gpus {args.gpus} but {world} ranks joined the process group", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
+    elif args.gpus != 1:
+        print(f"bench.py: --gpus {args.gpus} but this process is a single rank", file=sys.stderr)
+        sys.exit(3)
 
     pkg = graft.load_package()
     import importlib
@@ -125,7 +301,7 @@ def main():
     n = w["A"].shape[0]
     con = pkg.circular_contour_trapezoidal(w["c"], w["r"], args.nodes)
 
-    h = pkg.FeastHandle(local_rank)
+    h = pkg.FeastHandle(device)
     h.set_terms([w["A"], w["B"]], [1.0, -1.0])
     h.set_contour(con)
     h.set_node_shard(rank, world)
@@ -135,9 +311,12 @@ def main():
         h.set_precision(True)
     ldw = ((args.m0 + 15) // 16) * 16
     qbuf = None
+    reducer = None
     if use_dist:
-        qbuf = torch.zeros(2 * n * ldw * 2, dtype=torch.float64, device=f"cuda:{local_rank}")
+        qbuf = torch.zeros(2 * n * ldw * 2, dtype=torch.float64, device=f"cuda:{device}")
         h.set_q_buffer(qbuf.data_ptr(), qbuf.numel() * 8)
+        dmod = importlib.import_module(graft.PKG_NAME + ".distributed")
+        reducer = dmod.MomentReducer(h, qbuf, n, ldw, overlap=not args.no_overlap)
     t0 = time.perf_counter()
     h.analyze()
     t_analyze = time.perf_counter() - t0
@@ -155,11 +334,11 @@ def main():
             conv["at"] = conv["count"]
         conv["count"] += 1
         t1 = time.perf_counter()
-        h.contour_step()
-        t2 = time.perf_counter()
-        if use_dist:
-            dist.all_reduce(qbuf[: n * ldw * 2])
-            torch.cuda.synchronize()
+        if reducer is not None:
+            t2 = reducer.contour_step_and_reduce()        # returns when this rank's sweep has finished; the sum when it returns
+        else:
+            h.contour_step()
+            t2 = time.perf_counter()
         t3 = time.perf_counter()
         phase["rr"] += t1 - t0; phase["contour"] += t2 - t1; phase["allreduce"] += t3 - t2
         return lam, res, ins
@@ -179,7 +358,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     lam, res, ins = h.rr_step()
@@ -187,15 +366,8 @@ def main():
     prof = h.profile_solve() if rank == 0 else None
 
     if rank == 0:
-        pa = prof["panel_apply"]
-        traffic = None          # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/)
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(tpath) and args.grid == 46 and args.stencil == 19 and world == 1:
-            # the PMC run uses two streams (twice the launches of the single-stream profiling sweep): normalise per step
-            per_step = json.load(open(tpath)).get("traffic_bytes_per_contour_step")
-            traffic = per_step / max(1, pa["launches"]) if per_step else None
-        dom_gbs = pa["bytes"] / (pa["ms"] * 1e-3) / 1e9
-        dom_tf = pa["flops"] / (pa["ms"] * 1e-3) / 1e12
+        detail = h.last_profile_detail
+        levels = h.level_table()       # per tree depth: fronts, pivot columns, update rows, factor entries, widest pivot block
         out = {
             "metric": "FEAST iterations/sec (16 contour nodes, m0=64)",
             "value": args.steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,19 +379,10 @@ def main():
                 "n": n, "nnz_A": int(w["A"].nnz), "nodes": args.nodes, "m0": args.m0, "nodes_per_gpu": st["local_nodes"],
                 "conjugate_fold": bool(st["folded"]), "factorisations_per_gpu": st["factor_units"],
                 "nnz_L": st["nnz_l"], "nnz_U": st["nnz_u"], "supernodes": st["nsuper"], "max_front": st["max_front"],
+                "backend": (backend if use_dist else None), "allreduce_overlap": bool(reducer is not None and reducer.overlap),
+                "symmetric_factorisation": bool(st.get("symmetric", 0)),
             },
-            "roofline": {
-                "kernel": "k_apply (supernodal block forward/back substitution, all kinds)",
-                "bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": pa["bytes"] / max(1, pa["launches"]),
-                "launches_per_step": pa["launches"], "avg_launch_ms": pa["ms"] / max(1, pa["launches"]),
-                "f64_mfma": {"achieved": dom_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": dom_tf / F64_MFMA_PEAK_TF,
-                             "note": "m0=64 complex f64 is 32 flop/B (24 with the 3M product): the f64 matrix cores bind before HBM (ceiling 3.2 TB/s of factor bytes); achieved counts 8 flops per complex multiply-add"},
-                "contour_step": {"ms": st2["solve_ms"], "algorithmic_GB": st2["solve_bytes"] / 1e9, "streamed_GB_model": st2["solve_bytes_streamed"] / 1e9,
-                                 "GBps": st2["solve_bytes"] / (st2["solve_ms"] * 1e-3) / 1e9,
-                                 "TFLOPs": st2["solve_flops"] / (st2["solve_ms"] * 1e-3) / 1e12},
-                "kernel_classes_ms": {k: v["ms"] for k, v in prof.items()},
-            },
+            "roofline": roofline(args, st, st2, prof, detail, levels, world),
             "breakdown_ms_per_step": {k: 1e3 * v / args.steps for k, v in phase.items()},      # rank 0; rr is replicated, contour is this rank's node shard
             # analyze_s: ordering + symbolic analysis + plan upload; alloc_s: hipMalloc of the arenas (0.03 .. 2 s for the same
             # request depending on what the previous process left to scrub) -- reported separately, both count in time_to_solution_s
@@ -233,10 +396,11 @@ def main():
                        "time_to_solution_s": (t_analyze + st["factor_ms"] * 1e-3 + conv["at"] * dt / args.steps) if conv["at"] is not None else None,
                        "eigenpairs_per_s": (float(ins.sum()) / (t_analyze + st["factor_ms"] * 1e-3 + conv["at"] * dt / args.steps)) if conv["at"] is not None else None},
         }
-        if world == 1 and args.cpu_baseline == "auto":
+        if world == 1 and args.cpu_baseline != "off":
             h.close()
             out["cpu_baseline"] = cpu_baseline(pkg, wl, graft.load_oracle(), args)
         print(json.dumps(out))
+        sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -22,7 +22,7 @@ class Stats(C.Structure):
         ("solve_ms", C.c_double), ("rr_ms", C.c_double), ("solve_bytes", C.c_double), ("solve_flops", C.c_double),
         ("perturbed_pivots", C.c_int64), ("local_nodes", C.c_int32), ("m0", C.c_int32), ("ldw", C.c_int32),
         ("dense", C.c_int32), ("alloc_seconds", C.c_double),
-        ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double),
+        ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double), ("proj_ms", C.c_double),
     ]
 
 
@@ -48,7 +48,11 @@ PROTOTYPES = {
     "feasthip_get_x": (I, [VP, VP]),
     "feasthip_get_block": (I, [VP, I, VP]),
     "feasthip_rr_step": (I, [VP, VP, VP, VP]),
+    "feasthip_set_rr_only": (I, [VP, I]),
     "feasthip_contour_step": (I, [VP, I]),
+    "feasthip_contour_step_begin": (I, [VP, I, I]),
+    "feasthip_moment_chunk_wait": (I, [VP, I, C.POINTER(I64), C.POINTER(I64)]),
+    "feasthip_contour_step_end": (I, [VP]),
     "feasthip_nl_contour_step": (I, [VP, I]),
     "feasthip_nl_rr_step": (I, [VP, VP, VP, VP]),
     "feasthip_nl_orthonormalize_x": (I, [VP]),
@@ -81,6 +85,7 @@ PROTOTYPES = {
     "feasthip_get_stats": (I, [VP, C.POINTER(Stats)]),
     "feasthip_profile_solve": (I, [VP, VP]),
     "feasthip_profile_detail": (I, [VP, VP, I]),
+    "feasthip_level_table": (I, [VP, VP, I]),
     "feasthip_mm_last_error": (C.c_char_p, []),
     "feasthip_mm_info": (I, [C.c_char_p, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I)]),
     "feasthip_mm_read_csc": (I, [C.c_char_p, VP, VP, VP, I64]),

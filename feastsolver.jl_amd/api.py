@@ -264,6 +264,22 @@ class FeastHandle:
     def contour_step(self, refactor=False):
         return self._ck(self.lib.feasthip_contour_step(self.h, 1 if refactor else 0))
 
+    def set_rr_only(self, on=True):
+        self._ck(self.lib.feasthip_set_rr_only(self.h, 1 if on else 0))
+
+    def contour_step_begin(self, refactor=False, nchunks=1):
+        """feasthip_contour_step_begin: the step enqueued, the moment produced in `nchunks` row ranges (multi-GPU driver)."""
+        return self._ck(self.lib.feasthip_contour_step_begin(self.h, 1 if refactor else 0, int(nchunks)))
+
+    def moment_chunk_wait(self, c):
+        """Blocks until row range `c` of the moment is final; returns (row0, rows)."""
+        r0, rows = C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.feasthip_moment_chunk_wait(self.h, int(c), C.byref(r0), C.byref(rows)))
+        return r0.value, rows.value
+
+    def contour_step_end(self):
+        return self._ck(self.lib.feasthip_contour_step_end(self.h))
+
     def nl_orthonormalize_x(self):
         self._ck(self.lib.feasthip_nl_orthonormalize_x(self.h))
 
@@ -323,10 +339,16 @@ class FeastHandle:
         self._ck(self.lib.feasthip_get_stats(self.h, C.byref(s)))
         return {name: getattr(s, name) for name, _ in _lib.Stats._fields_}
 
+    def level_table(self):
+        """Per elimination-tree depth (root = 0): fronts, pivot columns, update rows, factor entries, widest pivot block."""
+        t = np.zeros((256, 5))
+        nl = self.lib.feasthip_level_table(self.h, _vp(t), 256)
+        return t[:max(0, min(nl, 256))]
+
     def profile_solve(self):
         out = np.zeros((8, 4))
         self._ck(self.lib.feasthip_profile_solve(self.h, _vp(out)))
-        det = np.zeros((4096, 5))
+        det = np.zeros((4096, 6))        # class, ms, bytes, flops, tiles, tree depth
         nd = self.lib.feasthip_profile_detail(self.h, _vp(det), 4096)
         self.last_profile_detail = det[:max(0, min(nd, 4096))]
         names = ["gather_rhs", "fwd_assemble", "diag_solve", "panel_apply", "accumulate"]
@@ -352,8 +374,11 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     ``conjugate_fold=False`` factorises every contour node separately like the reference even when the matrices are real
     and the contour is mirror-symmetric (FeastHandle.set_conjugate_fold).
 
-    ``factorizer``/``left_divider`` are accepted for signature parity; the built-in
-    GPU LU (the ``lu``/``ldiv`` of this module) is what runs.  ``info`` (a dict) receives
+    ``factorizer``/``left_divider`` (src/feast.jl:5,11,84,90): left at their defaults (None, or this module's ``lu`` /
+    ``ldiv``) the whole loop runs inside the library (batched factorisation of all nodes, fused sweeps).  Anything else is
+    honoured the way the reference does: the node loop (src/feast.jl:59-71 / 134-148) then runs on the host through
+    ``F = factorizer(ZmA)``, ``left_divider(temp, F, R)``, ``finalize(F)`` -- exactly the calls, order and arguments of the
+    reference -- while the Rayleigh-Ritz half stays on the GPU (``_gen_feast_plugin``).  ``info`` (a dict) receives
     iteration count, library statistics and the static-pivot warning count."""
     if A.shape[0] != A.shape[1]:
         raise ValueError("Incorrect dimensions of A, must be square")
@@ -362,6 +387,13 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     if contour is None:
         contour = circular_contour_trapezoidal(c, r, nodes)
     X_in, Xw = _inplace_target(X)
+    if (factorizer is not None and factorizer is not lu) or (left_divider is not None and left_divider is not ldiv):
+        lam, res, ins = _gen_feast_plugin(Xw, A, B, contour, iter, eps, debug, store, bool(_mixed_prec), factorizer or lu,
+                                          left_divider or ldiv, device, info)
+        _writeback(X_in, Xw)
+        if not ins.any():
+            print("no eigenvalues found in contour!")            # src/feast.jl:78
+        return lam[ins], Xw[:, ins], res[ins]
     h = FeastHandle(device)
     try:
         h.set_terms([A, B], scales=[1.0, -1.0])          # T(z) = A - z B
@@ -398,6 +430,71 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     if not ins.any():
         print("no eigenvalues found in contour!")                # src/feast.jl:78
     return lam[ins], Xw[:, ins], res[ins]
+
+
+def _gen_feast_plugin(Xw, A, B, contour, iter, eps, debug, store, mixed_prec, factorizer, left_divider, device, info):
+    """feast!/gen_feast! with a caller-supplied factorizer / left_divider: the reference's loop statement by statement
+    (src/feast.jl:19-76 / 98-152).  The shifted matrix is assembled on the host in the caller's matrix type (scipy sparse
+    stays sparse, arrays stay arrays; ComplexF32 when mixed_prec), every node goes through the plug-ins in the reference's
+    order (store: all factorisations first, :28-38; otherwise linsolve! = factor, solve, finalize per node and iteration,
+    src/utils.jl:175-179), Q is accumulated on the host; the Rayleigh-Ritz half (:41-50) is the library's rr_step."""
+    n, m0 = Xw.shape
+    ctype = np.complex64 if mixed_prec else np.complex128
+    z, w = np.asarray(contour.nodes, dtype=np.complex128), np.asarray(contour.weights, dtype=np.complex128)
+    K = len(z)
+    sparse = _issparse(A)
+    Ac = sp.csc_matrix(A, dtype=np.complex128) if sparse else np.asarray(A, dtype=np.complex128)
+    if B is None:
+        Bc = sp.identity(n, dtype=np.complex128, format="csc") if sparse else np.eye(n, dtype=np.complex128)
+    elif sparse:
+        Bc = sp.csc_matrix(B, dtype=np.complex128)
+    else:
+        Bc = np.asarray(B.toarray() if _issparse(B) else B, dtype=np.complex128)
+
+    def shifted(k):                                                   # ZmA .= (A - B*contour.nodes[i])   :29,35,65 / 105,111,141
+        M = Ac - Bc * z[k]
+        return sp.csc_matrix(M, dtype=ctype) if sparse else np.asfortranarray(M, dtype=ctype)
+
+    h = FeastHandle(device)
+    facts = []
+    try:
+        h.set_terms([A, B], scales=[1.0, -1.0])
+        h.set_contour(contour)
+        h.set_rr_only(True)
+        if store:
+            facts = [factorizer(shifted(k)) for k in range(K)]       # :28-38
+        temp = np.zeros((n, m0), dtype=ctype, order="F")
+        Q = Xw.copy(order="F")
+        nit = 0
+        for nit in range(iter + 1):                                   # :40
+            h.set_x(Q)                                                # Q into the handle; rr_step orthonormalises it   :41
+            lam, res, ins = h.rr_step()                               # :41-50
+            if debug:
+                ir = res[ins]
+                print(f"{nit:3d}: {int(ins.sum()):4d} ({int((ir < 1e-5).sum())})  {(ir.max() if ins.any() else float('nan')):.3e}")
+            if ins.any() and res[ins].max() < eps:                    # :53-56
+                break
+            if nit < iter:                                            # :57
+                Xh, R = h.get_block(0), h.get_block(1)
+                Q[...] = 0.0
+                for k in range(K):
+                    resolvent = 1.0 / (z[k] - lam)                    # :60
+                    if store:
+                        left_divider(temp, facts[k], R)               # :62
+                    else:                                             # linsolve!  src/utils.jl:175-179
+                        F = factorizer(shifted(k))
+                        left_divider(temp, F, R)
+                        finalize(F)
+                    Q += (Xh - temp) * (resolvent * w[k])[None, :]    # :68-70
+        Xw[...] = h.get_block(0)
+        if info is not None:
+            info.update(h.stats())
+            info.update(nit=nit, warn=0, lam_all=lam.copy(), res_all=res.copy(), inside=ins.copy(), plugin_seam=True)
+    finally:
+        for F in facts:                                               # foreach(finalize!, facts)   :74-76
+            finalize(F)
+        h.close()
+    return lam, res, ins
 
 
 def trim_memory():

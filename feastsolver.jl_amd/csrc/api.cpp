@@ -97,7 +97,11 @@ int feasthip_set_x(feasthip_handle_t h, const void* X, int64_t n, int m0) { GUAR
 int feasthip_get_x(feasthip_handle_t h, void* X) { GUARD(h) return h->e->get_block(0, X); ENDGUARD(h) }
 int feasthip_get_block(feasthip_handle_t h, int which, void* out) { GUARD(h) return h->e->get_block(which, out); ENDGUARD(h) }
 int feasthip_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside) { GUARD(h) return h->e->rr_step(lambda, res, inside); ENDGUARD(h) }
+int feasthip_set_rr_only(feasthip_handle_t h, int on) { GUARD(h) return h->e->set_rr_only(on); ENDGUARD(h) }
 int feasthip_contour_step(feasthip_handle_t h, int refactor) { GUARD(h) return h->e->contour_step(refactor); ENDGUARD(h) }
+int feasthip_contour_step_begin(feasthip_handle_t h, int refactor, int nchunks) { GUARD(h) return h->e->contour_step_begin(refactor, nchunks); ENDGUARD(h) }
+int feasthip_moment_chunk_wait(feasthip_handle_t h, int chunk, int64_t* row0, int64_t* rows) { GUARD(h) return h->e->moment_chunk_wait(chunk, row0, rows); ENDGUARD(h) }
+int feasthip_contour_step_end(feasthip_handle_t h) { GUARD(h) return h->e->contour_step_end(); ENDGUARD(h) }
 int feasthip_nl_contour_step(feasthip_handle_t h, int first) { GUARD(h) return h->e->nl_contour_step(first); ENDGUARD(h) }
 int feasthip_nl_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside) { GUARD(h) return h->e->nl_rr_step(lambda, res, inside); ENDGUARD(h) }
 int feasthip_nl_orthonormalize_x(feasthip_handle_t h) { GUARD(h) return h->e->nl_orthonormalize_x(); ENDGUARD(h) }
@@ -185,6 +189,7 @@ int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     o->solve_bytes = e->ldw ? e->solve_bytes() : 0; o->solve_flops = e->ldw ? e->solve_flops() : 0;
     o->perturbed_pivots = e->perturbed; o->local_nodes = e->nodes_local(); o->m0 = e->m0; o->ldw = e->ldw; o->dense = e->dense ? 1 : 0;
     o->factor_units = e->Kloc; o->folded = e->folded() ? 1 : 0; o->solve_bytes_streamed = e->ldw ? e->solve_bytes_streamed() : 0;
+    o->proj_ms = e->proj_ms;
     return 0;
     ENDGUARD(h)
 }
@@ -202,9 +207,22 @@ int feasthip_profile_solve(feasthip_handle_t h, double* out /* 8 rows x 4: ms, b
 
 int feasthip_profile_detail(feasthip_handle_t h, double* out, int cap) {
     GUARD(h)
-    int n = (int)(h->e->prof_detail.size() / 5);
-    if (out) for (int i = 0; i < n && i < cap; ++i) for (int j = 0; j < 5; ++j) out[5 * i + j] = h->e->prof_detail[5 * i + j];
+    int n = (int)(h->e->prof_detail.size() / 6);
+    if (out) for (int i = 0; i < n && i < cap; ++i) for (int j = 0; j < 6; ++j) out[6 * i + j] = h->e->prof_detail[6 * i + j];
     return n;
+    ENDGUARD(h)
+}
+
+int feasthip_level_table(feasthip_handle_t h, double* out, int cap) {
+    GUARD(h)
+    const Symbolic& S = h->e->S;
+    int nl = (int)S.levels.size();
+    if (out) for (int d = 0; d < nl && d < cap; ++d) {
+        double fronts = 0, sp = 0, su = 0, nz = 0, pmax = 0;
+        for (int s : S.levels[d]) { double p = S.p(s), u = S.u(s); fronts += 1; sp += p; su += u; nz += p * p + 2.0 * u * p; pmax = std::max(pmax, p); }
+        out[5 * d] = fronts; out[5 * d + 1] = sp; out[5 * d + 2] = su; out[5 * d + 3] = nz; out[5 * d + 4] = pmax;
+    }
+    return nl;
     ENDGUARD(h)
 }
 

@@ -106,6 +106,8 @@ Engine::Engine(int device) : device_(device) {
     own_stream_ = true;
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
+    (void)hipEventCreate(&ev_p0_);
+    (void)hipEventCreate(&ev_p1_);
     { void* q = nullptr; if (hipHostMalloc(&q, PIN_SLOTS * PIN_SLOT_BYTES, hipHostMallocDefault) == hipSuccess) pin_ = (char*)q; else (void)hipGetLastError(); }
     if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_GROUP")) group_panels_ = std::max(1, std::min(8, atoi(v)));
@@ -160,6 +162,7 @@ Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (hipStream_t s2 : aux_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipEvent_t e2 : ev_join_) (void)hipEventDestroy(e2);
+    for (hipEvent_t e2 : ev_chunk_) (void)hipEventDestroy(e2);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     for (hipEvent_t e3 : ev_la_) if (e3) (void)hipEventDestroy(e3);
     if (la_stream_) { (void)hipStreamSynchronize(la_stream_); (void)hipStreamDestroy(la_stream_); }
@@ -169,6 +172,8 @@ Engine::~Engine() {
     if (ev_fin_fork_) (void)hipEventDestroy(ev_fin_fork_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
+    if (ev_p0_) (void)hipEventDestroy(ev_p0_);
+    if (ev_p1_) (void)hipEventDestroy(ev_p1_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
     if (pin_) (void)hipHostFree(pin_);
 }
@@ -809,13 +814,13 @@ int Engine::analyze() {
               d_struct_.upload(S.struct_idx.empty() ? one.data() : S.struct_idx.data(), std::max<size_t>(1, S.struct_idx.size()), stream_) &&
               d_rel_.upload(S.rel.empty() ? one.data() : S.rel.data(), std::max<size_t>(1, S.rel.size()), stream_) &&
               d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
-              d_perm_.upload(S.perm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
+              d_perm_.upload(S.perm.data(), n, stream_) && d_iperm_.upload(S.iperm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
               d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_);
     if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
     for (int s = 0; s < S.nsuper; ++s) fr[s].sk_off = sk_off_[s];
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
-    dsym_.perm = d_perm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.n = n;
+    dsym_.perm = d_perm_.p; dsym_.iperm = d_iperm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.n = n;
     dsym_.asmflag = nullptr; dsym_.relfirst = nullptr;
     {
         // fused right-hand-side gather: pivot rows that receive contributions of children, and the first contribution to each
@@ -853,16 +858,46 @@ int Engine::analyze() {
     return 0;
 }
 
+// Rayleigh-Ritz only (feasthip_set_rr_only): the device copies of the terms that the products A Q, B Q need; no ordering, no
+// symbolic analysis, no factor arenas -- the shifted solves happen outside the library (a caller-supplied factorizer).
+int Engine::analyze_rr_only() {
+    if (n <= 0 || terms_.empty()) return fail(FEASTHIP_ESTATE, "analyze: no matrices set");
+    HIPCHK(hipSetDevice(device_));
+    if (!dense) {
+        for (SparseTerm& T : terms_) {
+            const int64_t nnz = T.colptr[n];
+            std::vector<int64_t> rp(n + 1, 0);
+            for (int64_t e = 0; e < nnz; ++e) rp[T.rowval[e] + 1]++;
+            for (int i = 0; i < n; ++i) rp[i + 1] += rp[i];
+            std::vector<int> col(std::max<int64_t>(1, nnz));
+            std::vector<zc> v(std::max<int64_t>(1, nnz));
+            std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
+            for (int j = 0; j < n; ++j)
+                for (int64_t e = T.colptr[j]; e < T.colptr[j + 1]; ++e) { int64_t q = pos[T.rowval[e]]++; col[q] = j; v[q] = T.val[e]; }
+            if (!T.d_rowptr.upload(rp.data(), n + 1, stream_) || !T.d_col.upload(col.data(), col.size(), stream_) ||
+                !T.d_val.upload((const cz*)v.data(), v.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+        }
+    }
+    S = Symbolic();
+    S.n = n;
+    dsym_ = DevSym();
+    dsym_.n = n;
+    analyzed_ = true;
+    factored_ = false;
+    return 0;
+}
+
 // f_t(z) of T(z) = sum_t f_t(z) scale_t M_t at the given points: powers z^t by default (polynomial NEP, linear pencil),
 // or the caller's functions (split form, feasthip_set_coef_functions).  out is point-major: out[i*nterms + t].
 int Engine::alloc_iteration_buffers() {
     size_t blk = (size_t)n * ldw;
     const size_t lw = (size_t)solve_width(), sblk = (size_t)n * lw;      // per-unit solve blocks (twice as wide with the conjugate fold)
     bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && (q_ext_ ? (q_ext_bytes_ >= 2 * blk * sizeof(cz)) : d_Q_.alloc(2 * blk)) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
-              d_MX_.alloc(blk * std::max(2, nterms)) && d_W_.alloc((size_t)Kloc * sblk) && d_Y_.alloc((size_t)Kloc * sblk) && d_sk_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * lw) &&
-              d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * lw) &&
-              d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * lw) &&
-              d_e0_.alloc((size_t)Kloc * lw) && d_e1_.alloc((size_t)Kloc * lw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
+              d_MX_.alloc(blk * std::max(2, nterms)) &&
+              (rr_only_ || (d_W_.alloc((size_t)Kloc * sblk) && d_Y_.alloc((size_t)Kloc * sblk) && d_sk_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * lw) &&
+                            d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * lw) &&
+                            d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * lw))) &&
+              d_e0_.alloc((size_t)std::max(1, Kloc) * lw) && d_e1_.alloc((size_t)std::max(1, Kloc) * lw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
               d_lam_.alloc(ldw) && d_gram_scratch_.alloc(gram_scratch_elems(n, ldw)) && d_io_.alloc((size_t)n * std::max(1, m0)) &&
               d_nrm_.alloc(ldw) && d_nrm_scratch_.alloc(colnorm_scratch_elems(n, ldw));
     if (ok && mixed_)
@@ -882,7 +917,7 @@ int Engine::set_x(const void* X, int64_t n_, int m0_) {
     if (!X || m0_ <= 0) return fail(FEASTHIP_EARG, "set_x: bad arguments");
     if (n_ != n) return fail(FEASTHIP_EDIM_X, "Incorrect dimensions of X, must match A");
     if (m0_ > n) return fail(FEASTHIP_EARG, "set_x: m0 must not exceed n");
-    if (!analyzed_) { int r = analyze(); if (r) return r; }
+    if (!analyzed_) { int r = rr_only_ ? analyze_rr_only() : analyze(); if (r) return r; }
     HIPCHK(hipSetDevice(device_));
     m0 = m0_;
     ldw = ((m0 + 15) / 16) * 16;

@@ -99,11 +99,16 @@ public:
     int set_node_coefficients(const double* coef, int K, int nterms);
     int nl_set_r(const void* R);
     int analyze();
+    int analyze_rr_only();
+    int set_rr_only(int on) { if ((on != 0) != rr_only_) { rr_only_ = on != 0; analyzed_ = factored_ = have_x_ = false; } return 0; }
     int factorize();
     int set_x(const void* X, int64_t n, int m0);
     int get_block(int which, void* out);
     int rr_step(double* lambda, double* res, uint8_t* inside);
     int contour_step(int refactor);
+    int contour_step_begin(int refactor, int nchunks);
+    int moment_chunk_wait(int c, int64_t* row0, int64_t* rows);
+    int contour_step_end();
     int nl_contour_step(int first);
     int nl_rr_step(double* lambda, double* res, uint8_t* inside, int external_residual = 0);
     int nl_orthonormalize_x();
@@ -128,10 +133,10 @@ public:
     int ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
     int estimate_count(const void* X, int64_t n, int m0, double* est);
     int profile_solve(ProfileRow* rows /*[8]*/);
-    std::vector<double> prof_detail;   // per launch: class, ms, bytes, flops, tiles (filled by profile_solve)
+    std::vector<double> prof_detail;   // per launch: class, ms, bytes, flops, tiles, tree depth (filled by profile_solve)
 
     // stats
-    double analyze_seconds = 0, alloc_seconds = 0, factor_ms = 0, solve_ms = 0, rr_ms = 0;
+    double analyze_seconds = 0, alloc_seconds = 0, factor_ms = 0, solve_ms = 0, rr_ms = 0, proj_ms = 0;
     int64_t perturbed = 0;
     Symbolic S;
     int n = 0, nterms = 0, K = 0, Kloc = 0, m0 = 0, ldw = 0;
@@ -147,7 +152,7 @@ private:
     bool streams_warm_ = false;
     bool fuse_b3_ = true;                 // plan kind-6 tiles (FEASTHIP_FUSE_B3=0: never)           // analyze() touches every stream once (queue creation) beside the host-side analysis
     bool own_stream_ = false;
-    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_p0_ = nullptr, ev_p1_ = nullptr;    // ev_p*: around the projection Aq = Q'(AQ) of rr_step
     std::vector<SparseTerm> terms_;
     std::vector<zc> nodes_, weights_;      // all K
     std::vector<int> local_;               // indices of local nodes (conjugate fold: the member of each local pair that is factorised)
@@ -164,7 +169,7 @@ private:
 
     // device symbolic
     DevBuf<FrontD> d_fr_;
-    DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_c0row_, d_cmap_, d_ebp_;
+    DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_iperm_, d_c0row_, d_cmap_, d_ebp_;
     DevBuf<int> d_asmflag_, d_relfirst_;  // fused right-hand-side gather (kernels.hpp: DevSym::asmflag / relfirst; FEASTHIP_FUSE_GATHER=0 turns it off)
     DevBuf<Tile> d_tiles_;
     DevBuf<int> d_lists_;
@@ -241,7 +246,7 @@ private:
     bool mixed_ = false;
     DevBuf<cf> d_fact32_, d_W32_, d_Y32_, d_crow32_[2], d_sk32_;
     int stream_groups() const;
-    void accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
+    void accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0 = 0, int nrows = -1);
     bool streams_forced_ = false;
     DevBuf<cz> d_mvpart_;                // split-K partial sums of the dense term products (k_dense_mv)
     hipStream_t la_stream_ = nullptr;    // high-priority stream of the look-ahead panels
@@ -258,6 +263,10 @@ private:
     int solve_nb(int s) const { int p = S.p(s); return p >= nb512_min_p_ ? 512 : p >= nb256_min_p_ ? 256 : 128; }
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipEvent_t> ev_join_;
+    std::vector<hipEvent_t> ev_chunk_;   // contour_step_begin: one per row range of the moment
+    std::vector<int> chunk_rows_;
+    bool step_open_ = false;
+    bool rr_only_ = false;               // feasthip_set_rr_only: only the Rayleigh-Ritz half runs on this handle
     hipEvent_t ev_fork_ = nullptr;
 };
 

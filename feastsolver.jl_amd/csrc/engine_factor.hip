@@ -29,6 +29,7 @@ int Engine::set_node_coefficients(const double* coef, int K_, int nterms_) {
 }
 
 int Engine::factorize() {
+    if (rr_only_) return fail(FEASTHIP_ESTATE, "factorize: this handle runs the Rayleigh-Ritz half only (feasthip_set_rr_only)");
     if (!analyzed_) { int r = analyze(); if (r) return r; }
     HIPCHK(hipSetDevice(device_));
     // per-node coefficients scale_t * f_t(z_k) (f_t = z^t unless overridden) and pivot thresholds

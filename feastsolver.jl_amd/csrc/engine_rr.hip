@@ -202,7 +202,9 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
     std::vector<zc> Aq((size_t)m * m), Bq((size_t)m * m), lam(m), Xq((size_t)m * m);
     apply_term(0, Qp(), d_R_.p, 1.0, false);                            // R = A Q          :42
+    HIPCHK(hipEventRecord(ev_p0_, stream_));
     launch_gram(stream_, n, m, ldw, Qp(), d_R_.p, d_gram_scratch_.p, dA);   // Aq = Q' R   :43
+    HIPCHK(hipEventRecord(ev_p1_, stream_));
     // B = -scale_1 * M_1
     bool b_is_identity = terms_[1].identity && std::abs(terms_[1].scale + 1.0) == 0.0;
     void *landA = nullptr, *landB = nullptr;
@@ -267,6 +269,8 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
     rr_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev_p0_, ev_p1_));
+    proj_ms = ms;
     return 0;
 }
 

@@ -25,7 +25,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     hipEvent_t pa = nullptr, pb = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&pa)); HIPCHK(hipEventCreate(&pb)); }
     if (prof) prof_detail.clear();
-    int cur_tiles = 0;
+    int cur_tiles = 0, cur_depth = -1;
     auto begin = [&]() { if (prof) (void)hipEventRecord(pa, st); };
     auto end = [&](int row, double bytes, double flops) {
         if (!prof) return;
@@ -34,7 +34,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         float ms = 0;
         (void)hipEventElapsedTime(&ms, pa, pb);
         prof[row].ms += ms; prof[row].bytes += bytes; prof[row].flops += flops; prof[row].launches++;
-        prof_detail.insert(prof_detail.end(), {(double)row, (double)ms, bytes, flops, (double)cur_tiles});
+        prof_detail.insert(prof_detail.end(), {(double)row, (double)ms, bytes, flops, (double)cur_tiles, (double)cur_depth});
     };
     double rowb = (double)ldw * sizeof(T);
     begin();
@@ -46,6 +46,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * kc; };
     for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
         SolveLevel& V = splan_[d];
+        cur_depth = d;
         int par = d & 1;
         int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
         begin();
@@ -68,6 +69,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
         SolveLevel& V = splan_[d];
+        cur_depth = d;
         double lvl_p = 0, lvl_u = 0;
         for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
@@ -101,10 +103,10 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
 }
 
 // Q0 (Q1) = sum_k T_k .* e0[k,:] (e1[k,:]) over the solution blocks of the last sweep (fp64 accumulation in either precision)
-void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
+void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0, int nrows) {
     const int lw = solve_width();
-    if (mixed_) launch_accumulate(stream_, dsym_, d_X_.p, d_W32_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1);
-    else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1);
+    if (mixed_) launch_accumulate(stream_, dsym_, d_X_.p, d_W32_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1, row0, nrows);
+    else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1, row0, nrows);
 }
 
 // Node groups that run on their own streams.  Two groups overlap the launch tails and the latency-bound small
@@ -160,17 +162,55 @@ double Engine::solve_flops() const {
 }
 
 int Engine::contour_step(int refactor) {
+    int r = contour_step_begin(refactor, 1);
+    if (r < 0) return r;
+    int r2 = contour_step_end();
+    return r2 ? r2 : r;
+}
+
+// The contour step without its final host synchronisation (multi-GPU driver): everything is enqueued, the moment is produced in
+// `nchunks` contiguous row ranges of Q (original row order) with one event each, so that the caller can hand a finished range to
+// the all-reduce while the later ranges are still being accumulated (moment_chunk_wait), then contour_step_end().
+int Engine::contour_step_begin(int refactor, int nchunks) {
     if (!have_x_) return fail(FEASTHIP_ESTATE, "contour_step: call set_x and rr_step first");
+    if (step_open_) return fail(FEASTHIP_ESTATE, "contour_step_begin: the previous step was not ended");
     HIPCHK(hipSetDevice(device_));
-    if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; }
+    int warn = 0;
+    if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; warn = r; }
     std::vector<zc> e0 = node_table([&](int k, int j, int) { return weights_[k] / (nodes_[k] - lambda_[j]); });      // src/feast.jl:60,69
     HIPCHK(h2d_async(5, d_e0_.p, e0.data(), e0.size() * sizeof(zc)));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66
     if (r) return r;
-    accumulate_solutions(Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);                                // :68-70
+    nchunks = std::max(1, std::min(nchunks, std::min(64, n)));
+    while ((int)ev_chunk_.size() < nchunks) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_chunk_.push_back(e); }
+    chunk_rows_.assign(nchunks + 1, 0);
+    for (int c = 0; c <= nchunks; ++c) chunk_rows_[c] = (int)((int64_t)n * c / nchunks);
+    for (int c = 0; c < nchunks; ++c) {
+        accumulate_solutions(Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr, chunk_rows_[c], chunk_rows_[c + 1] - chunk_rows_[c]);     // :68-70
+        if (nchunks > 1) HIPCHK(hipEventRecord(ev_chunk_[c], stream_));
+    }
     HIPCHK(hipEventRecord(ev1_, stream_));
+    step_open_ = true;
+    return warn;
+}
+
+int Engine::moment_chunk_wait(int c, int64_t* row0, int64_t* rows) {
+    if (!step_open_) return fail(FEASTHIP_ESTATE, "moment_chunk_wait: no open contour step");
+    const int nchunks = (int)chunk_rows_.size() - 1;
+    if (c < 0 || c >= nchunks) return fail(FEASTHIP_EARG, "moment_chunk_wait: chunk out of range");
+    HIPCHK(hipSetDevice(device_));
+    if (nchunks > 1) HIPCHK(hipEventSynchronize(ev_chunk_[c])); else HIPCHK(hipEventSynchronize(ev1_));
+    if (row0) *row0 = chunk_rows_[c];
+    if (rows) *rows = chunk_rows_[c + 1] - chunk_rows_[c];
+    return 0;
+}
+
+int Engine::contour_step_end() {
+    if (!step_open_) return fail(FEASTHIP_ESTATE, "contour_step_end: no open contour step");
+    step_open_ = false;
+    HIPCHK(hipSetDevice(device_));
     HIPCHK(hipEventSynchronize(ev1_));
     HIPCHK(hipGetLastError());
     float ms = 0;

@@ -18,6 +18,7 @@ struct DevSym {          // device copies of the symbolic structure
     const int* rel;
     const int* child_idx;
     const int* perm;     // new -> old
+    const int* iperm;    // old -> new
     const int* c0_of_row;  // first column of the supernode owning (new) row i
     const int* cmap;       // per front with children: [contribution row][child slot] -> row in the children's arena, or -1
     const int* ebp;        // extend-add break points, see FrontD::ebp
@@ -102,7 +103,7 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* Y, int64_t ws, int ldw,
                           const cf* skbuf, int64_t sks, int K);
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,
-                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0 = 0, int nrows = -1);
 void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out);
 // Kind-3 tiles may be split along K (Tile.a bits 16.. = number of parts, Tile.c = part): each part writes
 // -U12[:, part] * x[part] into its own slab of `skbuf`; launch_splitk_reduce then adds the slabs to Y in a fixed order.
@@ -111,8 +112,9 @@ void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, in
 // (gather = true for launches made only of kind-3 tiles: V rows are gathered through struct_idx)
 // Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order;
 // lds = leading dimension of W and of the coefficient tables (2 ldw: conjugate fold, see k_accumulate)
+// row0 / nrows: the rows of Q (original order) this launch produces; nrows < 0 = all from row0
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int lds, int K,
-                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1);
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0 = 0, int nrows = -1);
 
 // ---- Rayleigh-Ritz block ------------------------------------------------------
 void launch_spmm_csr(hipStream_t st, int n, const int64_t* rowptr, const int* col, const cz* val, const cz* V, int ldw,

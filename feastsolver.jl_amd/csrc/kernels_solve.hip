@@ -1095,13 +1095,14 @@ void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, in
 // Conjugate fold (lds = 2 ldw): unit k carries two contour nodes; columns [ldw, 2 ldw) of W_k hold T(z_k)^-1 conj(R),
 // whose conjugate is the solution of the node conj(z_k); its coefficients are columns [ldw, 2 ldw) of e0 / e1.
 template <typename T>
-__global__ void k_accumulate(const int* __restrict__ perm, int n, const cz* __restrict__ X, const T* __restrict__ W,
+__global__ void k_accumulate(const int* __restrict__ iperm, int row0, int nrows, const cz* __restrict__ X, const T* __restrict__ W,
                              int64_t ws, int ldw, int lds, int K, const cz* __restrict__ e0, const cz* __restrict__ e1, int mode,
                              cz* Q0, cz* Q1) {
-    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
-    if (i >= n) return;
-    int64_t old = perm[i];
+    if (r >= nrows) return;
+    int64_t old = row0 + r;            // rows [row0, row0 + nrows) of Q in ORIGINAL order (a contiguous chunk for the all-reduce)
+    int i = iperm[old];
     const bool fold = lds > ldw;
     for (int j = lane; j < ldw; j += 64) {
         cz x = mode ? X[old * ldw + j] : cz_make(0, 0);
@@ -1126,12 +1127,16 @@ __global__ void k_accumulate(const int* __restrict__ perm, int n, const cz* __re
 }
 
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int lds, int K,
-                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
-    hipLaunchKernelGGL(k_accumulate<cz>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0, int nrows) {
+    if (nrows < 0) nrows = S.n - row0;
+    if (nrows <= 0) return;
+    hipLaunchKernelGGL(k_accumulate<cz>, dim3((nrows + 3) / 4), dim3(256), 0, st, S.iperm, row0, nrows, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
 }
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,
-                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1) {
-    hipLaunchKernelGGL(k_accumulate<cf>, dim3((S.n + 3) / 4), dim3(256), 0, st, S.perm, S.n, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0, int nrows) {
+    if (nrows < 0) nrows = S.n - row0;
+    if (nrows <= 0) return;
+    hipLaunchKernelGGL(k_accumulate<cf>, dim3((nrows + 3) / 4), dim3(256), 0, st, S.iperm, row0, nrows, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
 }
 
 }  // namespace feasthip

@@ -55,7 +55,53 @@ def allreduce_moment(q, group=None):
     return q
 
 
-def gen_feast_distributed(X, A, B, contour, *, iter=10, eps=1e-12, store=True, device=None, group=None, info=None):
+class MomentReducer:
+    """One contour step of this rank's node shard + the sum of the partial moments over the ranks.
+
+    overlap=True: the library produces the moment in `chunks` contiguous row ranges (feasthip_contour_step_begin); as soon as
+    a range is final its all-reduce is issued (async), so the collective of range c runs while the ranges after it are still
+    being accumulated, and only the last range's collective is exposed.  overlap=False: contour step, then one all-reduce of
+    the whole n x ldw block.  Either way the result is the same sum in the same order per element (the collective is
+    element-wise), so both settings are bit-identical for a given backend.
+    `q` is the torch tensor handed to feasthip_set_q_buffer (float64 view of the complex128 moment)."""
+
+    def __init__(self, handle, q, n, ldw, overlap=True, chunks=4, group=None):
+        self.h, self.q, self.n, self.ldw, self.group = handle, q, int(n), int(ldw), group
+        self.overlap = bool(overlap)
+        self.chunks = max(1, int(chunks)) if self.overlap else 1
+
+    def contour_step_and_reduce(self, refactor=False):
+        """Returns the host time at which this rank's own contour step had finished (for the Amdahl breakdown)."""
+        import time
+        import torch
+        import torch.distributed as dist
+        live = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        gloo = live and dist.get_backend(self.group) == "gloo"
+        row = self.ldw * 2                                   # float64 per row of the complex128 block
+        self.h.contour_step_begin(refactor, self.chunks)
+        works = []
+        for c in range(self.chunks):
+            r0, rows = self.h.moment_chunk_wait(c)          # the library's stream is not torch's: host-side wait, then enqueue
+            if not live:
+                continue
+            part = self.q[r0 * row:(r0 + rows) * row]
+            if gloo and part.is_cuda:                        # rehearsal without RCCL (ranks sharing one GPU): stage through the host
+                tmp = part.cpu()
+                works.append((dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=True), part, tmp))
+            else:
+                works.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+        self.h.contour_step_end()
+        t_done = time.perf_counter()
+        for w, part, tmp in works:
+            w.wait()
+            if tmp is not None:
+                part.copy_(tmp)
+        if live:
+            torch.cuda.synchronize()                         # the next Rayleigh-Ritz step reads Q on the library's stream
+        return t_done
+
+
+def gen_feast_distributed(X, A, B, contour, *, iter=10, eps=1e-12, store=True, device=None, group=None, info=None, overlap=True):
     """gen_feast! (src/feast.jl:89-156) with the node loop sharded over the ranks of `group`.
     Every rank passes the same X, A, B, contour and receives the same result.  B=None: feast!."""
     import torch
@@ -82,16 +128,14 @@ def gen_feast_distributed(X, A, B, contour, *, iter=10, eps=1e-12, store=True, d
         if store:
             h.factorize()
         h.set_x(np.asfortranarray(X, dtype=np.complex128))
+        red = MomentReducer(h, q, n, ldw, overlap=overlap, group=group)
         nit = 0
         for nit in range(iter + 1):                                   # src/feast.jl:40
             lam, res, ins = h.rr_step()
             if ins.any() and res[ins].max() < eps:                    # :53
                 break
             if nit < iter:                                            # :57
-                h.contour_step(refactor=not store)
-                torch.cuda.synchronize()
-                allreduce_moment(q[: n * ldw * 2], group)
-                torch.cuda.synchronize()
+                red.contour_step_and_reduce(refactor=not store)
         Xo = h.get_block(0)
         if info is not None:
             info.update(h.stats())

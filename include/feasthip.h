@@ -102,9 +102,21 @@ int feasthip_get_block(feasthip_handle_t h, int which /*0 X,1 R,2 Q,3 Q1*/, void
  * Outputs: lambda (m0 complex, sorted by (re,im)), res (m0), inside (m0 bytes). */
 int feasthip_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside);
 
+/* on != 0: this handle runs only the Rayleigh-Ritz half (feasthip_set_x / feasthip_rr_step / feasthip_get_block): no ordering,
+ * no symbolic analysis, no factor arenas; factorize / contour_step return FEASTHIP_ESTATE.  For callers that supply their own
+ * factorizer / left_divider (src/feast.jl:5,11,84,90) and run the node loop (:59-71) themselves.  Call before feasthip_set_x. */
+int feasthip_set_rr_only(feasthip_handle_t h, int on);
+
 /* Contour half (src/feast.jl:57-72 / 134-148): Q = sum_k (X - T(z_k)^-1 R) diag(w_k/(z_k-lambda))
  * over the local nodes.  refactor != 0 reproduces store=false (src/utils.jl:175-179). */
 int feasthip_contour_step(feasthip_handle_t h, int refactor);
+/* The same step for the multi-GPU driver, without the final host synchronisation: _begin enqueues the sweeps and the
+ * accumulation, the latter in `nchunks` contiguous row ranges of Q (rows of the n x ldq moment, original order);
+ * _moment_chunk_wait(c) blocks until range c is final and returns it, so that its all-reduce can run while the later ranges
+ * are still being accumulated; _end waits for the whole step (and fills stats.solve_ms).  feasthip_contour_step = begin(1 chunk) + end. */
+int feasthip_contour_step_begin(feasthip_handle_t h, int refactor, int nchunks);
+int feasthip_moment_chunk_wait(feasthip_handle_t h, int chunk, int64_t* row0, int64_t* rows);
+int feasthip_contour_step_end(feasthip_handle_t h);
 
 /* NLFEAST halves (src/nlfeast.jl:32-61 and :64-67, src/utils.jl:69-77,104-109,151-157). */
 int feasthip_nl_contour_step(feasthip_handle_t h, int first_iteration);
@@ -229,14 +241,20 @@ typedef struct {
     int32_t factor_units;       /* factorisations held: local_nodes, or local_nodes / 2 with the conjugate fold */
     int32_t folded;             /* 1 if the conjugate fold is active (feasthip_set_conjugate_fold) */
     double solve_bytes_streamed;/* bytes the sweeps of one contour step move (a folded pair reads its factor once) */
+    double proj_ms;             /* last feasthip_rr_step: the projection Aq = Q'(AQ) (src/feast.jl:43,118), 8 n m0^2 flops on the f64 matrix cores */
 } feasthip_stats_t;
 int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* out);
 /* One instrumented contour sweep: HIP-event time per kernel class.  out = 8 rows x
  * {ms, algorithmic bytes, flops, launches}: 0 gather, 1 assemble, 2 diag solve,
  * 3 panel apply (the dominant kernel), 4 accumulate. */
 int feasthip_profile_solve(feasthip_handle_t h, double* out);
-/* per-launch rows of the last feasthip_profile_solve: {class, ms, bytes, flops, tiles}; returns the row count */
+/* per-launch rows of the last feasthip_profile_solve: {class, ms, bytes, flops, tiles, tree depth (-1: not a level launch)};
+ * returns the row count */
 int feasthip_profile_detail(feasthip_handle_t h, double* out, int cap);
+/* Elimination-tree levels of the analysed pattern, root = depth 0: per depth 5 doubles {fronts, sum of pivot columns p, sum of
+ * update rows u, factor entries sum(p*p + 2*u*p) = that level's share of nnz(L)+nnz(U), widest pivot block}; returns the number of levels.  With it the
+ * SURVEY 8(d) bytes of a contour step, (nnz(L)+nnz(U))*20 + 2(n+1)*4 + 4*n*m0*16 per node, split by tree level. */
+int feasthip_level_table(feasthip_handle_t h, double* out, int cap);
 
 /* ---- MatrixMarket coordinate files: the on-disk format of the reference's data sets (the data/ .mtx files,
  * written by test/gen_butterfly.jl:6-41, read with MatrixMarket.jl in test/butterfly.jl:57-59, test/polynomial.jl:5-11).

@@ -135,3 +135,16 @@ def test_two_rank_moment_allreduce_gloo():
     res.sort()
     assert res[0][1] == list(range(0, 16, 2)) and res[1][1] == list(range(1, 16, 2))
     assert all(r[2] < 1e-12 for r in res)
+
+
+def test_bench_gpus_n_never_reports_a_single_rank():
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself and must fail loudly when they cannot
+    form a 2-rank job (here: no GPU) -- it must never print a line with n_gpus = 1."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "8",
+                        "--cpu-baseline", "off"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert r.returncode != 0
+        assert '"n_gpus": 1' not in r.stdout

@@ -692,6 +692,28 @@ def test_distributed_driver_two_ranks_share_one_gpu(gpu, golden):
     assert res[0][1] == res[1][1] and res[0][5] == res[1][5]          # replicated Rayleigh-Ritz: bitwise identical on both ranks
 
 
+def test_bench_self_launch_two_ranks(gpu):
+    """`python bench.py --gpus 2` started plainly (no torch.distributed.run, no RANK / WORLD_SIZE) starts its two ranks itself.
+    On this one-GPU box the ranks share the card and sum the moment through gloo (bench.py --backend auto); the line must say
+    n_gpus = 2, half of the nodes per rank, and the converged result of the single-process run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--grid", "12",
+                        "--cpu-baseline", "off"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["nodes_per_gpu"] == 8 and line["config"]["backend"] == "gloo"
+    assert line["result"]["inside"] == line["result"]["expected_inside"] and line["result"]["max_res_inside"] < 1e-10
+    # and a request that cannot be met is an error, not a silent single-rank line
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "8",
+                         "--cpu-baseline", "off"], env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r1.returncode != 0 and '"n_gpus"' not in r1.stdout
+
+
 def test_symbolic_analysis_cache_is_pattern_only(gpu, pkg, wl):
     """Handles on matrices with the same pattern share the cached ordering / symbolic analysis (spectrum slicing runs many
     contours on one pencil); the values must still be each handle's own."""
