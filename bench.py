@@ -90,12 +90,22 @@ def self_launch(args):
 def cpu_node_body(fo, w, grid_desc):
     """The reference's per-node body (src/feast.jl:134-148) + its Rayleigh-Ritz block (:116-127) through the oracle, timed
     on this host: ONE node factorised (SuperLU, serial like the reference's UMFPACK) and block-solved for the m0 columns."""
+    import threading
     import numpy as np
     import scipy.sparse as sp
     A = sp.csc_matrix(w["A"], dtype=np.complex128)
     B = sp.csc_matrix(w["B"], dtype=np.complex128)
     con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
     n, m0 = A.shape[0], w["X0"].shape[1]
+    stop = threading.Event()
+
+    def heartbeat():          # the serial sparse LU of the 46^3 pencil runs for minutes without a word: say that it is alive
+        t_start = time.perf_counter()
+        while not stop.wait(60.0):
+            print(f"bench.py: cpu baseline on the {grid_desc} grid still running ({time.perf_counter() - t_start:.0f} s)", file=sys.stderr, flush=True)
+
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
     X = w["X0"].copy()
     t0 = time.perf_counter()
     Q, _ = np.linalg.qr(X, mode="reduced")
@@ -115,6 +125,7 @@ def cpu_node_body(fo, w, grid_desc):
     fo.ldiv(temp, F, R)
     temp = (Xr - temp) * ((1.0 / (con.nodes[0] - lam)) * con.weights[0])[None, :]
     t_node = time.perf_counter() - t0
+    stop.set()
     return {"n": n, "t_rr_s": t_rr, "t_factor_node_s": t_fact, "t_solve_node_s": t_node,
             "iterations_per_s": 1.0 / (16 * t_node + t_rr), "store_false_iterations_per_s": 1.0 / (16 * (t_node + t_fact) + t_rr),
             "grid": grid_desc}

@@ -22,7 +22,7 @@ class Stats(C.Structure):
         ("solve_ms", C.c_double), ("rr_ms", C.c_double), ("solve_bytes", C.c_double), ("solve_flops", C.c_double),
         ("perturbed_pivots", C.c_int64), ("local_nodes", C.c_int32), ("m0", C.c_int32), ("ldw", C.c_int32),
         ("dense", C.c_int32), ("alloc_seconds", C.c_double),
-        ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double), ("proj_ms", C.c_double),
+        ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double), ("symmetric", C.c_int32), ("pad_", C.c_int32), ("growth", C.c_double), ("proj_ms", C.c_double),
     ]
 
 
@@ -82,6 +82,7 @@ PROTOTYPES = {
     "feasthip_lu_csc": (I, [I, I64, VP, VP, VP, I, I, PVP]),
     "feasthip_ldiv": (I, [VP, VP, I64, VP, I64, I]),
     "feasthip_fact_free": (I, [VP]),
+    "feasthip_fact_info": (I, [VP, C.POINTER(I), C.POINTER(D), C.POINTER(I64)]),
     "feasthip_get_stats": (I, [VP, C.POINTER(Stats)]),
     "feasthip_profile_solve": (I, [VP, VP]),
     "feasthip_profile_detail": (I, [VP, VP, I]),

@@ -776,6 +776,9 @@ class HipLU:
     def __init__(self, handle, n, lib, info=0):
         self._h, self.n, self._lib = handle, n, lib
         self.info = info          # > 0: number of statically perturbed pivots (LAPACK info convention)
+        sym, gr = C.c_int(0), C.c_double(0.0)
+        lib.feasthip_fact_info(handle, C.byref(sym), C.byref(gr), None)
+        self.symmetric, self.growth = bool(sym.value), gr.value     # pivot-light elimination (C == C^T, growth-checked) or partial pivoting
 
     def __del__(self):
         try:

@@ -7,7 +7,12 @@ namespace feasthip {
 // Large device blocks (factor arena, block vectors, contribution stacks) are kept in a small process-wide cache when a handle
 // releases them and handed to the next handle that asks for a block of about that size: FEAST is typically run several times
 // per process (other contours / spectrum slices), and a fresh multi-GB hipMalloc costs 1 ms to 0.8 s depending on what the
-// driver has to map.  feasthip_trim_memory() returns the cached blocks to the driver; so does an allocation that fails.
+// driver has to map.  What stays cached is bounded by ONE handle's footprint: when a handle is destroyed, whatever earlier
+// handles left on its device is returned to the driver first (pool_drop_device), then its own blocks are cached -- other
+// allocators of the process (torch, RCCL, the caller's hipMalloc) never face more idle memory than the last solver run used.
+// feasthip_trim_memory() returns the cached blocks to the driver; so does an allocation that fails.  FEASTHIP_POOL_GB caps the
+// cache (default 48; 0 switches it off), FEASTHIP_POOL_POISON=1 fills a recycled block with 0xFF bytes before it is handed out
+// (NaN patterns: a dependence on what a previous problem left in a block then shows in the tests).
 namespace {
 struct CachedBlock { int dev; void* p; size_t bytes; };
 std::mutex g_pool_mu;
@@ -17,26 +22,36 @@ size_t pool_limit_bytes() {
     static const size_t lim = [] { const char* e = getenv("FEASTHIP_POOL_GB"); return (size_t)((e ? atof(e) : 48.0) * 1073741824.0); }();
     return lim;
 }
-void* pool_take(size_t bytes, size_t& got) {       // smallest cached block of this device with bytes <= size <= 1.25 bytes
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    int best = -1;
-    for (int i = 0; i < (int)g_pool.size(); ++i)
-        if (g_pool[i].dev == dev && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 4 && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
-    if (best < 0) return nullptr;
-    void* q = g_pool[best].p;
-    got = g_pool[best].bytes;
-    g_pool.erase(g_pool.begin() + best);
+bool pool_poison() {
+    static const bool on = [] { const char* e = getenv("FEASTHIP_POOL_POISON"); return e && atoi(e) != 0; }();
+    return on;
+}
+void* pool_take(int dev, size_t bytes, size_t& got) {       // smallest cached block of this device with bytes <= size <= 1.25 bytes
+    void* q = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); ++i)
+            if (g_pool[i].dev == dev && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 4 && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+        if (best < 0) return nullptr;
+        q = g_pool[best].p;
+        got = g_pool[best].bytes;
+        g_pool.erase(g_pool.begin() + best);
+    }
+    if (pool_poison()) { (void)hipMemset(q, 0xFF, got); (void)hipDeviceSynchronize(); }
     return q;
 }
-bool pool_put(void* q, size_t bytes) {
-    if (bytes < POOL_MIN_BYTES) return false;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
+// `dev` is the device the block was allocated on (DevBuf records it), not whatever device is current in the releasing thread
+bool pool_put(int dev, void* q, size_t bytes) {
+    if (bytes < POOL_MIN_BYTES || pool_limit_bytes() == 0) return false;
     // hipFree waits for the device before it returns the memory; a block that goes to another handle instead must not have
     // work in flight either
-    if (hipDeviceSynchronize() != hipSuccess) return false;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return false;
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) return false;
+    const bool idle = hipDeviceSynchronize() == hipSuccess;
+    if (cur != dev) (void)hipSetDevice(cur);
+    if (!idle) return false;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     size_t held = 0;
     for (const CachedBlock& b : g_pool) held += b.bytes;
@@ -44,19 +59,34 @@ bool pool_put(void* q, size_t bytes) {
     g_pool.push_back({dev, q, bytes});
     return true;
 }
-}  // namespace
-
-void trim_device_memory() {
-    std::vector<CachedBlock> blocks;
-    { std::lock_guard<std::mutex> lk(g_pool_mu); blocks.swap(g_pool); }
+void pool_free_blocks(std::vector<CachedBlock>& blocks) {
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (const CachedBlock& b : blocks) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
     (void)hipSetDevice(cur);
 }
+}  // namespace
+
+void trim_device_memory() {
+    std::vector<CachedBlock> blocks;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); blocks.swap(g_pool); }
+    pool_free_blocks(blocks);
+}
+
+// what earlier handles left cached on this device goes back to the driver (called when a handle is destroyed, before its own
+// blocks are released into the cache)
+void pool_drop_device(int dev) {
+    std::vector<CachedBlock> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size();)
+            if (g_pool[i].dev == dev) { blocks.push_back(g_pool[i]); g_pool.erase(g_pool.begin() + i); } else ++i;
+    }
+    pool_free_blocks(blocks);
+}
 
 template <class T> void DevBuf<T>::release() {
-    if (p) { if (!pool_put((void*)p, cap_bytes)) (void)hipFree((void*)p); p = nullptr; n = 0; cap_bytes = 0; }
+    if (p) { if (!pool_put(dev, (void*)p, cap_bytes)) { int cur = 0; (void)hipGetDevice(&cur); if (cur != dev) (void)hipSetDevice(dev); (void)hipFree((void*)p); if (cur != dev) (void)hipSetDevice(cur); } p = nullptr; n = 0; cap_bytes = 0; }
 }
 template <class T> bool DevBuf<T>::alloc(size_t count) {
     if (count <= n && p) return true;
@@ -64,7 +94,9 @@ template <class T> bool DevBuf<T>::alloc(size_t count) {
     if (count == 0) count = 1;
     const size_t bytes = count * sizeof(T);
     size_t got = bytes;
-    void* q = bytes >= POOL_MIN_BYTES ? pool_take(bytes, got) : nullptr;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return false; }
+    void* q = bytes >= POOL_MIN_BYTES ? pool_take(cur, bytes, got) : nullptr;
     if (!q) {
         got = bytes;
         if (hipMalloc(&q, bytes) != hipSuccess) {
@@ -76,6 +108,7 @@ template <class T> bool DevBuf<T>::alloc(size_t count) {
     p = (T*)q;
     n = count;
     cap_bytes = got;
+    dev = cur;
     return true;
 }
 template <class T> bool DevBuf<T>::upload(const T* h, size_t count, hipStream_t st) {
@@ -119,6 +152,8 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FUSE_B3")) fuse_b3_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
+    if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
+    if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
@@ -160,6 +195,8 @@ Engine::Engine(int device) : device_(device) {
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    pool_drop_device(device_);       // the cache holds at most what ONE handle used: earlier leftovers go back to the driver now
+    for (hipStream_t s2 : up_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipStream_t s2 : aux_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipEvent_t e2 : ev_join_) (void)hipEventDestroy(e2);
     for (hipEvent_t e2 : ev_chunk_) (void)hipEventDestroy(e2);
@@ -222,7 +259,7 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
     terms_.clear();
     terms_.resize(nterms);
     terms_real_ = false;
-    bool real = true;
+    bool real = true, sym = true;
     std::vector<zc> tmp;
     for (int t = 0; t < nterms; ++t) {
         SparseTerm& T = terms_[t];
@@ -236,10 +273,18 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
         for (size_t e = 0; e < nn; ++e) { tmp[e] = read_val(mats[t], ty, (int64_t)e); mx = std::max(mx, std::abs(tmp[e])); }
         T.maxabs = mx;
         for (size_t e = 0; e < nn && real; ++e) if (tmp[e].imag() != 0.0) real = false;
+        // M == M^T (exactly): blocked so that both access directions stay in cache; stops at the first mismatch
+        for (int jb = 0; jb < n && sym; jb += 64)
+            for (int ib = jb; ib < n && sym; ib += 64)
+                for (int j = jb; j < std::min(n, jb + 64) && sym; ++j)
+                    for (int i = std::max(ib, j + 1); i < std::min(n, ib + 64); ++i)
+                        if (tmp[i + (size_t)j * n] != tmp[j + (size_t)i * n]) { sym = false; break; }
         if (!T.d_dense.upload((const cz*)tmp.data(), nn, stream_)) return fail(FEASTHIP_EHIP, "set_dense: device allocation/upload failed");
     }
     for (auto& T : terms_) if (T.scale.imag() != 0.0) real = false;
     terms_real_ = real;
+    terms_symmetric_ = sym;
+    nopiv_failed_ = false;
     rebuild_shard();
     return 0;
 }
@@ -291,6 +336,8 @@ int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const
         T.maxabs = mx;
     }
     terms_real_ = real;
+    terms_symmetric_ = false;          // decided in analyze(), where the transposes of the terms are built anyway
+    nopiv_failed_ = false;
     rebuild_shard();
     return 0;
 }
@@ -459,11 +506,21 @@ bool Engine::build_plans() {
                     for (int a = 0; a < cdiv(p - k0 - b + u, 32); ++a) tiles.push_back({s, a, 0, 0});
                 }
             st.grp.count = (int)(tiles.size() - st.grp.off);
+            st.lsc.off = (int64_t)tiles.size();
+            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); for (int a = 0; a < cdiv(p + u - k0 - b, 256); ++a) tiles.push_back({s, a, 0, 0}); }
+            st.lsc.count = (int)(tiles.size() - st.lsc.off);
             F.steps.push_back(st);
         }
         F.cbgemm.off = (int64_t)tiles.size();
         for (int s : lv) if (S.u(s) > 0) { int nt = cdiv(S.u(s), 64); push_supertiles(s, 2, nt, nt); }
         F.cbgemm.count = (int)(tiles.size() - F.cbgemm.off);
+        F.cbgemm_sym.off = (int64_t)tiles.size();
+        for (int s : lv) if (S.u(s) > 0) {      // lower triangle of tiles, still in 8 x 8 super-tile runs for the XCD-local operand reuse
+            int nt = cdiv(S.u(s), 64);
+            for (int A = 0; A < nt; A += 8) for (int C = 0; C <= A; C += 8)
+                for (int a = A; a < std::min(nt, A + 8); ++a) for (int c = C; c < std::min(nt, C + 8); ++c) if (c <= a) tiles.push_back({s, 2, a, c});
+        }
+        F.cbgemm_sym.count = (int)(tiles.size() - F.cbgemm_sym.off);
         F.fronts.off = (int64_t)lists.size();
         for (int s : lv) lists.push_back(s);
         F.fronts.count = (int)lv.size();
@@ -680,9 +737,18 @@ int Engine::analyze() {
         mix((uint64_t)opt.leaf_size); mix((uint64_t)opt.relax_small); mix((uint64_t)opt.relax_mid); mix((uint64_t)(opt.zmid * 1e6)); mix((uint64_t)(opt.zbig * 1e6)); mix((uint64_t)opt.ordering);
         // CSR copies of the terms for SpMM (a transpose of the caller's CSC arrays) do not depend on the ordering: one host thread
         // per term builds them while the nested dissection leaves most cores idle at its top levels
-        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0; };
+        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0; };
         std::vector<TermHost> th(terms_.size());
         std::vector<std::thread> csr_pool;
+        // The helper threads overwrite device buffers a previous analysis of this handle may still be using (DevBuf::alloc keeps a
+        // buffer that is large enough): everything queued on the handle's stream has to be through first.  One upload stream per
+        // term, created once per handle (a stream gets its hardware queue with its first operation: 25-30 ms).
+        HIPCHK(hipStreamSynchronize(stream_));
+        while (up_streams_.size() < terms_.size()) {
+            hipStream_t us = nullptr;
+            if (hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) return fail(FEASTHIP_EHIP, "analyze: stream creation failed");
+            up_streams_.push_back(us);
+        }
         for (size_t ti = 0; ti < terms_.size(); ++ti)
             csr_pool.emplace_back([&, ti]() {
                 const SparseTerm& T = terms_[ti];
@@ -696,13 +762,20 @@ int Engine::analyze() {
                 std::vector<int64_t> pos(H.rp.begin(), H.rp.end() - 1);
                 for (int j = 0; j < n; ++j)
                     for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; H.col[q] = j; H.v[q] = T.val[e2]; }
+                // The CSR arrays of M are the CSC arrays of M^T with sorted indices: M == M^T iff they equal the caller's CSC arrays
+                // (unsorted caller indices compare unequal and merely keep the pivoted factorisation).
+                {
+                    bool eq = true;
+                    for (int j = 0; j <= n && eq; ++j) eq = H.rp[j] == T.colptr[j];
+                    for (int64_t e2 = 0; e2 < nnz && eq; ++e2) eq = H.col[e2] == T.rowval[e2] && H.v[e2] == T.val[e2];
+                    H.sym = eq ? 1 : 0;
+                }
                 // ... and uploads them (and the CSC values the factorisation scatters) from this thread, on its own stream
                 SparseTerm& Tw = terms_[ti];
-                hipStream_t us = nullptr;
-                bool ok = hipSetDevice(device_) == hipSuccess && hipStreamCreateWithFlags(&us, hipStreamNonBlocking) == hipSuccess;
+                hipStream_t us = up_streams_[ti];
+                bool ok = hipSetDevice(device_) == hipSuccess;
                 ok = ok && Tw.d_cscval.upload((const cz*)T.val.data(), nnz, us) && Tw.d_rowptr.upload(H.rp.data(), n + 1, us) &&
                      Tw.d_col.upload(H.col.data(), nnz, us) && Tw.d_val.upload((const cz*)H.v.data(), nnz, us);
-                if (us) (void)hipStreamDestroy(us);
                 if (!ok) H.bad = 2;
             });
         struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& t : p) if (t.joinable()) t.join(); } } csr_join{csr_pool};
@@ -749,6 +822,8 @@ int Engine::analyze() {
             for (auto& t2 : tpool) t2.join();
         }
         for (auto& t2 : csr_pool) t2.join();
+        terms_symmetric_ = true;
+        for (TermHost& H : th) if (!H.sym) terms_symmetric_ = false;
         for (TermHost& H : th) if (H.bad_dest) H.bad = 1;
         for (size_t ti = 0; ti < terms_.size(); ++ti) {
             SparseTerm& T = terms_[ti];
@@ -849,7 +924,7 @@ int Engine::analyze() {
     ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
          d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
          d_rowperm_.alloc((size_t)Kloc * n) && d_rowinv_.alloc((size_t)Kloc * n) && d_nperturb_.alloc(Kloc) &&
-         d_tiny_.alloc(Kloc) && d_coef_.alloc((size_t)Kloc * nterms);
+         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)2 * Kloc) && d_coef_.alloc((size_t)Kloc * nterms);
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
     alloc_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);
@@ -977,6 +1052,9 @@ int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int st
 int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
     if (!Y || !R || m0_ <= 0 || ldy < n || ldr < n) return fail(FEASTHIP_EARG, "ldiv: bad arguments");
     if (!factored_) return fail(FEASTHIP_ESTATE, "ldiv: not factorised");
+    // unit 0 of the coefficient table must be node 0 itself: under the conjugate fold it would be the upper-half-plane member of
+    // the first pair (possibly the mirror image of node 0), and the solve would silently be the one at conj(z_0)
+    if (fold_ || Kloc != 1) return fail(FEASTHIP_ESTATE, "ldiv: factor handles hold exactly one unfolded node");
     HIPCHK(hipSetDevice(device_));
     if (m0_ != m0 || !have_x_) {
         m0 = m0_;

@@ -20,11 +20,12 @@ struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     size_t cap_bytes = 0;              // size of the underlying block (a recycled block may be larger than n elements)
+    int dev = 0;                       // device the block was allocated on (a block is released to the cache / the driver of THAT device)
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), cap_bytes(o.cap_bytes) { o.p = nullptr; o.n = 0; o.cap_bytes = 0; }
-    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap_bytes = o.cap_bytes; o.p = nullptr; o.n = 0; o.cap_bytes = 0; } return *this; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), cap_bytes(o.cap_bytes), dev(o.dev) { o.p = nullptr; o.n = 0; o.cap_bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap_bytes = o.cap_bytes; dev = o.dev; o.p = nullptr; o.n = 0; o.cap_bytes = 0; } return *this; }
     ~DevBuf() { release(); }
     void release();
     bool alloc(size_t count);          // false on failure
@@ -32,6 +33,7 @@ struct DevBuf {
 };
 
 void trim_device_memory();     // frees the process-wide cache of released device blocks (engine.hip)
+void pool_drop_device(int dev); // ... of one device
 
 struct Launch {        // a slice of the tile / list buffers
     int64_t off = 0;
@@ -41,8 +43,11 @@ struct Launch {        // a slice of the tile / list buffers
     int sl = 4;                    // tile height of the launch in 16-row slabs (launch_apply: max_slabs)
 };
 
-struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp; };
-struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm; Launch fronts; Launch binv, couple, scale;
+struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp;
+                    Launch lsc; };     // pivot-light path: 256-row slices of the rows below the diagonal block (k_lscale_np)
+struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm;
+                     Launch cbgemm_sym;     // symmetric pencils: the tiles on and below the diagonal of the contribution block only (mirrored on store)
+                     Launch fronts; Launch binv, couple, scale;
                      Launch outer[2], inner[2]; };      // coupling of 128 -> 256 ([0]) and 256 -> 512 ([1]) super blocks (launch_couple_outer / _level)
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     Launch b3s;       // B3 tiles of the fronts whose B1 tile is kind 6 (launched only when the apply kernel does not fuse them)
@@ -141,6 +146,8 @@ public:
     Symbolic S;
     int n = 0, nterms = 0, K = 0, Kloc = 0, m0 = 0, ldw = 0;
     bool dense = false;
+    bool nopiv_used = false;              // the last factorisation ran the pivot-light path (symmetric pencil) and passed its growth check
+    double growth = 0;                    // max |l_ij| it saw (0 on the pivoted path, where |l_ij| <= 1 by construction)
     double solve_bytes() const;           // algorithmic bytes of one contour step (per contour NODE)
     double solve_bytes_streamed() const;  // what the sweeps actually stream (folded pairs read their factor once)
     double solve_flops() const;
@@ -158,6 +165,10 @@ private:
     std::vector<int> local_;               // indices of local nodes (conjugate fold: the member of each local pair that is factorised)
     std::vector<int> partner_;             // conjugate fold: index of the mirror node of local_[kk], else -1
     bool fold_ = false, fold_enabled_ = true, terms_real_ = false;
+    bool terms_symmetric_ = false;         // every coefficient matrix equals its transpose: T(z) = T(z)^T for all z (pivot-light factorisation)
+    bool nopiv_enabled_ = true, nopiv_failed_ = false;   // FEASTHIP_NOPIV=0 / a factorisation whose growth check failed: pivoted path from then on
+    double nopiv_max_growth_ = 1024.0;     // largest multiplier |l_ij| the pivot-light path may produce (FEASTHIP_NOPIV_GROWTH)
+    bool use_nopiv() const { return terms_symmetric_ && nopiv_enabled_ && !nopiv_failed_; }
     void rebuild_shard();                  // local_ / partner_ / fold_ / Kloc from contour, shard, terms and overrides
     template <class F> std::vector<zc> node_table(F f, int nq = 1) const;   // [q][unit][solve_width] table of f(node, column, q) for the accumulation kernel
     int shard_first_ = 0, shard_stride_ = 1;
@@ -181,6 +192,7 @@ private:
     DevBuf<const cz*> d_matptr_;
     DevBuf<int> d_piv_, d_rowperm_, d_rowinv_, d_nperturb_;
     DevBuf<double> d_tiny_;
+    DevBuf<int64_t> d_growth_;            // per unit: max |l_ij| of the pivot-light path (bit pattern of a double)
     // iteration state (row-major n x ldw)
     DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_Y_, d_crow_[2], d_sk_;
     int64_t sk_rows_ = 0;                   // rows of split-K scratch per node
@@ -262,6 +274,7 @@ private:
     int nb256_min_p_ = 193, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
     int solve_nb(int s) const { int p = S.p(s); return p >= nb512_min_p_ ? 512 : p >= nb256_min_p_ ? 256 : 128; }
     std::vector<hipStream_t> aux_streams_;
+    std::vector<hipStream_t> up_streams_;  // analyze(): one upload stream per term (helper threads)
     std::vector<hipEvent_t> ev_join_;
     std::vector<hipEvent_t> ev_chunk_;   // contour_step_begin: one per row range of the moment
     std::vector<int> chunk_rows_;

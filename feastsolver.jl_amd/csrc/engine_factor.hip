@@ -49,9 +49,25 @@ int Engine::factorize() {
     HIPCHK(hipMemcpyAsync(d_coef_.p, coef.data(), coef.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(d_tiny_.p, tiny.data(), tiny.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemsetAsync(d_nperturb_.p, 0, Kloc * sizeof(int), stream_));
+    HIPCHK(hipMemsetAsync(d_growth_.p, 0, 2 * Kloc * sizeof(int64_t), stream_));
+    const int64_t fs = S.fact_size;
+    const Tile* tl = d_tiles_.p;
+    const int* ls = d_lists_.p;
     HIPCHK(hipStreamSynchronize(stream_));   // coef/tiny are stack-owned host buffers
+    // Symmetric pencil (every coefficient matrix equals its transpose): no row interchanges, growth-checked afterwards (see
+    // k_diag_np); the contribution blocks are symmetric, so only their lower tile triangle is computed.
+    const bool nopiv = use_nopiv();
+    const int sym_bits = nopiv ? 2 : 0;        // launch_gemm_nn: skip the U12 updates and the strictly upper tiles of the pivot block
+    unsigned long long* growth_dev = reinterpret_cast<unsigned long long*>(d_growth_.p);
+    auto panel_step = [&](hipStream_t s, FactorStep& sj, bool tall, int max_rows) {
+        if (nopiv) {
+            launch_diag_np(s, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, growth_dev, Kloc);
+            launch_lscale_np(s, dsym_, tl + sj.lsc.off, sj.lsc.count, sj.k0, d_fact_.p, fs, growth_dev, Kloc);
+        } else {
+            launch_panel(s, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, max_rows);
+        }
+    };
     HIPCHK(hipEventRecord(ev0_, stream_));
-    int64_t fs = S.fact_size;
     if (dense) {
         std::vector<const cz*> ptrs(nterms);
         for (int t = 0; t < nterms; ++t) ptrs[t] = terms_[t].identity ? nullptr : terms_[t].d_dense.p;
@@ -62,8 +78,6 @@ int Engine::factorize() {
         for (int t = 0; t < nterms; ++t)
             launch_scatter(stream_, d_fact_.p, fs, terms_[t].d_dest.p, terms_[t].d_cscval.p, terms_[t].colptr[n], d_coef_.p, nterms, t, Kloc);
     }
-    const Tile* tl = d_tiles_.p;
-    const int* ls = d_lists_.p;
     bool fin_used = false;
     // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
     const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
@@ -76,7 +90,7 @@ int Engine::factorize() {
         cz* cbp = d_cb_[par].p;
         int64_t cbs = std::max<int64_t>(1, S.cb_size[par]);
         launch_extend_add(stream_, dsym_, tl + F.extend.off, F.extend.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
-                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 0);
+                          std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 0, nopiv ? 1 : 0);
         int level_ld = 0;
         for (int s2 : S.levels[d]) level_ld = std::max(level_ld, S.p(s2) + S.u(s2));
         const bool tall = level_ld >= 1024;      // wide panel workgroups for tall fronts (launch_panel picks the width)
@@ -86,10 +100,12 @@ int Engine::factorize() {
         stamp();
         if (!lookahead) {
             for (FactorStep& st : F.steps) {
-                launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - st.k0);
-                launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
-                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
-                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
+                panel_step(stream_, st, tall, level_ld - st.k0);
+                if (!nopiv) {
+                    launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
+                    launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
+                }
+                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc, ColSel(), FACT_NB, 0, nullptr, 0, sym_bits);
             }
         } else {
             // LU with look-ahead for the big fronts at the top of the tree (few fronts x nodes: the panel factorisation runs on a
@@ -124,8 +140,10 @@ int Engine::factorize() {
                 };
                 FactorStep& s0 = F.steps[j0];
                 const int gw = F.steps[j1 - 1].k0 + FACT_NB - k0g;        // group width
-                launch_swap(s, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, sel(k0g + gw), gw);
-                if (s0.grp.count > 0 && fused_utrsm_) {       // U rows of the whole group in one launch
+                if (!nopiv) launch_swap(s, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, sel(k0g + gw), gw);
+                if (nopiv) {
+                    // the group's U rows are already there (D L^T, written with the L columns)
+                } else if (s0.grp.count > 0 && fused_utrsm_) {       // U rows of the whole group in one launch
                     launch_group_utrsm(s, dsym_, tl + s0.grp.off, s0.grp.count, k0g, gw, d_fact_.p, fs, Kloc, sel(k0g + gw));
                 } else {
                     for (int j = j0; j < j1; ++j) {
@@ -142,7 +160,7 @@ int Engine::factorize() {
                 // the next group's columns are the first two tile columns right of this group: the short list does
                 const bool narrow = !others && c_hi - (k0g + gw) <= 128 && c_lo == k0g + gw;
                 const Launch& gl = narrow ? s0.gemm_in : s0.gemm;
-                launch_gemm_nn(s, dsym_, tl + gl.off, gl.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0);
+                launch_gemm_nn(s, dsym_, tl + gl.off, gl.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0, nullptr, 0, sym_bits);
             };
             for (int g = 0; g < ng; ++g) {
                 const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
@@ -153,20 +171,19 @@ int Engine::factorize() {
                 }
                 for (int j = j0; j < j1; ++j) {
                     FactorStep& sj = F.steps[j];
-                    launch_panel(P, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall,
-                                 level_ld - sj.k0);
+                    panel_step(P, sj, tall, level_ld - sj.k0);
                     // inside the group: interchanges on the group's earlier L columns and its remaining columns, U rows and update
                     // of the remaining columns
                     ColSel c;
                     c.llo = k0g; c.lhi = sj.k0; c.clo = 0; c.chi = kend >= INF ? INF : std::max(0, kend - sj.k0 - FACT_NB); c.u12 = 0;
-                    launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
+                    if (!nopiv) launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
                     if (c.chi > 0) {
                         c.llo = c.lhi = 0;
-                        launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                        if (!nopiv) launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
                         {
                             // columns left in the group fit the first two tile columns unless the groups are wider than 160
                             const Launch& gl = (G - 1) * FACT_NB <= 128 ? sj.gemm_in : sj.gemm;
-                            launch_gemm_nn(P, dsym_, tl + gl.off, gl.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
+                            launch_gemm_nn(P, dsym_, tl + gl.off, gl.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c, FACT_NB, 0, nullptr, 0, sym_bits);
                         }
                     }
                 }
@@ -184,8 +201,9 @@ int Engine::factorize() {
         // enough to carry the extra dependent loads (pivot blocks of 128 columns and more: extend-add 39 -> 17 ms for +9 ms of
         // products on C3); the levels of small fronts keep the separate second extend-add pass.
         const bool fuse = fuse_extend_ && level_p >= fuse_min_p_;
-        launch_gemm_nn(stream_, dsym_, tl + F.cbgemm.off, F.cbgemm.count, 0, d_fact_.p, fs, cbp, cbs, Kloc, ColSel(), FACT_NB, 0,
-                       fuse ? d_cb_[par ^ 1].p : nullptr, std::max<int64_t>(1, S.cb_size[par ^ 1]));
+        const Launch& cbl = nopiv ? F.cbgemm_sym : F.cbgemm;
+        launch_gemm_nn(stream_, dsym_, tl + cbl.off, cbl.count, 0, d_fact_.p, fs, cbp, cbs, Kloc, ColSel(), FACT_NB, 0,
+                       fuse ? d_cb_[par ^ 1].p : nullptr, std::max<int64_t>(1, S.cb_size[par ^ 1]), nopiv ? 1 : 0);
         stamp();
         // The solve-ready conversion of this level (row permutations, block inverses, panel scaling) only touches this
         // level's own panels, which nothing above reads (parents take the contribution blocks): it runs on a side stream
@@ -234,14 +252,37 @@ int Engine::factorize() {
     }
     HIPCHK(hipEventRecord(ev1_, stream_));
     std::vector<int> np(Kloc);
+    std::vector<int64_t> gr((size_t)2 * Kloc, 0);
     HIPCHK(hipMemcpyAsync(np.data(), d_nperturb_.p, Kloc * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (nopiv) HIPCHK(hipMemcpyAsync(gr.data(), d_growth_.p, 2 * Kloc * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
-    factor_ms = ms;
     perturbed = 0;
     for (int v : np) perturbed += v;
+    nopiv_used = nopiv;
+    growth = 0;
+    if (nopiv) {
+        // growth = max over the units of max |l_ij| and of max |pivot| / ||T(z_k)|| (tiny[kk] = 2.2e-19 ||T(z_k)||): with
+        // U = D L^T the product of the two bounds the element growth of the elimination
+        for (int kk = 0; kk < Kloc; ++kk) {
+            double l, d;
+            std::memcpy(&l, &gr[kk], sizeof(l)); std::memcpy(&d, &gr[(size_t)Kloc + kk], sizeof(d));
+            growth = std::max(growth, std::max(l, d * 2.2e-19 / tiny[kk]));
+        }
+        // the elimination without interchanges was not harmless (a multiplier beyond the bound, or a pivot that had to be
+        // perturbed): this matrix gets partial pivoting, now and on every later factorisation of this handle
+        if (!(growth <= nopiv_max_growth_) || perturbed > 0) {
+            if (getenv("FEASTHIP_FACTOR_TRACE")) fprintf(stderr, "[feasthip factor] pivot-light path rejected (max |l| %.3g, %lld perturbed pivots): refactorising with partial pivoting\n", growth, (long long)perturbed);
+            nopiv_failed_ = true;
+            const double t_first = ms;
+            int r = factorize();
+            factor_ms += t_first;
+            return r;
+        }
+    }
+    factor_ms = ms;
     factored_ = true;
     return perturbed > 0 ? (int)std::min<int64_t>(perturbed, 0x7fffffff) : 0;
 }

@@ -35,9 +35,17 @@ void launch_scatter(hipStream_t st, cz* fact, int64_t fs, const int64_t* dest, c
 void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz* const* mats, int nterms,
                            const cz* coef, int K);
 void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,
-                       cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K, int phase);
+                       cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K, int phase, int sym = 0);
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
                   int* piv, const double* tiny, int* nperturb, int K, bool tall = false, int max_rows = 1 << 30);
+// Pivot-light panel step for symmetric pencils (no row interchanges): LU of the 32 x 32 diagonal block in one wave (identity
+// written to piv), then L = A inv(U11) for the rows below (Tile {front, 256-row slice of the rows below the block}), which also
+// writes the block's U rows as D L^T (no triangular solve for U, no update of the U12 panel or of the upper triangle).  growth[k]
+// receives max |l_ij| as the bit pattern of a double (atomicMax), nperturb[k] the perturbed pivots.
+void launch_diag_np(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
+                    int* piv, const double* tiny, int* nperturb, unsigned long long* growth, int K);
+void launch_lscale_np(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                      unsigned long long* growth, int K);
 // Column selection of one launch of an elimination step (look-ahead schedule): left columns [llo, lhi), pivot-block
 // columns right of the panel with offset in [clo, chi), U12 columns iff u12.  The default selects everything.
 struct ColSel { int llo = 0, lhi = 1 << 30, clo = 0, chi = 1 << 30, u12 = 1; };
@@ -49,7 +57,9 @@ void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntile
 void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int gw, cz* fact, int64_t fs, int K, ColSel cs);
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                     cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0,
-                    const cz* cb_child = nullptr, int64_t cbs_child = 0);     // cb_child: fuse the children's extend-add into the contribution block (kind 2)
+                    const cz* cb_child = nullptr, int64_t cbs_child = 0,     // cb_child: fuse the children's extend-add into the contribution block (kind 2)
+                    int mirror = 0);     // symmetric elimination.  bit 0: kind-2 tiles with b > c also store their transpose (the list holds b >= c only);
+                                         // bit 1: kind-1 tiles and kind-0 tiles strictly above the diagonal are skipped (see k_lscale_np)
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled
 void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);

@@ -53,9 +53,11 @@ int feasthip_version(void);
 int feasthip_device_count(void);
 int feasthip_create(feasthip_handle_t* h, int device_id);
 int feasthip_destroy(feasthip_handle_t h);
-/* Device blocks of 64 MiB and more that a destroyed (or re-analysed) handle releases stay in a process-wide cache (at most
- * FEASTHIP_POOL_GB, default 48) for the next handle of this process; this call returns them to the driver.  The counterpart of
- * the reference's finalize! for whole solver runs (src/utils.jl:173): memory is the library's, the caller decides when it goes. */
+/* Device blocks of 64 MiB and more that a destroyed (or re-analysed) handle releases stay in a process-wide cache for the next
+ * handle of this process.  The cache never holds more than ONE handle's footprint (a handle that is destroyed first returns what
+ * earlier handles left on its device to the driver) and at most FEASTHIP_POOL_GB (default 48, 0 = no cache); this call returns
+ * all of it to the driver.  The counterpart of the reference's finalize! for whole solver runs (src/utils.jl:173): memory is the
+ * library's, the caller decides when it goes. */
 int feasthip_trim_memory(void);
 const char* feasthip_last_error(feasthip_handle_t h);   /* h may be NULL: last create() error */
 /* run all work of this handle on an existing hipStream_t (e.g. the caller's) */
@@ -165,6 +167,11 @@ int feasthip_set_conjugate_fold(feasthip_handle_t h, int on);
  *     fn = NULL restores the polynomial default f_t(z) = z^t. */
 typedef void (*feasthip_coef_fn)(const double* z, int count, double* f, void* user);
 int feasthip_set_coef_functions(feasthip_handle_t h, feasthip_coef_fn fn, void* user);
+/* Call order: feasthip_set_coef_functions, feasthip_set_node_coefficients, feasthip_set_conjugate_fold, feasthip_set_contour and
+ * feasthip_set_node_shard may change whether the conjugate fold applies (per-node overrides and complex data switch it off) and
+ * with it the number of factorisations this handle holds.  When they do, the analysis and the iteration state are invalidated:
+ * feasthip_factorize re-analyses by itself, but feasthip_set_x has to be called again before the next feasthip_rr_step /
+ * feasthip_contour_step (which otherwise return FEASTHIP_ESTATE).  Install overrides BEFORE feasthip_set_x. */
 /* (2) arbitrary closure: hand over T(z_k) for every node as terms 0..K-1 together with the K x nterms table of node
  *     coefficients (row k = coefficients of T(z_k); identity for one matrix per node), run the loop from the host with
  *     feasthip_nl_contour_step / feasthip_nl_beyn_step, form R[:,i] = T(lambda_i) x_i on the host (the reference's
@@ -223,6 +230,9 @@ int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64
                     const void* nzval, int type, int index_base, feasthip_fact_t* F);
 int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
 int feasthip_fact_free(feasthip_fact_t F);
+/* How F was factorised: *symmetric = 1 if C equals its transpose and the pivot-light elimination passed its growth check
+ * (*growth = max |l_ij| it saw), 0 for partial pivoting; *perturbed = statically perturbed pivots.  Any pointer may be NULL. */
+int feasthip_fact_info(feasthip_fact_t F, int* symmetric, double* growth, int64_t* perturbed);
 
 /* ---- statistics ------------------------------------------------------------ */
 typedef struct {
@@ -241,6 +251,10 @@ typedef struct {
     int32_t factor_units;       /* factorisations held: local_nodes, or local_nodes / 2 with the conjugate fold */
     int32_t folded;             /* 1 if the conjugate fold is active (feasthip_set_conjugate_fold) */
     double solve_bytes_streamed;/* bytes the sweeps of one contour step move (a folded pair reads its factor once) */
+    int32_t symmetric;          /* 1 if the last factorisation took the pivot-light path: every coefficient matrix equals its transpose
+                                 * (complex symmetric T(z)), no row interchanges, growth-checked; 0: partial pivoting inside the fronts */
+    int32_t pad_;
+    double growth;              /* max |l_ij| of that factorisation (pivot-light path; beyond 1024 the handle refactorises with pivoting) */
     double proj_ms;             /* last feasthip_rr_step: the projection Aq = Q'(AQ) (src/feast.jl:43,118), 8 n m0^2 flops on the f64 matrix cores */
 } feasthip_stats_t;
 int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* out);

@@ -44,6 +44,26 @@ def test_seam_dense_lu_ldiv(gpu, pkg, n, m0):
     assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y)
 
 
+@pytest.mark.parametrize("n,m0", [(1, 1), (5, 3), (31, 4), (32, 4), (33, 16), (64, 64), (100, 20), (129, 7), (257, 64), (300, 100), (700, 37), (1100, 8),
+                                  (2100, 4), (193, 7), (385, 3), (513, 2), (1025, 5), (1537, 3)])
+def test_seam_dense_symmetric_lu_ldiv(gpu, pkg, n, m0):
+    """Complex SYMMETRIC C (C = C^T, not Hermitian) with a definite imaginary part -- the shape of FEAST's shifted matrices
+    z B - A for real symmetric A, B -- takes the elimination without interchanges (F.symmetric, U = D L^T) at every size on a
+    panel / panel-group / super-block seam, to the same backward error as the pivoted factorisation."""
+    rng = np.random.default_rng(n * 77 + m0)
+    S = rng.standard_normal((n, n)); S = S + S.T
+    G = rng.standard_normal((n, n)); Pd = G @ G.T / n + 0.5 * np.eye(n)
+    Cm = (S + 1j * Pd).astype(np.complex128)
+    assert np.array_equal(Cm, Cm.T)
+    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
+    F = pkg.lu(Cm)
+    assert F.symmetric and F.growth < 1024
+    Y = np.zeros((n, m0), dtype=np.complex128, order="F")
+    pkg.ldiv(Y, F, R)
+    pkg.finalize(F)
+    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y)
+
+
 def test_seam_is_reentrant_across_host_threads(gpu, pkg, wl):
     """The reference calls `factorizer` from Threads.@threads (src/feast.jl:34-37, src/nlfeast.jl:19-26) and
     `left_divider` concurrently in nlfeast! (src/nlfeast.jl:36-55): factor objects created and used from several host
@@ -517,6 +537,87 @@ def test_irregular_trees_sparse_lu(gpu, pkg, shape, extra):
         assert np.abs(Y - ref).max() <= 1e-8 * np.abs(ref).max()
 
 
+def test_symmetric_pencil_takes_pivot_light_path(gpu, pkg, wl, golden):
+    """Complex symmetric T(z) = A - z B (A, B real symmetric, Im z != 0: definite imaginary part) is factorised without row
+    interchanges (stats.symmetric = 1, growth = max |l_ij| reported and small); the result is the fixture's, and equal to
+    the pivoted factorisation's (FEASTHIP_NOPIV=0) to rounding.  A numerically unsymmetric matrix with the same pattern keeps
+    partial pivoting (stats.symmetric = 0)."""
+    import os
+    w = wl.c3_sparse_generalized(12, 19, 64)
+    g = golden["c3_g12_s19"]
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["FEASTHIP_NOPIV"] = mode
+        try:
+            info = {}
+            X = w["X0"].copy()
+            lam, V, res = pkg.gen_feast(X, w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), iter=w["iter"], eps=w["eps"],
+                                        store=True, info=info)
+        finally:
+            os.environ.pop("FEASTHIP_NOPIV", None)
+        out[mode] = (lam, res, info)
+        assert len(lam) == len(g["lam"]) and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
+        assert abs(info["nit"] - g["history"][-1][0]) <= 1
+    assert out["1"][2]["symmetric"] == 1 and 0.0 < out["1"][2]["growth"] < 64.0
+    assert out["0"][2]["symmetric"] == 0
+    assert match_sets(out["1"][0], out["0"][0]) < 1e-11
+    # numerically unsymmetric values on a symmetric pattern: pivoted
+    rng = np.random.default_rng(8)
+    A2 = w["A"].copy().tocsc()
+    A2.data = A2.data * rng.uniform(0.9, 1.1, A2.nnz)
+    info = {}
+    pkg.gen_feast(w["X0"].copy(), A2, w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), iter=1, eps=w["eps"], store=True, info=info)
+    assert info["symmetric"] == 0
+
+
+def test_pivot_light_path_falls_back_when_elimination_is_unsafe(gpu, pkg):
+    """Symmetric matrices for which elimination without interchanges is NOT harmless.  (i) 2 x 2 diagonal blocks
+    [[1e-14, 1], [1, 1]] coupled weakly: whichever order the dissection eliminates them in, multipliers of 1e14 appear; the
+    growth check must reject the factorisation and the handle must refactorise with partial pivoting (F.symmetric False), to
+    the usual backward error, bit-identical to a handle that never tried (FEASTHIP_NOPIV=0).  (ii) a saddle-point matrix with
+    a zero diagonal block: accurate, or reported through the LAPACK-style positive status."""
+    import os
+    rng = np.random.default_rng(3)
+    m = 40
+    blk = sp.csc_matrix(np.array([[1e-14, 1.0], [1.0, 1e-14]]))
+    T2 = sp.kron(sp.identity(m), blk) + 1e-3 * sp.kron(sp.diags([np.ones(m - 1), np.ones(m - 1)], [-1, 1]), sp.csc_matrix(np.ones((2, 2))))
+    T2 = sp.csc_matrix(T2, dtype=np.complex128)
+    assert abs(T2 - T2.T).max() == 0
+    R2 = np.asfortranarray(rng.standard_normal((2 * m, 3)) + 0j)
+    sols = {}
+    for mode in ("1", "0"):
+        os.environ["FEASTHIP_NOPIV"] = mode
+        try:
+            F = pkg.lu(T2)
+        finally:
+            os.environ.pop("FEASTHIP_NOPIV", None)
+        assert not F.symmetric
+        Y2 = np.zeros_like(R2)
+        pkg.ldiv(Y2, F, R2)
+        pkg.finalize(F)
+        sols[mode] = Y2
+        assert np.linalg.norm(T2 @ Y2 - R2) <= 1e-11 * spla.norm(T2) * np.linalg.norm(Y2)
+    assert np.array_equal(sols["1"], sols["0"])
+    # the same pattern with a definite imaginary part stays on the pivot-light path
+    T3 = sp.csc_matrix(T2 + 0.5j * sp.identity(2 * m))
+    F = pkg.lu(T3)
+    assert F.symmetric and F.growth < 8
+    Y3 = np.zeros_like(R2)
+    pkg.ldiv(Y3, F, R2)
+    pkg.finalize(F)
+    assert np.linalg.norm(T3 @ Y3 - R2) <= 1e-11 * spla.norm(T3) * np.linalg.norm(Y3)
+    nA, nB = 60, 20
+    A = sp.random(nA, nA, density=0.2, random_state=1)
+    Bm = sp.random(nB, nA, density=0.3, random_state=2)
+    Ksad = sp.bmat([[A + A.T + 4 * sp.identity(nA), Bm.T], [Bm, None]], format="csc").astype(np.complex128)
+    R = np.asfortranarray(rng.standard_normal((nA + nB, 6)) + 0j)
+    F = pkg.lu(Ksad)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    assert np.linalg.norm(Ksad @ Y - R) <= 1e-9 * spla.norm(Ksad) * np.linalg.norm(Y) or F.info > 0
+    pkg.finalize(F)
+
+
 def test_c3_full_size_g46(gpu, pkg, wl):
     """BASELINE configs[2] at its full size (n = 97,336, 16 nodes, m0 = 64): right count, true residuals, real spectrum,
     and the moment of the first contour step is linear in X (contour_step on 2 X == 2 contour_step on X)."""
@@ -526,6 +627,11 @@ def test_c3_full_size_g46(gpu, pkg, wl):
                                 store=True, info=info)
     assert len(lam) == w["n_inside"] == 35
     assert info["nit"] <= 5
+    # golden eigenvalues of the same seeded pencil (tests/golden/c3_contours.json: eigsh shift-invert, make_fixtures.py --full)
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_contours.json")) as fjs:
+        gold = np.sort(np.asarray(json.load(fjs)["g46_s19"]["eigs"], dtype=float))
+    assert len(gold) == 35 and np.abs(np.sort(lam.real) - gold).max() <= 1e-10
     BV = w["B"] @ V
     r_true = np.linalg.norm(w["A"] @ V - BV * lam[None, :], axis=0) / np.linalg.norm(BV, axis=0)
     assert r_true.max() < 1e-9
@@ -538,13 +644,20 @@ def test_c3_full_size_g46(gpu, pkg, wl):
 
 
 def test_c2_full_size_dense4096(gpu, pkg, wl):
-    """BASELINE configs[1] at its full size (dense generalized 4096 x 4096, 16 nodes, m0 = 64; the radius is the circular-law
-    estimate of tools/bench_c2.py, so the count is only bounded): every returned pair is a true eigenpair inside the contour."""
+    """BASELINE configs[1] at its full size (dense generalized 4096 x 4096, 16 nodes, m0 = 64).  The contour and the
+    eigenvalues inside it come from a one-off host eigensolve of the same seeded pencil (tests/golden/c2_contour_n4096.json,
+    made by tests/golden/make_c2_fixture.py with LAPACK zggev): exact count, eigenvalues to 1e-9 (non-Hermitian pencil),
+    every returned pair a true eigenpair."""
+    import json, os
     n, m0 = 4096, 64
-    w = wl.c2_dense_generalized(n, m0, radius=float(np.sqrt(32.0 / n)) * 1.03)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_contour_n4096.json")) as fjs:
+        gold = json.load(fjs)
+    w = wl.c2_dense_generalized(n, m0, radius=gold["r"])
     info = {}
     lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10, store=True, info=info)
-    assert 16 <= len(lam) <= m0 and info["nit"] < 20
+    assert len(lam) == gold["n_inside"] == 32 and info["nit"] < 20
+    assert match_sets(lam, c2n(gold["eigs"])) <= 1e-9 and match_sets(c2n(gold["eigs"]), lam) <= 1e-9
+    assert info["symmetric"] == 0                              # complex non-symmetric: partial pivoting
     assert np.all(np.abs(lam - w["c"]) < w["r"])
     BV = w["B"] @ V
     r_true = np.linalg.norm(w["A"] @ V - BV * lam[None, :], axis=0) / np.linalg.norm(BV, axis=0)
@@ -690,6 +803,48 @@ def test_distributed_driver_two_ranks_share_one_gpu(gpu, golden):
         assert match_sets(c2n(lam), c2n(g["lam"])) < 1e-10 and len(lam) == len(g["lam"]) and rmax < 1e-10
         assert abs(nit - g["history"][-1][0]) <= 1
     assert res[0][1] == res[1][1] and res[0][5] == res[1][5]          # replicated Rayleigh-Ritz: bitwise identical on both ranks
+
+
+@pytest.mark.parametrize("store", [True, False])
+def test_custom_factorizer_is_called_per_node(gpu, pkg, wl, golden, store):
+    """factorizer / left_divider kwargs are honoured (src/feast.jl:5,11,28-38,61-66,74-76): a counting factorizer sees K calls
+    with store=true (every node once, before the loop) and K per solve sweep with store=false (linsolve!, src/utils.jl:175-179),
+    the left_divider K calls per sweep with the reference's argument order, every factor is finalized, and the result is the
+    fixture's."""
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    calls = {"lu": 0, "ldiv": 0, "shapes": set(), "live": []}
+
+    def counting_lu(Cm):
+        calls["lu"] += 1
+        assert sp.issparse(Cm) and Cm.dtype == np.complex128       # the caller's matrix type survives the assembly of ZmA
+        F = pkg.lu(Cm)
+        calls["live"].append(F)
+        return F
+
+    def counting_ldiv(Y, F, R):
+        calls["ldiv"] += 1
+        calls["shapes"].add((Y.shape, R.shape))
+        return pkg.ldiv(Y, F, R)
+
+    K = w["nodes"]
+    X = w["X0"].copy()
+    info = {}
+    lam, V, res = pkg.gen_feast(X, w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], K), iter=w["iter"], eps=w["eps"],
+                                store=store, factorizer=counting_lu, left_divider=counting_ldiv, info=info)
+    sweeps = info["nit"]                                              # converged at rr step nit: nit solve sweeps ran
+    assert info["plugin_seam"] and sweeps >= 1
+    assert calls["ldiv"] == K * sweeps and calls["shapes"] == {((w["A"].shape[0], 16), (w["A"].shape[0], 16))}
+    assert calls["lu"] == (K if store else K * sweeps)
+    assert all(F._h is None for F in calls["live"])                   # finalize!(F) reached every factor object
+    assert len(lam) == w["n_inside"] and res.max() < w["eps"]
+    X2 = w["X0"].copy()
+    lam2, _, _ = pkg.gen_feast(X2, w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], K), iter=w["iter"], eps=w["eps"], store=True)
+    assert match_sets(lam, lam2) < 1e-10 and np.array_equal(X, V if False else X)
+    # only one of the two overridden: still the plug-in path
+    calls["lu"] = 0
+    pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], K), iter=1, eps=w["eps"], store=True,
+                  factorizer=counting_lu)
+    assert calls["lu"] == K
 
 
 def test_bench_self_launch_two_ranks(gpu):
@@ -1022,11 +1177,44 @@ def test_device_block_cache_reuse_is_invisible(gpu, pkg, wl):
     w = wl.c3_sparse_generalized(24, 19, 64)
     contour = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
     outs = []
-    for rep in range(3):
+    for rep in range(4):
         X = np.array(w["X0"], copy=True)
         lam, Xo, res = pkg.gen_feast(X, w["A"], w["B"], contour, iter=4, eps=1e-13, store=True)
         outs.append((lam.copy(), Xo.copy(), res.copy()))
-        if rep == 1:
+        if rep == 0:
+            # a DIFFERENT problem leaves its bytes in the blocks the next run recycles: other m0 (other padding columns), mixed
+            # precision, the conjugate fold off, another pencil
+            w2 = wl.c3_sparse_generalized(22, 19, 48)
+            pkg.gen_feast(np.array(w2["X0"], copy=True), w2["A"], w2["B"], pkg.circular_contour_trapezoidal(w2["c"], w2["r"], 8), iter=2, eps=1e-13,
+                          store=True, conjugate_fold=False)
+            pkg.feast(np.array(w["X0"][:, :40], copy=True), w["A"], contour, iter=2, eps=1e-13, store=True, mixed_prec=True)
+        if rep == 2:
             pkg.trim_memory()
     for lam, Xo, res in outs[1:]:
         assert np.array_equal(lam, outs[0][0]) and np.array_equal(Xo, outs[0][1]) and np.array_equal(res, outs[0][2])
+
+
+def test_recycled_blocks_poisoned(gpu, wl):
+    """The same with FEASTHIP_POOL_POISON=1 in a fresh process: every recycled block is filled with 0xFF bytes (NaN patterns)
+    before it is handed out, so any read of memory the new problem has not written itself shows up as NaN or as a difference."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, importlib, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as graft
+pkg = graft.load_package(); wl = importlib.import_module(graft.PKG_NAME + ".workloads")
+w = wl.c3_sparse_generalized(20, 19, 64)
+con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+outs = []
+for rep in range(3):
+    lam, Xo, res = pkg.gen_feast(np.array(w["X0"], copy=True), w["A"], w["B"], con, iter=4, eps=1e-13, store=True)
+    outs.append((lam, Xo, res))
+    if rep == 0:
+        w2 = wl.c3_sparse_generalized(18, 19, 32)
+        pkg.gen_feast(np.array(w2["X0"], copy=True), w2["A"], w2["B"], pkg.circular_contour_trapezoidal(w2["c"], w2["r"], 8), iter=2, eps=1e-13, store=True, conjugate_fold=False)
+ok = all(np.isfinite(o[0]).all() and np.isfinite(o[1]).all() for o in outs) and all(np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) for o in outs[1:])
+print("POISON_OK" if ok else "POISON_DIFF")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FEASTHIP_POOL_POISON="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "POISON_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

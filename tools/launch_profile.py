@@ -26,5 +26,5 @@ for i in np.argsort(-d[:, 1])[:40]: print(f"  class {int(d[i,0])} {d[i,1]*1e3:8.
 print("launches < 50us:", len(small), "total ms", small[:, 1].sum(), "GF", small[:, 3].sum() / 1e9)
 print("launch sequence (class ms tiles GB GB/s TF/s):")
 for i in range(len(d)):
-    c, ms, by, fl, ti = d[i]
-    print(f"  {i:3d} c{int(c)} {ms*1e3:8.1f}us tiles {int(ti):6d}  {by/1e9:7.3f} GB {by/ms/1e9 if ms>0 else 0:7.1f} GB/s {fl/ms/1e9 if ms>0 else 0:6.1f} TF")
+    c, ms, by, fl, ti, dep = d[i]
+    print(f"  {i:3d} d{int(dep):2d} c{int(c)} {ms*1e3:8.1f}us tiles {int(ti):6d}  {by/1e9:7.3f} GB {by/ms/1e9 if ms>0 else 0:7.1f} GB/s {fl/ms/1e9 if ms>0 else 0:6.1f} TF")
