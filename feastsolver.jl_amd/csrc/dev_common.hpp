@@ -18,7 +18,8 @@ struct FrontD {
     int64_t crow;             // row offset into the solve-contribution arena of depth&1
     int64_t child_ptr;
     int nchild, depth;
-    int nb, pad_;             // diagonal super-block size of the solve-ready form of this front (128, 256 or 512), see kernels.hpp
+    int nb, wslot;            // nb: diagonal super-block size of the solve-ready form of this front (128, 256 or 512), see kernels.hpp;
+                              // wslot: position of the front within its tree level (scratch slot of the pivot-light group kernels)
     int64_t sk_off;           // row offset of this front's split-K partial sums in the scratch (backward U12 product), or -1
     int64_t cmap;             // offset into the contribution-row pull map (u x nchild ints), or -1 without children
     int64_t ebp;              // as a child: offset into the extend-add break points (first contribution row that lands at or

@@ -154,6 +154,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
+    if (const char* v = getenv("FEASTHIP_NOPIV_GROUP")) nopiv_group_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
@@ -509,6 +510,10 @@ bool Engine::build_plans() {
             st.lsc.off = (int64_t)tiles.size();
             for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); for (int a = 0; a < cdiv(p + u - k0 - b, 256); ++a) tiles.push_back({s, a, 0, 0}); }
             st.lsc.count = (int)(tiles.size() - st.lsc.off);
+            st.lsg.off = (int64_t)tiles.size();
+            if ((int)F.steps.size() % 4 == 0)
+                for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), gw = std::min(128, p - k0); for (int a = 0; a < cdiv(p + u - k0 - gw, 64); ++a) tiles.push_back({s, a, 0, 0}); }
+            st.lsg.count = (int)(tiles.size() - st.lsg.off);
             F.steps.push_back(st);
         }
         F.cbgemm.off = (int64_t)tiles.size();
@@ -845,7 +850,12 @@ int Engine::analyze() {
         f.sk_off = -1;
         f.cmap = -1;
         f.ebp = -1;
-        f.nb = solve_nb(s); f.pad_ = 0;
+        f.nb = solve_nb(s); f.wslot = 0;
+    }
+    wstride_ = 4;
+    for (const std::vector<int>& lv : S.levels) {
+        for (size_t i = 0; i < lv.size(); ++i) fr[lv[i]].wslot = (int)i;
+        wstride_ = std::max<int64_t>(wstride_, 4 * (int64_t)lv.size());
     }
     // pull map of the forward sweep: for every contribution row of a front and every child slot, the row of the child's
     // contribution block that is added to it (rel >= p), as an absolute row of the children's arena; -1 if none
@@ -924,7 +934,7 @@ int Engine::analyze() {
     ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
          d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
          d_rowperm_.alloc((size_t)Kloc * n) && d_rowinv_.alloc((size_t)Kloc * n) && d_nperturb_.alloc(Kloc) &&
-         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)2 * Kloc) && d_coef_.alloc((size_t)Kloc * nterms);
+         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)2 * Kloc) && d_wscr_.alloc((size_t)Kloc * wstride_ * 1024) && d_coef_.alloc((size_t)Kloc * nterms);
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
     alloc_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);

@@ -98,7 +98,15 @@ int Engine::factorize() {
         for (int s2 : S.levels[d]) level_p = std::max(level_p, S.p(s2));
         const bool lookahead = look_ahead_ && level_p >= 256 && la_stream_ && F.steps.size() >= 4;
         stamp();
-        if (!lookahead) {
+        const bool grp = nopiv && nopiv_group_;      // whole 128-column groups per step: diagonal block, rows below, one product
+        if (!lookahead && grp) {
+            for (size_t j = 0; j < F.steps.size(); j += 4) {
+                FactorStep& st = F.steps[j];
+                launch_diag_grp(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, growth_dev, d_wscr_.p, wstride_, Kloc);
+                launch_lscale_grp(stream_, dsym_, tl + st.lsg.off, st.lsg.count, st.k0, d_fact_.p, fs, growth_dev, d_wscr_.p, wstride_, Kloc);
+                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc, ColSel(), 128, 0, nullptr, 0, sym_bits);
+            }
+        } else if (!lookahead) {
             for (FactorStep& st : F.steps) {
                 panel_step(stream_, st, tall, level_ld - st.k0);
                 if (!nopiv) {
@@ -124,7 +132,7 @@ int Engine::factorize() {
             HIPCHK(hipEventRecord(ev_la_[4], stream_));
             HIPCHK(hipStreamWaitEvent(P, ev_la_[4], 0));
             if (R != stream_) HIPCHK(hipStreamWaitEvent(R, ev_la_[4], 0));
-            const int ns = (int)F.steps.size(), G = group_panels_, ng = (ns + G - 1) / G;
+            const int ns = (int)F.steps.size(), G = grp ? 4 : group_panels_, ng = (ns + G - 1) / G;
             const int INF = 1 << 30;
             auto K0 = [&](int g) { return g * G < ns ? F.steps[(size_t)g * G].k0 : INF; };       // first column of group g
             // all of group g (panels already factored) applied to the columns [c_lo, c_hi) of the pivot block, and to the left
@@ -169,7 +177,12 @@ int Engine::factorize() {
                     if (g > 1) HIPCHK(hipStreamWaitEvent(P, ev_la_[2 + (g & 1)], 0));      // rest of group g-2 reaches these columns
                     apply_group(P, g - 1, k0g, kend, false);
                 }
-                for (int j = j0; j < j1; ++j) {
+                if (grp) {
+                    FactorStep& s0 = F.steps[j0];
+                    launch_diag_grp(P, dsym_, ls + s0.panel.off, s0.panel.count, k0g, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, growth_dev, d_wscr_.p, wstride_, Kloc);
+                    launch_lscale_grp(P, dsym_, tl + s0.lsg.off, s0.lsg.count, k0g, d_fact_.p, fs, growth_dev, d_wscr_.p, wstride_, Kloc);
+                }
+                for (int j = j0; j < j1 && !grp; ++j) {
                     FactorStep& sj = F.steps[j];
                     panel_step(P, sj, tall, level_ld - sj.k0);
                     // inside the group: interchanges on the group's earlier L columns and its remaining columns, U rows and update

@@ -46,6 +46,14 @@ void launch_diag_np(hipStream_t st, const DevSym& S, const int* list, int nlist,
                     int* piv, const double* tiny, int* nperturb, unsigned long long* growth, int K);
 void launch_lscale_np(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                       unsigned long long* growth, int K);
+// ... and per GROUP of up to 128 pivot columns (the path the engine takes): k_diag_grp factorises the group's diagonal block in one
+// workgroup per (front, node) and leaves W_c = inv(U_cc) of its 32-column blocks in wscr[(k * wstride + FrontD::wslot * 4 + c) * 1024];
+// k_lscale_grp (Tile {front, 64-row slice of the rows below the block}) solves X U11 = A for the rows below on the matrix cores
+// and writes L and U = D L^T.  See kernels_factor.hip.
+void launch_diag_grp(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
+                     const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K);
+void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                       unsigned long long* growth, const cz* wscr, int64_t wstride, int K);
 // Column selection of one launch of an elimination step (look-ahead schedule): left columns [llo, lhi), pivot-block
 // columns right of the panel with offset in [clo, chi), U12 columns iff u12.  The default selects everything.
 struct ColSel { int llo = 0, lhi = 1 << 30, clo = 0, chi = 1 << 30, u12 = 1; };

@@ -624,6 +624,278 @@ void launch_lscale_np(hipStream_t st, const DevSym& S, const Tile* tiles, int nt
 }
 
 // ---------------------------------------------------------------------------
+// Pivot-light elimination, one GROUP of up to 128 pivot columns per step (the per-panel kernels above cost three dependent
+// launches per 32 columns -- diagonal block, rows below, in-group update -- and on the big fronts that chain, not the
+// matrix cores, set the pace).  Per group [k0, k0 + gw):
+//   k_diag_grp   one workgroup per (front, node) factorises the gw x gw diagonal block LEFT-looking in 32-column blocks: the rows
+//                of block c first get their L entries of the earlier blocks and the Schur update of block (c, c) (grp_substitute),
+//                then two waves eliminate block (c, c) in registers: wave 0 the block itself (L\U in place), wave 1 the identity
+//                with the same multipliers, which yields inv(L_cc) at no extra time; W_c = inv(U_cc) = inv(L_cc)^T D^-1 goes to a
+//                scratch slot.
+//   k_lscale_grp every wave takes 16 rows below the block and solves X U11 = A for them over the whole group on the matrix cores,
+//                X_c = (A_c - sum_{k < 32 c} Z_k L11[32 c + j][k]) W_c with Z = X D (U11 = D L11^T), without any exchange between
+//                waves: the D-layout of one product (lane (li, lk) holds columns lk + 4 s of row li) IS the B-operand layout of
+//                the next when the k-steps are taken with stride 4.  It writes the L rows and, transposed, the U rows (U = D L^T).
+// After that the rows below and right of the group see ONE product of depth gw (k_gemm_nn), nothing else.
+// ---------------------------------------------------------------------------
+constexpr int GRP_W = 128;
+
+// 16 rows (row = rbase + li < rend) of the group [k0, k0 + gw): substitution over the column blocks c < ncb; with upd_next the
+// Schur update of column block ncb (A -= Z L11^T) is written back in place instead.  Wt: W blocks, element [c][k][j].
+__device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __restrict__ F12, int ld, int p, int k0, int gw, int ncb, bool upd_next,
+                                                 int rbase, int rend, const cz* __restrict__ Wt) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int row = rbase + li;
+    const bool rok = row < rend;
+    const int row_c = min(row, rend - 1);
+    const cz* D0 = Lp + k0 + (int64_t)k0 * ld;          // diagonal block of the group: L11 strictly below, U11 on and above the diagonal
+    cz* ucol = (row_c < p) ? Lp + k0 + (int64_t)row_c * ld : F12 + k0 + (int64_t)(row_c - p) * p;
+    cz z[8][4];                                          // Z = X D, tile t (16 columns), k-step s: column 16 t + lk + 4 s
+    double lmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c > ncb || (c == ncb && !upd_next) || 32 * c >= gw) break;
+        const bool solve = c < ncb;
+        cz y[2][4];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int col = 32 * c + 16 * tl + lk + 4 * sidx;
+                cz v = Lp[row_c + (int64_t)(k0 + min(col, gw - 1)) * ld];
+                const bool keep = rok && col < gw;
+                y[tl][sidx].x = keep ? v.x : 0.0; y[tl][sidx].y = keep ? v.y : 0.0;
+            }
+        if (c > 0) {
+            d4 t1[2], t2[2], t3[2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) { t1[tl] = (d4){0, 0, 0, 0}; t2[tl] = (d4){0, 0, 0, 0}; t3[tl] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+            for (int tp = 0; tp < 2 * c; ++tp)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int kk = 16 * tp + lk + 4 * sidx;
+                    const cz zb = z[tp][sidx];
+                    const double zs = zb.x + zb.y;
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        const int jrow = 32 * c + 16 * tl + li;
+                        cz a = D0[min(jrow, gw - 1) + (int64_t)kk * ld];
+                        if (jrow >= gw) { a.x = 0.0; a.y = 0.0; }
+                        t1[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, zb.x, t1[tl], 0, 0, 0);
+                        t2[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, zb.y, t2[tl], 0, 0, 0);
+                        t3[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, zs, t3[tl], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    y[tl][sidx].x -= t1[tl][sidx] - t2[tl][sidx];
+                    y[tl][sidx].y -= t3[tl][sidx] - t1[tl][sidx] - t2[tl][sidx];
+                }
+        }
+        if (!solve) {       // the updated block (ncb, ncb) of these rows goes back in place
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int col = 32 * c + 16 * tl + lk + 4 * sidx;
+                    if (rok && col < gw) Lp[row + (int64_t)(k0 + col) * ld] = y[tl][sidx];
+                }
+            break;
+        }
+        // X_c = Y_c W_c
+        d4 u1[2], u2[2], u3[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) { u1[tl] = (d4){0, 0, 0, 0}; u2[tl] = (d4){0, 0, 0, 0}; u3[tl] = (d4){0, 0, 0, 0}; }
+        const cz* Wc = Wt + c * 1024;
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int kk = 16 * ts + lk + 4 * sidx;
+                const cz yb = y[ts][sidx];
+                const double ys = yb.x + yb.y;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const cz a = Wc[kk * 32 + 16 * tl + li];
+                    u1[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, yb.x, u1[tl], 0, 0, 0);
+                    u2[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, yb.y, u2[tl], 0, 0, 0);
+                    u3[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, ys, u3[tl], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int col = 32 * c + 16 * tl + lk + 4 * sidx;
+                const bool cok = col < gw;
+                const cz x = cz_make(u1[tl][sidx] - u2[tl][sidx], u3[tl][sidx] - u1[tl][sidx] - u2[tl][sidx]);
+                cz dk = D0[min(col, gw - 1) + (int64_t)min(col, gw - 1) * ld];
+                if (!cok) { dk.x = 0.0; dk.y = 0.0; }
+                const cz zz = cz_mul(x, dk);
+                z[2 * c + tl][sidx] = zz;
+                if (rok && cok) {
+                    Lp[row + (int64_t)(k0 + col) * ld] = x;
+                    ucol[col] = zz;                       // U[k0 + col][row] = d_col l_(row, col)
+                    lmax = fmax(lmax, fabs(x.x) + fabs(x.y));
+                }
+            }
+    }
+    return lmax;
+}
+
+// two-wave elimination of one b x b (b <= 32) block at D (leading dimension ld): wave 0 keeps row i of the block in lane i and
+// eliminates without interchanges; wave 1 applies the same row operations to the identity (multipliers through LDS, one
+// barrier per step), which leaves inv(L) in its registers.  The 32 steps run as four rolled loops of eight (static register
+// indices per block, the step inside a block picked with selects): fully unrolled the code is 260 KB and the kernel is bound by
+// instruction fetch.  Returns (wave 0) max |l|, max |pivot|, perturbed pivots via references.
+template <int KB>
+__device__ __forceinline__ void lu32_steps(double (&xr)[FACT_NB], double (&xi)[FACT_NB], const int i, const int b, const int wave, const double tiny_k,
+                                           cz (*s_l)[FACT_NB], double& lmax, double& dmax, int& npert) {
+#pragma unroll 1
+    for (int jj = 0; jj < 8; ++jj) {
+        const int j = KB + jj;
+        const int buf = j & 1;
+        if (wave == 0) {
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { sr = (jj == q) ? xr[KB + q] : sr; si = (jj == q) ? xi[KB + q] : si; }
+            double pr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sr), j), __builtin_amdgcn_readlane(__double2loint(sr), j));
+            double pi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(si), j), __builtin_amdgcn_readlane(__double2loint(si), j));
+            const double pa = fabs(pr) + fabs(pi);
+            if (j < b) dmax = fmax(dmax, pa);
+            if (!(pa >= tiny_k)) {             // static pivot perturbation (also catches NaN), as in k_panel_reg
+                if (pa > 0.0) { pr *= tiny_k / pa; pi *= tiny_k / pa; } else { pr = tiny_k; pi = 0.0; }
+                if (i == j) { sr = pr; si = pi; }
+                if (j < b) ++npert;
+            }
+            const cz inv = cz_inv(cz_make(pr, pi));
+            const bool below = i > j && i < FACT_NB;
+            const double lr = below ? sr * inv.x - si * inv.y : 0.0, lim = below ? sr * inv.y + si * inv.x : 0.0;
+            if (below) { sr = lr; si = lim; lmax = fmax(lmax, fabs(lr) + fabs(lim)); }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { xr[KB + q] = (jj == q) ? sr : xr[KB + q]; xi[KB + q] = (jj == q) ? si : xi[KB + q]; }
+            if (i < FACT_NB) s_l[buf][i] = cz_make(lr, lim);
+            __syncthreads();
+#pragma unroll
+            for (int c = KB + 1; c < FACT_NB; ++c) {
+                const double ur = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xr[c]), j), __builtin_amdgcn_readlane(__double2loint(xr[c]), j));
+                const double ui = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi[c]), j), __builtin_amdgcn_readlane(__double2loint(xi[c]), j));
+                if (c > j) { xr[c] -= lr * ur - lim * ui; xi[c] -= lr * ui + lim * ur; }       // lr = lim = 0 on and above the pivot row
+            }
+        } else {
+            __syncthreads();
+            const cz l = i < FACT_NB ? s_l[buf][i] : cz_make(0, 0);
+#pragma unroll
+            for (int c = 0; c < KB + 8; ++c) {
+                const double ur = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xr[c]), j), __builtin_amdgcn_readlane(__double2loint(xr[c]), j));
+                const double ui = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi[c]), j), __builtin_amdgcn_readlane(__double2loint(xi[c]), j));
+                if (c <= j) { xr[c] -= l.x * ur - l.y * ui; xi[c] -= l.x * ui + l.y * ur; }
+            }
+        }
+    }
+}
+
+// (a call, not inlined: the substitution's registers and the elimination's are never live together, and inlined into the block
+// loop the allocator spills)
+__device__ __attribute__((noinline)) double grp_substitute_call(cz* Lp, cz* F12, int ld, int p, int k0, int gw, int ncb, int rbase, int rend, const cz* Wt) {
+    return grp_substitute(Lp, F12, ld, p, k0, gw, ncb, true, rbase, rend, Wt);
+}
+
+__global__ __launch_bounds__(128) void k_diag_grp(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
+                                                  cz* fact, int64_t fs, int* piv, int npiv, const double* __restrict__ tiny, int* nperturb,
+                                                  unsigned long long* growth, cz* wscr, int64_t wstride) {
+    __shared__ cz s_l[2][FACT_NB];
+    __shared__ cz s_d[FACT_NB];
+    __builtin_amdgcn_s_setprio(3);             // the few waves of the dependency chain go first wherever they share a SIMD
+    FrontD f = fr[list[blockIdx.x]];
+    const int k = blockIdx.y;
+    const int p = f.p, ld = f.p + f.u;
+    const int gw = min(GRP_W, p - k0), nb = (gw + FACT_NB - 1) / FACT_NB;
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* F12 = fact + (int64_t)k * fs + f.f12;
+    cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot * 4) * 1024;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;     // (scalar: the role branches below are wave-uniform)
+    const double tiny_k = tiny[k];
+    double lmax = 0.0, dmax = 0.0;
+    int npert = 0;
+    for (int c = 0; c < nb; ++c) {
+        const int b = min(FACT_NB, gw - FACT_NB * c);
+        if (c > 0) {
+            // rows of block c: L entries of the blocks before it, then the update of block (c, c), 16 rows per wave
+            const double lm = grp_substitute_call(Lp, F12, ld, p, k0, gw, c, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt);
+            lmax = fmax(lmax, lm);
+            __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the two waves below
+        }
+        cz* D = Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld;
+        double xr[FACT_NB], xi[FACT_NB];
+        const bool rok = i < b;
+#pragma unroll
+        for (int cc = 0; cc < FACT_NB; ++cc) {
+            cz v = cz_make(i == cc ? 1.0 : 0.0, 0.0);
+            if (wave == 0 && rok && cc < b) v = D[i + (int64_t)cc * ld];
+            xr[cc] = v.x; xi[cc] = v.y;
+        }
+        lu32_steps<0>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
+        lu32_steps<8>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
+        lu32_steps<16>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
+        lu32_steps<24>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
+        if (wave == 0) {
+#pragma unroll
+            for (int cc = 0; cc < FACT_NB; ++cc) {
+                if (rok && cc < b) D[i + (int64_t)cc * ld] = cz_make(xr[cc], xi[cc]);
+                if (i == cc) s_d[cc] = cz_make(xr[cc], xi[cc]);
+            }
+            if (rok) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + i] = k0 + FACT_NB * c + i;
+        }
+        __syncthreads();
+        if (wave == 1 && i < FACT_NB) {        // W_c[kk][j] = inv(U_cc)[kk][j] = inv(L_cc)[j][kk] / d_j   (lane j holds row j of inv(L_cc))
+            const cz dinv = cz_inv(s_d[i]);
+            cz* Wc = Wt + c * 1024;
+#pragma unroll
+            for (int kk = 0; kk < FACT_NB; ++kk) Wc[kk * 32 + i] = cz_mul(cz_make(xr[kk], xi[kk]), dinv);
+        }
+        __syncthreads();                       // W_c, L\U of block c: visible to the next block's substitution
+    }
+    if (wave == 0) {
+        if (i == 0 && npert > 0) atomicAdd(nperturb + k, npert);
+        growth_max(growth + gridDim.y + k, i == 0 ? dmax : 0.0);
+    }
+    growth_max(growth + k, lmax);
+}
+
+// rows below the group's diagonal block, 64 per workgroup (Tile.a): see grp_substitute
+__global__ __launch_bounds__(256) void k_lscale_grp(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
+                                                    cz* fact, int64_t fs, unsigned long long* growth, const cz* __restrict__ wscr, int64_t wstride) {
+    Tile t = tiles[blockIdx.x];
+    const int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    const int p = f.p, ld = p + f.u;
+    const int gw = min(GRP_W, p - k0), nb = (gw + FACT_NB - 1) / FACT_NB;
+    const int r0 = k0 + gw + t.a * 64 + 16 * (threadIdx.x >> 6);
+    if (r0 >= ld) return;                      // (no barriers in this kernel: a wave without rows may leave)
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* F12 = fact + (int64_t)k * fs + f.f12;
+    const cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot * 4) * 1024;
+    const double lm = grp_substitute(Lp, F12, ld, p, k0, gw, nb, false, r0, ld, Wt);
+    growth_max(growth + k, lm);
+}
+
+void launch_diag_grp(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
+                     const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K) {
+    if (nlist <= 0) return;
+    hipLaunchKernelGGL(k_diag_grp, dim3(nlist, K), dim3(128), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
+}
+
+void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                       unsigned long long* growth, const cz* wscr, int64_t wstride, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_lscale_grp, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth, wscr, wstride);
+}
+
+// ---------------------------------------------------------------------------
 // apply the panel's row interchanges to every other column of the front
 // ---------------------------------------------------------------------------
 // ColSel picks the columns an elimination step touches in one launch, for the look-ahead schedule of Engine::factorize:
