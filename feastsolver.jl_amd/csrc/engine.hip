@@ -189,6 +189,13 @@ Engine::Engine(int device) : device_(device) {
                 for (int m = 0; m < reserve_cus_; ++m) mask[x] &= ~(1u << (8 * m + x));
             }
             if (hipExtStreamCreateWithCUMask(&rest_stream_, 8, mask) != hipSuccess) { rest_stream_ = nullptr; (void)hipGetLastError(); }
+            // The solve-ready conversion of the finished levels (long-running workgroups on a low-priority stream) must not sit on the
+            // reserved CUs either: a chain kernel's workgroup would wait for one of those to drain.  FEASTHIP_FIN_MASK=1 trades the
+            // stream's low priority for the same CU mask.
+            if (const char* v = getenv("FEASTHIP_FIN_MASK")) if (atoi(v) != 0) {
+                hipStream_t fm = nullptr;
+                if (hipExtStreamCreateWithCUMask(&fm, 8, mask) == hipSuccess) { if (fin_stream_) (void)hipStreamDestroy(fin_stream_); fin_stream_ = fm; } else (void)hipGetLastError();
+            }
         }
     }
 }
@@ -852,10 +859,10 @@ int Engine::analyze() {
         f.ebp = -1;
         f.nb = solve_nb(s); f.wslot = 0;
     }
-    wstride_ = 4;
+    wstride_ = 1;
     for (const std::vector<int>& lv : S.levels) {
         for (size_t i = 0; i < lv.size(); ++i) fr[lv[i]].wslot = (int)i;
-        wstride_ = std::max<int64_t>(wstride_, 4 * (int64_t)lv.size());
+        wstride_ = std::max<int64_t>(wstride_, (int64_t)lv.size());
     }
     // pull map of the forward sweep: for every contribution row of a front and every child slot, the row of the child's
     // contribution block that is added to it (rel >= p), as an absolute row of the children's arena; -1 if none
@@ -934,7 +941,7 @@ int Engine::analyze() {
     ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
          d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
          d_rowperm_.alloc((size_t)Kloc * n) && d_rowinv_.alloc((size_t)Kloc * n) && d_nperturb_.alloc(Kloc) &&
-         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)2 * Kloc) && d_wscr_.alloc((size_t)Kloc * wstride_ * 1024) && d_coef_.alloc((size_t)Kloc * nterms);
+         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)2 * Kloc) && d_wscr_.alloc((size_t)Kloc * wstride_ * (4 * 1024 + 128)) && d_coef_.alloc((size_t)Kloc * nterms);
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
     alloc_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);

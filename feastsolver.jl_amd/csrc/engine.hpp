@@ -194,7 +194,7 @@ private:
     DevBuf<int> d_piv_, d_rowperm_, d_rowinv_, d_nperturb_;
     DevBuf<double> d_tiny_;
     DevBuf<cz> d_wscr_;                   // pivot-light group kernels: inv(U_cc) of the 32-column blocks of the current group, per unit and front of the level
-    int64_t wstride_ = 0;                 // ... blocks of 1024 entries per unit (4 per front of the widest level)
+    int64_t wstride_ = 0;                 // ... scratch slots per unit (one per front of the widest level; kernels_factor.hip: WSLOT entries each)
     bool nopiv_group_ = true;             // FEASTHIP_NOPIV_GROUP=0: the per-panel kernels (k_diag_np / k_lscale_np) instead of the group kernels
     DevBuf<int64_t> d_growth_;            // per unit: max |l_ij| of the pivot-light path (bit pattern of a double)
     // iteration state (row-major n x ldw)

@@ -168,7 +168,7 @@ int Engine::factorize() {
                 // the next group's columns are the first two tile columns right of this group: the short list does
                 const bool narrow = !others && c_hi - (k0g + gw) <= 128 && c_lo == k0g + gw;
                 const Launch& gl = narrow ? s0.gemm_in : s0.gemm;
-                launch_gemm_nn(s, dsym_, tl + gl.off, gl.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0, nullptr, 0, sym_bits);
+                launch_gemm_nn(s, dsym_, tl + gl.off, gl.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, sel(k0g + gw), gw, 0, nullptr, 0, sym_bits | (others ? 0 : 4));
             };
             for (int g = 0; g < ng; ++g) {
                 const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
@@ -224,7 +224,8 @@ int Engine::factorize() {
         hipStream_t fin = (finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_) ? fin_stream_ : stream_;
         if (fin != stream_) { HIPCHK(hipEventRecord(ev_fin_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fin_fork_, 0)); fin_used = true; }
         launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
-        launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
+        if (grp) launch_couple32(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);      // the 32 x 32 inverses are in place already
+        else launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
         for (int lvl = 0; lvl < 2; ++lvl) {       // 256- and 512-column super blocks of the fronts with many pivot columns

@@ -67,9 +67,13 @@ void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntil
                     cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0,
                     const cz* cb_child = nullptr, int64_t cbs_child = 0,     // cb_child: fuse the children's extend-add into the contribution block (kind 2)
                     int mirror = 0);     // symmetric elimination.  bit 0: kind-2 tiles with b > c also store their transpose (the list holds b >= c only);
-                                         // bit 1: kind-1 tiles and kind-0 tiles strictly above the diagonal are skipped (see k_lscale_np)
+                                         // bit 1: kind-1 tiles and kind-0 tiles strictly above the diagonal are skipped (see k_lscale_np);
+                                         // bit 2: raised wave priority (products on the dependency chain of the look-ahead schedule)
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled
 void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
+// pivot-light path: the 32 x 32 diagonal blocks already hold their inverses (k_diag_grp); couple pairs into 64 x 64 block inverses
+// (same tiles as launch_block_inverse, which this replaces)
+void launch_couple32(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 // Coupling of two solve-ready super blocks of `half` columns (a = [k0, k0+half), b = [k0+half, ...)) into one of 2*half, k0 = pair * 2*half:

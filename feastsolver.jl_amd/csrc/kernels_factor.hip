@@ -639,6 +639,7 @@ void launch_lscale_np(hipStream_t st, const DevSym& S, const Tile* tiles, int nt
 // After that the rows below and right of the group see ONE product of depth gw (k_gemm_nn), nothing else.
 // ---------------------------------------------------------------------------
 constexpr int GRP_W = 128;
+constexpr int WSLOT = 4 * 1024 + GRP_W;      // scratch entries per (node, front): W_c of the four 32-column blocks, then the group's pivots d
 
 // 16 rows (row = rbase + li < rend) of the group [k0, k0 + gw): substitution over the column blocks c < ncb; with upd_next the
 // Schur update of column block ncb (A -= Z L11^T) is written back in place instead.  Wt: W blocks, element [c][k][j].
@@ -732,7 +733,7 @@ __device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __rest
                 const int col = 32 * c + 16 * tl + lk + 4 * sidx;
                 const bool cok = col < gw;
                 const cz x = cz_make(u1[tl][sidx] - u2[tl][sidx], u3[tl][sidx] - u1[tl][sidx] - u2[tl][sidx]);
-                cz dk = D0[min(col, gw - 1) + (int64_t)min(col, gw - 1) * ld];
+                cz dk = Wt[4096 + min(col, gw - 1)];        // pivot d_col (the diagonal block itself holds the blocks' inverses by now)
                 if (!cok) { dk.x = 0.0; dk.y = 0.0; }
                 const cz zz = cz_mul(x, dk);
                 z[2 * c + tl][sidx] = zz;
@@ -746,69 +747,98 @@ __device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __rest
     return lmax;
 }
 
-// two-wave elimination of one b x b (b <= 32) block at D (leading dimension ld): wave 0 keeps row i of the block in lane i and
-// eliminates without interchanges; wave 1 applies the same row operations to the identity (multipliers through LDS, one
-// barrier per step), which leaves inv(L) in its registers.  The 32 steps run as four rolled loops of eight (static register
-// indices per block, the step inside a block picked with selects): fully unrolled the code is 260 KB and the kernel is bound by
-// instruction fetch.  Returns (wave 0) max |l|, max |pivot|, perturbed pivots via references.
-template <int KB>
-__device__ __forceinline__ void lu32_steps(double (&xr)[FACT_NB], double (&xi)[FACT_NB], const int i, const int b, const int wave, const double tiny_k,
-                                           cz (*s_l)[FACT_NB], double& lmax, double& dmax, int& npert) {
-#pragma unroll 1
-    for (int jj = 0; jj < 8; ++jj) {
-        const int j = KB + jj;
-        const int buf = j & 1;
-        if (wave == 0) {
-            double sr = 0.0, si = 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { sr = (jj == q) ? xr[KB + q] : sr; si = (jj == q) ? xi[KB + q] : si; }
-            double pr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sr), j), __builtin_amdgcn_readlane(__double2loint(sr), j));
-            double pi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(si), j), __builtin_amdgcn_readlane(__double2loint(si), j));
-            const double pa = fabs(pr) + fabs(pi);
-            if (j < b) dmax = fmax(dmax, pa);
-            if (!(pa >= tiny_k)) {             // static pivot perturbation (also catches NaN), as in k_panel_reg
-                if (pa > 0.0) { pr *= tiny_k / pa; pi *= tiny_k / pa; } else { pr = tiny_k; pi = 0.0; }
-                if (i == j) { sr = pr; si = pi; }
-                if (j < b) ++npert;
+// reciprocal of a pivot: 1 / (x + i y) = (x - i y) / (x^2 + y^2) with one hardware reciprocal and two Newton steps (the IEEE
+// division sequences of Smith's algorithm are three times as long, and this sits on the critical path of every elimination step);
+// magnitudes whose square leaves the double range take the careful route
+__device__ __forceinline__ cz cz_inv_pivot(cz a) {
+    const double den = a.x * a.x + a.y * a.y;
+    if (!(den > 1e-280 && den < 1e280)) return cz_inv(a);
+    double r = __builtin_amdgcn_rcp(den);
+    r = r * (2.0 - den * r);
+    r = r * (2.0 - den * r);
+    return cz_make(a.x * r, -a.y * r);
+}
+
+// Elimination of one b x b (b <= 32) block at D (leading dimension ld) by 512 threads: thread (i, q) = (tid & 31, tid >> 5) keeps
+// the entries (i, q) and (i, q + 16) of the block AND of an identity that receives the same row operations (it ends as inv(L)) in
+// registers.  A step publishes what the next one needs -- the pivot column, the pivot rows of both matrices, the reciprocal of the
+// pivot -- through LDS: one barrier per step, no register indexing, a rolled loop.  (The earlier one-wave version kept whole rows
+// in registers and paid 2 us per step in selects, lane reads and double-precision issue slots.)
+// On return the block holds ITS INVERSES in place -- inv(L) strictly below the diagonal (unit diagonal implied), inv(U) = inv(L)^T D^-1
+// on and above it: the first level of the solve-ready form (k_couple32 couples two such blocks into what k_block_inverse makes of a
+// 64 x 64 block of L\U), nothing after this kernel reads L\U of a diagonal 32 x 32 block -- Wc[kk * 32 + j] = inv(U)[kk][j], and
+// dout[j] = the pivots d_j.
+struct LuShared {
+    cz col[2][FACT_NB], row[2][FACT_NB], erow[2][FACT_NB], pinv[2], dinv[FACT_NB];
+};
+
+__device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, const int b, const double tiny_k, LuShared& sh, cz* __restrict__ Wc,
+                                           cz* __restrict__ dout, double& lmax, double& dmax, int& npert) {
+    const int i = threadIdx.x & 31, q = threadIdx.x >> 5, c0 = q, c1 = q + 16;
+    const bool rok = i < b;
+    cz a0 = (rok && c0 < b) ? D[i + (int64_t)c0 * ld] : cz_make(i == c0 ? 1.0 : 0.0, 0.0);
+    cz a1 = (rok && c1 < b) ? D[i + (int64_t)c1 * ld] : cz_make(i == c1 ? 1.0 : 0.0, 0.0);
+    cz e0 = cz_make(i == c0 ? 1.0 : 0.0, 0.0), e1 = cz_make(i == c1 ? 1.0 : 0.0, 0.0);
+    auto publish = [&](int jn, int nbuf) {       // what step jn reads: column jn, row jn of both matrices, the pivot's reciprocal
+        if (c0 == jn) sh.col[nbuf][i] = a0;
+        if (c1 == jn) sh.col[nbuf][i] = a1;
+        if (i == jn) {
+            if (c0 == jn || c1 == jn) {
+                cz pv = (c0 == jn) ? a0 : a1;
+                const double pa = fabs(pv.x) + fabs(pv.y);
+                if (jn < b) dmax = fmax(dmax, pa);
+                if (!(pa >= tiny_k)) {            // static pivot perturbation (also catches NaN), as in k_panel_reg
+                    pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+                    if (c0 == jn) a0 = pv; else a1 = pv;
+                    if (jn < b) ++npert;
+                }
+                const cz pin = cz_inv_pivot(pv);
+                sh.pinv[nbuf] = pin;
+                sh.dinv[jn] = pin;
             }
-            const cz inv = cz_inv(cz_make(pr, pi));
-            const bool below = i > j && i < FACT_NB;
-            const double lr = below ? sr * inv.x - si * inv.y : 0.0, lim = below ? sr * inv.y + si * inv.x : 0.0;
-            if (below) { sr = lr; si = lim; lmax = fmax(lmax, fabs(lr) + fabs(lim)); }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { xr[KB + q] = (jj == q) ? sr : xr[KB + q]; xi[KB + q] = (jj == q) ? si : xi[KB + q]; }
-            if (i < FACT_NB) s_l[buf][i] = cz_make(lr, lim);
-            __syncthreads();
-#pragma unroll
-            for (int c = KB + 1; c < FACT_NB; ++c) {
-                const double ur = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xr[c]), j), __builtin_amdgcn_readlane(__double2loint(xr[c]), j));
-                const double ui = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi[c]), j), __builtin_amdgcn_readlane(__double2loint(xi[c]), j));
-                if (c > j) { xr[c] -= lr * ur - lim * ui; xi[c] -= lr * ui + lim * ur; }       // lr = lim = 0 on and above the pivot row
-            }
-        } else {
-            __syncthreads();
-            const cz l = i < FACT_NB ? s_l[buf][i] : cz_make(0, 0);
-#pragma unroll
-            for (int c = 0; c < KB + 8; ++c) {
-                const double ur = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xr[c]), j), __builtin_amdgcn_readlane(__double2loint(xr[c]), j));
-                const double ui = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi[c]), j), __builtin_amdgcn_readlane(__double2loint(xi[c]), j));
-                if (c <= j) { xr[c] -= l.x * ur - l.y * ui; xi[c] -= l.x * ui + l.y * ur; }
-            }
+            sh.row[nbuf][c0] = a0; sh.row[nbuf][c1] = a1;
+            sh.erow[nbuf][c0] = e0; sh.erow[nbuf][c1] = e1;
         }
+    };
+    publish(0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < FACT_NB; ++j) {
+        const int buf = j & 1;
+        if (i > j) {
+            const cz l = cz_mul(sh.col[buf][i], sh.pinv[buf]);
+            if (c0 > j) cz_msub(a0, l, sh.row[buf][c0]); else { cz_msub(e0, l, sh.erow[buf][c0]); if (c0 == j) { a0 = l; lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } }
+            if (c1 > j) cz_msub(a1, l, sh.row[buf][c1]); else { cz_msub(e1, l, sh.erow[buf][c1]); if (c1 == j) { a1 = l; lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } }
+        }
+        if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
+        __syncthreads();
+    }
+    // thread (i, c) holds inv(L)[i][c] = inv(U)[c][i] d_i; a diagonal thread holds the pivot d_i
+    const cz dinv = sh.dinv[i];
+    const cz w0 = cz_mul(e0, dinv), w1 = cz_mul(e1, dinv);
+    Wc[c0 * 32 + i] = w0;
+    Wc[c1 * 32 + i] = w1;
+    if (c0 == i) dout[i] = a0;
+    if (c1 == i) dout[i] = a1;
+    if (rok) {
+        if (c0 < i) D[i + (int64_t)c0 * ld] = e0;              // inv(L)[i][c0]           (c0 < i < b)
+        if (c0 <= i) D[c0 + (int64_t)i * ld] = w0;             // inv(U)[c0][i]
+        if (c1 < i) D[i + (int64_t)c1 * ld] = e1;
+        if (c1 <= i) D[c1 + (int64_t)i * ld] = w1;
     }
 }
 
-// (a call, not inlined: the substitution's registers and the elimination's are never live together, and inlined into the block
-// loop the allocator spills)
+// (the substitution's registers and the elimination's are never live together; as a call the two are allocated separately)
 __device__ __attribute__((noinline)) double grp_substitute_call(cz* Lp, cz* F12, int ld, int p, int k0, int gw, int ncb, int rbase, int rend, const cz* Wt) {
     return grp_substitute(Lp, F12, ld, p, k0, gw, ncb, true, rbase, rend, Wt);
 }
 
-__global__ __launch_bounds__(128) void k_diag_grp(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
-                                                  cz* fact, int64_t fs, int* piv, int npiv, const double* __restrict__ tiny, int* nperturb,
-                                                  unsigned long long* growth, cz* wscr, int64_t wstride) {
-    __shared__ cz s_l[2][FACT_NB];
-    __shared__ cz s_d[FACT_NB];
+constexpr int DIAG_NT = 512;
+
+__global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
+                                                      cz* fact, int64_t fs, int* piv, int npiv, const double* __restrict__ tiny, int* nperturb,
+                                                      unsigned long long* growth, cz* wscr, int64_t wstride) {
+    __shared__ LuShared sh;
     __builtin_amdgcn_s_setprio(3);             // the few waves of the dependency chain go first wherever they share a SIMD
     FrontD f = fr[list[blockIdx.x]];
     const int k = blockIdx.y;
@@ -816,53 +846,24 @@ __global__ __launch_bounds__(128) void k_diag_grp(const FrontD* __restrict__ fr,
     const int gw = min(GRP_W, p - k0), nb = (gw + FACT_NB - 1) / FACT_NB;
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* F12 = fact + (int64_t)k * fs + f.f12;
-    cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot * 4) * 1024;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;     // (scalar: the role branches below are wave-uniform)
+    cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double tiny_k = tiny[k];
     double lmax = 0.0, dmax = 0.0;
     int npert = 0;
     for (int c = 0; c < nb; ++c) {
         const int b = min(FACT_NB, gw - FACT_NB * c);
         if (c > 0) {
-            // rows of block c: L entries of the blocks before it, then the update of block (c, c), 16 rows per wave
-            const double lm = grp_substitute_call(Lp, F12, ld, p, k0, gw, c, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt);
-            lmax = fmax(lmax, lm);
-            __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the two waves below
+            // rows of block c: L entries of the blocks before it, then the update of block (c, c); 16 rows per wave, two waves
+            if (wave < 2) lmax = fmax(lmax, grp_substitute_call(Lp, F12, ld, p, k0, gw, c, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt));
+            __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
         }
-        cz* D = Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld;
-        double xr[FACT_NB], xi[FACT_NB];
-        const bool rok = i < b;
-#pragma unroll
-        for (int cc = 0; cc < FACT_NB; ++cc) {
-            cz v = cz_make(i == cc ? 1.0 : 0.0, 0.0);
-            if (wave == 0 && rok && cc < b) v = D[i + (int64_t)cc * ld];
-            xr[cc] = v.x; xi[cc] = v.y;
-        }
-        lu32_steps<0>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
-        lu32_steps<8>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
-        lu32_steps<16>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
-        lu32_steps<24>(xr, xi, i, b, wave, tiny_k, s_l, lmax, dmax, npert);
-        if (wave == 0) {
-#pragma unroll
-            for (int cc = 0; cc < FACT_NB; ++cc) {
-                if (rok && cc < b) D[i + (int64_t)cc * ld] = cz_make(xr[cc], xi[cc]);
-                if (i == cc) s_d[cc] = cz_make(xr[cc], xi[cc]);
-            }
-            if (rok) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + i] = k0 + FACT_NB * c + i;
-        }
-        __syncthreads();
-        if (wave == 1 && i < FACT_NB) {        // W_c[kk][j] = inv(U_cc)[kk][j] = inv(L_cc)[j][kk] / d_j   (lane j holds row j of inv(L_cc))
-            const cz dinv = cz_inv(s_d[i]);
-            cz* Wc = Wt + c * 1024;
-#pragma unroll
-            for (int kk = 0; kk < FACT_NB; ++kk) Wc[kk * 32 + i] = cz_mul(cz_make(xr[kk], xi[kk]), dinv);
-        }
+        lu32_block(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
+        if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
         __syncthreads();                       // W_c, L\U of block c: visible to the next block's substitution
     }
-    if (wave == 0) {
-        if (i == 0 && npert > 0) atomicAdd(nperturb + k, npert);
-        growth_max(growth + gridDim.y + k, i == 0 ? dmax : 0.0);
-    }
+    if (npert > 0) atomicAdd(nperturb + k, npert);
+    growth_max(growth + gridDim.y + k, dmax);
     growth_max(growth + k, lmax);
 }
 
@@ -876,9 +877,10 @@ __global__ __launch_bounds__(256) void k_lscale_grp(const FrontD* __restrict__ f
     const int gw = min(GRP_W, p - k0), nb = (gw + FACT_NB - 1) / FACT_NB;
     const int r0 = k0 + gw + t.a * 64 + 16 * (threadIdx.x >> 6);
     if (r0 >= ld) return;                      // (no barriers in this kernel: a wave without rows may leave)
+    __builtin_amdgcn_s_setprio(2);             // part of the dependency chain of the big fronts: ahead of the trailing products
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* F12 = fact + (int64_t)k * fs + f.f12;
-    const cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot * 4) * 1024;
+    const cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
     const double lm = grp_substitute(Lp, F12, ld, p, k0, gw, nb, false, r0, ld, Wt);
     growth_max(growth + k, lm);
 }
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(256) void k_lscale_grp(const FrontD* __restrict__ f
 void launch_diag_grp(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
                      const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K) {
     if (nlist <= 0) return;
-    hipLaunchKernelGGL(k_diag_grp, dim3(nlist, K), dim3(128), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
+    hipLaunchKernelGGL(k_diag_grp, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
 }
 
 void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
@@ -1109,6 +1111,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
     // Workgroups go to the XCDs round-robin.  XCD x takes the work items (node, tile) in chunks of GEMM_CHUNK consecutive items:
     // the host lists the tiles of a front in 8 x 8 super-tiles, so the tiles in flight on one XCD share their A row panels
     // and B column panels through that XCD's L2 instead of every tile fetching both from memory.
+    if (mirror & 4) __builtin_amdgcn_s_setprio(2);      // a product on the dependency chain of the look-ahead schedule
     const int64_t seq = blockIdx.x >> 3;
     const int64_t item = (seq / GEMM_CHUNK) * (8 * GEMM_CHUNK) + (int64_t)(blockIdx.x & 7) * GEMM_CHUNK + seq % GEMM_CHUNK;
     if (item >= (int64_t)ntiles * K) return;
@@ -1287,6 +1290,73 @@ void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntil
 //   forward  w_r -= P_rt w_t,  y_t = inv(L_tt) w_t      backward  t_r -= PU_rt t_t,  x_t = inv(U_tt) t_t
 // (inverse-based blocked TRSM as in MAGMA), i.e. only GEMM-shaped work for the matrix cores.
 // ---------------------------------------------------------------------------
+// Pivot-light path: k_diag_grp leaves the inverses of the 32 x 32 diagonal blocks in place.  Two of them and the two blocks
+// between them (C: L entries below the first block, Dd: U entries right of it) are coupled into the inverses of the 64 x 64
+// block -- exactly what k_block_inverse computes from L\U by substitution, here four products of 32 x 32 blocks:
+//   inv([L1 0; C L2]) = [I1 0; -I2 C I1, I2],   inv([U1 Dd; 0 U2]) = [J1, -J1 Dd J2; 0, J2].     Tile.a = 64-column block.
+__global__ __launch_bounds__(256) void k_couple32(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, cz* fact, int64_t fs) {
+    __shared__ cz M0[32][33], M1[32][33], T0[32][33], T1[32][33];
+    Tile t = tiles[blockIdx.x];
+    const int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    const int ld = f.p + f.u, k0 = t.a * INV_NB;
+    const int b2 = min(32, f.p - k0 - 32);          // size of the second 32-block (the tile exists only if b2 > 0)
+    if (b2 <= 0) return;
+    cz* D0 = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;
+    auto at = [&](int i, int j) -> cz& { return D0[i + (int64_t)j * ld]; };
+    const int tid = threadIdx.x;
+    // ---- lower: C (rows 32.., cols 0..31) <- -I2 (C I1);  I1 = unit lower inverse of block 1 (strictly lower stored), I2 of block 2
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        int i = idx % 32, j = idx / 32;
+        M0[i][j] = i < b2 ? at(32 + i, j) : cz_make(0, 0);                                   // C
+        T0[i][j] = i > j ? at(i, j) : cz_make(i == j ? 1.0 : 0.0, 0.0);                        // I1
+        T1[i][j] = (i > j && i < b2) ? at(32 + i, 32 + j) : cz_make(i == j ? 1.0 : 0.0, 0.0);  // I2
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        int i = idx % 32, j = idx / 32;
+        cz sacc = cz_make(0, 0);
+        for (int q = j; q < 32; ++q) cz_madd(sacc, M0[i][q], T0[q][j]);        // (C I1)[i][j], I1 lower
+        M1[i][j] = sacc;
+    }
+    __syncthreads();
+    cz lo[4];
+    for (int r = 0; r < 4; ++r) {
+        int idx = tid + 256 * r, i = idx % 32, j = idx / 32;
+        cz sacc = cz_make(0, 0);
+        for (int q = 0; q <= i; ++q) cz_madd(sacc, T1[i][q], M1[q][j]);        // (I2 (C I1))[i][j], I2 lower
+        lo[r] = cz_make(-sacc.x, -sacc.y);
+    }
+    __syncthreads();
+    // ---- upper: Dd (rows 0..31, cols 32..) <- -J1 (Dd J2);  J1, J2 = upper inverses incl. diagonal
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        int i = idx % 32, j = idx / 32;
+        M0[i][j] = j < b2 ? at(i, 32 + j) : cz_make(0, 0);                                    // Dd
+        T0[i][j] = i <= j ? at(i, j) : cz_make(0, 0);                                            // J1
+        T1[i][j] = (i <= j && j < b2) ? at(32 + i, 32 + j) : cz_make(0, 0);                      // J2
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        int i = idx % 32, j = idx / 32;
+        cz sacc = cz_make(0, 0);
+        for (int q = 0; q <= j; ++q) cz_madd(sacc, M0[i][q], T1[q][j]);        // (Dd J2)[i][j], J2 upper
+        M1[i][j] = sacc;
+    }
+    __syncthreads();
+    for (int r = 0; r < 4; ++r) {
+        int idx = tid + 256 * r, i = idx % 32, j = idx / 32;
+        cz sacc = cz_make(0, 0);
+        for (int q = i; q < 32; ++q) cz_madd(sacc, T0[i][q], M1[q][j]);        // (J1 (Dd J2))[i][j], J1 upper
+        if (j < b2) at(i, 32 + j) = cz_make(-sacc.x, -sacc.y);
+        if (i < b2) at(32 + i, j) = lo[r];
+    }
+}
+
+void launch_couple32(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_couple32, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, fact, fs);
+}
+
 __global__ __launch_bounds__(128) void k_block_inverse(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                        cz* fact, int64_t fs) {
     __shared__ cz T[INV_NB][INV_NB + 1];
@@ -1332,8 +1402,9 @@ void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, in
 // inv([U1 D; 0 U2]) = [J1  -J1 D J2; 0 J2], in place.  One workgroup per (front, super block, node).
 __global__ __launch_bounds__(256) void k_couple_inverse(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                         cz* fact, int64_t fs) {
+    // one staging buffer (66 KB; two of them kept every other LDS user off the CU): a product is formed in registers (16 entries
+    // per thread) and replaces its input in LDS after a barrier
     __shared__ cz M0[INV_NB][INV_NB + 1];
-    __shared__ cz M1[INV_NB][INV_NB + 1];
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -1342,43 +1413,67 @@ __global__ __launch_bounds__(256) void k_couple_inverse(const FrontD* __restrict
     cz* D0 = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;      // super block origin
     auto at = [&](int i, int j) -> cz& { return D0[i + (int64_t)j * ld]; };
     int tid = threadIdx.x;
+    constexpr int PER = INV_NB * INV_NB / 256;
+    cz acc[PER];
     // ---- lower: C (rows 64.., cols 0..63) <- -I2 (C I1)
     for (int idx = tid; idx < b2 * INV_NB; idx += 256) { int i = idx % b2, j = idx / b2; M0[i][j] = at(INV_NB + i, j); }
     __syncthreads();
-    for (int idx = tid; idx < b2 * INV_NB; idx += 256) {
-        int i = idx % b2, j = idx / b2;
-        cz s = M0[i][j];                                   // I1[j][j] = 1
-        for (int q = j + 1; q < INV_NB; ++q) cz_madd(s, M0[i][q], at(q, j));
-        M1[i][j] = s;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        int idx = tid + 256 * r;
+        acc[r] = cz_make(0, 0);
+        if (idx < b2 * INV_NB) {
+            int i = idx % b2, j = idx / b2;
+            cz sacc = M0[i][j];                                // I1[j][j] = 1
+            for (int q = j + 1; q < INV_NB; ++q) cz_madd(sacc, M0[i][q], at(q, j));
+            acc[r] = sacc;
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < b2 * INV_NB; idx += 256) {
-        int i = idx % b2, j = idx / b2;
-        cz s = M1[i][j];                                   // I2[i][i] = 1
-        for (int q = 0; q < i; ++q) cz_madd(s, at(INV_NB + i, INV_NB + q), M1[q][j]);
-        M0[i][j] = cz_make(-s.x, -s.y);
-    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { int idx = tid + 256 * r; if (idx < b2 * INV_NB) M0[idx % b2][idx / b2] = acc[r]; }
     __syncthreads();
-    for (int idx = tid; idx < b2 * INV_NB; idx += 256) { int i = idx % b2, j = idx / b2; at(INV_NB + i, j) = M0[i][j]; }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        int idx = tid + 256 * r;
+        if (idx < b2 * INV_NB) {
+            int i = idx % b2, j = idx / b2;
+            cz sacc = M0[i][j];                                // I2[i][i] = 1
+            for (int q = 0; q < i; ++q) cz_madd(sacc, at(INV_NB + i, INV_NB + q), M0[q][j]);
+            acc[r] = cz_make(-sacc.x, -sacc.y);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { int idx = tid + 256 * r; if (idx < b2 * INV_NB) at(INV_NB + idx % b2, idx / b2) = acc[r]; }
     __syncthreads();
     // ---- upper: D (rows 0..63, cols 64..) <- -J1 (D J2)
     for (int idx = tid; idx < INV_NB * b2; idx += 256) { int i = idx % INV_NB, j = idx / INV_NB; M0[i][j] = at(i, INV_NB + j); }
     __syncthreads();
-    for (int idx = tid; idx < INV_NB * b2; idx += 256) {
-        int i = idx % INV_NB, j = idx / INV_NB;
-        cz s = cz_make(0, 0);
-        for (int q = 0; q <= j; ++q) cz_madd(s, M0[i][q], at(INV_NB + q, INV_NB + j));
-        M1[i][j] = s;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        int idx = tid + 256 * r;
+        acc[r] = cz_make(0, 0);
+        if (idx < INV_NB * b2) {
+            int i = idx % INV_NB, j = idx / INV_NB;
+            cz sacc = cz_make(0, 0);
+            for (int q = 0; q <= j; ++q) cz_madd(sacc, M0[i][q], at(INV_NB + q, INV_NB + j));
+            acc[r] = sacc;
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < INV_NB * b2; idx += 256) {
-        int i = idx % INV_NB, j = idx / INV_NB;
-        cz s = cz_make(0, 0);
-        for (int q = i; q < INV_NB; ++q) cz_madd(s, at(i, q), M1[q][j]);
-        M0[i][j] = cz_make(-s.x, -s.y);
-    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { int idx = tid + 256 * r; if (idx < INV_NB * b2) M0[idx % INV_NB][idx / INV_NB] = acc[r]; }
     __syncthreads();
-    for (int idx = tid; idx < INV_NB * b2; idx += 256) { int i = idx % INV_NB, j = idx / INV_NB; at(i, INV_NB + j) = M0[i][j]; }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        int idx = tid + 256 * r;
+        if (idx < INV_NB * b2) {
+            int i = idx % INV_NB, j = idx / INV_NB;
+            cz sacc = cz_make(0, 0);
+            for (int q = i; q < INV_NB; ++q) cz_madd(sacc, at(i, q), M0[q][j]);
+            at(i, INV_NB + j) = cz_make(-sacc.x, -sacc.y);
+        }
+    }
 }
 
 void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K) {
@@ -1390,9 +1485,16 @@ void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, i
 // above (tile.c = 0: row <- row * inv(U_TT)) or below (tile.c = 1: row <- row * inv(L_TT)).  In place: the
 // two 64-column halves are produced in an order that never overwrites an input that is still needed, and every
 // wave reads its 16 rows completely before it writes them.  f64 MFMA, transposed-tile layout of k_gemm_nn.
-__global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
-                                                      cz* fact, int64_t fs) {
-    __shared__ cz Bs[SOLVE_NB][65];      // Bs[k][n] = Inv[kfirst + k][ncol0 + n]
+constexpr int SCALE_KC = 32;        // k rows of the inverse block staged per step (33 KB of LDS, like k_gemm_nn)
+
+// The earlier version staged a whole 128 x 64 half of the inverse block (133 KB of LDS: one workgroup per CU, and no other LDS user
+// beside it while it ran in the background of the levels above) and kept the wave's 16 x 128 row slab in registers (450 registers:
+// one wave per SIMD).  Here the K loop runs in chunks of 32 like k_gemm_nn: the row entries of a chunk are loaded when the chunk is
+// multiplied; in place is still safe because a wave writes its rows only after the last chunk of a pass, and the second pass reads
+// the half of the row the first pass did not write.
+__global__ __launch_bounds__(256, 2) void k_scale_panels(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+                                                         cz* fact, int64_t fs) {
+    __shared__ cz Bs[SCALE_KC][65];      // Bs[k][n] = Inv[kfirst + kc + k][ncol0 + n]
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -1410,47 +1512,51 @@ __global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__
         int ncol0 = h * INV_NB, ncols = min(INV_NB, b - ncol0);
         int kfirst = below ? ncol0 : 0;
         int klen = below ? b - ncol0 : ncol0 + ncols;
-        __syncthreads();
-        for (int idx = tid; idx < SOLVE_NB * 64; idx += 256) {
-            int kk = idx % SOLVE_NB, nn = idx / SOLVE_NB;
-            cz v = cz_make(0, 0);
-            if (kk < klen && nn < ncols) {
-                int gi = kfirst + kk, gj = ncol0 + nn;          // element (gi, gj) of the super-block inverse
-                if (below) { if (gi > gj) v = Lp[(k0 + gi) + (int64_t)(k0 + gj) * ld]; else if (gi == gj) v = cz_make(1, 0); }
-                else if (gi <= gj) v = Lp[(k0 + gi) + (int64_t)(k0 + gj) * ld];
-            }
-            Bs[kk][nn] = v;
-        }
-        __syncthreads();
-        // the staged inverse block is reused for SCALE_ROWTILES consecutive 64-row tiles (it is as large as a row tile's
-        // own factor bytes, so re-reading it per tile doubled the traffic of this pass)
         for (int sub = 0; sub < SCALE_ROWTILES; ++sub) {
             int rbase = (below ? k0 + b : 0) + (t.b * SCALE_ROWTILES + sub) * 64;
             if (rbase >= rend) break;
             int mrow = rbase + wave * 16 + li;
             bool mok = mrow < rend;
             int mrow_c = min(mrow, rend - 1);
-            cz av[SOLVE_NB / 4];
+            d4 t1[4], t2[4], t3[4];       // 3M complex product, see k_gemm_nn
 #pragma unroll
-            for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
-                int kk = ks * 4 + lk;
-                cz v = Lp[mrow_c + (int64_t)(k0 + kfirst + min(kk, klen - 1)) * ld];
-                bool keep = mok && kk < klen;
-                av[ks].x = keep ? v.x : 0.0;
-                av[ks].y = keep ? v.y : 0.0;
-            }
-            d4 cr[4], ci[4];
+            for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
+            for (int kc = 0; kc < klen; kc += SCALE_KC) {
+                cz av[SCALE_KC / 4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) { cr[nt] = (d4){0, 0, 0, 0}; ci[nt] = (d4){0, 0, 0, 0}; }
-            int nks = (klen + 3) >> 2;
+                for (int ks = 0; ks < SCALE_KC / 4; ++ks) {
+                    int kk = kc + ks * 4 + lk;
+                    cz v = Lp[mrow_c + (int64_t)(k0 + kfirst + min(kk, klen - 1)) * ld];
+                    bool keep = mok && kk < klen;
+                    av[ks].x = keep ? v.x : 0.0;
+                    av[ks].y = keep ? v.y : 0.0;
+                }
+                cz bvals[SCALE_KC * 64 / 256];
 #pragma unroll
-            for (int ks = 0; ks < SOLVE_NB / 4; ++ks) {
-                if (ks < nks) {
-                    int kk = ks * 4 + lk;
+                for (int q = 0; q < SCALE_KC * 64 / 256; ++q) {
+                    int idx = tid + 256 * q, kk = idx % SCALE_KC, nn = idx / SCALE_KC;
+                    int gi = kfirst + kc + kk, gj = ncol0 + nn;              // element (gi, gj) of the super-block inverse
+                    cz v = Lp[(k0 + min(gi, b - 1)) + (int64_t)(k0 + min(gj, b - 1)) * ld];
+                    const bool in = kc + kk < klen && nn < ncols;
+                    const bool nz = below ? gi > gj : gi <= gj;
+                    if (!(in && nz)) v = cz_make((in && below && gi == gj) ? 1.0 : 0.0, 0.0);
+                    bvals[q] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < SCALE_KC * 64 / 256; ++q) { int idx = tid + 256 * q; Bs[idx % SCALE_KC][idx / SCALE_KC] = bvals[q]; }
+                __syncthreads();
+#pragma unroll
+                for (int ks = 0; ks < SCALE_KC / 4; ++ks) {
+                    const int kk = ks * 4 + lk;
+                    const double ar = av[ks].x, ai = av[ks].y, as = ar + ai;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        cz bv = Bs[kk][nt * 16 + li];
-                        cmfma(cr[nt], ci[nt], bv.x, bv.y, av[ks].x, av[ks].y);     // D[n][m] = sum_k Inv[k][n] A[m][k]
+                        const cz bv = Bs[kk][nt * 16 + li];
+                        // D[n][m] = sum_k Inv[k][n] A[m][k]
+                        t1[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv.x, ar, t1[nt], 0, 0, 0);
+                        t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv.y, ai, t2[nt], 0, 0, 0);
+                        t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv.x + bv.y, as, t3[nt], 0, 0, 0);
                     }
                 }
             }
@@ -1460,7 +1566,7 @@ __global__ __launch_bounds__(256) void k_scale_panels(const FrontD* __restrict__
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int gn = nt * 16 + lk + 4 * r;
-                        if (gn < ncols) Lp[mrow + (int64_t)(k0 + ncol0 + gn) * ld] = cz_make(cr[nt][r], ci[nt][r]);
+                        if (gn < ncols) Lp[mrow + (int64_t)(k0 + ncol0 + gn) * ld] = cz_make(t1[nt][r] - t2[nt][r], t3[nt][r] - t1[nt][r] - t2[nt][r]);
                     }
             }
         }
@@ -1483,7 +1589,7 @@ void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // vector units: a few hundred workgroups of < 20 us per tree level.
 __global__ __launch_bounds__(256) void k_couple_level(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int half,
                                                       cz* fact, int64_t fs) {
-    __shared__ cz Ss[256][16];          // half <= 256
+    __shared__ cz Ss[256][17];          // half <= 256
     Tile t = tiles[blockIdx.x];
     const int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -1499,17 +1605,33 @@ __global__ __launch_bounds__(256) void k_couple_level(const FrontD* __restrict__
     const int tid = threadIdx.x;
     for (int idx = tid; idx < m * 16; idx += 256) { int i = idx % m, j = idx / m; Ss[i][j] = j < nc ? Cb[i + (int64_t)j * ld] : cz_make(0, 0); }
     __syncthreads();
-    for (int i = tid; i < m; i += 256) {
-        cz acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = upper ? cz_make(0, 0) : Ss[i][j];           // unit diagonal of inv(L_bb)
-        const int klo = upper ? i : 0, khi = upper ? m : i;                                   // upper incl. diagonal / strictly lower
-        for (int kk = klo; kk < khi; ++kk) {
-            const cz a = Tb[i + (int64_t)kk * ld];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) cz_madd(acc[j], a, Ss[kk][j]);
+    // out = -T S on the matrix cores (the vector-unit version read 16 LDS values per multiply-add row and thread: 1.4 ms for the
+    // 512-column blocks of the root front, at the very end of the factorisation).  Transposed tile as in k_gemm_nn:
+    // D[j][i] = sum_k S[k][j] T[i][k], so the result is stored with 16 consecutive rows per lane group.
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    for (int rt = wave; rt * 16 < m; rt += 4) {
+        const int i = rt * 16 + li;
+        const bool iok = i < m;
+        const int ic = min(i, m - 1);
+        const int kbeg = upper ? rt * 16 : 0, kend = upper ? m : min(m, rt * 16 + 16);      // upper incl. diagonal / strictly lower + unit diagonal
+        d4 t1 = (d4){0, 0, 0, 0}, t2 = (d4){0, 0, 0, 0}, t3 = (d4){0, 0, 0, 0};
+#pragma unroll 8
+        for (int kk0 = kbeg; kk0 < kend; kk0 += 4) {
+            const int kk = kk0 + lk, kkc = min(kk, m - 1);
+            const cz tv = Tb[ic + (int64_t)kkc * ld];
+            const bool keep = iok && kk < kend && (upper ? kk >= i : kk < i);
+            const double br = keep ? tv.x : ((!upper && iok && kk == i) ? 1.0 : 0.0), bi = keep ? tv.y : 0.0;
+            cz sv = Ss[kkc][li];
+            if (kk >= m) { sv.x = 0.0; sv.y = 0.0; }
+            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sv.x, br, t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sv.y, bi, t2, 0, 0, 0);
+            t3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sv.x + sv.y, br + bi, t3, 0, 0, 0);
         }
-        for (int j = 0; j < nc; ++j) Cb[i + (int64_t)j * ld] = cz_make(-acc[j].x, -acc[j].y);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = lk + 4 * r;
+            if (iok && j < nc) Cb[i + (int64_t)j * ld] = cz_make(-(t1[r] - t2[r]), -(t3[r] - t1[r] - t2[r]));
+        }
     }
 }
 
