@@ -641,9 +641,12 @@ void launch_lscale_np(hipStream_t st, const DevSym& S, const Tile* tiles, int nt
 constexpr int GRP_W = 128;
 constexpr int WSLOT = 4 * 1024 + GRP_W;      // scratch entries per (node, front): W_c of the four 32-column blocks, then the group's pivots d
 
-// 16 rows (row = rbase + li < rend) of the group [k0, k0 + gw): substitution over the column blocks c < ncb; with upd_next the
-// Schur update of column block ncb (A -= Z L11^T) is written back in place instead.  Wt: W blocks, element [c][k][j].
-__device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __restrict__ F12, int ld, int p, int k0, int gw, int ncb, bool upd_next,
+// 16 rows (row = rbase + li < rend) of the group [k0, k0 + gw).  upd_only = false: substitution over the column blocks c < ncb.
+// upd_only = true: the Schur update of column block ncb of these rows, A -= Z L11^T written back in place, with Z = (L D) of the
+// rows re-read from memory -- the L11 operand of that update are the L entries of ALL rows of block ncb, i.e. also what the other
+// wave of k_diag_grp has just computed, so the caller separates the two passes by a workgroup barrier.
+// Wt: W blocks, element [c][k][j], then the pivots.
+__device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __restrict__ F12, int ld, int p, int k0, int gw, int ncb, bool upd_only,
                                                  int rbase, int rend, const cz* __restrict__ Wt) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int row = rbase + li;
@@ -655,8 +658,19 @@ __device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __rest
     double lmax = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (c > ncb || (c == ncb && !upd_next) || 32 * c >= gw) break;
+        if (c > ncb || (c == ncb && !upd_only) || 32 * c >= gw) break;
         const bool solve = c < ncb;
+        if (upd_only && solve) {          // Z of this block from the stored L entries of these rows
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int col = 32 * c + 16 * tl + lk + 4 * sidx;          // (< 32 ncb <= gw)
+                    const cz x = Lp[row_c + (int64_t)(k0 + col) * ld];
+                    z[2 * c + tl][sidx] = rok ? cz_mul(x, Wt[4096 + col]) : cz_make(0, 0);
+                }
+            continue;
+        }
         cz y[2][4];
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl)
@@ -829,8 +843,8 @@ __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, con
 }
 
 // (the substitution's registers and the elimination's are never live together; as a call the two are allocated separately)
-__device__ __attribute__((noinline)) double grp_substitute_call(cz* Lp, cz* F12, int ld, int p, int k0, int gw, int ncb, int rbase, int rend, const cz* Wt) {
-    return grp_substitute(Lp, F12, ld, p, k0, gw, ncb, true, rbase, rend, Wt);
+__device__ __attribute__((noinline)) double grp_substitute_call(cz* Lp, cz* F12, int ld, int p, int k0, int gw, int ncb, bool upd_only, int rbase, int rend, const cz* Wt) {
+    return grp_substitute(Lp, F12, ld, p, k0, gw, ncb, upd_only, rbase, rend, Wt);
 }
 
 constexpr int DIAG_NT = 512;
@@ -854,8 +868,11 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
     for (int c = 0; c < nb; ++c) {
         const int b = min(FACT_NB, gw - FACT_NB * c);
         if (c > 0) {
-            // rows of block c: L entries of the blocks before it, then the update of block (c, c); 16 rows per wave, two waves
-            if (wave < 2) lmax = fmax(lmax, grp_substitute_call(Lp, F12, ld, p, k0, gw, c, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt));
+            // rows of block c, 16 per wave, two waves: L entries of the blocks before it; barrier (the update multiplies with the L
+            // entries of all 32 rows); update of block (c, c)
+            if (wave < 2) lmax = fmax(lmax, grp_substitute_call(Lp, F12, ld, p, k0, gw, c, false, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt));
+            __syncthreads();
+            if (wave < 2) grp_substitute_call(Lp, F12, ld, p, k0, gw, c, true, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt);
             __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
         }
         lu32_block(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
@@ -1615,7 +1632,6 @@ __global__ __launch_bounds__(256) void k_couple_level(const FrontD* __restrict__
         const int ic = min(i, m - 1);
         const int kbeg = upper ? rt * 16 : 0, kend = upper ? m : min(m, rt * 16 + 16);      // upper incl. diagonal / strictly lower + unit diagonal
         d4 t1 = (d4){0, 0, 0, 0}, t2 = (d4){0, 0, 0, 0}, t3 = (d4){0, 0, 0, 0};
-#pragma unroll 8
         for (int kk0 = kbeg; kk0 < kend; kk0 += 4) {
             const int kk = kk0 + lk, kkc = min(kk, m - 1);
             const cz tv = Tb[ic + (int64_t)kkc * ld];
