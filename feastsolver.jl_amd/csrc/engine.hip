@@ -154,7 +154,6 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
-    if (const char* v = getenv("FEASTHIP_NOPIV_GROUP")) nopiv_group_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
@@ -514,9 +513,6 @@ bool Engine::build_plans() {
                     for (int a = 0; a < cdiv(p - k0 - b + u, 32); ++a) tiles.push_back({s, a, 0, 0});
                 }
             st.grp.count = (int)(tiles.size() - st.grp.off);
-            st.lsc.off = (int64_t)tiles.size();
-            for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), b = std::min(FACT_NB, p - k0); for (int a = 0; a < cdiv(p + u - k0 - b, 256); ++a) tiles.push_back({s, a, 0, 0}); }
-            st.lsc.count = (int)(tiles.size() - st.lsc.off);
             st.lsg.off = (int64_t)tiles.size();
             if ((int)F.steps.size() % 4 == 0)
                 for (int s : lv) if (S.p(s) > k0) { int p = S.p(s), u = S.u(s), gw = std::min(128, p - k0); for (int a = 0; a < cdiv(p + u - k0 - gw, 64); ++a) tiles.push_back({s, a, 0, 0}); }

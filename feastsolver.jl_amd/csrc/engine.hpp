@@ -44,8 +44,7 @@ struct Launch {        // a slice of the tile / list buffers
 };
 
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp;
-                    Launch lsc;        // pivot-light path: 256-row slices of the rows below the diagonal block (k_lscale_np)
-                    Launch lsg; };     // ... at the first step of a 128-column group: 64-row slices of the rows below the group's diagonal block (k_lscale_grp)
+                    Launch lsg; };     // pivot-light path, first step of a 128-column group: 64-row slices of the rows below the group's diagonal block (k_lscale_grp)
 struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm;
                      Launch cbgemm_sym;     // symmetric pencils: the tiles on and below the diagonal of the contribution block only (mirrored on store)
                      Launch fronts; Launch binv, couple, scale;
@@ -195,7 +194,6 @@ private:
     DevBuf<double> d_tiny_;
     DevBuf<cz> d_wscr_;                   // pivot-light group kernels: inv(U_cc) of the 32-column blocks of the current group, per unit and front of the level
     int64_t wstride_ = 0;                 // ... scratch slots per unit (one per front of the widest level; kernels_factor.hip: WSLOT entries each)
-    bool nopiv_group_ = true;             // FEASTHIP_NOPIV_GROUP=0: the per-panel kernels (k_diag_np / k_lscale_np) instead of the group kernels
     DevBuf<int64_t> d_growth_;            // per unit: max |l_ij| of the pivot-light path (bit pattern of a double)
     // iteration state (row-major n x ldw)
     DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_Y_, d_crow_[2], d_sk_;

@@ -54,19 +54,12 @@ int Engine::factorize() {
     const Tile* tl = d_tiles_.p;
     const int* ls = d_lists_.p;
     HIPCHK(hipStreamSynchronize(stream_));   // coef/tiny are stack-owned host buffers
-    // Symmetric pencil (every coefficient matrix equals its transpose): no row interchanges, growth-checked afterwards (see
-    // k_diag_np); the contribution blocks are symmetric, so only their lower tile triangle is computed.
+    // Symmetric pencil (every coefficient matrix equals its transpose): elimination without row interchanges by groups of 128
+    // columns (k_diag_grp / k_lscale_grp, U = D L^T), growth-checked afterwards; the trailing matrix and the contribution blocks
+    // stay symmetric, so only their lower tile triangle is computed.
     const bool nopiv = use_nopiv();
     const int sym_bits = nopiv ? 2 : 0;        // launch_gemm_nn: skip the U12 updates and the strictly upper tiles of the pivot block
     unsigned long long* growth_dev = reinterpret_cast<unsigned long long*>(d_growth_.p);
-    auto panel_step = [&](hipStream_t s, FactorStep& sj, bool tall, int max_rows) {
-        if (nopiv) {
-            launch_diag_np(s, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, growth_dev, Kloc);
-            launch_lscale_np(s, dsym_, tl + sj.lsc.off, sj.lsc.count, sj.k0, d_fact_.p, fs, growth_dev, Kloc);
-        } else {
-            launch_panel(s, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, max_rows);
-        }
-    };
     HIPCHK(hipEventRecord(ev0_, stream_));
     if (dense) {
         std::vector<const cz*> ptrs(nterms);
@@ -98,8 +91,7 @@ int Engine::factorize() {
         for (int s2 : S.levels[d]) level_p = std::max(level_p, S.p(s2));
         const bool lookahead = look_ahead_ && level_p >= 256 && la_stream_ && F.steps.size() >= 4;
         stamp();
-        const bool grp = nopiv && nopiv_group_;      // whole 128-column groups per step: diagonal block, rows below, one product
-        if (!lookahead && grp) {
+        if (!lookahead && nopiv) {      // whole 128-column groups per step: diagonal block, rows below, one product
             for (size_t j = 0; j < F.steps.size(); j += 4) {
                 FactorStep& st = F.steps[j];
                 launch_diag_grp(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, growth_dev, d_wscr_.p, wstride_, Kloc);
@@ -108,12 +100,10 @@ int Engine::factorize() {
             }
         } else if (!lookahead) {
             for (FactorStep& st : F.steps) {
-                panel_step(stream_, st, tall, level_ld - st.k0);
-                if (!nopiv) {
-                    launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
-                    launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
-                }
-                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc, ColSel(), FACT_NB, 0, nullptr, 0, sym_bits);
+                launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - st.k0);
+                launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
+                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
+                launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
             }
         } else {
             // LU with look-ahead for the big fronts at the top of the tree (few fronts x nodes: the panel factorisation runs on a
@@ -128,11 +118,13 @@ int Engine::factorize() {
             // substitution: a 32-row product with the panels before it, then the triangular solve with the panel's own L11) and
             // the rest is one product.  Against per-panel updates the product reads and writes C once per group instead of once
             // per panel, which is what bounds it.
+            // Pivot-light path: the same pipeline with groups of 128 columns; P runs k_diag_grp + k_lscale_grp instead of the panels
+            // (no interchanges, no U-row solves: U = D L^T is written with the L columns), the products skip the upper triangle.
             hipStream_t P = la_stream_, R = rest_stream_ ? rest_stream_ : stream_;
             HIPCHK(hipEventRecord(ev_la_[4], stream_));
             HIPCHK(hipStreamWaitEvent(P, ev_la_[4], 0));
             if (R != stream_) HIPCHK(hipStreamWaitEvent(R, ev_la_[4], 0));
-            const int ns = (int)F.steps.size(), G = grp ? 4 : group_panels_, ng = (ns + G - 1) / G;
+            const int ns = (int)F.steps.size(), G = nopiv ? 4 : group_panels_, ng = (ns + G - 1) / G;
             const int INF = 1 << 30;
             auto K0 = [&](int g) { return g * G < ns ? F.steps[(size_t)g * G].k0 : INF; };       // first column of group g
             // all of group g (panels already factored) applied to the columns [c_lo, c_hi) of the pivot block, and to the left
@@ -177,26 +169,26 @@ int Engine::factorize() {
                     if (g > 1) HIPCHK(hipStreamWaitEvent(P, ev_la_[2 + (g & 1)], 0));      // rest of group g-2 reaches these columns
                     apply_group(P, g - 1, k0g, kend, false);
                 }
-                if (grp) {
+                if (nopiv) {
                     FactorStep& s0 = F.steps[j0];
                     launch_diag_grp(P, dsym_, ls + s0.panel.off, s0.panel.count, k0g, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, growth_dev, d_wscr_.p, wstride_, Kloc);
                     launch_lscale_grp(P, dsym_, tl + s0.lsg.off, s0.lsg.count, k0g, d_fact_.p, fs, growth_dev, d_wscr_.p, wstride_, Kloc);
                 }
-                for (int j = j0; j < j1 && !grp; ++j) {
+                for (int j = j0; j < j1 && !nopiv; ++j) {
                     FactorStep& sj = F.steps[j];
-                    panel_step(P, sj, tall, level_ld - sj.k0);
+                    launch_panel(P, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - sj.k0);
                     // inside the group: interchanges on the group's earlier L columns and its remaining columns, U rows and update
                     // of the remaining columns
                     ColSel c;
                     c.llo = k0g; c.lhi = sj.k0; c.clo = 0; c.chi = kend >= INF ? INF : std::max(0, kend - sj.k0 - FACT_NB); c.u12 = 0;
-                    if (!nopiv) launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
+                    launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
                     if (c.chi > 0) {
                         c.llo = c.lhi = 0;
-                        if (!nopiv) launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                        launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
                         {
                             // columns left in the group fit the first two tile columns unless the groups are wider than 160
                             const Launch& gl = (G - 1) * FACT_NB <= 128 ? sj.gemm_in : sj.gemm;
-                            launch_gemm_nn(P, dsym_, tl + gl.off, gl.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c, FACT_NB, 0, nullptr, 0, sym_bits);
+                            launch_gemm_nn(P, dsym_, tl + gl.off, gl.count, sj.k0, d_fact_.p, fs, cbp, cbs, Kloc, c);
                         }
                     }
                 }
@@ -224,7 +216,7 @@ int Engine::factorize() {
         hipStream_t fin = (finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_) ? fin_stream_ : stream_;
         if (fin != stream_) { HIPCHK(hipEventRecord(ev_fin_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fin_fork_, 0)); fin_used = true; }
         launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
-        if (grp) launch_couple32(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);      // the 32 x 32 inverses are in place already
+        if (nopiv) launch_couple32(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);      // the 32 x 32 inverses are in place already
         else launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);

@@ -38,15 +38,7 @@ void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int n
                        cz* cb_parent, int64_t cbs_parent, const cz* cb_child, int64_t cbs_child, int K, int phase, int sym = 0);
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
                   int* piv, const double* tiny, int* nperturb, int K, bool tall = false, int max_rows = 1 << 30);
-// Pivot-light panel step for symmetric pencils (no row interchanges): LU of the 32 x 32 diagonal block in one wave (identity
-// written to piv), then L = A inv(U11) for the rows below (Tile {front, 256-row slice of the rows below the block}), which also
-// writes the block's U rows as D L^T (no triangular solve for U, no update of the U12 panel or of the upper triangle).  growth[k]
-// receives max |l_ij| as the bit pattern of a double (atomicMax), nperturb[k] the perturbed pivots.
-void launch_diag_np(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
-                    int* piv, const double* tiny, int* nperturb, unsigned long long* growth, int K);
-void launch_lscale_np(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                      unsigned long long* growth, int K);
-// ... and per GROUP of up to 128 pivot columns (the path the engine takes): k_diag_grp factorises the group's diagonal block in one
+// Pivot-light elimination for symmetric pencils (no row interchanges), per GROUP of up to 128 pivot columns: k_diag_grp factorises the group's diagonal block in one
 // workgroup per (front, node) and leaves W_c = inv(U_cc) of its 32-column blocks in wscr[(k * wstride + FrontD::wslot * 4 + c) * 1024];
 // k_lscale_grp (Tile {front, 64-row slice of the rows below the block}) solves X U11 = A for the rows below on the matrix cores
 // and writes L and U = D L^T.  See kernels_factor.hip.
@@ -67,7 +59,7 @@ void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntil
                     cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0,
                     const cz* cb_child = nullptr, int64_t cbs_child = 0,     // cb_child: fuse the children's extend-add into the contribution block (kind 2)
                     int mirror = 0);     // symmetric elimination.  bit 0: kind-2 tiles with b > c also store their transpose (the list holds b >= c only);
-                                         // bit 1: kind-1 tiles and kind-0 tiles strictly above the diagonal are skipped (see k_lscale_np);
+                                         // bit 1: kind-1 tiles and kind-0 tiles strictly above the diagonal are skipped (U = D L^T is written by k_lscale_grp);
                                          // bit 2: raised wave priority (products on the dependency chain of the look-ahead schedule)
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled
 void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);

@@ -457,20 +457,13 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
 }
 
 // ---------------------------------------------------------------------------
-// Pivot-light panel step for complex SYMMETRIC pencils (T = T^T: real symmetric / complex symmetric coefficient matrices; the
+// Pivot-light elimination for complex SYMMETRIC pencils (T = T^T: real symmetric / complex symmetric coefficient matrices; the
 // shifted matrices of FEAST, z B - A with Im z != 0 and B definite, have a definite imaginary part, so every leading principal
-// block and every Schur complement is nonsingular and Gaussian elimination needs no row interchanges).  The serial chain of a
-// 32-column panel shrinks from 32 workgroup-wide pivot searches (k_panel_reg: two barriers, a shuffle reduction and a scan per
-// pivot, 288 us on a 3000-row front) to the LU of the 32 x 32 diagonal block in ONE wave's registers (k_diag_np) followed by a
-// row-parallel triangular solve for the rows below (k_lscale_np).  Safety: the magnitude of the multipliers |l_ij| is recorded
-// per node (growth[k] = max, as the bit pattern of a non-negative double) and tiny pivots are perturbed and counted exactly like
-// in the pivoted kernels; Engine::factorize falls back to the pivoted path when either says the elimination was not harmless.
+// block and every Schur complement is nonsingular and Gaussian elimination needs no row interchanges).  Safety: the magnitude of
+// the multipliers |l_ij| and of the pivots is recorded per node (growth[], as the bit patterns of non-negative doubles) and tiny
+// pivots are perturbed and counted exactly like in the pivoted kernels; Engine::factorize falls back to the pivoted path when
+// either says the elimination was not harmless.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ void growth_max(unsigned long long* g, double v) {
     // wave-wide maximum, one atomic per wave (non-negative doubles order like their bit patterns; NaN counts as +inf)
     if (!(v == v)) v = __longlong_as_double(0x7ff0000000000000ll);
@@ -478,155 +471,10 @@ __device__ __forceinline__ void growth_max(unsigned long long* g, double v) {
     if ((threadIdx.x & 63) == 0 && v > 0.0) atomicMax(g, (unsigned long long)__double_as_longlong(v));
 }
 
-// LU without interchanges of the b x b (b <= 32) diagonal block at (k0, k0) of every listed front, in place (unit lower L11 below
-// the diagonal, U11 on and above).  One wave per (front, node): lane i holds row i, all 32 columns in registers; the pivot row
-// reaches the other lanes through v_readlane with a compile-time lane (the loop is fully unrolled), so a pivot step is a few
-// dozen register instructions and the whole block costs a few microseconds.  Rows / columns beyond b are padded with the
-// identity.  piv gets the identity permutation (k_rowperm and the solves then see "no interchanges").
-__global__ __launch_bounds__(64) void k_diag_np(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
-                                                cz* fact, int64_t fs, int* piv, int npiv,
-                                                const double* __restrict__ tiny, int* nperturb, unsigned long long* growth) {
-    FrontD f = fr[list[blockIdx.x]];
-    const int k = blockIdx.y;
-    const int p = f.p, ld = f.p + f.u;
-    const int b = min(FACT_NB, p - k0);
-    cz* D = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;
-    const int i = threadIdx.x;                 // row
-    const bool rok = i < b;
-    double xr[FACT_NB], xi[FACT_NB];
-#pragma unroll
-    for (int c = 0; c < FACT_NB; ++c) {
-        cz v = (rok && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);
-        xr[c] = v.x; xi[c] = v.y;
-    }
-    const double tiny_k = tiny[k];
-    double lmax = 0.0, dmax = 0.0;
-    int npert = 0;
-#pragma unroll
-    for (int j = 0; j < FACT_NB; ++j) {
-        double pr = readlane_d(xr[j], j), pi = readlane_d(xi[j], j);
-        double pa = fabs(pr) + fabs(pi);
-        if (j < b) dmax = fmax(dmax, pa);
-        if (!(pa >= tiny_k)) {                 // static pivot perturbation (also catches NaN), as in k_panel_reg
-            if (pa > 0.0) { pr *= tiny_k / pa; pi *= tiny_k / pa; } else { pr = tiny_k; pi = 0.0; }
-            if (i == j) { xr[j] = pr; xi[j] = pi; }
-            if (j < b) ++npert;
-        }
-        cz inv = cz_inv(cz_make(pr, pi));
-        const bool below = i > j;
-        double lr = xr[j] * inv.x - xi[j] * inv.y, li = xr[j] * inv.y + xi[j] * inv.x;
-        if (below) { xr[j] = lr; xi[j] = li; lmax = fmax(lmax, fabs(lr) + fabs(li)); }
-#pragma unroll
-        for (int c = j + 1; c < FACT_NB; ++c) {
-            double ur = readlane_d(xr[c], j), ui = readlane_d(xi[c], j);
-            if (below) { xr[c] -= lr * ur - li * ui; xi[c] -= lr * ui + li * ur; }
-        }
-    }
-    if (rok) {
-#pragma unroll
-        for (int c = 0; c < FACT_NB; ++c)
-            if (c < b) D[i + (int64_t)c * ld] = cz_make(xr[c], xi[c]);
-        piv[(int64_t)k * npiv + f.c0 + k0 + i] = k0 + i;
-    }
-    if (i == 0 && npert > 0) atomicAdd(nperturb + k, npert);
-    growth_max(growth + k, rok ? lmax : 0.0);
-    // largest pivot: with U = D L^T (symmetric elimination) max |u_ij| <= max |d_i| max |l_ji|, so the two maxima bound the element growth
-    growth_max(growth + gridDim.y + k, i == 0 ? dmax : 0.0);
-}
-
-// Rows below the diagonal block: L[r, k0 : k0+b) = A[r, k0 : k0+b) inv(U11), one thread per row (rows of a wave are consecutive:
-// every column access is one coalesced 1 KiB segment), U11 broadcast from LDS (strictly upper part, zeros elsewhere, so every
-// later column is updated unconditionally; reciprocal diagonal beside it).  Column sweeps in a real loop with the multiplier
-// picked by bit masks, as in k_trsm_u: fully unrolled the compiler hoists all 496 LDS reads and spills.  Tile.a indexes 256-row
-// slices of the rows [k0 + b, ld).
-template <int KB>
-__device__ __forceinline__ void lscale_sweeps(cz (&x)[FACT_NB], const cz (*s_u)[FACT_NB + 1], const cz* s_d) {
-#pragma unroll 1
-    for (int kk = KB; kk < KB + 8; ++kk) {
-        long long xr = 0, xi = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            long long m = -(long long)(kk == KB + j);
-            xr |= m & __double_as_longlong(x[KB + j].x);
-            xi |= m & __double_as_longlong(x[KB + j].y);
-        }
-        const cz xk = cz_mul(cz_make(__longlong_as_double(xr), __longlong_as_double(xi)), s_d[kk]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool hit = kk == KB + j;
-            x[KB + j].x = hit ? xk.x : x[KB + j].x;
-            x[KB + j].y = hit ? xk.y : x[KB + j].y;
-        }
-        const cz* urow = s_u[kk];
-#pragma unroll
-        for (int j = KB + 1; j < FACT_NB; ++j) cz_msub(x[j], xk, urow[j]);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_lscale_np(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
-                                                   cz* fact, int64_t fs, unsigned long long* growth) {
-    __shared__ cz s_u[FACT_NB][FACT_NB + 1];        // s_u[kk][j] = U11[kk][j] for kk < j, else 0
-    __shared__ cz s_d[FACT_NB], s_dd[FACT_NB];      // 1 / U11[j][j], U11[j][j]
-    Tile t = tiles[blockIdx.x];
-    const int k = blockIdx.y;
-    FrontD f = fr[t.f];
-    const int p = f.p, ld = p + f.u;
-    const int b = min(FACT_NB, p - k0);
-    const int r0 = k0 + b + t.a * 256;
-    if (r0 >= ld) return;
-    cz* Lp = fact + (int64_t)k * fs + f.lp;
-    for (int idx = threadIdx.x; idx < FACT_NB * FACT_NB; idx += 256) {
-        int kk = idx % FACT_NB, j = idx / FACT_NB;
-        cz v = cz_make(0, 0);
-        if (kk < b && j < b && kk <= j) v = Lp[(k0 + kk) + (int64_t)(k0 + j) * ld];
-        if (kk == j) { s_d[j] = j < b ? cz_inv(v) : cz_make(1, 0); s_dd[j] = v; v = cz_make(0, 0); }
-        s_u[kk][j] = v;
-    }
-    __syncthreads();
-    const int r = r0 + threadIdx.x;
-    const bool rok = r < ld;
-    cz* row = Lp + min(r, ld - 1) + (int64_t)k0 * ld;
-    cz x[FACT_NB];
-#pragma unroll
-    for (int c = 0; c < FACT_NB; ++c) x[c] = (rok && c < b) ? row[(int64_t)c * ld] : cz_make(0, 0);
-    lscale_sweeps<0>(x, s_u, s_d);
-    lscale_sweeps<8>(x, s_u, s_d);
-    lscale_sweeps<16>(x, s_u, s_d);
-    lscale_sweeps<24>(x, s_u, s_d);
-    double lmax = 0.0;
-#pragma unroll
-    for (int c = 0; c < FACT_NB; ++c) lmax = fmax(lmax, fabs(x[c].x) + fabs(x[c].y));
-    if (rok) {
-#pragma unroll
-        for (int c = 0; c < FACT_NB; ++c)
-            if (c < b) row[(int64_t)c * ld] = x[c];
-        // The elimination of a symmetric matrix without interchanges gives U = D L^T: the U entries of this block's rows in
-        // column r are d_c l_rc, written here (32 consecutive elements of column r: the pivot block's upper triangle, or the U12
-        // panel for r >= p) instead of by a triangular solve with L11 on rows the trailing updates would have to keep current.
-        cz* ucol = (r < p) ? Lp + k0 + (int64_t)r * ld : fact + (int64_t)k * fs + f.f12 + k0 + (int64_t)(r - p) * p;
-#pragma unroll
-        for (int c = 0; c < FACT_NB; ++c)
-            if (c < b) ucol[c] = cz_mul(x[c], s_dd[c]);
-    }
-    growth_max(growth + k, rok ? lmax : 0.0);
-}
-
-void launch_diag_np(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
-                    int* piv, const double* tiny, int* nperturb, unsigned long long* growth, int K) {
-    if (nlist <= 0) return;
-    hipLaunchKernelGGL(k_diag_np, dim3(nlist, K), dim3(64), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth);
-}
-
-void launch_lscale_np(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
-                      unsigned long long* growth, int K) {
-    if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_lscale_np, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth);
-}
-
 // ---------------------------------------------------------------------------
-// Pivot-light elimination, one GROUP of up to 128 pivot columns per step (the per-panel kernels above cost three dependent
-// launches per 32 columns -- diagonal block, rows below, in-group update -- and on the big fronts that chain, not the
-// matrix cores, set the pace).  Per group [k0, k0 + gw):
+// Pivot-light elimination, one GROUP of up to 128 pivot columns per step (a first version worked per 32-column panel: three dependent
+// launches per panel -- diagonal block, rows below, in-group update -- and on the big fronts that chain, not the matrix cores,
+// set the pace: 97 ms for the 8 factorisations of C3 instead of 84).  Per group [k0, k0 + gw):
 //   k_diag_grp   one workgroup per (front, node) factorises the gw x gw diagonal block LEFT-looking in 32-column blocks: the rows
 //                of block c first get their L entries of the earlier blocks and the Schur update of block (c, c) (grp_substitute),
 //                then two waves eliminate block (c, c) in registers: wave 0 the block itself (L\U in place), wave 1 the identity
