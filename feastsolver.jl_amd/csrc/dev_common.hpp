@@ -21,6 +21,7 @@ struct FrontD {
     int nb, wslot;            // nb: diagonal super-block size of the solve-ready form of this front (128, 256 or 512), see kernels.hpp;
                               // wslot: position of the front within its tree level (scratch slot of the pivot-light group kernels)
     int64_t sk_off;           // row offset of this front's split-K partial sums in the scratch (backward U12 product), or -1
+    int64_t skf_off;          // ... of the forward L21 product (part q of contribution row i: skf_off + q u + i), or -1
     int64_t cmap;             // offset into the contribution-row pull map (u x nchild ints), or -1 without children
     int64_t ebp;              // as a child: offset into the extend-add break points (first contribution row that lands at or
                               // beyond parent row 64 b, b = 0 .. ceil(ld_parent / 64)), or -1 for a root

@@ -152,6 +152,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FUSE_B3")) fuse_b3_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
+    if (const char* v = getenv("FEASTHIP_FWD_SPLITK")) fwd_splitk_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
@@ -435,6 +436,7 @@ bool Engine::build_plans() {
     fplan_.assign(nd, FactorLevel());
     splan_.assign(nd, SolveLevel());
     sk_off_.assign(S.nsuper, -1);
+    skf_off_.assign(S.nsuper, -1);
     sk_rows_ = 0;
     std::vector<int> nchild(S.nsuper);
     for (int s = 0; s < S.nsuper; ++s) nchild[s] = (int)(S.child_ptr[s + 1] - S.child_ptr[s]);
@@ -601,20 +603,43 @@ bool Engine::build_plans() {
         }
         V.f2.off = (int64_t)tiles.size();
         int sl2 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.u(s)); });
+        {   // few, long tiles (top of the tree, few nodes on this GPU): split the K = p loop of the L21 products over several workgroups
+            int64_t wgs = 0;
+            for (int s : lv) if (S.u(s) > 0) wgs += cdiv(S.u(s), 64);
+            const int keff = std::max(1, nodes_local() / stream_groups());     // nodes per launch
+            int ns = 0;
+            if (fwd_splitk_ && wgs > 0 && wgs * keff < 1024 && pmax >= 256) ns = (int)std::min<int64_t>(8, std::min<int64_t>(pmax / 128, cdiv(2048, (int)(wgs * keff))));
+            V.f2split = ns >= 2 ? ns : 0;
+            if (V.f2split) sl2 = 4;
+        }
+        int64_t skf_level = 0;
         for (int s : lv) {
             int p = S.p(s), u = S.u(s), NB = solve_nb(s);
-            for (int a = 0; a < cdiv(u, 16 * sl2); ++a) tiles.push_back({s, 1 | (sl2 << 8), a, 0});
+            if (V.f2split && u > 0) {
+                const int Kp = (cdiv(p, V.f2split) + 31) & ~31, nparts = cdiv(p, Kp);
+                skf_off_[s] = skf_level; skf_level += (int64_t)nparts * u;
+                for (int q = 0; q < nparts; ++q) for (int a = 0; a < cdiv(u, 16 * sl2); ++a) tiles.push_back({s, 1 | (sl2 << 8) | (V.f2split << 16), a, q});
+            } else {
+                for (int a = 0; a < cdiv(u, 16 * sl2); ++a) tiles.push_back({s, 1 | (sl2 << 8), a, 0});
+            }
             for (int t = 0; t < cdiv(p, NB); ++t)
                 for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * sl2); ++rt) tiles.push_back({s, 2 | (sl2 << 8), t, rt});
             V.f2.bytes += ((double)u * p + 0.5 * p * std::min(p, NB)) * 16.0; V.f2.flops += (double)u * p + 0.5 * p * std::min(p, NB);
         }
         V.f2.count = (int)(tiles.size() - V.f2.off);
         V.f2.sl = sl2;
-        // longest tiles first (LPT): the K loop of a tile is p (kind 1) or at most the super-block size (kind 2); fronts stay together
-        std::stable_sort(tiles.begin() + V.f2.off, tiles.end(), [&](const Tile& a, const Tile& b) {
-            int ka = (a.a & 0xff) == 1 ? S.p(a.f) : std::min(solve_nb(a.f), S.p(a.f)), kb2 = (b.a & 0xff) == 1 ? S.p(b.f) : std::min(solve_nb(b.f), S.p(b.f));
-            return ka > kb2;
-        });
+        sk_rows_ = std::max(sk_rows_, skf_level);
+        // longest tiles first (LPT): the K loop of a tile is p (kind 1; a part of it when split) or at most the super-block size (kind 2); fronts stay together
+        {
+            const int nsp = V.f2split;
+            std::stable_sort(tiles.begin() + V.f2.off, tiles.end(), [&](const Tile& a, const Tile& b) {
+                auto klen = [&](const Tile& t) { return (t.a & 0xff) == 1 ? (nsp ? (cdiv(S.p(t.f), nsp) + 31) & ~31 : S.p(t.f)) : std::min(solve_nb(t.f), S.p(t.f)); };
+                return klen(a) > klen(b);
+            });
+        }
+        V.f2red.off = (int64_t)tiles.size();
+        if (V.f2split) for (int s : lv) if (S.u(s) > 0) for (int a = 0; a < cdiv(S.u(s), 64); ++a) tiles.push_back({s, a, 0, 0});
+        V.f2red.count = (int)(tiles.size() - V.f2red.off);
         V.b1.off = (int64_t)tiles.size();
         int sl3 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
         // 64-row tiles where 32 rows were only chosen for the short K loops of small fronts (the gather's K loop is long): fronts of up
@@ -851,6 +876,7 @@ int Engine::analyze() {
         f.sptr = S.struct_ptr[s]; f.crow = S.crow_off[s];
         f.child_ptr = S.child_ptr[s]; f.nchild = (int)(S.child_ptr[s + 1] - S.child_ptr[s]); f.depth = S.depth[s];
         f.sk_off = -1;
+        f.skf_off = -1;
         f.cmap = -1;
         f.ebp = -1;
         f.nb = solve_nb(s); f.wslot = 0;
@@ -905,7 +931,7 @@ int Engine::analyze() {
               d_perm_.upload(S.perm.data(), n, stream_) && d_iperm_.upload(S.iperm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
               d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_);
     if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
-    for (int s = 0; s < S.nsuper; ++s) fr[s].sk_off = sk_off_[s];
+    for (int s = 0; s < S.nsuper; ++s) { fr[s].sk_off = sk_off_[s]; fr[s].skf_off = skf_off_[s]; }
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
     dsym_.perm = d_perm_.p; dsym_.iperm = d_iperm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.n = n;

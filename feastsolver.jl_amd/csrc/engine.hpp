@@ -50,6 +50,7 @@ struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Laun
                      Launch fronts; Launch binv, couple, scale;
                      Launch outer[2], inner[2]; };      // coupling of 128 -> 256 ([0]) and 256 -> 512 ([1]) super blocks (launch_couple_outer / _level)
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
+                    Launch f2red; int f2split = 0;      // forward L21 products split along K (few nodes per GPU): number of parts, reduction tiles
                     Launch b3s;       // B3 tiles of the fronts whose B1 tile is kind 6 (launched only when the apply kernel does not fuse them)
                     double asm_rows = 0, pull_rows = 0; };   // children's contribution rows landing in pivot blocks / in contribution rows of this level
 
@@ -198,7 +199,7 @@ private:
     // iteration state (row-major n x ldw)
     DevBuf<cz> d_X_, d_R_, d_Q_, d_Q1_, d_T1_, d_T2_, d_MX_, d_W_, d_Y_, d_crow_[2], d_sk_;
     int64_t sk_rows_ = 0;                   // rows of split-K scratch per node
-    std::vector<int64_t> sk_off_;          // per front (or -1)
+    std::vector<int64_t> sk_off_, skf_off_;  // per front (or -1): backward / forward split-K scratch rows
     DevBuf<cz> d_e0_, d_e1_, d_small_, d_lam_, d_gram_scratch_, d_io_;
     DevBuf<double> d_nrm_, d_nrm_scratch_;
 
@@ -272,6 +273,9 @@ private:
     bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true, fuse_extend_ = true;
     int fuse_min_p_ = 128;            // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself
     int group_panels_ = 4;            // panels per deferred trailing update in the look-ahead factorisation
+    bool fwd_splitk_ = false;         // FEASTHIP_FWD_SPLITK=1: split the long forward L21 products along K when few nodes are left on this GPU.
+                                      // Measured at one unit per GPU (C3): the split launches gain 10-40 us each, their reductions cost 50-80 us:
+                                      // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)
     int short_k_max_p_ = 96;          // levels whose fronts have at most this many pivot columns use 32-row substitution tiles
     int nb256_min_p_ = 193, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
     int solve_nb(int s) const { int p = S.p(s); return p >= nb512_min_p_ ? 512 : p >= nb256_min_p_ ? 256 : 128; }

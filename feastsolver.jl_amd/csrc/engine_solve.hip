@@ -63,9 +63,18 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         begin();
         // contribution rows of the children that pass through to this level's contribution rows are pulled in the
         // epilogue of the F2a tiles (kind 1), so there is no second assembly pass
+        const int64_t sksf = std::max<int64_t>(1, sk_rows_) * ldw;
         launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
-                     nullptr, 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2.sl);
+                     V.f2split ? skall + (int64_t)kb * sksf : nullptr, V.f2split ? sksf : 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2.sl);
         if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows + V.pull_rows), stat_flops(V.f2)); }
+        if (V.f2split) {
+            begin();
+            launch_splitk_reduce_fwd(st, dsym_, tl + V.f2red.off, V.f2red.count, V.f2split, (crowb[par] + (int64_t)kb * crs), crs, ldw,
+                                     skall + (int64_t)kb * sksf, sksf, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, kc);
+            double urows = 0;
+            for (int s : S.levels[d]) urows += S.u(s);
+            cur_tiles = V.f2red.count; end(1, (V.f2split + 1.0) * urows * rowb * kc, 0);
+        }
     }
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
         SolveLevel& V = splan_[d];

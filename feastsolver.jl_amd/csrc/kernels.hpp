@@ -123,6 +123,13 @@ void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out);
 // -U12[:, part] * x[part] into its own slab of `skbuf`; launch_splitk_reduce then adds the slabs to Y in a fixed order.
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,
                           const cz* skbuf, int64_t sks, int K);
+// Kind-1 tiles may be split the same way (K = p; few nodes per GPU leave too few, too long tiles at the top of the tree): part
+// Tile.c writes -P21[:, part] W[part] into its slab; launch_splitk_reduce_fwd (Tile {front, 64-row slice of the contribution rows})
+// adds the children's rows and the slabs in a fixed order.
+void launch_splitk_reduce_fwd(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* crow, int64_t crs, int ldw,
+                              const cz* skbuf, int64_t sks, const cz* crow_child, int64_t crs_child, int K);
+void launch_splitk_reduce_fwd(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* crow, int64_t crs, int ldw,
+                              const cf* skbuf, int64_t sks, const cf* crow_child, int64_t crs_child, int K);
 // (gather = true for launches made only of kind-3 tiles: V rows are gathered through struct_idx)
 // Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order;
 // lds = leading dimension of W and of the coefficient tables (2 ldw: conjugate fold, see k_accumulate)

@@ -229,7 +229,7 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
                                            T* skbuf, int64_t sks, const int* cmap, const T* crow_child, int64_t crs_child) {
     int kind = t.a & 0xff;
     int th = ((t.a >> 8) & 0xff) ? 16 * ((t.a >> 8) & 0xff) : 64;   // tile height in rows (16, 32 or 64), chosen per launch by the host
-    int nsplit = t.a >> 16;                            // kind 3 only: number of K parts (0 = not split)
+    int nsplit = t.a >> 16;                            // kinds 1 and 3: number of K parts (0 = not split), part index in t.c
     int p = f.p, u = f.u, ld = p + u;
     const T* Lp = fact + (int64_t)k * fs + f.lp;
     T* Wk = W + (int64_t)k * ws;
@@ -243,6 +243,13 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
     else if (kind == 1) {
         g.rbase = p + t.b * th; g.rend = ld; g.A = Lp; g.Kd = p; g.Vk = Wk; g.vrow0 = f.c0; g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2;
         if (f.cmap >= 0) { g.mode = 3; g.pull = cmap + f.cmap; g.npull = f.nchild; g.pullbase = crow_child + (int64_t)k * crs_child; }
+        if (nsplit > 0) {   // split-K part t.c of the long products at the top of the tree when few nodes are left on this GPU: -P21[:, part] W[part]
+                            // into the scratch slab (part, row); k_splitk_reduce_fwd adds the slabs and the children's rows
+            int Kp = (((p + nsplit - 1) / nsplit) + 31) & ~31;
+            int kbeg = t.c * Kp;
+            g.A += (int64_t)kbeg * ld; g.vrow0 += kbeg; g.Kd = min(Kp, p - kbeg);
+            g.out = skbuf + (int64_t)k * sks + (f.skf_off + (int64_t)t.c * u) * ldw; g.mode = 2; g.pull = nullptr; g.npull = 0;
+        }
     }
     else if (kind == 2) {   // unit lower inverse: row tile c only needs the columns left of its last row
         g.k0 = t.b * NB; int b = min(NB, p - g.k0); g.rbase = g.k0 + t.c * th; g.rend = g.k0 + b; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = min(b, t.c * th + th); g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 1; g.mode = 1;
@@ -1077,6 +1084,54 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const FrontD* __restrict_
             if (e0 + u * 256 < total) y0[e0 + u * 256] = v[u];
         }
     }
+}
+
+// Forward counterpart: C_I[r, :] = sum_children C_child[...] + sum_part scratch[part][r, :]  (the slabs hold -P21[:, part] W[part];
+// children in slot order, parts in increasing order: the same additions in the same order as the unsplit tile makes them).
+// Tile.a = 64-row slice of the front's contribution rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_reduce_fwd(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int nsplit, T* crow, int64_t crs,
+                                                           int ldw, const T* __restrict__ skbuf, int64_t sks, const int* __restrict__ cmap,
+                                                           const T* __restrict__ crow_child, int64_t crs_child) {
+    Tile t = tiles[blockIdx.x];
+    const int k = blockIdx.y;
+    FrontD f = fr[t.f];
+    const int u = f.u, p = f.p;
+    const int Kp = (((p + nsplit - 1) / nsplit) + 31) & ~31;
+    const int nparts = (p + Kp - 1) / Kp;
+    const int r0 = t.a * 64, nr = min(u, r0 + 64) - r0;
+    T* out = crow + (int64_t)k * crs + (f.crow + (int64_t)r0) * ldw;
+    const T* p0 = skbuf + (int64_t)k * sks + (f.skf_off + (int64_t)r0) * ldw;
+    const int64_t pstride = (int64_t)u * ldw;
+    const T* cbase = crow_child + (int64_t)k * crs_child;
+    const int nch = f.cmap >= 0 ? f.nchild : 0;
+    for (int e = threadIdx.x; e < nr * ldw; e += 256) {
+        const int i = e / ldw, j = e - i * ldw;
+        T v; v.x = 0; v.y = 0;
+        for (int c = 0; c < nch; ++c) {
+            const int src = cmap[f.cmap + (int64_t)(r0 + i) * nch + c];
+            if (src >= 0) { const T w = cbase[(int64_t)src * ldw + j]; v.x += w.x; v.y += w.y; }
+        }
+        T a[SPLITK_MAX];
+#pragma unroll
+        for (int q = 0; q < SPLITK_MAX; ++q) a[q] = p0[(int64_t)min(q, nparts - 1) * pstride + e];
+        // (out = children - acc_0 - acc_1 ...: the slabs hold -acc_q)
+#pragma unroll
+        for (int q = 0; q < SPLITK_MAX; ++q)
+            if (q < nparts) { v.x += a[q].x; v.y += a[q].y; }
+        out[e] = v;
+    }
+}
+
+void launch_splitk_reduce_fwd(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* crow, int64_t crs, int ldw,
+                              const cz* skbuf, int64_t sks, const cz* crow_child, int64_t crs_child, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_splitk_reduce_fwd<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, nsplit, crow, crs, ldw, skbuf, sks, S.cmap, crow_child, crs_child);
+}
+void launch_splitk_reduce_fwd(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* crow, int64_t crs, int ldw,
+                              const cf* skbuf, int64_t sks, const cf* crow_child, int64_t crs_child, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_splitk_reduce_fwd<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, nsplit, crow, crs, ldw, skbuf, sks, S.cmap, crow_child, crs_child);
 }
 
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,

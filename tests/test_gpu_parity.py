@@ -981,6 +981,39 @@ def test_node_shards_sum_to_full_moment(gpu, pkg, wl):
     assert np.abs(even + odd - full).max() <= 1e-13 * np.abs(full).max()
 
 
+@pytest.mark.parametrize("mixed", [False, True])
+def test_forward_splitk_matches_unsplit(gpu, pkg, wl, mixed):
+    """With one factorisation unit per GPU (the 8-GPU shard) the long L21 products at the top of the tree are split along K
+    (FEASTHIP_FWD_SPLITK=1; off by default, it measured slower: slabs + a fixed-order reduction that also pulls the children's rows).  The moment of
+    the shard must agree with the unsplit schedule to rounding -- complex128 and the complex64 sweeps of mixed_prec."""
+    import os
+    w = wl.c3_sparse_generalized(24, 19, 64)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["FEASTHIP_FWD_SPLITK"] = mode
+        try:
+            h = pkg.FeastHandle(0)
+        finally:
+            os.environ.pop("FEASTHIP_FWD_SPLITK", None)
+        try:
+            h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+            h.set_contour(con)
+            h.set_node_shard(0, 8)
+            if mixed:
+                h.set_precision(True)
+            h.factorize()
+            h.set_x(w["X0"])
+            h.rr_step()
+            h.contour_step()
+            out[mode] = (h.get_block(2).copy(), h.profile_solve()["fwd_assemble"]["launches"])
+        finally:
+            h.close()
+    q1, q0 = out["1"][0], out["0"][0]
+    assert out["1"][1] > out["0"][1]                      # the split schedule ran its reduction launches (counted with the assembly)
+    assert np.isfinite(q1).all() and np.abs(q1 - q0).max() <= (1e-5 if mixed else 1e-12) * np.abs(q0).max()
+
+
 def _moment(pkg, w, con, fold, shard=(0, 1), nl=False):
     h = pkg.FeastHandle(0)
     h.set_terms([w["A"], w["B"]], [1.0, -1.0])
