@@ -223,7 +223,7 @@ private:
     struct Tall { int rows, m, ld; cz* small; cz* lam; cz* gram; double* nrm; double* nrm_scratch; };
     Tall tall_default() { return Tall{n, m0, ldw, d_small_.p, d_lam_.p, d_gram_scratch_.p, d_nrm_.p, d_nrm_scratch_.p}; }
     int orthonormalize(cz* Q, cz* tmp, std::vector<zc>* Rtotal) { return orthonormalize(tall_default(), Q, tmp, Rtotal); }
-    int orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal);
+    int orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal, int min_passes = 2);
     int orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rtot, std::vector<uint8_t>& keep);
     int col_norms(const cz* V, std::vector<double>& out) { return col_norms(tall_default(), V, out); }
     int col_norms(const Tall& t, const cz* V, std::vector<double>& out);

@@ -36,7 +36,7 @@ int Engine::col_norms(const Tall& t, const cz* V, std::vector<double>& out) {
 // Column-scaled CholeskyQR2: columns are normalised first (the FEAST filter scales column j by
 // rho(lambda_j), which is the dominant source of ill-conditioning), then two Cholesky passes on
 // the f64-MFMA Gram matrix.  Rtotal (optional) receives R with Q_in = Q_out * R.
-int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal) {
+int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtotal, int min_passes) {
     const int m = t.m, rows = t.rows, ld = t.ld;
     std::vector<zc> G((size_t)m * m), Rn((size_t)m * m), Rt, Tm((size_t)m * m);
     if (Rtotal) { Rt.assign((size_t)m * m, zc(0.0)); for (int j = 0; j < m; ++j) Rt[j + (size_t)j * m] = 1.0; }
@@ -48,6 +48,10 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
     // The column scaling is folded into the first pass on the host: the Gram matrix of the scaled block is
     // D G D with D = diag(G)^-1/2 (each G_ij carries a relative error eps in units of |q_i||q_j| either way),
     // which saves a norm pass, a scaling pass and a host round trip over the n x m block.
+    // min_passes = 1 (generalized Rayleigh-Ritz, where Bq = Q'BQ is formed explicitly and any well-conditioned basis of span(Q)
+    // gives the same Ritz pairs): the second pass is dropped when the first Cholesky factor says the scaled block was well
+    // conditioned (ratio of its extreme diagonal entries >= 1e-2: the basis after one pass is orthonormal to 1e-12 or better; in the
+    // steady state of a FEAST run the ratio is 0.5 .. 1).
     int need = 2;
     for (int pass = 0; pass < 6 && need > 0; ++pass) {
         launch_gram(stream_, rows, m, ld, src, src, t.gram, dG);
@@ -81,6 +85,12 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
             need = 1;
         } else {
             --need;
+            if (pass == 0 && min_passes <= 1) {
+                double dmin = 1e300, dmax2 = 0;
+                for (int j = 0; j < m; ++j) { const double dj = std::abs(Gc[j + (size_t)j * m]); dmin = std::min(dmin, dj); dmax2 = std::max(dmax2, dj); }
+                if (getenv("FEASTHIP_RR_TRACE")) fprintf(stderr, "[feasthip] CholeskyQR pass 1: diag(R) min/max = %.3e\n", dmin / dmax2);
+                if (dmin >= 1e-2 * dmax2) need = 0;
+            }
         }
         if (Rtotal) {   // Q_src = Q_dst (R D^-1)  ->  Rt <- (R D^-1) Rt   (only the Beyn step needs the accumulated factor)
             std::vector<zc> Rd(Gc);
@@ -195,7 +205,9 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     int m = m0;
-    int r = orthonormalize(Qp(), d_T1_.p, nullptr);                     // src/feast.jl:41
+    // B = -scale_1 * M_1
+    const bool b_is_identity = terms_[1].identity && std::abs(terms_[1].scale + 1.0) == 0.0;
+    int r = orthonormalize(tall_default(), Qp(), d_T1_.p, nullptr, b_is_identity ? 2 : 1);      // src/feast.jl:41, 117
     if (r) return r;
     cz* dA = d_small_.p;
     cz* dB = d_small_.p + (size_t)ldw * ldw;
@@ -205,8 +217,6 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     HIPCHK(hipEventRecord(ev_p0_, stream_));
     launch_gram(stream_, n, m, ldw, Qp(), d_R_.p, d_gram_scratch_.p, dA);   // Aq = Q' R   :43
     HIPCHK(hipEventRecord(ev_p1_, stream_));
-    // B = -scale_1 * M_1
-    bool b_is_identity = terms_[1].identity && std::abs(terms_[1].scale + 1.0) == 0.0;
     void *landA = nullptr, *landB = nullptr;
     if (!b_is_identity) {
         apply_term(1, Qp(), d_T1_.p, -1.0, false);                      // R = B Q          :120
