@@ -122,10 +122,6 @@ int feasthip_set_precision(feasthip_handle_t h, int mixed) {
     GUARD(h) return h->e->set_precision(mixed); ENDGUARD(h)
 }
 
-int feasthip_select_apply_kernel(int barrier_free) {
-    select_apply_kernel(barrier_free);
-    return 0;
-}
 
 int feasthip_set_conjugate_fold(feasthip_handle_t h, int on) {
     GUARD(h) return h->e->set_fold(on); ENDGUARD(h)

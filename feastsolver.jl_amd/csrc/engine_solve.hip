@@ -86,9 +86,9 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, skall + (int64_t)kb * sks, sks, nullptr, 0, V.b1.sl);
         if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Yp, ws, ldw, skall + (int64_t)kb * sks, sks, kc);
         if (V.b1.count) {
-            Launch b1s = V.b1;          // the kind-6 tiles carry their fronts' B3 products when the kernel fuses them
+            Launch b1s = V.b1;          // the kind-6 tiles carry their fronts' B3 products
             double rows = lvl_u + 2.0 * lvl_p;          // algorithmic row transfers stay what the step needs, fused or not
-            if (apply_kernel_fuses_b3()) { b1s.bytes += V.b3s.bytes; b1s.flops += V.b3s.flops; rows += V.b3s.vrows; }
+            b1s.bytes += V.b3s.bytes; b1s.flops += V.b3s.flops; rows += V.b3s.vrows;
             cur_tiles = -V.b1.count; end(3, stat_bytes(b1s, rows), stat_flops(b1s));
         }
         for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
@@ -100,11 +100,6 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         begin();
         launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, V.b3.sl);
         if (V.b3.count) { cur_tiles = V.b3.count; end(3, stat_bytes(V.b3, V.b3.vrows), stat_flops(V.b3)); }
-        if (V.b3s.count && !apply_kernel_fuses_b3()) {     // B3 of the fronts with kind-6 tiles, for the kernels that run those as plain B1
-            begin();
-            launch_apply(st, dsym_, tl + V.b3s.off, V.b3s.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, V.b3s.sl);
-            cur_tiles = V.b3s.count; end(3, stat_bytes(V.b3s, V.b3s.vrows), stat_flops(V.b3s));
-        }
     }
     if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }
     HIPCHK(hipGetLastError());

@@ -100,11 +100,8 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false,
                   cz* skbuf = nullptr, int64_t sks = 0, const cz* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4);
-// complex128 tiles run on k_apply2 (no LDS, no barriers) unless FEASTHIP_APPLY2=0 / select_apply_kernel(0) picks k_apply (LDS-staged)
-void select_apply_kernel(int barrier_free);
 // Tile kind 6 = the B1 tile of a front whose pivot block fits one row tile; k_apply2 multiplies it by the front's upper inverse in
-// the same workgroup (so the front has no separate B3 tile), the other kernels run it as kind 3 and need the B3 tiles launched.
-int apply_kernel_fuses_b3();
+// the same workgroup (so the front has no separate B3 tile).
 // complex64 twins for the mixed-precision solve path (same tiles, same plans)
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather = false,

@@ -7,28 +7,14 @@
 // Block vectors are ROW-major n x ldw (one row = ldw contiguous complex128), so a
 // supernode's rows are one contiguous slab and update rows gather as whole 1 KiB
 // lines.  The factor panels are streamed from HBM exactly once per sweep and go
-// straight into the f64 matrix cores; the block-vector rows either come the same way,
-// per k-step, into the other operand registers (k_apply2, the default) or are staged
-// in LDS per 32-column chunk (k_apply).  With the conjugate fold of real pencils a
+// straight into the f64 matrix cores; the block-vector rows come the same way, per k-step,
+// into the other operand registers (k_apply2).  With the conjugate fold of real pencils a
 // unit's block vectors are 2 m0 columns wide: [R, conj(R)].
 #include "kernels.hpp"
 #include <cstdlib>
 #include <type_traits>
 
 namespace feasthip {
-
-__device__ inline int lower_bound_dev2(const int* a, int n, int v) {
-    int lo = 0, hi = n;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
-__device__ inline void cmfma2(d4& cr, d4& ci, double ar, double ai, double br, double bi) {
-    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
-    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ci, 0, 0, 0);
-    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cr, 0, 0, 0);
-    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
-}
 
 // The mixed-precision path (feast!'s mixed_prec, src/feast.jl:19-25) runs the same sweeps on complex64 copies of
 // the factors and block vectors: the small kernels are templates over the element type T (cz or cf).
@@ -156,48 +142,12 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 }
 
 // ---------------------------------------------------------------------------
-// THE hot kernel.  Every step of the block substitution on the solve-ready factors
-// (kernels_factor.hip: k_block_inverse / k_scale_panels) is  out (-)= A * V  with
-// A a column-major slab of a factor panel, streamed from HBM exactly once per sweep,
-// and V up to 64 columns of block-vector rows staged in LDS.  Workgroup = 64 output
-// rows x 64 columns, wave w owns rows [16w, 16w+16): its A fragment is one 16-byte
-// load per lane per k-step (16 consecutive rows = 256 B segments) that goes straight
-// into v_mfma_f64_16x16x4_f64; V fragments are conflict-free ds_read_b128; D's layout
-// (row = (l>>4)+4r, col = l&15) writes 16 consecutive columns of one block-vector row
-// per lane group.  The K loop is software pipelined: the next chunk's A and V loads are
-// in flight while the current chunk runs on the matrix cores.
-// Tile kinds: see kernels.hpp (launch_apply).
+// The hot kernel: every step of the block substitution on the solve-ready factors (kernels_factor.hip: k_couple32 /
+// k_block_inverse, k_scale_panels) is  out (-)= A * V  with A a column-major slab of a factor panel, streamed from HBM exactly
+// once per sweep, and V up to 64 columns of block-vector rows.  Tile kinds: see kernels.hpp (launch_apply).
+// (Round 1 staged the V rows in LDS by LDS-DMA with one workgroup barrier per 32-column chunk -- k_apply, and k_apply32 for the
+// complex64 sweeps; round 2's k_apply2 below replaced both, bit-identically, and they were removed in round 3.)
 // ---------------------------------------------------------------------------
-constexpr int APPLY_KC = 32;
-#ifndef FEASTHIP_ABLATE
-#define FEASTHIP_ABLATE 0      // timing experiments only (tools/ablate.sh), bit mask: 1 no factor loads, 2 no LDS-DMA, 4 no epilogue, 8 no MFMA, 16 no barrier, 32 no LDS reads
-#endif
-
-// LDS reads of the staged block-vector rows are issued as inline asm: the compiler cannot tell the two
-// halves of the double buffer apart and would otherwise put an s_waitcnt vmcnt(0) (= wait for the NEXT
-// chunk's LDS-DMA and factor loads) in front of every ds_read, serialising prefetch and matrix cores.
-typedef double dv2 __attribute__((ext_vector_type(2)));
-template <int OFF>
-__device__ __forceinline__ dv2 lds_ld16(uint32_t a) {
-    dv2 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-// k-step KS of a chunk: rows 4 KS + (lane >> 4), column tiles ct0 .. ct0 + NS - 1 (1 KiB rows, 256 B per column tile)
-template <int KS, int NS>
-__device__ __forceinline__ void lds_ld_step(dv2 (&bv)[NS], uint32_t a) {
-    bv[0] = lds_ld16<KS * 4096>(a);
-    if constexpr (NS > 1) bv[1] = lds_ld16<KS * 4096 + 256>(a);
-    if constexpr (NS > 2) { bv[2] = lds_ld16<KS * 4096 + 512>(a); bv[3] = lds_ld16<KS * 4096 + 768>(a); }
-}
-// the registers are operands so that no use of them can be scheduled above the wait
-template <int NS>
-__device__ __forceinline__ void lds_wait(dv2 (&bv)[NS]) {
-    if constexpr (NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]));
-    else if constexpr (NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
-}
-
 template <typename T>
 struct ApplyGeomT {
     const T* A;          // factor slab, column-major
@@ -278,217 +228,6 @@ __device__ __forceinline__ int xcd_item() {
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
 }
 
-// NS = number of 16-row slabs of this tile that carry data (1, 2 or 4).  The 4 waves are arranged
-// as NS slabs x 4/NS column parts, so a tile with <= 16 (<= 32) rows still keeps every matrix core
-// busy with useful columns instead of multiplying zero rows.
-template <bool GATHER, int NS>
-__device__ __forceinline__ void apply_body(const ApplyGeom& g, cz (*Vs)[APPLY_KC][LDS_COLS], int cg, int ldw) {
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: DMA row addresses stay in SGPRs
-    const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
-    const bool wave_active = g.rbase + slab * 16 < g.rend;          // wave-uniform
-    const int arow = g.rbase + slab * 16 + li;
-    const bool aok = arow < g.rend;
-    const int adiag = arow - g.k0;
-    const int Kd = g.Kd;
-    // Loads are unconditional (addresses clamped into the slab); A is masked with selects when it is
-    // consumed, V needs no mask at all: k-steps beyond Kd are multiplied by the zeros of A and columns
-    // beyond ldw are never stored.
-    const int arow_c = min(arow, g.rend - 1);
-    const int vcol_c = min(cg + lane, ldw - 1);
-    const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
-    const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
-    const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&Vs[0][lk][ct0 * 16 + li];
-    cz av[APPLY_KC / 4], an[APPLY_KC / 4];
-    // gather kinds: lane q (< 8) holds the block-vector row of this wave's q-th DMA row, loaded one chunk
-    // before it is needed so that the DMA issue never waits on an index
-    int idxv = 0;
-    auto load_idx = [&](int kc) {
-        if (GATHER) idxv = g.sidx[min(kc + wave + 4 * (lane & 7), Kd - 1)];
-    };
-    // A: one 16-byte load per lane per k-step, straight to registers.  V: LDS-DMA, one
-    // global_load_lds_dwordx4 per block-vector row (64 lanes x 16 B = the 1 KiB LDS row), no VGPR staging.
-    auto load_chunk = [&](int kc, int buf) {
-#pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) {
-            int gk = kc + ks * 4 + lk;
-#if !(FEASTHIP_ABLATE & 1)
-            an[ks] = g.A[arow_c + (int64_t)min(gk, Kd - 1) * g.lda];
-#else
-            an[ks] = cz_make(gk, lane);
-#endif
-        }
-#pragma unroll
-        for (int q = 0; q < APPLY_KC / 4; ++q) {
-            int r = wave + 4 * q;
-            int vrow = GATHER ? __builtin_amdgcn_readlane(idxv, q) : g.vrow0 + min(kc + r, Kd - 1);
-            const cz* src = g.Vk + (int64_t)vrow * ldw + vcol_c;
-#if !(FEASTHIP_ABLATE & 2)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)&Vs[buf][r][0], 16, 0, 0);
-#else
-            if (src == nullptr) Vs[buf][r][lane] = cz_make(1, 2);
-#endif
-        }
-    };
-    auto mask_a = [&](cz v, int gk) {
-        bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
-        v.x = keep ? v.x : (gk == unit_at ? 1.0 : 0.0);
-        v.y = keep ? v.y : 0.0;
-        return v;
-    };
-    // 3M complex product: T1 = ar*br, T2 = ai*bi, T3 = (ar+ai)*(br+bi);  re = T1 - T2, im = T3 - T1 - T2
-    // -> 3 instead of 4 v_mfma_f64_16x16x4_f64 per k-step and column tile (the kernel is matrix-core bound).
-    d4 t1[NS], t2[NS], t3[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) { t1[q] = (d4){0, 0, 0, 0}; t2[q] = (d4){0, 0, 0, 0}; t3[q] = (d4){0, 0, 0, 0}; }
-    // output rows of this lane (D layout: row (l>>4)+4r, columns ct0*16 + li + 16 q)
-    cz* dptr[4];
-    bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int orow = g.rbase + slab * 16 + lk + 4 * r;
-        rok[r] = orow < g.rend;
-        dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
-    }
-    auto mf = [&](const cz& a, dv2 (&bv)[NS]) {
-        const double ar = a.x, ai = a.y, as = a.x + a.y;
-#if FEASTHIP_ABLATE & 8
-#pragma unroll
-        for (int q = 0; q < NS; ++q) { t1[q][0] += ar * bv[q][0]; t2[q][0] += ai * bv[q][1]; t3[q][0] += as; }
-        return;
-#endif
-#pragma unroll
-        for (int q = 0; q < NS; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bv[q][0], t1[q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < NS; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv[q][1], t2[q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < NS; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv[q][0] + bv[q][1], t3[q], 0, 0, 0);
-    };
-    // k-step KS runs on the matrix cores while the LDS reads of k-step KS+1 are in flight
-#if FEASTHIP_ABLATE & 32
-#define FEASTHIP_KSTEP(KS, CUR, NXT) if (KS < nks) { mf(av[KS], b0); }
-#else
-#define FEASTHIP_KSTEP(KS, CUR, NXT)                                                  \
-    if (KS < nks) {                                                                   \
-        if (KS + 1 < APPLY_KC / 4) lds_ld_step<(KS + 1) % (APPLY_KC / 4), NS>(NXT, la); \
-        mf(av[KS], CUR);                                                              \
-        if (KS + 1 < APPLY_KC / 4) lds_wait<NS>(NXT);                                 \
-    }
-#endif
-    auto mfma_chunk = [&](int kc, int buf) {
-        const int nks = (min(APPLY_KC, Kd - kc) + 3) >> 2;    // k-steps that carry data (uniform)
-        if (wave_active) {
-            const uint32_t la = lds0 + buf * (APPLY_KC * LDS_COLS * 16);
-            dv2 b0[NS], b1[NS];
-            lds_ld_step<0, NS>(b0, la);
-            lds_wait<NS>(b0);
-            FEASTHIP_KSTEP(0, b0, b1) FEASTHIP_KSTEP(1, b1, b0) FEASTHIP_KSTEP(2, b0, b1) FEASTHIP_KSTEP(3, b1, b0)
-            FEASTHIP_KSTEP(4, b0, b1) FEASTHIP_KSTEP(5, b1, b0) FEASTHIP_KSTEP(6, b0, b1) FEASTHIP_KSTEP(7, b1, b0)
-        }
-    };
-#undef FEASTHIP_KSTEP
-    static_assert(APPLY_KC == 32 && LDS_COLS == 64, "the LDS offsets of lds_ld_step assume 32 x 64 chunks");
-    load_idx(0);
-    load_chunk(0, 0);
-    load_idx(APPLY_KC);
-    int it = 0, kc = 0;
-    for (; kc + APPLY_KC < Kd; kc += APPLY_KC, ++it) {       // all chunks but the last: prefetch the next one
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's A registers and V rows have landed
-#pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
-        if (!(FEASTHIP_ABLATE & 16)) __syncthreads();         // everyone's rows landed; buffer buf^1 is free again
-        load_chunk(kc + APPLY_KC, buf ^ 1);
-        load_idx(kc + 2 * APPLY_KC);
-        mfma_chunk(kc, buf);
-    }
-    // last chunk: instead of a prefetch, issue the read-modify-write loads of the epilogue so that their
-    // latency overlaps with the last block of MFMAs (the prefetch registers are free by now)
-    cz old[4][NS];
-    {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < APPLY_KC / 4; ++ks) av[ks] = mask_a(an[ks], kc + ks * 4 + lk);
-        if (!(FEASTHIP_ABLATE & 16)) __syncthreads();
-        if (g.mode == 0 && wave_active && !(FEASTHIP_ABLATE & 4)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][min(cg + (ct0 + q) * 16 + li, ldw - 1)];
-        } else if (g.mode == 3 && wave_active) {
-            // extend-add of the forward sweep fused into the producer: pull the children's contribution rows that
-            // land on this tile's rows (fixed child order: deterministic), instead of a separate read-modify-write pass
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int q = 0; q < NS; ++q) old[r][q] = cz_make(0, 0);
-            for (int c = 0; c < g.npull; ++c) {
-                int src[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int orow = g.rbase + slab * 16 + lk + 4 * r;
-                    src[r] = rok[r] ? g.pull[(int64_t)(orow + g.orow_shift) * g.npull + c] : -1;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (src[r] >= 0) {
-#pragma unroll
-                        for (int q = 0; q < NS; ++q) {
-                            cz v = g.pullbase[(int64_t)src[r] * ldw + min(cg + (ct0 + q) * 16 + li, ldw - 1)];
-                            old[r][q].x += v.x; old[r][q].y += v.y;
-                        }
-                    }
-            }
-        }
-        mfma_chunk(kc, buf);
-    }
-    d4 cr[NS], ci[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) { cr[q] = t1[q] - t2[q]; ci[q] = t3[q] - t1[q] - t2[q]; }
-    // ---- epilogue (the read-modify-write loads were issued before the last MFMA block)
-    if (!wave_active) return;
-    const double sgn = (g.mode == 2) ? -1.0 : 1.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            int col = cg + (ct0 + q) * 16 + li;
-            cz v;
-            if (g.mode == 1 || g.mode == 2) v = cz_make(sgn * cr[q][r], sgn * ci[q][r]);
-            else v = cz_make(old[r][q].x - cr[q][r], old[r][q].y - ci[q][r]);
-#if FEASTHIP_ABLATE & 4
-            if (v.x == 123.456)
-#endif
-            if (rok[r] && col < ldw) dptr[r][col] = v;
-        }
-}
-
-template <bool GATHER>
-__global__ __launch_bounds__(256, 2) void k_apply(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
-                                               const int* __restrict__ struct_idx, const cz* __restrict__ fact, int64_t fs,
-                                               cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, cz* skbuf, int64_t sks,
-                                               int ntiles, int ncg, const int* __restrict__ cmap, const cz* __restrict__ crow_child, int64_t crs_child) {
-    __shared__ cz Vs[2][APPLY_KC][LDS_COLS];      // double buffered, filled by LDS-DMA
-    // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the
-    // (node, tile) items are handed out in node-major order with a contiguous range per XCD: the tiles of
-    // one front of one node then run on ONE XCD and re-read their block-vector rows from that L2.
-    // the column groups of one (node, tile) are consecutive items: they run on the same XCD at about the same time, so the
-    // factor slab they share comes from HBM once
-    const int item0 = xcd_item(), item = item0 / ncg;
-    Tile t = tiles[item % ntiles];
-    int k = item / ntiles, cg = (item0 % ncg) * LDS_COLS;
-    FrontD f = fr[t.f];
-    ApplyGeom g;
-    int trows = decode_tile<cz>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
-    if (trows <= 16) apply_body<GATHER, 1>(g, Vs, cg, ldw);
-    else if (trows <= 32) apply_body<GATHER, 2>(g, Vs, cg, ldw);
-    else apply_body<GATHER, 4>(g, Vs, cg, ldw);
-}
-
-static int apply2_enabled();
 template <typename T>
 static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const T* fact, int64_t fs,
                           T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, int K, bool gather, T* skbuf, int64_t sks,
@@ -498,15 +237,11 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
                   const cz* crow_child, int64_t crs_child, int max_slabs) {
     if (ntiles <= 0) return;
-    const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
-    dim3 g(ntiles * K * ncg);
-    if (apply2_enabled()) { launch_apply2<cz>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs); return; }
-    if (gather) hipLaunchKernelGGL(k_apply<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
-    else hipLaunchKernelGGL(k_apply<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
+    launch_apply2<cz>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs);
 }
 
 // ---------------------------------------------------------------------------
-// k_apply2 -- the same tiles without LDS and without workgroup barriers (the default; FEASTHIP_APPLY2=0 selects k_apply).
+// k_apply2 -- no LDS staging, no workgroup barriers.
 // Every wave owns 16 output rows x 16*NS block-vector columns and streams BOTH operands straight from global memory into the
 // matrix-core operand registers: the factor slab (HBM) A2_DA - 1 k-steps ahead, the block-vector rows (they are shared by
 // the waves and tiles of a front, so they come from L1 / L2) A2_DV - 1 k-steps ahead -- a 16 B load per lane IS the MFMA
@@ -514,7 +249,7 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
 // The loop body is straight-line code (8 k-steps, uniform exits every second step), so the compiler's s_waitcnt vmcnt(N) waits
 // for exactly the loads a k-step consumes while 15-20 younger ones stay in flight; waves never wait for each other.
 // Measured on random operands (tools/probes/apply2_bench.hip): +21 % on matrix-core-bound tiles (K = 1024: 60.7 -> 73.8 TFLOP/s),
-// +12 % on short-K tiles; bit-identical results (same summation order).
+// +12 % on short-K tiles against the LDS-staged kernel of round 1; bit-identical results (same summation order).
 // ---------------------------------------------------------------------------
 constexpr int A2_DA = 8, A2_DV = 4, A2_DI = 2;
 
@@ -846,14 +581,6 @@ __global__ __launch_bounds__(256, NSMAX == 4 ? 2 : 3) void k_apply2(const FrontD
     else if (NSMAX == 4) apply2_body<T, GATHER, 4>(g, cg, ldw, Ys);
 }
 
-static int g_apply2 = -1;
-static int apply2_enabled() {
-    if (g_apply2 < 0) { const char* e = getenv("FEASTHIP_APPLY2"); g_apply2 = e ? (atoi(e) != 0) : 1; }
-    return g_apply2;
-}
-void select_apply_kernel(int barrier_free) { g_apply2 = barrier_free ? 1 : 0; }
-int apply_kernel_fuses_b3() { return apply2_enabled(); }      // kind-6 tiles end with their B3 product only in k_apply2
-
 template <typename T>
 static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const T* fact, int64_t fs,
                           T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, int K, bool gather, T* skbuf, int64_t sks,
@@ -867,175 +594,12 @@ static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, in
 }
 
 // ---------------------------------------------------------------------------
-// Mixed precision (feast!'s mixed_prec, src/feast.jl:19-25), round-1 kernel (FEASTHIP_APPLY2=0; the default is k_apply2<cf>
-// above): the same tiles on complex64 copies of the solve-ready factors and block vectors -- half the bytes per sweep, f32
-// matrix cores (v_mfma_f32_16x16x4_f32, 3M product).  The V rows go through registers (global load one chunk ahead, ds_write
-// into the other half of a padded double buffer) and 4 waves per SIMD fit.
-// D layout of the f32 instruction: register r of lane l holds row 4 (l >> 4) + r, column l & 15.
-// ---------------------------------------------------------------------------
-constexpr int A32_KC = 32;
-constexpr int A32_LD = 80;     // LDS row stride in complex64 (640 B): rows k and k+1 fall on disjoint halves of the banks
-
-template <bool GATHER, int NS>
-__device__ __forceinline__ void apply32_body(const ApplyGeomT<cf>& g, cf (*Vs)[A32_KC][A32_LD], int cg, int ldw) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;
-    const bool wave_active = g.rbase + slab * 16 < g.rend;
-    const int arow = g.rbase + slab * 16 + li;
-    const bool aok = arow < g.rend;
-    const int adiag = arow - g.k0;
-    const int Kd = g.Kd;
-    const int arow_c = min(arow, g.rend - 1);
-    const int lo_keep = (g.mask == 2) ? adiag : 0;
-    const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
-    const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
-    // V staging: thread t moves rows (t >> 5) + 8 q, q < 4, column pair t & 31 (16 bytes) of every chunk
-    const int vr = tid >> 5, vcp = min(cg + 2 * (tid & 31), ldw - 2);
-    cf an[A32_KC / 4], av[A32_KC / 4];
-    float4 vn[4];
-    int idxn[4] = {0, 0, 0, 0};
-    auto load_idx = [&](int kc) {
-        if (GATHER) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) idxn[q] = g.sidx[min(kc + vr + 8 * q, Kd - 1)];
-        }
-    };
-    auto load_chunk = [&](int kc) {
-#pragma unroll
-        for (int ks = 0; ks < A32_KC / 4; ++ks) an[ks] = g.A[arow_c + (int64_t)min(kc + ks * 4 + lk, Kd - 1) * g.lda];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int vrow = GATHER ? idxn[q] : g.vrow0 + min(kc + vr + 8 * q, Kd - 1);
-            vn[q] = *reinterpret_cast<const float4*>(g.Vk + (int64_t)vrow * ldw + vcp);
-        }
-    };
-    auto stage = [&](int kc, int buf) {      // registers -> LDS / masked A
-#pragma unroll
-        for (int ks = 0; ks < A32_KC / 4; ++ks) {
-            int gk = kc + ks * 4 + lk;
-            bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
-            av[ks].x = keep ? an[ks].x : (gk == unit_at ? 1.0f : 0.0f);
-            av[ks].y = keep ? an[ks].y : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(&Vs[buf][vr + 8 * q][2 * (tid & 31)]) = vn[q];
-    };
-    // 3M complex product as in apply_body: T1 = ar*br, T2 = ai*bi, T3 = (ar+ai)*(br+bi);  re = T1 - T2, im = T3 - T1 - T2
-    f4 t1[NS], t2[NS], t3[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) { t1[q] = (f4){0, 0, 0, 0}; t2[q] = (f4){0, 0, 0, 0}; t3[q] = (f4){0, 0, 0, 0}; }
-    cf* dptr[4];
-    bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int orow = g.rbase + slab * 16 + 4 * lk + r;
-        rok[r] = orow < g.rend;
-        dptr[r] = g.out + (int64_t)(min(orow, g.rend - 1) + g.orow_shift) * ldw;
-    }
-    auto mfma_chunk = [&](int kc, int buf) {
-        const int nks = (min(A32_KC, Kd - kc) + 3) >> 2;
-        if (wave_active) {
-#pragma unroll
-            for (int ks = 0; ks < A32_KC / 4; ++ks) {
-                if (ks < nks) {
-                    const int kk = ks * 4 + lk;
-                    const float ar = av[ks].x, ai = av[ks].y, as = ar + ai;
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        cf b = Vs[buf][kk][(ct0 + q) * 16 + li];
-                        t1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, b.x, t1[q], 0, 0, 0);
-                        t2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.y, t2[q], 0, 0, 0);
-                        t3[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, b.x + b.y, t3[q], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    };
-    load_idx(0);
-    load_chunk(0);
-    load_idx(A32_KC);
-    stage(0, 0);
-    __syncthreads();
-    int it = 0, kc = 0;
-    for (; kc + A32_KC < Kd; kc += A32_KC, ++it) {
-        const int buf = it & 1;
-        load_chunk(kc + A32_KC);                 // in flight during this chunk's MFMAs
-        load_idx(kc + 2 * A32_KC);
-        mfma_chunk(kc, buf);
-        stage(kc + A32_KC, buf ^ 1);             // everyone passed the previous barrier, so nobody still reads buf ^ 1
-        __syncthreads();
-    }
-    cf old[4][NS];
-    if (g.mode == 0 && wave_active) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < NS; ++q) old[r][q] = dptr[r][min(cg + (ct0 + q) * 16 + li, ldw - 1)];
-    } else if (g.mode == 3 && wave_active) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < NS; ++q) { old[r][q].x = 0.0f; old[r][q].y = 0.0f; }
-        for (int c = 0; c < g.npull; ++c) {
-            int src[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int orow = g.rbase + slab * 16 + 4 * lk + r;
-                src[r] = rok[r] ? g.pull[(int64_t)(orow + g.orow_shift) * g.npull + c] : -1;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (src[r] >= 0) {
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        cf v = g.pullbase[(int64_t)src[r] * ldw + min(cg + (ct0 + q) * 16 + li, ldw - 1)];
-                        old[r][q].x += v.x; old[r][q].y += v.y;
-                    }
-                }
-        }
-    }
-    mfma_chunk(kc, it & 1);
-    if (!wave_active) return;
-    const float sgn = (g.mode == 2) ? -1.0f : 1.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            int col = cg + (ct0 + q) * 16 + li;
-            cf v;
-            const float re = t1[q][r] - t2[q][r], im = t3[q][r] - t1[q][r] - t2[q][r];
-            if (g.mode == 1 || g.mode == 2) { v.x = sgn * re; v.y = sgn * im; }
-            else { v.x = old[r][q].x - re; v.y = old[r][q].y - im; }
-            if (rok[r] && col < ldw) dptr[r][col] = v;
-        }
-}
-
-template <bool GATHER>
-__global__ __launch_bounds__(256) void k_apply32(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
-                                                 const int* __restrict__ struct_idx, const cf* __restrict__ fact, int64_t fs,
-                                                 cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, cf* skbuf, int64_t sks,
-                                                 int ntiles, int ncg, const int* __restrict__ cmap, const cf* __restrict__ crow_child, int64_t crs_child) {
-    __shared__ cf Vs[2][A32_KC][A32_LD];
-    const int item0 = xcd_item(), item = item0 / ncg;
-    Tile t = tiles[item % ntiles];
-    int k = item / ntiles, cg = (item0 % ncg) * LDS_COLS;
-    FrontD f = fr[t.f];
-    ApplyGeomT<cf> g;
-    int trows = decode_tile<cf>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
-    if (trows <= 16) apply32_body<GATHER, 1>(g, Vs, cg, ldw);
-    else if (trows <= 32) apply32_body<GATHER, 2>(g, Vs, cg, ldw);
-    else apply32_body<GATHER, 4>(g, Vs, cg, ldw);
-}
-
+// Mixed precision (feast!'s mixed_prec, src/feast.jl:19-25): the complex64 instance of k_apply2 (v_mfma_f32_16x16x4_f32, paired 16-byte lanes)
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather, cf* skbuf, int64_t sks,
                   const cf* crow_child, int64_t crs_child, int max_slabs) {
     if (ntiles <= 0) return;
-    if (apply2_enabled()) { launch_apply2<cf>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs); return; }
-    const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
-    dim3 g(ntiles * K * ncg);
-    if (gather) hipLaunchKernelGGL(k_apply32<true>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
-    else hipLaunchKernelGGL(k_apply32<false>, g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child);
+    launch_apply2<cf>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs);
 }
 
 __global__ void k_to_f32(int64_t total, const cz* __restrict__ in, cf* out) {

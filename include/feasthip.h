@@ -282,12 +282,6 @@ int feasthip_mm_read_csc(const char* path, int64_t* colptr, int64_t* rowval, voi
 int feasthip_mm_write_csc(const char* path, int64_t rows, int64_t cols, const int64_t* colptr, const int64_t* rowval,
                           const void* nzval, int type, int index_base);
 
-/* Diagnostic, process-wide: which kernel runs the complex128 block-substitution tiles.  1 (default): k_apply2, every wave streams
- * both operands from global memory into the matrix cores, no LDS, no workgroup barriers; 0: k_apply, block-vector rows staged
- * in LDS by LDS-DMA.  Both produce bit-identical results (same summation order); the environment variable FEASTHIP_APPLY2 sets
- * the initial choice. */
-int feasthip_select_apply_kernel(int barrier_free);
-
 /* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------- */
 /* symbolic analysis of a pattern: stats[0..7] = nsuper, nnz_l, nnz_u, fact_elems,
  * max_front, max_p, depth, flops(as int64).  perm_out (n ints, new->old) optional;
