@@ -369,10 +369,11 @@ def _writeback(X_in, Xw):
 
 
 def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=False, store=False, eps=1e-12,
-              factorizer=None, left_divider=None, device=0, info=None, _mixed_prec=False, conjugate_fold=True):
+              factorizer=None, left_divider=None, device=0, info=None, _mixed_prec=False, conjugate_fold=None):
     """gen_feast!(X, A, B[, contour]; ...)  src/feast.jl:82-156.  B=None gives feast!.
     ``conjugate_fold=False`` factorises every contour node separately like the reference even when the matrices are real
-    and the contour is mirror-symmetric (FeastHandle.set_conjugate_fold).
+    and the contour is mirror-symmetric (FeastHandle.set_conjugate_fold); ``True`` asks for the fold, ``None`` leaves the
+    library's default (on, unless FEASTHIP_FOLD=0).
 
     ``factorizer``/``left_divider`` (src/feast.jl:5,11,84,90): left at their defaults (None, or this module's ``lu`` /
     ``ldiv``) the whole loop runs inside the library (batched factorisation of all nodes, fused sweeps).  Anything else is
@@ -398,8 +399,8 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
     try:
         h.set_terms([A, B], scales=[1.0, -1.0])          # T(z) = A - z B
         h.set_contour(contour)
-        if not conjugate_fold:
-            h.set_conjugate_fold(False)
+        if conjugate_fold is not None:
+            h.set_conjugate_fold(bool(conjugate_fold))
         if _mixed_prec:
             h.set_precision(True)
         if debug:

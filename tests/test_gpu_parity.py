@@ -14,6 +14,31 @@ def c2n(pairs):
     return np.array([complex(a, b) for a, b in pairs])
 
 
+def pivot_light_default():
+    """the suite is also run with FEASTHIP_NOPIV=0 (partial pivoting for symmetric matrices too)"""
+    import os
+    return os.environ.get("FEASTHIP_NOPIV", "1") != "0"
+
+
+class env_override:
+    """set environment variables for the creation of a handle and put the previous values back"""
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def match_sets(a, b):
     """max over a of the distance to the nearest element of b (order-insensitive, like approx_in in runtests.jl)"""
     a, b = np.asarray(a), np.asarray(b)
@@ -57,7 +82,7 @@ def test_seam_dense_symmetric_lu_ldiv(gpu, pkg, n, m0):
     assert np.array_equal(Cm, Cm.T)
     R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
     F = pkg.lu(Cm)
-    assert F.symmetric and F.growth < 1024
+    assert F.symmetric == pivot_light_default() and F.growth < 1024
     Y = np.zeros((n, m0), dtype=np.complex128, order="F")
     pkg.ldiv(Y, F, R)
     pkg.finalize(F)
@@ -510,7 +535,7 @@ def test_sparse_symmetric_factorisation_is_race_free(gpu, pkg, wl, g):
     sols = []
     for rep in range(3):
         F = pkg.lu(Cm)
-        assert F.symmetric
+        assert F.symmetric == pivot_light_default()
         Y = np.zeros_like(R)
         pkg.ldiv(Y, F, R)
         pkg.finalize(F)
@@ -569,14 +594,11 @@ def test_symmetric_pencil_takes_pivot_light_path(gpu, pkg, wl, golden):
     g = golden["c3_g12_s19"]
     out = {}
     for mode in ("1", "0"):
-        os.environ["FEASTHIP_NOPIV"] = mode
-        try:
+        with env_override(FEASTHIP_NOPIV=mode):
             info = {}
             X = w["X0"].copy()
             lam, V, res = pkg.gen_feast(X, w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), iter=w["iter"], eps=w["eps"],
                                         store=True, info=info)
-        finally:
-            os.environ.pop("FEASTHIP_NOPIV", None)
         out[mode] = (lam, res, info)
         assert len(lam) == len(g["lam"]) and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
         assert abs(info["nit"] - g["history"][-1][0]) <= 1
@@ -608,11 +630,8 @@ def test_pivot_light_path_falls_back_when_elimination_is_unsafe(gpu, pkg):
     R2 = np.asfortranarray(rng.standard_normal((2 * m, 3)) + 0j)
     sols = {}
     for mode in ("1", "0"):
-        os.environ["FEASTHIP_NOPIV"] = mode
-        try:
+        with env_override(FEASTHIP_NOPIV=mode):
             F = pkg.lu(T2)
-        finally:
-            os.environ.pop("FEASTHIP_NOPIV", None)
         assert not F.symmetric
         Y2 = np.zeros_like(R2)
         pkg.ldiv(Y2, F, R2)
@@ -622,7 +641,8 @@ def test_pivot_light_path_falls_back_when_elimination_is_unsafe(gpu, pkg):
     assert np.array_equal(sols["1"], sols["0"])
     # the same pattern with a definite imaginary part stays on the pivot-light path
     T3 = sp.csc_matrix(T2 + 0.5j * sp.identity(2 * m))
-    F = pkg.lu(T3)
+    with env_override(FEASTHIP_NOPIV="1"):
+        F = pkg.lu(T3)
     assert F.symmetric and F.growth < 8
     Y3 = np.zeros_like(R2)
     pkg.ldiv(Y3, F, R2)
@@ -943,8 +963,8 @@ def test_bitwise_reproducible_and_stream_independent(gpu, pkg, wl):
     con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
     outs = []
     for streams in ("2", "2", "1", "4"):
-        os.environ["FEASTHIP_STREAMS"] = streams
-        h = pkg.FeastHandle(0)
+        with env_override(FEASTHIP_STREAMS=streams):
+            h = pkg.FeastHandle(0)
         h.set_terms([w["A"], w["B"]], [1.0, -1.0])
         h.set_contour(con)
         h.factorize()
@@ -991,11 +1011,8 @@ def test_forward_splitk_matches_unsplit(gpu, pkg, wl, mixed):
     con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
     out = {}
     for mode in ("1", "0"):
-        os.environ["FEASTHIP_FWD_SPLITK"] = mode
-        try:
+        with env_override(FEASTHIP_FWD_SPLITK=mode):
             h = pkg.FeastHandle(0)
-        finally:
-            os.environ.pop("FEASTHIP_FWD_SPLITK", None)
         try:
             h.set_terms([w["A"], w["B"]], [1.0, -1.0])
             h.set_contour(con)
@@ -1059,6 +1076,7 @@ def test_conjugate_fold_only_where_it_is_exact(gpu, pkg, wl):
         h = pkg.FeastHandle(0)
         h.set_terms([A_, B_], [1.0, -1.0])
         h.set_contour(con)
+        h.set_conjugate_fold(True)             # (the suite also runs with FEASTHIP_FOLD=0 as the initial state)
         f = h.stats()["folded"]
         h.close()
         return f
@@ -1120,958 +1138,6 @@ def test_sweep_kernel_moment_against_oracle(gpu, pkg, fo, wl, m0, fold, mixed):
 
 
 @pytest.mark.parametrize("kind", ["circular", "rect_trap", "rect_gauss"])
-def test_runtests_sparse_contours(gpu, pkg, wl, golden, kind):
-    A = sp.diags([-np.ones(99), 2 * np.ones(100), -np.ones(99)], [-1, 0, 1], format="csc")
-    Cc, R = complex(0.05, 0.0), 0.05
-    con = {"circular": pkg.circular_contour_trapezoidal(Cc, R, 8),
-           "rect_trap": pkg.rectangular_contour_trapezoidal(0.0 - R * 1j, 2 * R + R * 1j, 8),
-           "rect_gauss": pkg.rectangular_contour_gauss(0.0 - R * 1j, 2 * R + R * 1j, 8)}[kind]
-    X = wl.rand_x0(100, 20, 21)
-    e, v, res = pkg.feast(X, A, con, eps=10e-15)
-    assert e.shape[0] == 10
-    assert res.max() < 10e-15
-    assert np.abs(np.sort(e.real) - np.array(golden["runtests_laplace1d_analytic"])).max() < 1e-13
-    # returned vectors are eigenvectors, X was updated in place
-    assert np.linalg.norm(A @ v - v * e[None, :], axis=0).max() < 1e-13
-    assert np.allclose(np.linalg.norm(X, axis=0), 1.0)
-
-
-# ---------------------------------------------------------------------------------------
-# BASELINE configs at oracle sizes against committed golden vectors
-# ---------------------------------------------------------------------------------------
-def _check_linear(pkg, w, g, store=True, tol_lam=1e-10):
-    info = {}
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
-    X = w["X0"].copy()
-    lam, V, res = pkg.gen_feast(X, w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=store, info=info)
-    glam = c2n(g["lam"])
-    assert len(lam) == len(glam) == w["n_inside"]
-    scale = np.maximum(1.0, np.abs(glam).max())
-    assert match_sets(lam, glam) < tol_lam * scale and match_sets(glam, lam) < tol_lam * scale
-    assert res.max() < w["eps"]
-    assert abs(info["nit"] - g["history"][-1][0]) <= 1
-    assert info["warn"] == 0
-    # true residual of the returned pairs, computed on the host
-    A, B = w["A"], w["B"]
-    BV = V if B is None else B @ V
-    r_true = np.linalg.norm(A @ V - BV * lam[None, :], axis=0)
-    assert r_true.max() < 10 * w["eps"] + 1e-12
-    return info
-
-
-def test_c1_dense_hermitian_n512(gpu, pkg, wl, golden):
-    _check_linear(pkg, wl.c1_dense_hermitian(512, 16), golden["c1_n512"])
-
-
-def test_c1_store_false(gpu, pkg, wl, golden):
-    _check_linear(pkg, wl.c1_dense_hermitian(512, 16), golden["c1_n512"], store=False)
-
-
-def test_c2_dense_generalized_n512(gpu, pkg, wl, golden):
-    g = golden["c2_n512"]
-    _check_linear(pkg, wl.c2_dense_generalized(512, 64, radius=g["radius"], n_inside=32), g, tol_lam=1e-9)
-
-
-def test_c3_sparse_g12(gpu, pkg, wl, golden):
-    info = _check_linear(pkg, wl.c3_sparse_generalized(12, 19, 64), golden["c3_g12_s19"])
-    assert info["dense"] == 0 and info["nsuper"] > 1
-
-
-def test_c3_sparse_g8_m16(gpu, pkg, wl, golden):
-    _check_linear(pkg, wl.c3_sparse_generalized(8, 19, 16), golden["c3_g8_s19_m16"])
-
-
-def test_c5_literal_companion_m30(gpu, pkg, fo, wl, golden):
-    C1, C2 = fo.companion_pencil(wl.deficient_quadratic_coeffs())     # oracle used only to build the input pencil
-    X = wl.rand_x0(30, 30, 5002)
-    lam, V, res = pkg.gen_feast(X, C1, C2, nodes=32, iter=20, c=0j, r=0.25, eps=1e-10)
-    glam = c2n(golden["deficient_quadratic"]["companion_inside"])
-    assert len(lam) == 4 and match_sets(lam, glam) < 1e-8
-
-
-def test_c4_butterfly_nlfeast(gpu, pkg, wl, golden):
-    w = wl.c4_butterfly()
-    T = pkg.PolynomialNEP(w["coeffs"])
-    X = w["X0"].copy()
-    info = {}
-    lam, Xo, res = pkg.nlfeast(T, X, 16, 10, c=w["c"], r=w["r"], eps=w["eps"], spurious=w["spurious"], info=info)
-    assert lam.shape == (32,) and Xo.shape == (64, 32)                  # all m0 pairs, unfiltered
-    ins = np.abs(lam - w["c"]) <= w["r"]
-    comp = c2n(golden["c4_butterfly"]["companion_inside"])
-    assert ins.sum() == 13
-    assert match_sets(lam[ins], comp) < 1e-10 and match_sets(comp, lam[ins]) < 1e-10
-    assert res[ins].max() < 1e-10
-    assert abs(info["nit"] - golden["c4_butterfly"]["history"][-1][0]) <= 1
-    assert np.allclose(np.linalg.norm(Xo, axis=0), 1.0)
-    # relative residual definition (src/utils.jl:151-157)
-    for j in np.nonzero(ins)[0]:
-        Tl = T(lam[j])
-        assert abs(np.linalg.norm(Tl @ Xo[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
-
-
-@pytest.mark.parametrize("case,comp_key", [("moments_deficient_quadratic", "deficient_quadratic"),
-                                           ("moments_butterfly", "c4_butterfly"), ("moments_system5", "system5")])
-def test_nlfeast_moments_parity(gpu, pkg, fo, wl, golden, case, comp_key):
-    """nlfeast_moments! (src/nlfeast.jl:173-318) through feasthip_nlfeast_moments_run against the
-    committed oracle fixture and the companion spectrum; dense (deficient, butterfly) and sparse (system5) terms."""
-    g = golden[case]
-    coeffs = {"moments_deficient_quadratic": wl.deficient_quadratic_coeffs, "moments_butterfly": lambda: wl.c4_butterfly()["coeffs"],
-              "moments_system5": lambda: wl.system5_coeffs(sparse=True)}[case]()
-    T = pkg.PolynomialNEP(coeffs)
-    X = wl.rand_x0(g["n"], g["m0"], g["seed"])
-    c = complex(*g["c"])
-    info = {}
-    lam, Y, res = pkg.nlfeast_moments(T, X, g["nodes"], g["iter"], c=c, r=g["r"], eps=g["eps"], moments=g["moments"], info=info)
-    M = g["moments"] * g["m0"]
-    assert lam.shape == (M,) and Y.shape == (g["n"], M) and res.shape == (M,)
-    assert np.all(np.diff(res[np.isfinite(res)]) >= 0)                                    # sorted by residual (utils.jl:125)
-    ins = (np.abs(lam - c) <= g["r"]) & (res < 1e-9)
-    comp = c2n(golden[comp_key]["companion_inside"])
-    assert ins.sum() == len(comp)
-    assert match_sets(lam[ins], comp) < 1e-9 and match_sets(comp, lam[ins]) < 1e-9
-    assert match_sets(lam[ins], c2n(g["lam_inside"])) < 1e-10                             # vs the oracle fixture
-    assert res[ins].max() < 1e-11
-    assert abs(info["nit"] - g["history"][-1][0]) <= 1
-    # Y columns are the normalised candidates and res is the relative residual of (lam, Y) (src/utils.jl:118-123, 159-164)
-    for j in np.nonzero(ins)[0][:8]:
-        Tl = T(lam[j])
-        Tl = Tl.toarray() if sp.issparse(Tl) else Tl
-        assert abs(np.linalg.norm(Y[:, j]) - 1.0) < 1e-12
-        assert abs(np.linalg.norm(Tl @ Y[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
-    # X holds the m0 best candidates, normalised (src/nlfeast.jl:309-311)
-    assert np.allclose(np.linalg.norm(X, axis=0), 1.0)
-    assert np.abs(X - Y[:, :g["m0"]]).max() < 1e-12
-
-
-@pytest.mark.parametrize("path", ["split", "closure", "moments", "moments_closure"])
-def test_hadeler_nonpolynomial_nep(gpu, pkg, wl, golden, path):
-    """Generic-T NLFEAST: the Hadeler problem of test/hadeler.jl in split form on the device
-    (feasthip_set_coef_functions), as an opaque closure (node matrices + host residual, feasthip_set_node_coefficients /
-    feasthip_nl_beyn_step / feasthip_nl_set_r) and through nlfeast_moments!, against the oracle fixture."""
-    w = wl.hadeler_split()
-    nep = pkg.SplitNEP(w["mats"], w["funcs"])
-    X = wl.rand_x0(200, w["m0"], w["seed"])
-    info = {}
-    kw = dict(c=w["c"], r=w["r"], eps=w["eps"], spurious=w["spurious"], info=info)
-    if path == "split":
-        lam, Xo, res = pkg.nlfeast(nep, X, w["nodes"], w["iter"], **kw)
-        g = golden["hadeler_nlfeast"]
-    elif path == "closure":
-        lam, Xo, res = pkg.nlfeast(lambda z: nep(z), X, w["nodes"], w["iter"], **kw)      # opaque callable
-        g = golden["hadeler_nlfeast"]
-    elif path == "moments":
-        lam, Xo, res = pkg.nlfeast_moments(nep, X, w["nodes"], w["iter"], moments=2, **kw)
-        g = golden["hadeler_moments"]
-    else:
-        lam, Xo, res = pkg.nlfeast_moments(lambda z: nep(z), X, w["nodes"], w["iter"], moments=2, **kw)     # opaque callable
-        g = golden["hadeler_moments"]
-    ins = (np.abs(lam - w["c"]) <= w["r"]) & (res < 1e-9)
-    gl = c2n(g["lam_inside"])
-    assert ins.sum() == len(gl) == 12
-    assert match_sets(lam[ins], gl) < 1e-9 and match_sets(gl, lam[ins]) < 1e-9
-    assert res[ins].max() < 1e-11
-    assert abs(info["nit"] - g["history"][-1][0]) <= 1
-    for j in np.nonzero(ins)[0][:4]:                        # relative residual definition (src/utils.jl:151-157)
-        Tl = nep(lam[j])
-        assert abs(np.linalg.norm(Tl @ Xo[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
-
-
-# ---------------------------------------------------------------------------------------
-# dual_gen_feast! (SURVEY 8f rank 3, src/feast.jl:158-257)
-# ---------------------------------------------------------------------------------------
-def test_dual_gen_feast_dense(gpu, pkg, wl, golden):
-    g = golden["dual_c2_n256"]
-    w = wl.c2_dense_generalized(256, 32, n_inside=12, radius=g["r"])
-    Xr, Xl = wl.rand_x0(256, 32, 8001), wl.rand_x0(256, 32, 8002)
-    info = {}
-    lam, xr, xl, res = pkg.dual_gen_feast(Xr, Xl, w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-11, store=True, info=info)
-    assert len(lam) == 12 and match_sets(lam, c2n(g["lam"])) < 1e-9 and match_sets(c2n(g["lam"]), lam) < 1e-9
-    assert res.max() < 1e-11 and abs(info["nit"] - g["history"][-1][0]) <= 1
-    A, B = w["A"], w["B"]
-    for i in range(len(lam)):
-        assert abs(np.linalg.norm(A @ xr[:, i] - lam[i] * (B @ xr[:, i])) - res[i]) < 1e-12      # absolute residual (utils.jl:166-171)
-        assert np.linalg.norm(xl[:, i].conj() @ A - lam[i] * (xl[:, i].conj() @ B)) < 1e-10       # left eigenvector
-    G = xl.conj().T @ B @ xr
-    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 and np.abs(np.diag(G)).min() > 1e-4
-    assert np.array_equal(Xr[:, info["inside"]], xr) and np.array_equal(Xl[:, info["inside"]], xl)   # in-place
-
-
-def test_dual_gen_feast_sparse_nonsymmetric(gpu, pkg, wl):
-    """sparse, structurally symmetric but non-Hermitian (convection-diffusion on a 10^3 grid), store=false: the adjoint
-    systems are factorised as extra nodes from the terms A', B'."""
-    g = 10
-    L = wl.laplacian_3d(g, 7)
-    n = g ** 3
-    idx = np.arange(n)
-    conv = sp.csc_matrix((np.r_[np.full(n - 1, 0.35), np.full(n - 1, -0.35)], (np.r_[idx[:-1], idx[1:]], np.r_[idx[1:], idx[:-1]])), shape=(n, n))
-    A = sp.csc_matrix(L + conv)
-    rng = np.random.default_rng(5)
-    B = sp.diags(rng.uniform(0.5, 1.5, n), format="csc")
-    import scipy.linalg as sla
-    ev = sla.eigvals(A.toarray(), B.toarray())
-    dist = np.sort(np.abs(ev - 0.8))
-    k = next(i for i in range(8, 20) if dist[i] - dist[i - 1] > 5e-3)          # do not cut through a conjugate pair
-    c, r = 0.8 + 0j, 0.5 * (dist[k - 1] + dist[k])
-    inside_ref = ev[np.abs(ev - c) <= r]
-    Xr, Xl = wl.rand_x0(n, 32, 31), wl.rand_x0(n, 32, 32)
-    lam, xr, xl, res = pkg.dual_gen_feast(Xr, Xl, A, B, nodes=16, iter=25, c=c, r=r, eps=1e-11, store=False)
-    assert len(lam) == k and match_sets(lam, inside_ref) < 1e-9 and match_sets(inside_ref, lam) < 1e-9 and res.max() < 1e-11
-    for i in range(len(lam)):
-        assert np.linalg.norm(xl[:, i].conj() @ A - lam[i] * (xl[:, i].conj() @ B)) < 1e-9
-
-
-# ---------------------------------------------------------------------------------------
-# mixed_prec (SURVEY 8f rank 2, src/feast.jl:10,19-25)
-# ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kind", ["dense", "sparse"])
-def test_mixed_prec_seam(gpu, pkg, wl, kind):
-    """factorizer(ZmA::ComplexF32) / left_divider(temp::ComplexF32, F, R): the complex64 sweeps reach single precision
-    (a few eps32 times the condition number), and the ComplexF32 `temp` of the reference is a cast of the result."""
-    rng = np.random.default_rng(99)
-    if kind == "dense":
-        n, m0 = 300, 40
-        Cm = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex64)
-        ref_solve = lambda R: np.linalg.solve(Cm.astype(np.complex128), R)                 # noqa: E731
-        cond = np.linalg.cond(Cm.astype(np.complex128))
-    else:
-        A = wl.laplacian_3d(14, 19).astype(np.complex128) - (0.3 + 0.2j) * sp.identity(14 ** 3, format="csc")
-        Cm = sp.csc_matrix(A, dtype=np.complex64)
-        n, m0 = A.shape[0], 64
-        f = spla.splu(sp.csc_matrix(Cm, dtype=np.complex128))
-        ref_solve, cond = f.solve, 50.0
-    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
-    F = pkg.lu(Cm)
-    temp = np.zeros((n, m0), dtype=np.complex64, order="F")
-    pkg.ldiv(temp, F, R)
-    pkg.finalize(F)
-    ref = ref_solve(R)
-    err = np.abs(temp - ref).max() / np.abs(ref).max()
-    assert 1e-9 < err < 2e-7 * cond                                   # single precision: not fp64, and not garbage
-
-
-def test_mixed_prec_feast_dense(gpu, pkg, fo, wl, golden):
-    """feast!(...; mixed_prec=true) on C1.  The oracle restates the reference literally (ComplexF32 factors AND a
-    ComplexF32 `temp = X - temp`, src/feast.jl:22,68), which stalls at a residual of ~5e-7; here only the solves are
-    complex64 and the RII update is accumulated in complex128, so the iteration follows the reference while it still
-    converges and then continues to the fp64 answer with the iteration count of the fp64 run."""
-    w = wl.c1_dense_hermitian(512, 16)
-    con = fo.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
-    hist = []
-    fo.gen_feast(w["X0"].copy(), w["A"], None, con, iter=6, eps=1e-12, store=True, history=hist, mixed_prec=True)
-    assert 1e-7 < hist[-1][2] < 5e-6                                   # the reference's single-precision floor
-    info = {}
-    X = w["X0"].copy()
-    lam, V, res = pkg.feast(X, w["A"], nodes=w["nodes"], iter=20, c=w["c"], r=w["r"], eps=1e-12, store=True, mixed_prec=True, info=info)
-    g = golden["c1_n512"]
-    assert len(lam) == 8 and match_sets(lam, c2n(g["lam"])) < 1e-10
-    assert res.max() < 1e-12
-    assert abs(info["nit"] - g["history"][-1][0]) <= 1
-    for j in range(len(lam)):
-        assert np.linalg.norm(w["A"] @ V[:, j] - lam[j] * V[:, j]) < 1e-11
-    # same early history as the literal restatement (before its floor)
-    info2 = {}
-    pkg.feast(w["X0"].copy(), w["A"], nodes=w["nodes"], iter=2, c=w["c"], r=w["r"], eps=1e-30, store=True, mixed_prec=True, info=info2)
-    r2 = info2["res_all"][info2["inside"]].max()
-    assert 0.3 < r2 / hist[2][2] < 3.0
-
-
-def test_mixed_prec_feast_sparse_store_false(gpu, pkg, wl):
-    """sparse standard problem, store=false (factor + complex64 copy every iteration): eigenvalues of the 19-point
-    Laplacian to fp64 accuracy."""
-    A = wl.laplacian_3d(12, 19)
-    ev = np.sort(np.linalg.eigvalsh(A.toarray()))
-    c, r = 0.5 * (ev[0] + ev[6]), 0.5 * (ev[6] - ev[0]) + 0.4 * (ev[7] - ev[6])
-    X0 = wl.rand_x0(12 ** 3, 16, 12)
-    lam, V, res = pkg.feast(X0, A, nodes=16, iter=20, c=c, r=r, eps=1e-12, store=False, mixed_prec=True)
-    assert len(lam) == 7 and np.abs(np.sort(lam.real) - ev[:7]).max() < 1e-11 and res.max() < 1e-12
-
-
-def test_c5_system5_companion_m128(gpu, pkg, wl, golden):
-    """C5 (ii): system5 quadratic, companion pencil 2000 x 2000, 32 nodes, m0 = 128."""
-    g = golden["c5_system5_companion"]
-    _check_linear(pkg, wl.c5_system5_companion(128), g, tol_lam=1e-9)
-    comp = c2n(golden["system5"]["companion_inside"])
-    assert match_sets(c2n(g["lam"]), comp) < 1e-9
-
-
-def test_butterfly_sparse_terms_nlfeast(gpu, pkg, wl, golden):
-    """same NEP through feasthip_set_csc (5 sparse terms): exercises the sparse polynomial path"""
-    w = wl.c4_butterfly()
-    T = pkg.PolynomialNEP([sp.csc_matrix(M) for M in w["coeffs"]])
-    lam, Xo, res = pkg.nlfeast(T, w["X0"].copy(), 16, 10, c=w["c"], r=w["r"], eps=w["eps"])
-    ins = np.abs(lam - w["c"]) <= w["r"]
-    comp = c2n(golden["c4_butterfly"]["companion_inside"])
-    assert ins.sum() == 13 and match_sets(lam[ins], comp) < 1e-10 and res[ins].max() < 1e-10
-
-
-def test_system5_nlfeast_first_moments(gpu, pkg, fo, wl):
-    """nlfeast! does not converge on system5 with one moment pair (the reference uses
-    nlfeast_moments! there, test/polynomial.jl:20); compare the contour moments instead:
-    after nit = 0 the oracle's Q0, Q1 and ours span the same spaces."""
-    coeffs = wl.system5_coeffs(sparse=True)
-    X0 = wl.rand_x0(1000, 40, 77)
-    h = pkg.FeastHandle(0)
-    h.set_terms(coeffs)
-    h.set_contour(pkg.circular_contour_trapezoidal(-1.55 + 0j, 0.05, 16))
-    h.set_x(X0)
-    h.nl_orthonormalize_x()
-    Xq = h.get_block(0)
-    assert np.abs(Xq.conj().T @ Xq - np.eye(40)).max() < 1e-13
-    h.factorize()
-    h.nl_contour_step(True)
-    Q0, Q1 = h.get_block(2), h.get_block(3)
-    h.close()
-    T = fo.poly_T(coeffs)
-    zs = pkg.circular_contour_trapezoidal(-1.55 + 0j, 0.05, 16)
-    R0 = np.zeros_like(Q0); R1 = np.zeros_like(Q1)
-    for z, wgt in zip(zs.nodes, zs.weights):
-        Y = fo.lu(T(z)).solve(Xq) * wgt
-        R0 += Y; R1 += Y * z
-    assert np.abs(Q0 - R0).max() < 1e-9 * np.abs(R0).max()
-    assert np.abs(Q1 - R1).max() < 1e-9 * np.abs(R1).max()
-
-
-# ---------------------------------------------------------------------------------------
-# properties at sizes the oracle cannot reach quickly
-# ---------------------------------------------------------------------------------------
-def test_large_sparse_solve_residual(gpu, pkg, wl):
-    A = wl.laplacian_3d(24, 19)
-    n = A.shape[0]
-    rng = np.random.default_rng(1)
-    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.17 + 0.17j) * sp.diags(rng.uniform(0.5, 1.5, n)))
-    R = np.asfortranarray(rng.standard_normal((n, 64)) + 1j * rng.standard_normal((n, 64)))
-    F = pkg.lu(Cm)
-    Y = np.zeros_like(R)
-    pkg.ldiv(Y, F, R)
-    # linearity: solve(2R) == 2 solve(R)
-    Y2 = np.zeros_like(R)
-    pkg.ldiv(Y2, F, np.asfortranarray(2 * R))
-    pkg.finalize(F)
-    assert np.linalg.norm(Cm @ Y - R) <= 1e-12 * spla.norm(Cm) * np.linalg.norm(Y)
-    assert np.abs(Y2 - 2 * Y).max() <= 1e-12 * np.abs(Y).max()
-
-
-@pytest.mark.parametrize("g", [22, 24, 26])
-def test_sparse_symmetric_factorisation_is_race_free(gpu, pkg, wl, g):
-    """Regression for a missing workgroup barrier in the diagonal-group kernel of the pivot-light path (two waves exchange L
-    entries through memory before the update of a diagonal block): the error showed on one factorisation in four at these
-    sizes, as residuals of 1e-6.  Three factorisations per size, each to full accuracy and bit-identical."""
-    A = wl.laplacian_3d(g, 19)
-    n = A.shape[0]
-    rng = np.random.default_rng(1)
-    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.17 + 0.17j) * sp.diags(rng.uniform(0.5, 1.5, n)))
-    R = np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8)))
-    sols = []
-    for rep in range(3):
-        F = pkg.lu(Cm)
-        assert F.symmetric
-        Y = np.zeros_like(R)
-        pkg.ldiv(Y, F, R)
-        pkg.finalize(F)
-        assert np.linalg.norm(Cm @ Y - R) <= 1e-13 * spla.norm(Cm) * np.linalg.norm(Y)
-        sols.append(Y)
-    assert np.array_equal(sols[0], sols[1]) and np.array_equal(sols[0], sols[2])
-
-
-def test_c3_g24_converges_with_right_count(gpu, pkg, wl):
-    w = wl.c3_sparse_generalized(24, 19, 64)
-    info = {}
-    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10,
-                                store=True, info=info)
-    assert len(lam) == w["n_inside"]
-    assert res.max() < 1e-10
-    r_true = np.linalg.norm(w["A"] @ V - (w["B"] @ V) * lam[None, :], axis=0)
-    assert r_true.max() < 1e-9
-    assert np.abs(lam.imag).max() < 1e-10      # Hermitian-definite pencil
-
-
-@pytest.mark.parametrize("shape,extra", [((48, 24, 14), 300), ((90, 70, 3), 0), ((30, 30, 30), 2000)])
-def test_irregular_trees_sparse_lu(gpu, pkg, shape, extra):
-    """Elimination trees whose levels mix fronts of very different pivot-block widths (non-cubic grids, random long-range
-    couplings): the grouped look-ahead schedule sees panel groups that end inside a front's pivot block."""
-    rng = np.random.default_rng(sum(shape) + extra)
-    def lap1(g):
-        return sp.diags([-np.ones(g - 1), 2.0 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
-    gx, gy, gz = shape
-    A = (sp.kron(sp.kron(lap1(gx), sp.identity(gy)), sp.identity(gz)) + sp.kron(sp.kron(sp.identity(gx), lap1(gy)), sp.identity(gz))
-         + sp.kron(sp.kron(sp.identity(gx), sp.identity(gy)), lap1(gz))).tocsc()
-    n = A.shape[0]
-    if extra:
-        i = rng.integers(0, n, extra)
-        j = rng.integers(0, n, extra)
-        E = sp.coo_matrix((rng.standard_normal(extra) * 0.3, (i, j)), shape=(n, n))
-        A = (A + E + 0.5 * E.T).tocsc()            # structurally symmetric, numerically not
-    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.31 + 0.23j) * sp.identity(n))
-    R = np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8)))
-    F = pkg.lu(Cm)
-    Y = np.zeros_like(R)
-    pkg.ldiv(Y, F, R)
-    pkg.finalize(F)
-    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * spla.norm(Cm) * np.linalg.norm(Y)
-    if extra == 0:          # (the host reference LU of the cases with long-range couplings takes minutes; the residual is the check)
-        ref = spla.splu(Cm).solve(np.ascontiguousarray(R))
-        assert np.abs(Y - ref).max() <= 1e-8 * np.abs(ref).max()
-
-
-def test_symmetric_pencil_takes_pivot_light_path(gpu, pkg, wl, golden):
-    """Complex symmetric T(z) = A - z B (A, B real symmetric, Im z != 0: definite imaginary part) is factorised without row
-    interchanges (stats.symmetric = 1, growth = max |l_ij| reported and small); the result is the fixture's, and equal to
-    the pivoted factorisation's (FEASTHIP_NOPIV=0) to rounding.  A numerically unsymmetric matrix with the same pattern keeps
-    partial pivoting (stats.symmetric = 0)."""
-    import os
-    w = wl.c3_sparse_generalized(12, 19, 64)
-    g = golden["c3_g12_s19"]
-    out = {}
-    for mode in ("1", "0"):
-        os.environ["FEASTHIP_NOPIV"] = mode
-        try:
-            info = {}
-            X = w["X0"].copy()
-            lam, V, res = pkg.gen_feast(X, w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), iter=w["iter"], eps=w["eps"],
-                                        store=True, info=info)
-        finally:
-            os.environ.pop("FEASTHIP_NOPIV", None)
-        out[mode] = (lam, res, info)
-        assert len(lam) == len(g["lam"]) and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
-        assert abs(info["nit"] - g["history"][-1][0]) <= 1
-    assert out["1"][2]["symmetric"] == 1 and 0.0 < out["1"][2]["growth"] < 64.0
-    assert out["0"][2]["symmetric"] == 0
-    assert match_sets(out["1"][0], out["0"][0]) < 1e-11
-    # numerically unsymmetric values on a symmetric pattern: pivoted
-    rng = np.random.default_rng(8)
-    A2 = w["A"].copy().tocsc()
-    A2.data = A2.data * rng.uniform(0.9, 1.1, A2.nnz)
-    info = {}
-    pkg.gen_feast(w["X0"].copy(), A2, w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), iter=1, eps=w["eps"], store=True, info=info)
-    assert info["symmetric"] == 0
-
-
-def test_pivot_light_path_falls_back_when_elimination_is_unsafe(gpu, pkg):
-    """Symmetric matrices for which elimination without interchanges is NOT harmless.  (i) 2 x 2 diagonal blocks
-    [[1e-14, 1], [1, 1]] coupled weakly: whichever order the dissection eliminates them in, multipliers of 1e14 appear; the
-    growth check must reject the factorisation and the handle must refactorise with partial pivoting (F.symmetric False), to
-    the usual backward error, bit-identical to a handle that never tried (FEASTHIP_NOPIV=0).  (ii) a saddle-point matrix with
-    a zero diagonal block: accurate, or reported through the LAPACK-style positive status."""
-    import os
-    rng = np.random.default_rng(3)
-    m = 40
-    blk = sp.csc_matrix(np.array([[1e-14, 1.0], [1.0, 1e-14]]))
-    T2 = sp.kron(sp.identity(m), blk) + 1e-3 * sp.kron(sp.diags([np.ones(m - 1), np.ones(m - 1)], [-1, 1]), sp.csc_matrix(np.ones((2, 2))))
-    T2 = sp.csc_matrix(T2, dtype=np.complex128)
-    assert abs(T2 - T2.T).max() == 0
-    R2 = np.asfortranarray(rng.standard_normal((2 * m, 3)) + 0j)
-    sols = {}
-    for mode in ("1", "0"):
-        os.environ["FEASTHIP_NOPIV"] = mode
-        try:
-            F = pkg.lu(T2)
-        finally:
-            os.environ.pop("FEASTHIP_NOPIV", None)
-        assert not F.symmetric
-        Y2 = np.zeros_like(R2)
-        pkg.ldiv(Y2, F, R2)
-        pkg.finalize(F)
-        sols[mode] = Y2
-        assert np.linalg.norm(T2 @ Y2 - R2) <= 1e-11 * spla.norm(T2) * np.linalg.norm(Y2)
-    assert np.array_equal(sols["1"], sols["0"])
-    # the same pattern with a definite imaginary part stays on the pivot-light path
-    T3 = sp.csc_matrix(T2 + 0.5j * sp.identity(2 * m))
-    F = pkg.lu(T3)
-    assert F.symmetric and F.growth < 8
-    Y3 = np.zeros_like(R2)
-    pkg.ldiv(Y3, F, R2)
-    pkg.finalize(F)
-    assert np.linalg.norm(T3 @ Y3 - R2) <= 1e-11 * spla.norm(T3) * np.linalg.norm(Y3)
-    nA, nB = 60, 20
-    A = sp.random(nA, nA, density=0.2, random_state=1)
-    Bm = sp.random(nB, nA, density=0.3, random_state=2)
-    Ksad = sp.bmat([[A + A.T + 4 * sp.identity(nA), Bm.T], [Bm, None]], format="csc").astype(np.complex128)
-    R = np.asfortranarray(rng.standard_normal((nA + nB, 6)) + 0j)
-    F = pkg.lu(Ksad)
-    Y = np.zeros_like(R)
-    pkg.ldiv(Y, F, R)
-    assert np.linalg.norm(Ksad @ Y - R) <= 1e-9 * spla.norm(Ksad) * np.linalg.norm(Y) or F.info > 0
-    pkg.finalize(F)
-
-
-def test_c3_full_size_g46(gpu, pkg, wl):
-    """BASELINE configs[2] at its full size (n = 97,336, 16 nodes, m0 = 64): right count, true residuals, real spectrum,
-    and the moment of the first contour step is linear in X (contour_step on 2 X == 2 contour_step on X)."""
-    w = wl.c3_sparse_generalized(46, 19, 64)
-    info = {}
-    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10,
-                                store=True, info=info)
-    assert len(lam) == w["n_inside"] == 35
-    assert info["nit"] <= 5
-    # golden eigenvalues of the same seeded pencil (tests/golden/c3_contours.json: eigsh shift-invert, make_fixtures.py --full)
-    import json, os
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_contours.json")) as fjs:
-        gold = np.sort(np.asarray(json.load(fjs)["g46_s19"]["eigs"], dtype=float))
-    assert len(gold) == 35 and np.abs(np.sort(lam.real) - gold).max() <= 1e-10
-    BV = w["B"] @ V
-    r_true = np.linalg.norm(w["A"] @ V - BV * lam[None, :], axis=0) / np.linalg.norm(BV, axis=0)
-    assert r_true.max() < 1e-9
-    assert np.abs(lam.imag).max() < 1e-10 and np.all(np.abs(lam - w["c"]) < w["r"])
-    G = V.conj().T @ BV                                  # B-orthogonality of eigenvectors of distinct eigenvalues
-    d = np.sqrt(np.abs(np.diag(G)))
-    G = G / d[:, None] / d[None, :]
-    sep = np.abs(lam[:, None] - lam[None, :]) > 1e-6 * w["r"]
-    assert np.abs(G[sep]).max() < 1e-6
-
-
-def test_c2_full_size_dense4096(gpu, pkg, wl):
-    """BASELINE configs[1] at its full size (dense generalized 4096 x 4096, 16 nodes, m0 = 64).  The contour and the
-    eigenvalues inside it come from a one-off host eigensolve of the same seeded pencil (tests/golden/c2_contour_n4096.json,
-    made by tests/golden/make_c2_fixture.py with LAPACK zggev): exact count, eigenvalues to 1e-9 (non-Hermitian pencil),
-    every returned pair a true eigenpair."""
-    import json, os
-    n, m0 = 4096, 64
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_contour_n4096.json")) as fjs:
-        gold = json.load(fjs)
-    w = wl.c2_dense_generalized(n, m0, radius=gold["r"])
-    info = {}
-    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10, store=True, info=info)
-    assert len(lam) == gold["n_inside"] == 32 and info["nit"] < 20
-    assert match_sets(lam, c2n(gold["eigs"])) <= 1e-9 and match_sets(c2n(gold["eigs"]), lam) <= 1e-9
-    assert info["symmetric"] == 0                              # complex non-symmetric: partial pivoting
-    assert np.all(np.abs(lam - w["c"]) < w["r"])
-    BV = w["B"] @ V
-    r_true = np.linalg.norm(w["A"] @ V - BV * lam[None, :], axis=0) / np.linalg.norm(BV, axis=0)
-    assert r_true.max() < 1e-8
-    # no inside eigenvalue was missed: the stochastic count estimate of the same contour agrees with the count
-    est = pkg.contour_estimate_eig(w["A"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), B=w["B"], samples=64, seed=7)
-    assert abs(est - len(lam)) <= 0.35 * len(lam) + 3
-
-
-@pytest.mark.parametrize("m0", [100, 128])
-def test_wide_blocks_sparse(gpu, pkg, wl, m0):
-    """m0 > 64: two 64-column groups per tile"""
-    A = wl.laplacian_3d(10, 19)
-    n = A.shape[0]
-    rng = np.random.default_rng(m0)
-    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.4 + 0.3j) * sp.identity(n))
-    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
-    F = pkg.lu(Cm)
-    Y = np.zeros_like(R)
-    pkg.ldiv(Y, F, R)
-    pkg.finalize(F)
-    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * spla.norm(Cm) * np.linalg.norm(Y)
-
-
-def test_sparse_store_false_and_handle_reuse(gpu, pkg, fo, wl, golden):
-    w = wl.c3_sparse_generalized(8, 19, 16)
-    g = golden["c3_g8_s19_m16"]
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
-    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=False)
-    assert len(lam) == w["n_inside"] and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
-    # one handle, two runs with different starting blocks: same eigenvalues
-    h = pkg.FeastHandle(0)
-    h.set_terms([w["A"], w["B"]], [1.0, -1.0])
-    h.set_contour(con)
-    outs = []
-    for seed in (1, 2):
-        X = wl.rand_x0(512, 16, seed)
-        lam2, res2, ins, nit, warn = h.feast_run(X, w["iter"], w["eps"], True)
-        outs.append(np.sort_complex(lam2[ins]))
-        assert res2[ins].max() < w["eps"] and warn == 0
-    h.close()
-    assert np.abs(outs[0] - outs[1]).max() < 1e-10
-
-
-def test_dense_nonhermitian_small_vs_oracle(gpu, pkg, fo, wl):
-    """general (non-Hermitian) reduced eigenproblem path, compared with the oracle run on the fly"""
-    w = wl.c2_dense_generalized(200, 24, seeds=(11, 12, 13), n_inside=10)
-    con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
-    lam_o, _, res_o = fo.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=20, eps=1e-10, store=True)
-    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-10, store=True)
-    assert len(lam) == len(lam_o) == 10
-    assert match_sets(lam, lam_o) < 1e-9 and res.max() < 1e-10
-
-
-def test_zero_diagonal_is_never_silently_wrong(gpu, pkg):
-    """Saddle-point matrix with a structurally zero diagonal block.  Pivoting is restricted to the pivot
-    block of each front (UMFPACK pivots globally): the solve must either be accurate or the factorisation
-    must report perturbed pivots through the LAPACK-style positive status."""
-    rng = np.random.default_rng(3)
-    nA, nB = 40, 12
-    A = sp.random(nA, nA, density=0.2, random_state=1) + 4 * sp.identity(nA)
-    B = sp.random(nB, nA, density=0.3, random_state=2)
-    K = sp.bmat([[A + A.T, B.T], [B, None]], format="csc").astype(np.complex128)
-    R = np.asfortranarray(rng.standard_normal((nA + nB, 5)) + 0j)
-    F = pkg.lu(K)
-    Y = np.zeros_like(R)
-    pkg.ldiv(Y, F, R)
-    accurate = np.linalg.norm(K @ Y - R) <= 1e-9 * spla.norm(K) * np.linalg.norm(Y)
-    assert accurate or F.info > 0
-    pkg.finalize(F)
-
-
-def test_distributed_driver_rccl_world1(gpu, pkg, wl, golden):
-    """distributed.py end to end on the GPU with backend nccl (= RCCL) and one rank: node sharding,
-    external moment buffer (torch tensor), all-reduce between the two halves of each iteration."""
-    import importlib, os
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as graft
-    dm = importlib.import_module(graft.PKG_NAME + ".distributed")
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29541"
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        w = wl.c3_sparse_generalized(8, 19, 16)
-        g = golden["c3_g8_s19_m16"]
-        con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
-        info = {}
-        lam, V, res = dm.gen_feast_distributed(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, device=0, info=info)
-    finally:
-        dist.destroy_process_group()
-    assert len(lam) == w["n_inside"] and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
-    assert abs(info["nit"] - g["history"][-1][0]) <= 1
-
-
-def _two_rank_worker(rank, world, port, out):
-    import os
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, root)
-    import importlib
-    import json
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as graft
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        pkg = graft.load_package()
-        dm = importlib.import_module(graft.PKG_NAME + ".distributed")
-        wl = importlib.import_module(graft.PKG_NAME + ".workloads")
-        w = wl.c3_sparse_generalized(12, 19, 64)
-        con = pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
-        info = {}
-        lam, X, res = dm.gen_feast_distributed(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, device=0, info=info)
-        out.put((rank, [[float(z.real), float(z.imag)] for z in lam], float(res.max()), int(info["nit"]), int(info["local_nodes"]),
-                 float(np.abs(X).sum())))
-    finally:
-        dist.destroy_process_group()
-
-
-def test_distributed_driver_two_ranks_share_one_gpu(gpu, golden):
-    """The multi-GPU driver with world_size 2 on real kernels: two processes (each with half of the contour nodes and
-    their factors) share this box's one GPU, the moment is summed through gloo instead of RCCL.  Both ranks must
-    return the same converged result as the single-process fixture."""
-    import os
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(out.get(timeout=600) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    g = golden["c3_g12_s19"]
-    for rank, lam, rmax, nit, local, xsum in res:
-        assert local == 8
-        assert match_sets(c2n(lam), c2n(g["lam"])) < 1e-10 and len(lam) == len(g["lam"]) and rmax < 1e-10
-        assert abs(nit - g["history"][-1][0]) <= 1
-    assert res[0][1] == res[1][1] and res[0][5] == res[1][5]          # replicated Rayleigh-Ritz: bitwise identical on both ranks
-
-
-@pytest.mark.parametrize("store", [True, False])
-def test_custom_factorizer_is_called_per_node(gpu, pkg, wl, golden, store):
-    """factorizer / left_divider kwargs are honoured (src/feast.jl:5,11,28-38,61-66,74-76): a counting factorizer sees K calls
-    with store=true (every node once, before the loop) and K per solve sweep with store=false (linsolve!, src/utils.jl:175-179),
-    the left_divider K calls per sweep with the reference's argument order, every factor is finalized, and the result is the
-    fixture's."""
-    w = wl.c3_sparse_generalized(8, 19, 16)
-    calls = {"lu": 0, "ldiv": 0, "shapes": set(), "live": []}
-
-    def counting_lu(Cm):
-        calls["lu"] += 1
-        assert sp.issparse(Cm) and Cm.dtype == np.complex128       # the caller's matrix type survives the assembly of ZmA
-        F = pkg.lu(Cm)
-        calls["live"].append(F)
-        return F
-
-    def counting_ldiv(Y, F, R):
-        calls["ldiv"] += 1
-        calls["shapes"].add((Y.shape, R.shape))
-        return pkg.ldiv(Y, F, R)
-
-    K = w["nodes"]
-    X = w["X0"].copy()
-    info = {}
-    lam, V, res = pkg.gen_feast(X, w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], K), iter=w["iter"], eps=w["eps"],
-                                store=store, factorizer=counting_lu, left_divider=counting_ldiv, info=info)
-    sweeps = info["nit"]                                              # converged at rr step nit: nit solve sweeps ran
-    assert info["plugin_seam"] and sweeps >= 1
-    assert calls["ldiv"] == K * sweeps and calls["shapes"] == {((w["A"].shape[0], 16), (w["A"].shape[0], 16))}
-    assert calls["lu"] == (K if store else K * sweeps)
-    assert all(F._h is None for F in calls["live"])                   # finalize!(F) reached every factor object
-    assert len(lam) == w["n_inside"] and res.max() < w["eps"]
-    X2 = w["X0"].copy()
-    lam2, _, _ = pkg.gen_feast(X2, w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], K), iter=w["iter"], eps=w["eps"], store=True)
-    assert match_sets(lam, lam2) < 1e-10 and np.array_equal(X, V if False else X)
-    # only one of the two overridden: still the plug-in path
-    calls["lu"] = 0
-    pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], pkg.circular_contour_trapezoidal(w["c"], w["r"], K), iter=1, eps=w["eps"], store=True,
-                  factorizer=counting_lu)
-    assert calls["lu"] == K
-
-
-def test_bench_self_launch_two_ranks(gpu):
-    """`python bench.py --gpus 2` started plainly (no torch.distributed.run, no RANK / WORLD_SIZE) starts its two ranks itself.
-    On this one-GPU box the ranks share the card and sum the moment through gloo (bench.py --backend auto); the line must say
-    n_gpus = 2, half of the nodes per rank, and the converged result of the single-process run."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--grid", "12",
-                        "--cpu-baseline", "off"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["nodes_per_gpu"] == 8 and line["config"]["backend"] == "gloo"
-    assert line["result"]["inside"] == line["result"]["expected_inside"] and line["result"]["max_res_inside"] < 1e-10
-    # and a request that cannot be met is an error, not a silent single-rank line
-    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "8",
-                         "--cpu-baseline", "off"], env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
-    assert r1.returncode != 0 and '"n_gpus"' not in r1.stdout
-
-
-def test_symbolic_analysis_cache_is_pattern_only(gpu, pkg, wl):
-    """Handles on matrices with the same pattern share the cached ordering / symbolic analysis (spectrum slicing runs many
-    contours on one pencil); the values must still be each handle's own."""
-    rng = np.random.default_rng(41)
-    A1 = wl.laplacian_3d(9, 19)
-    A2 = A1.copy()
-    A2.data = A2.data * rng.uniform(0.8, 1.2, A2.nnz)          # same pattern, different (unsymmetric) values
-    n = A1.shape[0]
-    R = np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8)))
-    infos = []
-    for A in (A1, A2, A1):
-        C = sp.csc_matrix(A.astype(np.complex128) - (0.31 + 0.2j) * sp.identity(n))
-        F = pkg.lu(C)
-        Y = np.zeros((n, 8), dtype=np.complex128, order="F")
-        pkg.ldiv(Y, F, R)
-        pkg.finalize(F)
-        assert np.linalg.norm(C @ Y - R) <= 1e-11 * np.linalg.norm(C.toarray()) * np.linalg.norm(Y)
-        infos.append(Y)
-    assert np.array_equal(infos[0], infos[2]) and not np.allclose(infos[0], infos[1])
-
-
-def test_caller_owned_stream(gpu, pkg, wl, golden):
-    """feasthip_set_stream: the whole loop on a torch-owned HIP stream gives the fixture result, and work queued on that
-    stream afterwards is ordered behind the library's launches."""
-    import torch
-    w = wl.c3_sparse_generalized(8, 19, 16)
-    st = torch.cuda.Stream()
-    h = pkg.FeastHandle(0)
-    try:
-        h.set_terms([w["A"], w["B"]], [1.0, -1.0])
-        h.set_contour(pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"]))
-        h.set_stream(st.cuda_stream)
-        X = w["X0"].copy()
-        lam, res, ins, nit, warn = h.feast_run(X, w["iter"], w["eps"], True)
-        with torch.cuda.stream(st):
-            marker = torch.ones(4, device="cuda") * 3.0
-        st.synchronize()
-        assert float(marker.sum()) == 12.0
-    finally:
-        h.close()
-    g = golden["c3_g8_s19_m16"]
-    assert match_sets(lam[ins], c2n(g["lam"])) < 1e-10 and ins.sum() == len(g["lam"]) and res[ins].max() < w["eps"]
-
-
-def test_bitwise_reproducible_and_stream_independent(gpu, pkg, wl):
-    """Every reduction has a fixed order (no float atomics): the moment Q is bit-identical from run to run,
-    and does not depend on how the contour nodes are spread over HIP streams."""
-    import os
-    w = wl.c3_sparse_generalized(12, 19, 64)
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
-    outs = []
-    for streams in ("2", "2", "1", "4"):
-        os.environ["FEASTHIP_STREAMS"] = streams
-        h = pkg.FeastHandle(0)
-        h.set_terms([w["A"], w["B"]], [1.0, -1.0])
-        h.set_contour(con)
-        h.factorize()
-        h.set_x(w["X0"])
-        h.rr_step()
-        h.contour_step()
-        outs.append(h.get_block(2).copy())
-        h.close()
-    os.environ.pop("FEASTHIP_STREAMS", None)
-    for q in outs[1:]:
-        assert np.array_equal(q, outs[0])
-
-
-def test_node_shards_sum_to_full_moment(gpu, pkg, wl):
-    """two handles owning the even / odd nodes (the 2-GPU layout): their partial moments add up to the
-    single-handle moment -- the quantity the RCCL all-reduce sums"""
-    w = wl.c3_sparse_generalized(8, 19, 16)
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
-
-    def moment(first, stride):
-        h = pkg.FeastHandle(0)
-        h.set_terms([w["A"], w["B"]], [1.0, -1.0])
-        h.set_contour(con)
-        h.set_node_shard(first, stride)
-        h.factorize()
-        h.set_x(w["X0"])
-        h.rr_step()
-        h.contour_step()
-        q = h.get_block(2).copy()
-        h.close()
-        return q
-
-    full, even, odd = moment(0, 1), moment(0, 2), moment(1, 2)
-    assert np.abs(even + odd - full).max() <= 1e-13 * np.abs(full).max()
-
-
-@pytest.mark.parametrize("mixed", [False, True])
-def test_forward_splitk_matches_unsplit(gpu, pkg, wl, mixed):
-    """With one factorisation unit per GPU (the 8-GPU shard) the long L21 products at the top of the tree are split along K
-    (FEASTHIP_FWD_SPLITK=1; off by default, it measured slower: slabs + a fixed-order reduction that also pulls the children's rows).  The moment of
-    the shard must agree with the unsplit schedule to rounding -- complex128 and the complex64 sweeps of mixed_prec."""
-    import os
-    w = wl.c3_sparse_generalized(24, 19, 64)
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
-    out = {}
-    for mode in ("1", "0"):
-        os.environ["FEASTHIP_FWD_SPLITK"] = mode
-        try:
-            h = pkg.FeastHandle(0)
-        finally:
-            os.environ.pop("FEASTHIP_FWD_SPLITK", None)
-        try:
-            h.set_terms([w["A"], w["B"]], [1.0, -1.0])
-            h.set_contour(con)
-            h.set_node_shard(0, 8)
-            if mixed:
-                h.set_precision(True)
-            h.factorize()
-            h.set_x(w["X0"])
-            h.rr_step()
-            h.contour_step()
-            out[mode] = (h.get_block(2).copy(), h.profile_solve()["fwd_assemble"]["launches"])
-        finally:
-            h.close()
-    q1, q0 = out["1"][0], out["0"][0]
-    assert out["1"][1] > out["0"][1]                      # the split schedule ran its reduction launches (counted with the assembly)
-    assert np.isfinite(q1).all() and np.abs(q1 - q0).max() <= (1e-5 if mixed else 1e-12) * np.abs(q0).max()
-
-
-def _moment(pkg, w, con, fold, shard=(0, 1), nl=False):
-    h = pkg.FeastHandle(0)
-    h.set_terms([w["A"], w["B"]], [1.0, -1.0])
-    h.set_contour(con)
-    h.set_conjugate_fold(fold)
-    h.set_node_shard(*shard)
-    h.factorize()
-    h.set_x(w["X0"])
-    h.rr_step()
-    h.contour_step()
-    q = h.get_block(2).copy()
-    st = h.stats()
-    h.close()
-    return q, st
-
-
-def test_conjugate_fold_matches_one_factorisation_per_node(gpu, pkg, wl):
-    """Real pencil + mirror-symmetric contour: a conjugate node pair shares one factorisation, the mirror system rides along
-    as m0 more right-hand-side columns conj(R).  The moment must equal the one from 16 separate factorisations to rounding,
-    with half the factorisations; shards deal out pairs and still add up to the full moment."""
-    w = wl.c3_sparse_generalized(12, 19, 64)
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
-    q1, s1 = _moment(pkg, w, con, True)
-    q0, s0 = _moment(pkg, w, con, False)
-    assert s1["folded"] == 1 and s1["factor_units"] == 8 and s1["local_nodes"] == 16
-    assert s0["folded"] == 0 and s0["factor_units"] == 16 and s0["local_nodes"] == 16
-    assert s1["solve_bytes"] == s0["solve_bytes"] and s1["solve_bytes_streamed"] < 0.9 * s0["solve_bytes_streamed"]
-    assert np.abs(q1 - q0).max() <= 1e-12 * np.abs(q0).max()
-    parts = [_moment(pkg, w, con, True, (r, 4)) for r in range(4)]
-    assert all(p[1]["factor_units"] == 2 and p[1]["local_nodes"] == 4 for p in parts)
-    assert np.abs(sum(p[0] for p in parts) - q1).max() <= 1e-13 * np.abs(q1).max()
-    # more ranks than pairs: every rank falls back to single nodes, consistently
-    parts = [_moment(pkg, w, con, True, (r, 16)) for r in (0, 5, 15)]
-    assert all(p[1]["folded"] == 0 and p[1]["local_nodes"] == 1 for p in parts)
-
-
-def test_conjugate_fold_only_where_it_is_exact(gpu, pkg, wl):
-    """No fold for complex matrices, for a contour that is not mirror-symmetric, or with a node on the real axis."""
-    w = wl.c3_sparse_generalized(8, 19, 16)
-    A, B = w["A"], w["B"]
-
-    def folded(A_, B_, con):
-        h = pkg.FeastHandle(0)
-        h.set_terms([A_, B_], [1.0, -1.0])
-        h.set_contour(con)
-        f = h.stats()["folded"]
-        h.close()
-        return f
-
-    assert folded(A, B, pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)) == 1
-    assert folded(A.astype(np.complex128) * (1.0 + 0.0j) + 1e-3j * B, B, pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)) == 0
-    assert folded(A, B, pkg.circular_contour_trapezoidal(w["c"] + 0.01j, w["r"], 16)) == 0
-    import copy
-    con2 = copy.copy(pkg.circular_contour_trapezoidal(w["c"], w["r"], 16))
-    con2.nodes = con2.nodes.copy()
-    con2.nodes[0], con2.nodes[-1] = con2.nodes[0].real, con2.nodes[-1].real        # two nodes on the real axis: their own mirror images
-    assert folded(A, B, con2) == 0
-
-
-@pytest.mark.parametrize("fold", [True, False])
-def test_c3_sparse_g12_fold_switch(gpu, pkg, wl, golden, fold):
-    """the whole gen_feast loop with and without the conjugate fold against the same oracle fixture"""
-    w = wl.c3_sparse_generalized(12, 19, 64)
-    g = golden["c3_g12_s19"]
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
-    info = {}
-    lam, X, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, info=info, conjugate_fold=fold)
-    assert info["folded"] == (1 if fold else 0)
-    assert len(lam) == len(g["lam"]) and match_sets(lam, c2n(g["lam"])) < 1e-10 and res.max() < w["eps"]
-    assert abs(info["nit"] - g["history"][-1][0]) <= 1
-
-
-@pytest.mark.parametrize("m0,fold,mixed", [(64, True, False), (64, False, False), (24, True, False), (100, False, False),
-                                           (64, True, True), (40, False, True), (24, True, True)])
-def test_apply_kernels_bit_identical(gpu, pkg, wl, m0, fold, mixed):
-    """k_apply2 (operands streamed from global memory, no LDS, no barriers) and k_apply (LDS-staged) run the same tiles in the
-    same summation order: the moment Q must be bit-identical (all tile kinds, row-tile heights, masks, split-K, gathers).
-    mixed: the complex64 instance of k_apply2 (paired 16-byte lanes) against k_apply32."""
-    w = wl.c3_sparse_generalized(14, 19, m0)
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
-    lib = pkg.load_library()
-    outs = []
-    try:
-        for sel in (1, 0):
-            lib.feasthip_select_apply_kernel(sel)
-            h = pkg.FeastHandle(0)
-            h.set_terms([w["A"], w["B"]], [1.0, -1.0])
-            h.set_contour(con)
-            h.set_conjugate_fold(fold)
-            if mixed:
-                h.set_precision(1)
-            h.factorize()
-            h.set_x(w["X0"])
-            h.rr_step()
-            h.contour_step()
-            outs.append(h.get_block(2).copy())
-            h.close()
-    finally:
-        lib.feasthip_select_apply_kernel(1)
-    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
-    assert np.array_equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize("kind", ["circular", "rect_trap", "rect_gauss"])
 def test_conjugate_fold_on_the_reference_contours(gpu, pkg, wl, kind):
     """The three contour constructors of test/runtests.jl:33-49 on a real matrix: where the nodes come in mirror pairs the fold
     halves the factorisations, and the moment equals the unfolded one either way."""
@@ -2100,12 +1166,9 @@ def test_conjugate_fold_nlfeast_polynomial(gpu, pkg, fo, wl):
     X0 = wl.rand_x0(n, m0, 77)
     outs = []
     for fold in (True, False):
-        os.environ["FEASTHIP_FOLD"] = "1" if fold else "0"
-        try:
+        with env_override(FEASTHIP_FOLD="1" if fold else "0"):
             info = {}
             lam, X, res = pkg.nlfeast(pkg.PolynomialNEP(Ms), X0.copy(), 16, 2, c=-1.55, r=0.05, eps=1e-14, info=info)
-        finally:
-            os.environ.pop("FEASTHIP_FOLD", None)
         assert info["folded"] == (1 if fold else 0) and info["factor_units"] == (8 if fold else 16)
         outs.append((lam.copy(), res.copy()))
     # the same iteration either way: after three sweeps the Ritz values inside the contour and their residuals agree
@@ -2127,6 +1190,7 @@ def test_conjugate_fold_nlfeast_rii_step_against_oracle(gpu, pkg, fo, wl):
     h = pkg.FeastHandle(0)
     h.set_terms(coeffs)
     h.set_contour(con)
+    h.set_conjugate_fold(True)             # (the suite also runs with FEASTHIP_FOLD=0 as the initial state)
     assert h.stats()["folded"] == 1
     h.set_x(X0)
     h.nl_orthonormalize_x()
