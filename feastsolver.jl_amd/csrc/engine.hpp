@@ -271,7 +271,7 @@ private:
     int reserve_cus_ = 2;
     std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join, [6] rest stream join
     bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true, fuse_extend_ = true;
-    int fuse_min_p_ = 128;            // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself
+    int fuse_min_p_ = 1;              // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself (round 3: every level; 128 before, A/B 84.5 -> 82.7 ms)
     int group_panels_ = 4;            // panels per deferred trailing update in the look-ahead factorisation
     bool fwd_splitk_ = false;         // FEASTHIP_FWD_SPLITK=1: split the long forward L21 products along K when few nodes are left on this GPU.
                                       // Measured at one unit per GPU (C3): the split launches gain 10-40 us each, their reductions cost 50-80 us:

@@ -183,7 +183,9 @@ int Engine::contour_step_begin(int refactor, int nchunks) {
     if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; warn = r; }
     std::vector<zc> e0 = node_table([&](int k, int j, int) { return weights_[k] / (nodes_[k] - lambda_[j]); });      // src/feast.jl:60,69
     HIPCHK(h2d_async(5, d_e0_.p, e0.data(), e0.size() * sizeof(zc)));
-    HIPCHK(hipStreamSynchronize(stream_));
+    // the table sits in pinned slot 5, which nothing else uses and which is rewritten only after the synchronisations of the next
+    // Rayleigh-Ritz step: no host wait here (one wake-up of the host thread less per iteration); without a slot the copy reads e0 itself
+    if (!pin_slot(5, e0.size() * sizeof(zc))) HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66
     if (r) return r;

@@ -1091,6 +1091,53 @@ def test_conjugate_fold_only_where_it_is_exact(gpu, pkg, wl):
     assert folded(A, B, con2) == 0
 
 
+def test_override_after_analyze_invalidates_and_recovers(gpu, pkg, wl):
+    """Per-node coefficient overrides switch the conjugate fold off (include/feasthip.h: call order).  Installed AFTER analyze /
+    set_x on a folded handle they invalidate the analysis and the iteration state: the phase calls fail with FEASTHIP_ESTATE
+    instead of running on stale units, factorize re-analyses by itself, and after set_x the handle gives exactly what a
+    handle that had the overrides from the start gives."""
+    import importlib
+    import __graft_entry__ as graft
+    _lib = importlib.import_module(graft.PKG_NAME + "._lib")
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    z = np.asarray(con.nodes)
+    table = np.stack([np.ones(8), z], axis=1)                 # row k = (1, z_k): the same pencil, spelled as per-node coefficients
+
+    def run(late):
+        h = pkg.FeastHandle(0)
+        try:
+            h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+            h.set_contour(con)
+            if not late:
+                h.set_node_coefficients(table)
+            h.analyze()
+            h.set_x(w["X0"])
+            if late:
+                assert h.stats()["folded"] == (1 if os.environ.get("FEASTHIP_FOLD", "1") != "0" else 0)
+                h.rr_step()
+                h.set_node_coefficients(table)
+                assert h.stats()["folded"] == 0
+                if os.environ.get("FEASTHIP_FOLD", "1") != "0":
+                    with pytest.raises(_lib.FeastHipError) as ei:
+                        h.contour_step()
+                    assert ei.value.code == -4                    # FEASTHIP_ESTATE
+                h.factorize()                                      # re-analyses by itself
+                h.set_x(w["X0"])
+            else:
+                h.factorize()
+            h.rr_step()
+            h.contour_step()
+            return h.get_block(2).copy(), h.stats()["factor_units"]
+        finally:
+            h.close()
+
+    import os
+    (q_late, u_late), (q_first, u_first) = run(True), run(False)
+    assert u_late == u_first == 8
+    assert np.array_equal(q_late, q_first)
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_c3_sparse_g12_fold_switch(gpu, pkg, wl, golden, fold):
     """the whole gen_feast loop with and without the conjugate fold against the same oracle fixture"""
