@@ -770,7 +770,7 @@ int Engine::analyze() {
         mix((uint64_t)opt.leaf_size); mix((uint64_t)opt.relax_small); mix((uint64_t)opt.relax_mid); mix((uint64_t)(opt.zmid * 1e6)); mix((uint64_t)(opt.zbig * 1e6)); mix((uint64_t)opt.ordering);
         // CSR copies of the terms for SpMM (a transpose of the caller's CSC arrays) do not depend on the ordering: one host thread
         // per term builds them while the nested dissection leaves most cores idle at its top levels
-        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0; };
+        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, diag = 0; };
         std::vector<TermHost> th(terms_.size());
         std::vector<std::thread> csr_pool;
         // The helper threads overwrite device buffers a previous analysis of this handle may still be using (DevBuf::alloc keeps a
@@ -802,6 +802,12 @@ int Engine::analyze() {
                     for (int j = 0; j <= n && eq; ++j) eq = H.rp[j] == T.colptr[j];
                     for (int64_t e2 = 0; e2 < nnz && eq; ++e2) eq = H.col[e2] == T.rowval[e2] && H.v[e2] == T.val[e2];
                     H.sym = eq ? 1 : 0;
+                }
+                {   // entries on the diagonal only: the Rayleigh-Ritz step then scales rows instead of running SpMM products
+                    bool dg = !dense;
+                    for (int j = 0; j < n && dg; ++j)
+                        for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) if (T.rowval[e2] != j) { dg = false; break; }
+                    H.diag = dg ? 1 : 0;
                 }
                 // ... and uploads them (and the CSC values the factorisation scatters) from this thread, on its own stream
                 SparseTerm& Tw = terms_[ti];
@@ -857,6 +863,15 @@ int Engine::analyze() {
         for (auto& t2 : csr_pool) t2.join();
         terms_symmetric_ = true;
         for (TermHost& H : th) if (!H.sym) terms_symmetric_ = false;
+        for (size_t ti = 0; ti < terms_.size(); ++ti) {
+            SparseTerm& T = terms_[ti];
+            T.diagonal = th[ti].diag != 0;
+            if (T.diagonal) {
+                std::vector<zc> dg(n, zc(0.0));
+                for (int j = 0; j < n; ++j) for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) dg[j] += T.val[e2];
+                if (!T.d_diag.upload((const cz*)dg.data(), n, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+            }
+        }
         for (TermHost& H : th) if (H.bad_dest) H.bad = 1;
         for (size_t ti = 0; ti < terms_.size(); ++ti) {
             SparseTerm& T = terms_[ti];

@@ -68,6 +68,8 @@ struct SparseTerm {
     DevBuf<int64_t> d_dest;     // arena destination of each CSC entry
     DevBuf<cz> d_cscval;
     DevBuf<cz> d_dense;         // dense column-major copy (dense path)
+    bool diagonal = false;      // sparse term with entries on the diagonal only (a lumped mass matrix, Diagonal(...) in the reference's tests)
+    DevBuf<cz> d_diag;          // ... its diagonal (n entries, zeros where no entry is stored)
 };
 
 struct ProfileRow { double ms = 0, bytes = 0, flops = 0; int launches = 0; };

@@ -218,7 +218,13 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     launch_gram(stream_, n, m, ldw, Qp(), d_R_.p, d_gram_scratch_.p, dA);   // Aq = Q' R   :43
     HIPCHK(hipEventRecord(ev_p1_, stream_));
     void *landA = nullptr, *landB = nullptr;
-    if (!b_is_identity) {
+    // B = -scale_1 M_1 with M_1 diagonal (lumped mass matrix; Diagonal(...) in test/runtests.jl:21): Bq = Q' diag(b) Q straight from
+    // the Gram kernel and B X = diag(b) X inside the residual kernel -- two SpMM passes over n x m0 blocks less per iteration
+    const bool b_diag = !b_is_identity && !dense && terms_[1].diagonal && terms_[1].scale == zc(-1.0);
+    if (b_diag) {
+        launch_gram(stream_, n, m, ldw, Qp(), Qp(), d_gram_scratch_.p, dB, terms_[1].d_diag.p);      // Bq    :121
+        HIPCHK(d2h_async(2, Bq.data(), dB, (size_t)m * m * sizeof(zc), &landB));
+    } else if (!b_is_identity) {
         apply_term(1, Qp(), d_T1_.p, -1.0, false);                      // R = B Q          :120
         launch_gram(stream_, n, m, ldw, Qp(), d_T1_.p, d_gram_scratch_.p, dB);   // Bq    :121
         HIPCHK(d2h_async(2, Bq.data(), dB, (size_t)m * m * sizeof(zc), &landB));
@@ -266,8 +272,8 @@ int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
         // A X = (A Q) Xq: one tall-skinny GEMM on the product the projection already formed instead of a second
         // SpMM with A (the gather of 19 block-vector rows per row costs twice as much); B X is a cheap SpMM
         launch_ts_gemm(stream_, n, m, ldw, d_R_.p, dM, d_T1_.p);        // A X
-        if (!b_is_identity) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
-        launch_residual_combine(stream_, n, ldw, d_T1_.p, BX, d_lam_.p, d_R_.p);
+        if (!b_is_identity && !b_diag) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
+        launch_residual_combine(stream_, n, ldw, d_T1_.p, BX, d_lam_.p, d_R_.p, b_diag ? terms_[1].d_diag.p : nullptr);
     }
     r = col_norms(d_R_.p, nr);                                           // residuals! :166-171
     if (r) return r;

@@ -143,7 +143,8 @@ int dense_mv_parts(int n, int ldw);
 void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate, cz* part = nullptr);
 // G(m x m, column-major, ld m) = V^H W  (row-major n x ldw blocks); scratch >= gram_scratch_elems()
 size_t gram_scratch_elems(int n, int m);
-void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G);
+// rowscale (n entries, optional): G = V^H diag(rowscale) W -- the projection with a diagonal B without forming B W
+void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G, const cz* rowscale = nullptr);
 // out = V * M  (M m x m column-major on device)
 void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* M, cz* out);
 // nrm2[j] = sum_i |V[i,j]|^2 ; scratch >= colnorm_scratch_elems()
@@ -152,8 +153,8 @@ void launch_colnorm2(hipStream_t st, int n, int ldw, const cz* V, double* scratc
 void launch_scale_cols(hipStream_t st, int n, int ldw, cz* V, const cz* s);
 // out = alpha*V (+ out)
 void launch_axpby(hipStream_t st, int n, int ldw, cz* out, cz alpha, const cz* V, int accumulate);
-// R = AX - BX .* lam[j]
-void launch_residual_combine(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* R);
+// R = AX - BX .* lam[j]   (rowscale: BX = diag(rowscale) * the block passed as BX)
+void launch_residual_combine(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* R, const cz* rowscale = nullptr);
 // R = sum_t MX[t] .* lam[j]^t   (polynomial NEP residual; MX blocks contiguous with stride blk)
 void launch_poly_combine(hipStream_t st, int n, int ldw, const cz* MX, int64_t blk, int nterms, const cz* lam, cz* R);
 // block-Hankel matrix of contour moments: H (mm n x ldh, row-major), block (i, j) = Q_{i+j+shift}

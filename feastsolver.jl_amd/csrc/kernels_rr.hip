@@ -139,7 +139,7 @@ size_t gram_scratch_elems(int n, int m) {
 }
 
 __global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, const cz* __restrict__ V, const cz* __restrict__ W,
-                                                       cz* scratch) {
+                                                       cz* scratch, const cz* __restrict__ rowscale) {
     int chunk = blockIdx.x;
     int r0 = chunk * GRAM_ROWS, r1 = min(n, r0 + GRAM_ROWS);
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, co
             for (int h = 0; h < 2; ++h) {
                 int row = min(r + 4 * h + lk, n - 1);
                 aa[h] = V[(int64_t)row * ldw + it * 16 + li];
+                if (rowscale) aa[h] = cz_mul(aa[h], cz_conj(rowscale[row]));       // G = V^H diag(d) W: conj(v d~) w with d~ = conj(d)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) bb[h][nt] = W[(int64_t)row * ldw + colb[nt]];
             }
@@ -220,10 +221,10 @@ __global__ __launch_bounds__(256) void k_gram_reduce(int nchunks, int mp, int m,
     }
 }
 
-void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G) {
+void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G, const cz* rowscale) {
     int chunks = (n + GRAM_ROWS - 1) / GRAM_ROWS;
     int mp = ((m + 15) / 16) * 16;    // ldw >= mp by construction
-    hipLaunchKernelGGL(k_gram_partial, dim3(chunks), dim3(256), 0, st, n, mp, ldw, V, W, scratch);
+    hipLaunchKernelGGL(k_gram_partial, dim3(chunks), dim3(256), 0, st, n, mp, ldw, V, W, scratch, rowscale);
     hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 63) / 64), dim3(256), 0, st, chunks, mp, m, scratch, G);
 }
 
@@ -387,17 +388,19 @@ void launch_axpby(hipStream_t st, int n, int ldw, cz* out, cz alpha, const cz* V
 }
 
 __global__ void k_residual_combine(int64_t total, int ldw, const cz* __restrict__ AX, const cz* __restrict__ BX,
-                                   const cz* __restrict__ lam, cz* R) {
+                                   const cz* __restrict__ lam, cz* R, const cz* __restrict__ rowscale) {
     int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= total) return;
     cz r = AX[e];
-    cz_msub(r, BX[e], lam[e % ldw]);
+    cz bx = BX[e];
+    if (rowscale) bx = cz_mul(bx, rowscale[e / ldw]);          // BX is X itself, B = diag(rowscale)
+    cz_msub(r, bx, lam[e % ldw]);
     R[e] = r;
 }
 
-void launch_residual_combine(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* R) {
+void launch_residual_combine(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* R, const cz* rowscale) {
     int64_t total = (int64_t)n * ldw;
-    hipLaunchKernelGGL(k_residual_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, ldw, AX, BX, lam, R);
+    hipLaunchKernelGGL(k_residual_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, ldw, AX, BX, lam, R, rowscale);
 }
 
 __global__ void k_poly_combine(int64_t total, int ldw, const cz* __restrict__ MX, int64_t blk, int nterms,
