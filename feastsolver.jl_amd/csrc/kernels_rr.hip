@@ -125,12 +125,16 @@ void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, c
     }
 }
 
-// Tall-skinny projection G = V^H W on the f64 matrix cores.  Stage 1: each
-// workgroup reduces GRAM_ROWS rows; wave jobs are (16-row i tile) x (64-col j group),
-// operands are read straight from the row-major blocks (16 consecutive columns of a
-// row per lane group = 256 B segments), two k-steps (8 rows, ten 16-byte loads per lane)
-// in flight per iteration.  Stage 2 sums the partials in a fixed order.
-constexpr int GRAM_ROWS = 128;
+// Tall-skinny projection G = V^H W on the f64 matrix cores.  Stage 1: a workgroup reduces a contiguous range of rows (about
+// n / 512: two workgroups per CU, each with its accumulators in registers for the whole range, so a partial block is written
+// once per workgroup and not once per 128 rows); wave jobs are (16-row i tile) x (64-col j group), operands are read straight
+// from the row-major blocks (16 consecutive columns of a row per lane group = 256 B segments) through a ring of GRAM_ST
+// stages of one k-step (4 rows, five 16-byte loads per lane): GRAM_ST - 1 stages are in flight while one runs on the matrix
+// cores.  Stage 2 sums the partials in a fixed order.
+// (Round 2: 128 rows per workgroup, one stage in flight, the row scaling multiplied into the operand right behind its load:
+// 82 + 17 us for n = 97,336, m = 64, i.e. 31 TFLOP/s.)
+constexpr int GRAM_ROWS = 128;      // smallest row range of a workgroup; gram_scratch_elems() is sized for it
+constexpr int GRAM_ST = 5;
 
 size_t gram_scratch_elems(int n, int m) {
     size_t chunks = ((size_t)n + GRAM_ROWS - 1) / GRAM_ROWS;
@@ -138,52 +142,59 @@ size_t gram_scratch_elems(int n, int m) {
     return chunks * mp * mp;
 }
 
-__global__ __launch_bounds__(256) void k_gram_partial(int n, int mp, int ldw, const cz* __restrict__ V, const cz* __restrict__ W,
-                                                       cz* scratch, const cz* __restrict__ rowscale) {
-    int chunk = blockIdx.x;
-    int r0 = chunk * GRAM_ROWS, r1 = min(n, r0 + GRAM_ROWS);
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    int nit = mp / 16, njg = (mp + 63) / 64;
+static int gram_rows_per_wg(int n) {
+    int r = (n + 511) / 512;
+    r = (r + 3) / 4 * 4;
+    return r < GRAM_ROWS ? GRAM_ROWS : r;
+}
+
+template <bool SCALE>
+__global__ __launch_bounds__(256, 2) void k_gram_partial(int n, int mp, int ldw, const cz* __restrict__ V, const cz* __restrict__ W,
+                                                          cz* scratch, const cz* __restrict__ rowscale, int rows_per_wg) {
+    constexpr int ST = SCALE ? GRAM_ST - 1 : GRAM_ST;      // (the scale factors of a stage cost four registers more)
+    const int chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_wg, r1 = min(n, r0 + rows_per_wg);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int nit = mp / 16, njg = (mp + 63) / 64;
     cz* out = scratch + (size_t)chunk * mp * mp;
     for (int job = wave; job < nit * njg; job += 4) {
-        int it = job / njg, jg = job % njg;
+        const int it = job / njg, jg = job % njg;
         d4 t1[4], t2[4], t3[4];          // 3M product of conj(a) * b
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
         int colb[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) colb[nt] = min(jg * 64 + nt * 16 + li, mp - 1);      // clamped: the extra columns are not stored
-        // software pipelined: the 8 rows of the next step are in flight while this step runs on the matrix cores
-        cz a[2], b[2][4], an[2], bn[2][4];
-        auto load8 = [&](int r, cz (&aa)[2], cz (&bb)[2][4]) {
+        cz a[ST], b[ST][4], sc[SCALE ? ST : 1];
+        auto load4 = [&](int r, cz& aa, cz (&bb)[4], cz& ss) {
+            const int64_t row = min(r + lk, r1 - 1);
+            aa = V[row * ldw + it * 16 + li];
+            if constexpr (SCALE) ss = rowscale[row];       // G = V^H diag(d) W: applied when the stage is consumed, not behind the load
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int row = min(r + 4 * h + lk, n - 1);
-                aa[h] = V[(int64_t)row * ldw + it * 16 + li];
-                if (rowscale) aa[h] = cz_mul(aa[h], cz_conj(rowscale[row]));       // G = V^H diag(d) W: conj(v d~) w with d~ = conj(d)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) bb[h][nt] = W[(int64_t)row * ldw + colb[nt]];
-            }
+            for (int nt = 0; nt < 4; ++nt) bb[nt] = W[row * ldw + colb[nt]];
         };
-        load8(r0, a, b);
-        for (int r = r0; r < r1; r += 8) {
-            load8(min(r + 8, r1 - 1), an, bn);
+        auto mac4 = [&](int r, const cz& aa, const cz (&bb)[4], const cz& ss) {
+            const bool ok = r + lk < r1;
+            cz av = aa;
+            if constexpr (SCALE) av = cz_mul(av, cz_conj(ss));                              // conj(v d~) w with d~ = conj(d)
+            const double ar = ok ? av.x : 0.0, ai = ok ? -av.y : 0.0, as = ar + ai;         // conj(V)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bool ok = r + 4 * h + lk < r1;
-                double ar = ok ? a[h].x : 0.0, ai = ok ? -a[h].y : 0.0, as = ar + ai;     // conj(V)
+            for (int nt = 0; nt < 4; ++nt) t1[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bb[nt].x, t1[nt], 0, 0, 0);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    t1[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b[h][nt].x, t1[nt], 0, 0, 0);
-                    t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b[h][nt].y, t2[nt], 0, 0, 0);
-                    t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, b[h][nt].x + b[h][nt].y, t3[nt], 0, 0, 0);
-                }
-            }
+            for (int nt = 0; nt < 4; ++nt) t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bb[nt].y, t2[nt], 0, 0, 0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                a[h] = an[h];
+            for (int nt = 0; nt < 4; ++nt) t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bb[nt].x + bb[nt].y, t3[nt], 0, 0, 0);
+        };
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) b[h][nt] = bn[h][nt];
+        for (int s = 0; s < ST - 1; ++s) load4(r0 + 4 * s, a[s], b[s], sc[SCALE ? s : 0]);
+        for (int r = r0; r < r1; r += 4 * ST) {
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                constexpr int NX = ST - 1;
+                __builtin_amdgcn_sched_barrier(0);
+                load4(r + 4 * (s + NX), a[(s + NX) % ST], b[(s + NX) % ST], sc[SCALE ? (s + NX) % ST : 0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mac4(r + 4 * s, a[s], b[s], sc[SCALE ? s : 0]);
             }
         }
 #pragma unroll
@@ -222,9 +233,11 @@ __global__ __launch_bounds__(256) void k_gram_reduce(int nchunks, int mp, int m,
 }
 
 void launch_gram(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* W, cz* scratch, cz* G, const cz* rowscale) {
-    int chunks = (n + GRAM_ROWS - 1) / GRAM_ROWS;
+    const int rpw = gram_rows_per_wg(n);
+    int chunks = (n + rpw - 1) / rpw;
     int mp = ((m + 15) / 16) * 16;    // ldw >= mp by construction
-    hipLaunchKernelGGL(k_gram_partial, dim3(chunks), dim3(256), 0, st, n, mp, ldw, V, W, scratch, rowscale);
+    if (rowscale) hipLaunchKernelGGL(k_gram_partial<true>, dim3(chunks), dim3(256), 0, st, n, mp, ldw, V, W, scratch, rowscale, rpw);
+    else hipLaunchKernelGGL(k_gram_partial<false>, dim3(chunks), dim3(256), 0, st, n, mp, ldw, V, W, scratch, rowscale, rpw);
     hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 63) / 64), dim3(256), 0, st, chunks, mp, m, scratch, G);
 }
 
@@ -239,14 +252,17 @@ template <int KS>     // k-steps per pass (m rounded up to 4 KS, at most TS_KMAX
 __device__ __forceinline__ void ts_tile_loop(int n, int m, int ldw, const cz* __restrict__ V, cz* out, const cz (*Ms)[64], int kc, int klen,
                                              int cg, bool accumulate, int tile0, int tstride, int ntiles) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    // the V fragment of a k-step is reloaded for the NEXT tile as soon as this tile's products with it are issued: the whole next tile
+    // is in flight while this one runs on the matrix cores and writes its rows, in the same registers
+    cz av[KS];
+    {
+        const int64_t arow = min(tile0 * 64 + wave * 16 + li, n - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[ks] = V[arow * ldw + min(kc + ks * 4 + lk, ldw - 1)];
+    }
     for (int tile = tile0; tile < ntiles; tile += tstride) {
         asm volatile("" ::: "memory");     // M is the same for every tile: without this the compiler hoists all of its LDS reads (256 registers)
-        cz av[KS];
-        {
-            const int64_t arow = min(tile * 64 + wave * 16 + li, n - 1);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) av[ks] = V[arow * ldw + min(kc + ks * 4 + lk, ldw - 1)];
-        }
+        const cz* vnext = V + (int64_t)min(min(tile + tstride, ntiles - 1) * 64 + wave * 16 + li, n - 1) * ldw;
         d4 t1[4], t2[4], t3[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) { t1[nt] = (d4){0, 0, 0, 0}; t2[nt] = (d4){0, 0, 0, 0}; t3[nt] = (d4){0, 0, 0, 0}; }
@@ -261,6 +277,9 @@ __device__ __forceinline__ void ts_tile_loop(int n, int m, int ldw, const cz* __
                 t2[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bv.y, t2[nt], 0, 0, 0);
                 t3[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bv.x + bv.y, t3[nt], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            av[ks] = vnext[min(kc + ks * 4 + lk, ldw - 1)];
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int r0 = tile * 64 + wave * 16;
 #pragma unroll
