@@ -23,7 +23,8 @@ except Exception:  # pragma: no cover
 from . import _lib
 from .contour import CircularContour, circular_contour_trapezoidal
 
-F64, C128, I64T = 0, 1, 2
+F64, C128, I64T, C64T = 0, 1, 2, 3
+ROW_MAJOR = 0x100       # feasthip.h: FEASTHIP_ROW_MAJOR (dense matrices in C order)
 
 
 def _issparse(M):
@@ -35,17 +36,27 @@ def _vp(a):
 
 
 def _dense_arg(M):
-    """-> (array kept alive, type tag) column-major."""
+    """-> (array kept alive, type tag).  The bytes are handed over in the order they are stored in (C-ordered arrays with the
+    row-major flag: element type and storage order are converted on the device); only an unsupported dtype or a strided view
+    costs a host copy."""
     M = np.asarray(M)
     if M.dtype == np.complex128:
-        return np.asfortranarray(M), C128
-    if M.dtype == np.float64:
-        return np.asfortranarray(M), F64
-    if np.issubdtype(M.dtype, np.integer):
-        return np.asfortranarray(M.astype(np.int64)), I64T
-    if np.issubdtype(M.dtype, np.complexfloating):
-        return np.asfortranarray(M.astype(np.complex128)), C128
-    return np.asfortranarray(M.astype(np.float64)), F64
+        ty = C128
+    elif M.dtype == np.float64:
+        ty = F64
+    elif M.dtype == np.int64:
+        ty = I64T
+    elif M.dtype == np.complex64:
+        ty = C64T
+    elif np.issubdtype(M.dtype, np.integer) or M.dtype == np.bool_:
+        M, ty = M.astype(np.int64), I64T
+    elif np.issubdtype(M.dtype, np.complexfloating):
+        M, ty = M.astype(np.complex128), C128
+    else:
+        M, ty = M.astype(np.float64), F64
+    if M.flags.f_contiguous:
+        return M, ty
+    return np.ascontiguousarray(M), ty | ROW_MAJOR
 
 
 def _csc_arg(M):

@@ -254,13 +254,10 @@ int feasthip_lu_dense_c64(int device_id, const void* C, int64_t n, feasthip_fact
     if (!C || !F || n <= 0) return FEASTHIP_EARG;
     *F = nullptr;
     try {
-        std::vector<std::complex<double>> wide((size_t)n * n);
-        const std::complex<float>* src = static_cast<const std::complex<float>*>(C);
-        for (size_t i = 0; i < wide.size(); ++i) wide[i] = std::complex<double>(src[i].real(), src[i].imag());
         Engine* e = new Engine(device_id);
         if (e->status) { int st = e->status; { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return st; }
-        const void* mats[1] = {wide.data()};
-        int types[1] = {FEASTHIP_C128};
+        const void* mats[1] = {C};
+        int types[1] = {FEASTHIP_C64};       // widened on the device
         int r = e->set_dense(n, 1, mats, types, nullptr);
         if (r == 0) r = e->set_precision(1);
         if (r) { { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return r; }

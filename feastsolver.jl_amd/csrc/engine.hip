@@ -268,26 +268,39 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
     terms_.resize(nterms);
     terms_real_ = false;
     bool real = true, sym = true;
-    std::vector<zc> tmp;
+    // The caller's bytes go to the device as they are; element type, storage order (FEASTHIP_ROW_MAJOR), max |a_ij|, realness and
+    // M == M^T (exactly) are dealt with there (k_dense_import): the host touches the matrix once, for the copy.
+    DevBuf<int64_t> d_props;
+    DevBuf<cz> d_stage;
+    if (!d_props.alloc(3)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
     for (int t = 0; t < nterms; ++t) {
         SparseTerm& T = terms_[t];
         T.scale = scale ? zc(scale[2 * t], scale[2 * t + 1]) : zc(1.0);
         if (!mats[t]) { T.identity = true; T.maxabs = 1.0; continue; }
-        int ty = types ? types[t] : FEASTHIP_C128;
-        if (ty < 0 || ty > 2) return fail(FEASTHIP_EARG, "set_dense: bad element type");
-        size_t nn = (size_t)n * n;
-        tmp.resize(nn);
-        double mx = 0;
-        for (size_t e = 0; e < nn; ++e) { tmp[e] = read_val(mats[t], ty, (int64_t)e); mx = std::max(mx, std::abs(tmp[e])); }
+        const int tyf = types ? types[t] : FEASTHIP_C128;
+        const int ty = tyf & 0xff, row_major = (tyf & FEASTHIP_ROW_MAJOR) ? 1 : 0;
+        if (ty < 0 || ty > 3 || (tyf & ~(0xff | FEASTHIP_ROW_MAJOR))) return fail(FEASTHIP_EARG, "set_dense: bad element type");
+        const size_t nn = (size_t)n * n;
+        const size_t esz = ty == FEASTHIP_C128 ? 16 : 8;
+        if (!T.d_dense.alloc(nn)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
+        const bool in_place = ty == FEASTHIP_C128 && !row_major;
+        void* raw = T.d_dense.p;
+        if (!in_place) {
+            if (!d_stage.alloc((nn * esz + 15) / 16)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
+            raw = d_stage.p;
+        }
+        HIPCHK(hipMemsetAsync(d_props.p, 0, 3 * sizeof(int64_t), stream_));
+        HIPCHK(hipMemcpyAsync(raw, mats[t], nn * esz, hipMemcpyHostToDevice, stream_));
+        launch_dense_import(stream_, raw, ty, row_major, n, T.d_dense.p, reinterpret_cast<unsigned long long*>(d_props.p));
+        int64_t props[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(props, d_props.p, sizeof(props), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        HIPCHK(hipGetLastError());
+        double mx;
+        std::memcpy(&mx, &props[0], sizeof(mx));
         T.maxabs = mx;
-        for (size_t e = 0; e < nn && real; ++e) if (tmp[e].imag() != 0.0) real = false;
-        // M == M^T (exactly): blocked so that both access directions stay in cache; stops at the first mismatch
-        for (int jb = 0; jb < n && sym; jb += 64)
-            for (int ib = jb; ib < n && sym; ib += 64)
-                for (int j = jb; j < std::min(n, jb + 64) && sym; ++j)
-                    for (int i = std::max(ib, j + 1); i < std::min(n, ib + 64); ++i)
-                        if (tmp[i + (size_t)j * n] != tmp[j + (size_t)i * n]) { sym = false; break; }
-        if (!T.d_dense.upload((const cz*)tmp.data(), nn, stream_)) return fail(FEASTHIP_EHIP, "set_dense: device allocation/upload failed");
+        if (props[1]) real = false;
+        if (props[2]) sym = false;
     }
     for (auto& T : terms_) if (T.scale.imag() != 0.0) real = false;
     terms_real_ = real;

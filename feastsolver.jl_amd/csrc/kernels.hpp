@@ -32,6 +32,9 @@ struct DevSym {          // device copies of the symbolic structure
 // ---- numeric factorisation ------------------------------------------------
 void launch_scatter(hipStream_t st, cz* fact, int64_t fs, const int64_t* dest, const cz* val, int64_t nnz,
                     const cz* coef, int coef_stride, int term, int K);
+// caller's dense matrix (raw host element type / storage order, already on the device) -> complex128 column-major copy + properties
+// props[3]: bits of max |a_ij|, not-real flag, not-symmetric flag (zeroed by the caller)
+void launch_dense_import(hipStream_t st, const void* raw, int type, int row_major, int n, cz* out, unsigned long long* props);
 void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz* const* mats, int nterms,
                            const cz* coef, int K);
 void launch_extend_add(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs,

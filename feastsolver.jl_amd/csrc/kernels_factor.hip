@@ -71,6 +71,63 @@ void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz
     hipLaunchKernelGGL(k_dense_assemble, g, dim3(256), 0, st, fact, fs, n, mats, nterms, coef);
 }
 
+// Import of a caller's dense matrix (feasthip_set_dense): the raw host bytes are uploaded as they are and this kernel converts the
+// element type (Float64 / ComplexF64 / Int64 / ComplexF32) and the storage order (row-major callers: numpy) into the complex128
+// column-major copy the engine keeps, and collects max |a_ij| and "has an imaginary part" on the way; k_dense_symcheck then
+// compares the copy with its transpose.  props: [0] bits of max |a| (non-negative doubles order like their bit patterns),
+// [1] != 0: not real, [2] != 0: not equal to its transpose.  raw == out is allowed for complex128 column-major input.
+// (The first version did all of this on one host core before the upload: 1 s per 4096 x 4096 matrix.)
+__global__ __launch_bounds__(256) void k_dense_import(const void* raw, int type, int row_major, int n, cz* out, unsigned long long* props) {
+    __shared__ cz tile[32][33];
+    const int bi = blockIdx.x * 32, bj = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double mx = 0.0;
+    int notreal = 0;
+    for (int q = ty; q < 32; q += 8) {
+        const int i = row_major ? bi + q : bi + tx, j = row_major ? bj + tx : bj + q;
+        cz v = cz_make(0, 0);
+        if (i < n && j < n) {
+            const int64_t idx = row_major ? (int64_t)i * n + j : i + (int64_t)j * n;
+            if (type == 0) v = cz_make(static_cast<const double*>(raw)[idx], 0.0);
+            else if (type == 1) v = static_cast<const cz*>(raw)[idx];
+            else if (type == 2) v = cz_make((double)static_cast<const long long*>(raw)[idx], 0.0);
+            else { const cf w = static_cast<const cf*>(raw)[idx]; v = cz_make(w.x, w.y); }
+            mx = fmax(mx, hypot(v.x, v.y));
+            notreal |= (v.y != 0.0);
+        }
+        tile[i - bi][j - bj] = v;
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int i = bi + tx, j = bj + q;
+        if (i < n && j < n) out[i + (int64_t)j * n] = tile[tx][q];
+    }
+    for (int off = 32; off > 0; off >>= 1) { mx = fmax(mx, __shfl_xor(mx, off)); notreal |= __shfl_xor(notreal, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx > 0.0) atomicMax(props, (unsigned long long)__double_as_longlong(mx));
+        if (notreal) atomicOr(props + 1, 1ull);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dense_symcheck(int n, const cz* __restrict__ A, unsigned long long* props) {
+    const int bi = blockIdx.x * 32, bj = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (bi < bj) return;                    // the tile pairs on and below the diagonal cover every (i, j), i > j
+    int bad = 0;
+    for (int q = ty; q < 32; q += 8) {
+        const int i = bi + tx, j = bj + q;
+        if (i < n && j < n && i > j) {
+            const cz a = A[i + (int64_t)j * n], b = A[j + (int64_t)i * n];
+            if (!(a.x == b.x && a.y == b.y)) bad = 1;
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(props + 2, 1ull);
+}
+
+void launch_dense_import(hipStream_t st, const void* raw, int type, int row_major, int n, cz* out, unsigned long long* props) {
+    const dim3 g((n + 31) / 32, (n + 31) / 32);
+    hipLaunchKernelGGL(k_dense_import, g, dim3(256), 0, st, raw, type, row_major, n, out, props);
+    hipLaunchKernelGGL(k_dense_symcheck, g, dim3(256), 0, st, n, out, props);
+}
+
 // ---------------------------------------------------------------------------
 // extend-add: parent front += children contribution blocks.  One workgroup owns
 // a 64 x 64 tile of the parent front and pulls from every child in a fixed

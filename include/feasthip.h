@@ -43,7 +43,10 @@ enum {
 };
 
 /* element type tags for matrix values */
-enum { FEASTHIP_F64 = 0, FEASTHIP_C128 = 1, FEASTHIP_I64 = 2, FEASTHIP_C64 = 3 /* lu_dense_c64 / lu_csc only: ComplexF32 shifted matrix of the mixed_prec path */ };
+enum { FEASTHIP_F64 = 0, FEASTHIP_C128 = 1, FEASTHIP_I64 = 2, FEASTHIP_C64 = 3 /* dense matrices, lu_dense_c64 / lu_csc: ComplexF32 (the shifted matrix of the mixed_prec path) */ };
+/* feasthip_set_dense only: OR into the type tag of a matrix stored row-major (numpy's default order; Julia passes column-major, no flag).
+ * The library converts element type and storage order on the device. */
+#define FEASTHIP_ROW_MAJOR 0x100
 /* contour region kinds for the inside test (src/contour.jl:88-100) */
 enum { FEASTHIP_REGION_DISC = 0, FEASTHIP_REGION_RECT = 1 };
 

@@ -190,6 +190,43 @@ def test_runtests_dense_generalized(gpu, pkg, wl):
     assert match_sets([1, 2, 3], e.real) < 1e-10
 
 
+def test_dense_import_element_types_and_storage_orders(gpu, pkg, wl):
+    """feasthip_set_dense converts element type and storage order on the device: the same matrix handed over as Int64 / Float64 /
+    ComplexF32 / ComplexF64, C-ordered, Fortran-ordered or as a strided view gives the same eigenpairs (runtests.jl:16 passes an
+    Int matrix, numpy callers pass row-major arrays), and a non-symmetric matrix is not mistaken for a symmetric one."""
+    rng = np.random.default_rng(77)
+    n = 70                                                          # not a multiple of the 32 x 32 import tile
+    M = rng.integers(-3, 4, size=(n, n))
+    A = M + M.T + np.diag(np.arange(n))                             # integer symmetric
+    c, r = 10.0, 6.5
+    ref = np.linalg.eigvalsh(A.astype(float))
+    ref = ref[np.abs(ref - c) <= r]
+    X0 = wl.rand_x0(n, 24, 5)
+    big = np.zeros((2 * n, 2 * n)); big[::2, ::2] = A
+    variants = {"int64 C": A.astype(np.int64), "int32 C": A.astype(np.int32), "float64 C": A.astype(np.float64),
+                "float64 F": np.asfortranarray(A.astype(np.float64)), "complex128 C": A.astype(np.complex128),
+                "complex128 F": np.asfortranarray(A.astype(np.complex128)), "complex64 C": A.astype(np.complex64),
+                "float64 strided view": big[::2, ::2]}
+    for name, Av in variants.items():
+        info = {}
+        e, v, res = pkg.feast(X0.copy(), Av, nodes=8, iter=20, c=c, r=r, eps=1e-11, store=True, info=info)
+        assert len(e) == len(ref), name
+        assert match_sets(ref, e.real) < 1e-9, name
+        assert res.max() < 1e-10, name
+        assert info["symmetric"] == (1 if pivot_light_default() else 0), name
+    # a non-symmetric, complex matrix in both storage orders: A^T would have the same eigenvalues, so check the vectors
+    G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    lam = np.linalg.eigvals(G)
+    k = np.argsort(np.abs(lam))[:6]
+    rr = 0.5 * (np.sort(np.abs(lam))[5] + np.sort(np.abs(lam))[6])
+    for Gv in (G, np.asfortranarray(G)):
+        info = {}
+        e, v, res = pkg.feast(wl.rand_x0(n, 16, 6), Gv, nodes=16, iter=30, c=0.0, r=rr, eps=1e-10, store=True, info=info)
+        assert info["symmetric"] == 0
+        assert len(e) == 6 and match_sets(lam[k], e) < 1e-8
+        assert np.linalg.norm(G @ v - v * e[None, :], axis=0).max() < 1e-8
+
+
 @pytest.mark.parametrize("kind", ["circular", "rect_trap", "rect_gauss"])
 def test_runtests_sparse_contours(gpu, pkg, wl, golden, kind):
     A = sp.diags([-np.ones(99), 2 * np.ones(100), -np.ones(99)], [-1, 0, 1], format="csc")
