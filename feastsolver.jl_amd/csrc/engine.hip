@@ -749,6 +749,11 @@ int Engine::analyze() {
         });
     }
     struct JoinWarm { std::thread& t; ~JoinWarm() { if (t.joinable()) t.join(); } } join_warm{warm};
+    // per-term host work that runs beside the ordering (CSR copies + their uploads) and beside the launch plans (arena destinations)
+    struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, diag = 0; };
+    std::vector<TermHost> th;
+    std::vector<std::thread> csr_pool, dest_pool;
+    struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& t : p) if (t.joinable()) t.join(); } } csr_join{csr_pool}, dest_join{dest_pool};
     if (dense) {
         analyze_dense(n, S);
     } else {
@@ -783,13 +788,13 @@ int Engine::analyze() {
         mix((uint64_t)opt.leaf_size); mix((uint64_t)opt.relax_small); mix((uint64_t)opt.relax_mid); mix((uint64_t)(opt.zmid * 1e6)); mix((uint64_t)(opt.zbig * 1e6)); mix((uint64_t)opt.ordering);
         // CSR copies of the terms for SpMM (a transpose of the caller's CSC arrays) do not depend on the ordering: one host thread
         // per term builds them while the nested dissection leaves most cores idle at its top levels
-        struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, diag = 0; };
-        std::vector<TermHost> th(terms_.size());
-        std::vector<std::thread> csr_pool;
+        if (trace) fprintf(stderr, "[feasthip analyze] + pattern hash               %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        th.resize(terms_.size());
         // The helper threads overwrite device buffers a previous analysis of this handle may still be using (DevBuf::alloc keeps a
         // buffer that is large enough): everything queued on the handle's stream has to be through first.  One upload stream per
         // term, created once per handle (a stream gets its hardware queue with its first operation: 25-30 ms).
-        HIPCHK(hipStreamSynchronize(stream_));
+        if (analyzed_once_) HIPCHK(hipStreamSynchronize(stream_));      // (the first analysis of a handle has nothing to wait for)
+        analyzed_once_ = true;
         while (up_streams_.size() < terms_.size()) {
             hipStream_t us = nullptr;
             if (hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) return fail(FEASTHIP_EHIP, "analyze: stream creation failed");
@@ -830,7 +835,7 @@ int Engine::analyze() {
                      Tw.d_col.upload(H.col.data(), nnz, us) && Tw.d_val.upload((const cz*)H.v.data(), nnz, us);
                 if (!ok) H.bad = 2;
             });
-        struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& t : p) if (t.joinable()) t.join(); } } csr_join{csr_pool};
+        if (trace) fprintf(stderr, "[feasthip analyze] + stream sync, CSR threads   %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         bool hit = false;
         {
             std::lock_guard<std::mutex> lk(g_sym_mu);
@@ -845,56 +850,31 @@ int Engine::analyze() {
         }
         if (trace) fprintf(stderr, "[feasthip analyze] analyze_pattern total        %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         // arena destination of every entry (a binary search in the supernode's row structure): independent per column, fanned
-        // out over host threads per term; uploads afterwards from this thread
-        {
-            std::vector<std::thread> tpool;
-            for (size_t ti = 0; ti < terms_.size(); ++ti)
-                tpool.emplace_back([&, ti]() {
-                    SparseTerm& T = terms_[ti];
-                    TermHost& H = th[ti];
-                    int64_t nnz = T.colptr[n];
-                    H.dest.resize(nnz);
-                    int nth = (int)std::min<int64_t>(std::max(1, host_cpu_budget() / 2), std::max<int64_t>(1, nnz / 100000));
-                    std::vector<std::thread> pool;
-                    std::vector<char> bad(nth, 0);
-                    for (int tix = 1; tix <= nth; ++tix) {
-                        auto work = [&, tix]() {
-                            int j0 = (int)((int64_t)n * (tix - 1) / nth), j1 = (int)((int64_t)n * tix / nth);
-                            for (int j = j0; j < j1; ++j)
-                                for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
-                                    H.dest[e2] = entry_dest(S, T.rowval[e2], j);
-                                    if (H.dest[e2] < 0) bad[tix - 1] = 1;
-                                }
-                        };
-                        if (tix < nth) pool.emplace_back(work); else work();
-                    }
-                    for (auto& t2 : pool) t2.join();
-                    for (char b2 : bad) if (b2) H.bad_dest = 1;
-                });
-            for (auto& t2 : tpool) t2.join();
-        }
-        for (auto& t2 : csr_pool) t2.join();
-        terms_symmetric_ = true;
-        for (TermHost& H : th) if (!H.sym) terms_symmetric_ = false;
-        for (size_t ti = 0; ti < terms_.size(); ++ti) {
-            SparseTerm& T = terms_[ti];
-            T.diagonal = th[ti].diag != 0;
-            if (T.diagonal) {
-                std::vector<zc> dg(n, zc(0.0));
-                for (int j = 0; j < n; ++j) for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) dg[j] += T.val[e2];
-                if (!T.d_diag.upload((const cz*)dg.data(), n, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
-            }
-        }
-        for (TermHost& H : th) if (H.bad_dest) H.bad = 1;
-        for (size_t ti = 0; ti < terms_.size(); ++ti) {
-            SparseTerm& T = terms_[ti];
-            TermHost& H = th[ti];
-            if (H.bad == 1) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
-            int64_t nnz = T.colptr[n];
-            if (H.bad == 2 || !T.d_dest.upload(H.dest.data(), nnz, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
-        }
+        // out over host threads per term, beside the launch plans below; joined and uploaded after those
+        for (size_t ti = 0; ti < terms_.size(); ++ti)
+            dest_pool.emplace_back([&, ti]() {
+                SparseTerm& T = terms_[ti];
+                TermHost& H = th[ti];
+                int64_t nnz = T.colptr[n];
+                H.dest.resize(nnz);
+                int nth = (int)std::min<int64_t>(std::max(1, host_cpu_budget() / 2), std::max<int64_t>(1, nnz / 100000));
+                std::vector<std::thread> pool;
+                std::vector<char> bad(nth, 0);
+                for (int tix = 1; tix <= nth; ++tix) {
+                    auto work = [&, tix]() {
+                        int j0 = (int)((int64_t)n * (tix - 1) / nth), j1 = (int)((int64_t)n * tix / nth);
+                        for (int j = j0; j < j1; ++j)
+                            for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) {
+                                H.dest[e2] = entry_dest(S, T.rowval[e2], j);
+                                if (H.dest[e2] < 0) bad[tix - 1] = 1;
+                            }
+                    };
+                    if (tix < nth) pool.emplace_back(work); else work();
+                }
+                for (auto& t2 : pool) t2.join();
+                for (char b2 : bad) if (b2) H.bad_dest = 1;
+            });
     }
-    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + arena destinations, CSR    %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     // device symbolic
     std::vector<FrontD> fr(S.nsuper);
     for (int s = 0; s < S.nsuper; ++s) {
@@ -985,6 +965,30 @@ int Engine::analyze() {
             dsym_.asmflag = d_asmflag_.p; dsym_.relfirst = d_relfirst_.p;
         }
     }
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (!dense) {
+        for (auto& t2 : dest_pool) t2.join();
+        for (auto& t2 : csr_pool) t2.join();
+        terms_symmetric_ = true;
+        for (TermHost& H : th) if (!H.sym) terms_symmetric_ = false;
+        for (size_t ti = 0; ti < terms_.size(); ++ti) {
+            SparseTerm& T = terms_[ti];
+            T.diagonal = th[ti].diag != 0;
+            if (T.diagonal) {
+                std::vector<zc> dg(n, zc(0.0));
+                for (int j = 0; j < n; ++j) for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) dg[j] += T.val[e2];
+                if (!T.d_diag.upload((const cz*)dg.data(), n, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+            }
+        }
+        for (TermHost& H : th) if (H.bad_dest) H.bad = 1;
+        for (size_t ti = 0; ti < terms_.size(); ++ti) {
+            SparseTerm& T = terms_[ti];
+            TermHost& H = th[ti];
+            if (H.bad == 1) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
+            int64_t nnz = T.colptr[n];
+            if (H.bad == 2 || !T.d_dest.upload(H.dest.data(), nnz, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+        }
+    }
     // numeric arenas
     analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto t_alloc = std::chrono::steady_clock::now();
@@ -994,7 +998,7 @@ int Engine::analyze() {
          d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)2 * Kloc) && d_wscr_.alloc((size_t)Kloc * wstride_ * (4 * 1024 + 128)) && d_coef_.alloc((size_t)Kloc * nterms);
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
     alloc_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
-    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + arena destinations, CSR    %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);
     analyzed_ = true;
     factored_ = false;
     return 0;

@@ -168,6 +168,7 @@ private:
     std::vector<int> local_;               // indices of local nodes (conjugate fold: the member of each local pair that is factorised)
     std::vector<int> partner_;             // conjugate fold: index of the mirror node of local_[kk], else -1
     bool fold_ = false, fold_enabled_ = true, terms_real_ = false;
+    bool analyzed_once_ = false;           // analyze() ran on this handle before (its device buffers may be in use by queued work)
     bool terms_symmetric_ = false;         // every coefficient matrix equals its transpose: T(z) = T(z)^T for all z (pivot-light factorisation)
     bool nopiv_enabled_ = true, nopiv_failed_ = false;   // FEASTHIP_NOPIV=0 / a factorisation whose growth check failed: pivoted path from then on
     double nopiv_max_growth_ = 1024.0;     // largest multiplier |l_ij| the pivot-light path may produce (FEASTHIP_NOPIV_GROWTH)

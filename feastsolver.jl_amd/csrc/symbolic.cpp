@@ -46,31 +46,45 @@ struct Graph {
     std::vector<int> adj;
 };
 
+// adjacency of A + A^T without the diagonal, neighbours ascending.  The transpose comes out of a counting pass with its
+// lists already ascending; a column of A whose row indices ascend (every CSC matrix Julia or scipy builds) is then merged with
+// its row in one linear pass, any other column is sorted first.
 Graph symmetrize(int n, const int64_t* colptr, const int64_t* rowidx) {
     Graph g;
     g.n = n;
-    std::vector<int64_t> cnt(n + 1, 0);
+    std::vector<int64_t> tp(n + 1, 0);
     for (int j = 0; j < n; ++j)
-        for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) {
-            int i = (int)rowidx[t];
-            if (i != j) { cnt[i + 1]++; cnt[j + 1]++; }
-        }
-    for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
-    std::vector<int> tmp(cnt[n]);
-    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
-    for (int j = 0; j < n; ++j)
-        for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) {
-            int i = (int)rowidx[t];
-            if (i != j) { tmp[pos[i]++] = j; tmp[pos[j]++] = i; }
-        }
-    g.xadj.assign(n + 1, 0);
-    g.adj.reserve(cnt[n]);
-    for (int j = 0; j < n; ++j) {
-        std::sort(tmp.begin() + cnt[j], tmp.begin() + cnt[j + 1]);
-        auto e = std::unique(tmp.begin() + cnt[j], tmp.begin() + cnt[j + 1]);
-        g.adj.insert(g.adj.end(), tmp.begin() + cnt[j], e);
-        g.xadj[j + 1] = (int64_t)g.adj.size();
+        for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) tp[rowidx[t] + 1]++;
+    for (int j = 0; j < n; ++j) tp[j + 1] += tp[j];
+    std::vector<int> tr(tp[n]);                       // row i of A: the columns j with a_ij != 0, ascending
+    {
+        std::vector<int64_t> pos(tp.begin(), tp.end() - 1);
+        for (int j = 0; j < n; ++j)
+            for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) tr[pos[rowidx[t]]++] = j;
     }
+    g.xadj.assign(n + 1, 0);
+    g.adj.resize((size_t)colptr[n] + (size_t)tp[n]);
+    std::vector<int> own;
+    int64_t len = 0;
+    for (int j = 0; j < n; ++j) {
+        const int64_t c0 = colptr[j], c1 = colptr[j + 1];
+        bool sorted = true;
+        for (int64_t t = c0 + 1; t < c1 && sorted; ++t) sorted = rowidx[t - 1] < rowidx[t];
+        own.resize(c1 - c0);
+        for (int64_t t = c0; t < c1; ++t) own[t - c0] = (int)rowidx[t];
+        if (!sorted) { std::sort(own.begin(), own.end()); own.erase(std::unique(own.begin(), own.end()), own.end()); }
+        const int* a = own.data(); const int* ae = a + own.size();
+        const int* r = tr.data() + tp[j]; const int* re = tr.data() + tp[j + 1];
+        while (a < ae || r < re) {
+            int v;
+            if (r >= re || (a < ae && *a < *r)) v = *a++;
+            else if (a >= ae || *r < *a) v = *r++;
+            else { v = *a; ++a; ++r; }
+            if (v != j && (len == g.xadj[j] || g.adj[len - 1] != v)) g.adj[len++] = v;     // (duplicate entries of a column show up twice in its row)
+        }
+        g.xadj[j + 1] = len;
+    }
+    g.adj.resize(len);
     return g;
 }
 
@@ -379,16 +393,17 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t)
             if (rowidx[t] < 0 || rowidx[t] >= n) return "row index out of range";
     }
-    Graph g = symmetrize(n, colptr, rowidx);
-
     const bool trace = getenv("FEASTHIP_ANALYZE_TRACE") != nullptr;
     auto tph = std::chrono::steady_clock::now();
+    Graph g = symmetrize(n, colptr, rowidx);
+
     auto phase = [&](const char* name) {
         if (!trace) return;
         auto t1 = std::chrono::steady_clock::now();
         fprintf(stderr, "[feasthip analyze] %-28s %.1f ms\n", name, std::chrono::duration<double, std::milli>(t1 - tph).count());
         tph = t1;
     };
+    phase("A + A^T");
     // ---- 1. fill-reducing ordering --------------------------------------
     std::vector<int> perm(n), iperm(n);
     if (opt.ordering == 1) {
