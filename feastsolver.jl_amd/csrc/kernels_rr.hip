@@ -4,6 +4,8 @@
 // vectors and column norms.  Block vectors are row-major n x ldw complex128.
 #include "kernels.hpp"
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 namespace feasthip {
 
@@ -98,6 +100,81 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const cz* __restrict__ 
     }
 }
 
+// The same product without LDS and without barriers, as the sweep kernel k_apply2 does it (kernels_solve.hip): every wave owns
+// 16 rows x 64 columns and streams both operands into the matrix-core registers through rings (the matrix 8 k-steps ahead, the
+// block-vector rows 4), 3M complex products.  (k_dense_mv above, two barriers per 64 columns of A: 244 us per 4096 x 4096 x 64
+// product, 35 TFLOP/s; it stays for leading dimensions this kernel does not take.)
+constexpr int DMV_DA = 8, DMV_DV = 4;
+__global__ __launch_bounds__(256, 2) void k_dense_mv2(int n, const cz* __restrict__ A, const cz* __restrict__ V, int ldw,
+                                                      cz* out, cz alpha, int accumulate, int kparts, cz* part) {
+    const int rbase = blockIdx.x * 64, cg = blockIdx.y * 64;
+    const int kchunks = (n + 63) / 64, kper = (kchunks + kparts - 1) / kparts;
+    const int kbeg = blockIdx.z * kper * 64, kend = min(n, kbeg + kper * 64);
+    if (kparts > 1) { out = part + (int64_t)blockIdx.z * n * ldw; alpha = cz_make(1, 0); accumulate = 0; }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    if (rbase + wave * 16 >= n) return;                      // (no barriers: a wave without rows may leave)
+    const int arow = rbase + wave * 16 + li;
+    const bool aok = arow < n;
+    const cz* Ap = A + min(arow, n - 1);
+    const int Kd = kend - kbeg, nks = (Kd + 3) >> 2;
+    int vcol[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vcol[q] = min(cg + q * 16 + li, ldw - 1);
+    cz ar[DMV_DA], vr[DMV_DV][4];
+    auto kof = [&](int s2) { return kbeg + min(4 * s2 + lk, Kd - 1); };      // clamped: steps beyond the end re-read the last column (masked)
+    auto loadA = [&](int s2, int slot) { ar[slot] = Ap[(int64_t)kof(s2) * n]; };
+    auto loadV = [&](int s2, int slot) {
+        const cz* vp = V + (int64_t)kof(s2) * ldw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vr[slot][q] = vp[vcol[q]];
+    };
+    d4 t1[4], t2[4], t3[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { t1[q] = (d4){0, 0, 0, 0}; t2[q] = (d4){0, 0, 0, 0}; t3[q] = (d4){0, 0, 0, 0}; }
+    if (Kd > 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < DMV_DA - 1; ++s2) loadA(s2, s2);
+#pragma unroll
+        for (int s2 = 0; s2 < DMV_DV - 1; ++s2) loadV(s2, s2);
+        auto step = [&](int s2, auto jc) {
+            constexpr int j = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            loadV(s2 + DMV_DV - 1, (j + DMV_DV - 1) % DMV_DV);
+            loadA(s2 + DMV_DA - 1, (j + DMV_DA - 1) % DMV_DA);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool keep = aok && 4 * s2 + lk < Kd;
+            const double ax = keep ? ar[j % DMV_DA].x : 0.0, ay = keep ? ar[j % DMV_DA].y : 0.0, as = ax + ay;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, vr[j % DMV_DV][q].x, t1[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, vr[j % DMV_DV][q].y, t2[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, vr[j % DMV_DV][q].x + vr[j % DMV_DV][q].y, t3[q], 0, 0, 0);
+        };
+        for (int s0 = 0; s0 < nks; s0 += 8) {      // (a step beyond the end multiplies masked zeros)
+            step(s0 + 0, std::integral_constant<int, 0>{}); step(s0 + 1, std::integral_constant<int, 1>{});
+            step(s0 + 2, std::integral_constant<int, 2>{}); step(s0 + 3, std::integral_constant<int, 3>{});
+            step(s0 + 4, std::integral_constant<int, 4>{}); step(s0 + 5, std::integral_constant<int, 5>{});
+            step(s0 + 6, std::integral_constant<int, 6>{}); step(s0 + 7, std::integral_constant<int, 7>{});
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int orow = rbase + wave * 16 + lk + 4 * r;
+        if (orow >= n) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = cg + q * 16 + li;
+            if (col < ldw) {
+                cz v = cz_mul(alpha, cz_make(t1[q][r] - t2[q][r], t3[q][r] - t1[q][r] - t2[q][r]));
+                cz* d = out + (int64_t)orow * ldw + col;
+                if (accumulate) v = cz_add(v, *d);
+                *d = v;
+            }
+        }
+    }
+}
+
 __global__ void k_dense_mv_reduce(int64_t total, int kparts, const cz* __restrict__ part, cz* out, cz alpha, int accumulate) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -117,8 +194,12 @@ int dense_mv_parts(int n, int ldw) {
 
 void launch_dense_mv(hipStream_t st, int n, const cz* A, const cz* V, int ldw, cz* out, cz alpha, int accumulate, cz* part) {
     const int parts = part ? dense_mv_parts(n, ldw) : 1;
-    hipLaunchKernelGGL(k_dense_mv, dim3((n + 63) / 64, (ldw + LDS_COLS - 1) / LDS_COLS, parts), dim3(256), 0, st, n, A, V, ldw, out, alpha, accumulate,
-                       parts, part);
+    static const bool old_kernel = getenv("FEASTHIP_DENSE_MV_LDS") != nullptr;
+    if (LDS_COLS == 64 && !old_kernel)
+        hipLaunchKernelGGL(k_dense_mv2, dim3((n + 63) / 64, (ldw + 63) / 64, parts), dim3(256), 0, st, n, A, V, ldw, out, alpha, accumulate, parts, part);
+    else
+        hipLaunchKernelGGL(k_dense_mv, dim3((n + 63) / 64, (ldw + LDS_COLS - 1) / LDS_COLS, parts), dim3(256), 0, st, n, A, V, ldw, out, alpha, accumulate,
+                           parts, part);
     if (parts > 1) {
         const int64_t total = (int64_t)n * ldw;
         hipLaunchKernelGGL(k_dense_mv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, parts, part, out, alpha, accumulate);
