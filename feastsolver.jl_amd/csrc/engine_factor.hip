@@ -89,7 +89,8 @@ int Engine::factorize() {
         const bool tall = level_ld >= 1024;      // wide panel workgroups for tall fronts (launch_panel picks the width)
         int level_p = 0;
         for (int s2 : S.levels[d]) level_p = std::max(level_p, S.p(s2));
-        const bool lookahead = look_ahead_ && level_p >= 256 && la_stream_ && F.steps.size() >= 4;
+        static const int la_min_p = getenv("FEASTHIP_LA_MINP") ? atoi(getenv("FEASTHIP_LA_MINP")) : 256;
+        const bool lookahead = look_ahead_ && level_p >= la_min_p && la_stream_ && F.steps.size() >= 4;
         stamp();
         if (!lookahead && nopiv) {      // whole 128-column groups per step: diagonal block, rows below, one product
             for (size_t j = 0; j < F.steps.size(); j += 4) {
