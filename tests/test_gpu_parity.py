@@ -593,25 +593,47 @@ def test_c3_g24_converges_with_right_count(gpu, pkg, wl):
     assert np.abs(lam.imag).max() < 1e-10      # Hermitian-definite pencil
 
 
-@pytest.mark.parametrize("shape,extra", [((48, 24, 14), 300), ((90, 70, 3), 0), ((30, 30, 30), 2000)])
+@pytest.mark.parametrize("n,density", [(1, 1.0), (2, 1.0), (3, 0.5), (7, 0.4), (31, 0.2), (64, 0.1), (129, 0.05), (500, 0.01), (1500, 0.004)])
+def test_random_symmetric_sparse_lu(gpu, pkg, n, density):
+    """Complex symmetric matrices with random patterns (no grid structure: chains, stars, isolated vertices, fronts of one or two
+    columns) through the pivot-light factorisation, against a dense solve."""
+    rng = np.random.default_rng(1000 + n)
+    S = sp.random(n, n, density=density, random_state=np.random.RandomState(n), data_rvs=lambda k: rng.standard_normal(k)).tocsc()
+    A = (S + S.T).tocsc() + sp.diags(rng.uniform(1.0, 2.0, n) * (1 + np.abs(S + S.T).sum(axis=1).A1))
+    Cm = sp.csc_matrix(A.astype(np.complex128) - (0.2 + 0.4j) * sp.identity(n))
+    assert abs(Cm - Cm.T).max() == 0
+    R = np.asfortranarray(rng.standard_normal((n, 5)) + 1j * rng.standard_normal((n, 5)))
+    F = pkg.lu(Cm)
+    assert F.symmetric == (1 if pivot_light_default() else 0)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    pkg.finalize(F)
+    ref = np.linalg.solve(Cm.toarray(), R)
+    assert np.abs(Y - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("shape,extra", [((48, 24, 14), 300), ((90, 70, 3), 0), ((30, 30, 30), 2000), ((48, 24, 14), -300), ((30, 30, 30), -2000)])
 def test_irregular_trees_sparse_lu(gpu, pkg, shape, extra):
     """Elimination trees whose levels mix fronts of very different pivot-block widths (non-cubic grids, random long-range
     couplings): the grouped look-ahead schedule sees panel groups that end inside a front's pivot block."""
-    rng = np.random.default_rng(sum(shape) + extra)
+    rng = np.random.default_rng(sum(shape) + abs(extra))
     def lap1(g):
         return sp.diags([-np.ones(g - 1), 2.0 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
     gx, gy, gz = shape
     A = (sp.kron(sp.kron(lap1(gx), sp.identity(gy)), sp.identity(gz)) + sp.kron(sp.kron(sp.identity(gx), lap1(gy)), sp.identity(gz))
          + sp.kron(sp.kron(sp.identity(gx), sp.identity(gy)), lap1(gz))).tocsc()
     n = A.shape[0]
+    symmetric = extra <= 0          # negative: the same long-range couplings with symmetric VALUES (pivot-light path on an irregular tree)
+    extra = abs(extra)
     if extra:
         i = rng.integers(0, n, extra)
         j = rng.integers(0, n, extra)
         E = sp.coo_matrix((rng.standard_normal(extra) * 0.3, (i, j)), shape=(n, n))
-        A = (A + E + 0.5 * E.T).tocsc()            # structurally symmetric, numerically not
+        A = (A + E + (1.0 if symmetric else 0.5) * E.T).tocsc()            # structurally symmetric; numerically only if asked for
     Cm = sp.csc_matrix(A.astype(np.complex128) - (0.31 + 0.23j) * sp.identity(n))
     R = np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8)))
     F = pkg.lu(Cm)
+    assert F.symmetric == (1 if symmetric and pivot_light_default() else 0)
     Y = np.zeros_like(R)
     pkg.ldiv(Y, F, R)
     pkg.finalize(F)
