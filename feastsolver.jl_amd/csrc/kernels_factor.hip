@@ -831,7 +831,7 @@ void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 // places through LDS, and only the rows that changed are written back.  (The first version walked the interchanges one after
 // the other in every column, one thread per column: b dependent pairs of loads and stores, 0.74 ms per group of 128 on the
 // 4096 x 4096 fronts of C2 whatever the number of columns, a quarter of that factorisation.)
-constexpr int SWAP_MAXB = 256;
+constexpr int SWAP_MAXB = 256, SWAP_SPLIT = 4;
 __global__ __launch_bounds__(256) void k_swap(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
                                               const int* __restrict__ piv, int npiv, ColSel cs, int bw) {
     // bw: FACT_NB, or the width of a group of panels whose interchanges are applied in one pass
@@ -845,7 +845,9 @@ __global__ __launch_bounds__(256) void k_swap(const FrontD* __restrict__ fr, con
     const int p = f.p, u = f.u, ld = p + u;
     const int b = min(min(bw, SWAP_MAXB), p - k0);
     const int nv = (p - b) + u;
-    const int v0 = t.a * 256, v1 = min(v0 + 256, nv);
+    // a 256-column tile is shared by SWAP_SPLIT workgroups (blockIdx.z): the look-ahead steps select 96 .. 128 columns of one tile, and
+    // one workgroup moving them column after column was the longest kernel of the panel stream
+    const int v0 = t.a * 256 + blockIdx.z * (256 / SWAP_SPLIT), v1 = min(min(v0 + 256 / SWAP_SPLIT, t.a * 256 + 256), nv);
     if (v0 >= nv) return;
     {   // tile without a selected column (the look-ahead steps pick narrow column ranges)
         const bool left = v0 < k0 && v0 < cs.lhi && min(v1, k0) > cs.llo;
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(256) void k_swap(const FrontD* __restrict__ fr, con
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                  const int* piv, int K, ColSel cs, int bw) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_swap, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n, cs, bw);
+    hipLaunchKernelGGL(k_swap, dim3(ntiles, K, SWAP_SPLIT), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, piv, S.n, cs, bw);
 }
 
 // ---------------------------------------------------------------------------
