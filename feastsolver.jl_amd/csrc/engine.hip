@@ -127,6 +127,72 @@ template struct DevBuf<Tile>;
 template struct DevBuf<const cz*>;
 
 
+// Streams, events and the pinned landing slots of a handle are kept for the next handle of the same device and configuration
+// instead of being destroyed: creating them (six streams whose hardware queues come with their first operation, a pinned
+// allocation, two dozen events) costs 10-17 ms and destroying them 10 ms -- nothing beside a 0.1 s factorisation, but the
+// reference's plug-in seam creates and finalizes one factor object per contour node and iteration (src/feast.jl:29-36, 61-66
+// with store=false), and for a 64 x 64 matrix that was 20 ms of set-up around 0.3 ms of work.
+struct HandleResources {
+    int device = 0;
+    std::string sig;                       // the environment switches that shape the streams
+    hipStream_t stream = nullptr, la = nullptr, fin = nullptr, rest = nullptr;
+    std::vector<hipStream_t> aux, up;
+    std::vector<hipEvent_t> ev_join, ev_chunk, ev_la;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr, ev_fork = nullptr, ev_fin = nullptr, ev_fin_fork = nullptr;
+    char* pin = nullptr;
+    bool warm = false;
+};
+static std::mutex g_res_mu;
+static std::vector<HandleResources>& res_cache() { static std::vector<HandleResources>* v = new std::vector<HandleResources>(); return *v; }   // (never destroyed: the HIP runtime may be gone by then)
+static std::string res_signature() {
+    std::string s;
+    for (const char* k : {"FEASTHIP_STREAMS", "FEASTHIP_RESERVE_CUS", "FEASTHIP_FIN_MASK"}) { const char* v = getenv(k); s += v ? v : "-"; s += '|'; }
+    return s;
+}
+static const bool g_res_reuse = [] { const char* e = getenv("FEASTHIP_REUSE_STREAMS"); return e ? atoi(e) != 0 : true; }();
+
+bool Engine::take_resources() {
+    if (!g_res_reuse) return false;
+    HandleResources r;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        auto& c = res_cache();
+        const std::string sig = res_signature();
+        size_t i = 0;
+        for (; i < c.size(); ++i) if (c[i].device == device_ && c[i].sig == sig) break;
+        if (i == c.size()) return false;
+        r = std::move(c[i]);
+        c.erase(c.begin() + i);
+    }
+    stream_ = r.stream; own_stream_ = true; la_stream_ = r.la; fin_stream_ = r.fin; rest_stream_ = r.rest;
+    aux_streams_ = std::move(r.aux); up_streams_ = std::move(r.up);
+    ev_join_ = std::move(r.ev_join); ev_chunk_ = std::move(r.ev_chunk); ev_la_ = std::move(r.ev_la);
+    ev0_ = r.ev0; ev1_ = r.ev1; ev_p0_ = r.ev_p0; ev_p1_ = r.ev_p1; ev_fork_ = r.ev_fork; ev_fin_ = r.ev_fin; ev_fin_fork_ = r.ev_fin_fork;
+    pin_ = r.pin; streams_warm_ = r.warm;
+    return true;
+}
+
+bool Engine::give_resources() {
+    if (!g_res_reuse || !own_stream_ || !stream_) return false;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (res_cache().size() >= 64) return false;          // (handles alive at once beyond that are not worth keeping warm)
+    }
+    HandleResources r;
+    r.device = device_; r.sig = res_signature();
+    r.stream = stream_; r.la = la_stream_; r.fin = fin_stream_; r.rest = rest_stream_;
+    r.aux = std::move(aux_streams_); r.up = std::move(up_streams_);
+    r.ev_join = std::move(ev_join_); r.ev_chunk = std::move(ev_chunk_); r.ev_la = std::move(ev_la_);
+    r.ev0 = ev0_; r.ev1 = ev1_; r.ev_p0 = ev_p0_; r.ev_p1 = ev_p1_; r.ev_fork = ev_fork_; r.ev_fin = ev_fin_; r.ev_fin_fork = ev_fin_fork_;
+    r.pin = pin_; r.warm = streams_warm_;
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    res_cache().push_back(std::move(r));
+    stream_ = la_stream_ = fin_stream_ = rest_stream_ = nullptr;
+    ev0_ = ev1_ = ev_p0_ = ev_p1_ = ev_fork_ = ev_fin_ = ev_fin_fork_ = nullptr;
+    pin_ = nullptr;
+    return true;
+}
+
 Engine::Engine(int device) : device_(device) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { (void)hipGetLastError(); fail(FEASTHIP_ENOGPU, "no HIP device visible: feasthip has no CPU fallback"); return; }
@@ -135,13 +201,16 @@ Engine::Engine(int device) : device_(device) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(FEASTHIP_EHIP, "hipGetDeviceProperties failed"); return; }
     if (std::strstr(prop.gcnArchName, "gfx950") == nullptr) { fail(FEASTHIP_ENOGPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"); return; }
     if (hipSetDevice(device) != hipSuccess) { fail(FEASTHIP_EHIP, "hipSetDevice failed"); return; }
-    if (hipStreamCreate(&stream_) != hipSuccess) { fail(FEASTHIP_EHIP, "hipStreamCreate failed"); return; }
-    own_stream_ = true;
-    (void)hipEventCreate(&ev0_);
-    (void)hipEventCreate(&ev1_);
-    (void)hipEventCreate(&ev_p0_);
-    (void)hipEventCreate(&ev_p1_);
-    { void* q = nullptr; if (hipHostMalloc(&q, PIN_SLOTS * PIN_SLOT_BYTES, hipHostMallocDefault) == hipSuccess) pin_ = (char*)q; else (void)hipGetLastError(); }
+    const bool recycled = take_resources();
+    if (!recycled) {
+        if (hipStreamCreate(&stream_) != hipSuccess) { fail(FEASTHIP_EHIP, "hipStreamCreate failed"); return; }
+        own_stream_ = true;
+        (void)hipEventCreate(&ev0_);
+        (void)hipEventCreate(&ev1_);
+        (void)hipEventCreate(&ev_p0_);
+        (void)hipEventCreate(&ev_p1_);
+        { void* q = nullptr; if (hipHostMalloc(&q, PIN_SLOTS * PIN_SLOT_BYTES, hipHostMallocDefault) == hipSuccess) pin_ = (char*)q; else (void)hipGetLastError(); }
+    }
     if (const char* v = getenv("FEASTHIP_LOOKAHEAD")) look_ahead_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_GROUP")) group_panels_ = std::max(1, std::min(8, atoi(v)));
     if (const char* v = getenv("FEASTHIP_FUSED_UTRSM")) fused_utrsm_ = atoi(v) != 0;
@@ -158,6 +227,8 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
+    if (const char* v = getenv("FEASTHIP_RESERVE_CUS")) reserve_cus_ = std::max(0, std::min(4, atoi(v)));
+    if (recycled) return;
     if (nst > 1) {
         (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
         for (int i = 0; i < nst; ++i) {
@@ -180,7 +251,6 @@ Engine::Engine(int device) : device_(device) {
         // would only start when that update drains.  The trailing updates of the look-ahead levels therefore run on a stream
         // whose CU mask leaves reserve_cus_ CUs of every XCD alone (MI355X: 8 XCDs x 32 CUs).  The cleared bits are 32x + 8m + x
         // (x = XCD, m < reserve_cus_): two free CUs per XCD whether the mask bits enumerate the CUs XCD by XCD or round-robin.
-        if (const char* v = getenv("FEASTHIP_RESERVE_CUS")) reserve_cus_ = std::max(0, std::min(4, atoi(v)));
         hipDeviceProp_t prop;
         if (la_stream_ && reserve_cus_ > 0 && hipGetDeviceProperties(&prop, device_) == hipSuccess && prop.multiProcessorCount == 256) {
             uint32_t mask[8];
@@ -204,6 +274,10 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     pool_drop_device(device_);       // the cache holds at most what ONE handle used: earlier leftovers go back to the driver now
+    for (hipStream_t s2 : up_streams_) (void)hipStreamSynchronize(s2);
+    for (hipStream_t s2 : aux_streams_) (void)hipStreamSynchronize(s2);
+    for (hipStream_t s2 : {la_stream_, rest_stream_, fin_stream_}) if (s2) (void)hipStreamSynchronize(s2);
+    if (give_resources()) return;
     for (hipStream_t s2 : up_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipStream_t s2 : aux_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipEvent_t e2 : ev_join_) (void)hipEventDestroy(e2);

@@ -211,6 +211,8 @@ private:
     static constexpr int PIN_SLOTS = 8;
     static constexpr size_t PIN_SLOT_BYTES = (size_t)1 << 20;
     char* pin_ = nullptr;
+    bool take_resources();               // streams / events / pinned slots of an earlier handle of this device (engine.hip: HandleResources)
+    bool give_resources();
     void* pin_slot(int slot, size_t bytes) { return (pin_ && bytes <= PIN_SLOT_BYTES) ? (void*)(pin_ + (size_t)slot * PIN_SLOT_BYTES) : nullptr; }
     hipError_t d2h_async(int slot, void* host_dst, const void* dev, size_t bytes, void** landed);      // *landed: where the bytes arrive (copy out after the sync if != host_dst)
     hipError_t h2d_async(int slot, void* dev, const void* host_src, size_t bytes);
