@@ -1,6 +1,7 @@
 // extern "C" surface of libfeasthip.so (include/feasthip.h).  Nothing here
 // throws across the ABI: every entry point catches and maps to a status code.
 #include <cstring>
+#include <chrono>
 #include <complex>
 #include <mutex>
 #include <new>
@@ -240,13 +241,23 @@ int feasthip_lu_dense(int device_id, const void* C, int64_t n, feasthip_fact_t* 
     if (!C || !F || n <= 0) return FEASTHIP_EARG;
     *F = nullptr;
     try {
+        auto t0 = std::chrono::steady_clock::now();
         Engine* e = new Engine(device_id);
         if (e->status) { int st = e->status; { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return st; }
         const void* mats[1] = {C};
         int types[1] = {FEASTHIP_C128};
+        auto t1 = std::chrono::steady_clock::now();
         int r = e->set_dense(n, 1, mats, types, nullptr);
         if (r) { { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e->err; } delete e; return r; }
-        return make_fact(e, F);
+        auto t2 = std::chrono::steady_clock::now();
+        r = make_fact(e, F);
+        if (getenv("FEASTHIP_SEAM_TRACE")) {
+            auto t3 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[feasthip lu_dense n=%lld] handle %.3f ms, matrix hand-over %.3f ms, analysis + factorisation %.3f ms (analysis %.3f, factorisation kernels %.3f)\n", (long long)n,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                    std::chrono::duration<double, std::milli>(t3 - t2).count(), r >= 0 ? e->analyze_seconds * 1e3 : 0.0, r >= 0 ? e->factor_ms : 0.0);
+        }
+        return r;
     } catch (...) { return FEASTHIP_EARG; }
 }
 
