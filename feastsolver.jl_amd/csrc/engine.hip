@@ -67,10 +67,13 @@ void pool_free_blocks(std::vector<CachedBlock>& blocks) {
 }
 }  // namespace
 
+static void trim_handle_resources();     // streams / events / pinned slots kept from closed handles (below)
+
 void trim_device_memory() {
     std::vector<CachedBlock> blocks;
     { std::lock_guard<std::mutex> lk(g_pool_mu); blocks.swap(g_pool); }
     pool_free_blocks(blocks);
+    trim_handle_resources();
 }
 
 // what earlier handles left cached on this device goes back to the driver (called when a handle is destroyed, before its own
@@ -150,6 +153,23 @@ static std::string res_signature() {
     return s;
 }
 static const bool g_res_reuse = [] { const char* e = getenv("FEASTHIP_REUSE_STREAMS"); return e ? atoi(e) != 0 : true; }();
+
+static void trim_handle_resources() {
+    std::vector<HandleResources> sets;
+    { std::lock_guard<std::mutex> lk(g_res_mu); sets.swap(res_cache()); }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (HandleResources& r : sets) {
+        (void)hipSetDevice(r.device);
+        for (hipStream_t s2 : r.up) (void)hipStreamDestroy(s2);
+        for (hipStream_t s2 : r.aux) (void)hipStreamDestroy(s2);
+        for (hipStream_t s2 : {r.la, r.rest, r.fin, r.stream}) if (s2) (void)hipStreamDestroy(s2);
+        for (auto* v : {&r.ev_join, &r.ev_chunk, &r.ev_la}) for (hipEvent_t e2 : *v) if (e2) (void)hipEventDestroy(e2);
+        for (hipEvent_t e2 : {r.ev0, r.ev1, r.ev_p0, r.ev_p1, r.ev_fork, r.ev_fin, r.ev_fin_fork}) if (e2) (void)hipEventDestroy(e2);
+        if (r.pin) (void)hipHostFree(r.pin);
+    }
+    (void)hipSetDevice(cur);
+}
 
 bool Engine::take_resources() {
     if (!g_res_reuse) return false;

@@ -60,7 +60,10 @@ int feasthip_destroy(feasthip_handle_t h);
  * handle of this process.  The cache never holds more than ONE handle's footprint (a handle that is destroyed first returns what
  * earlier handles left on its device to the driver) and at most FEASTHIP_POOL_GB (default 48, 0 = no cache); this call returns
  * all of it to the driver.  The counterpart of the reference's finalize! for whole solver runs (src/utils.jl:173): memory is the
- * library's, the caller decides when it goes. */
+ * library's, the caller decides when it goes.
+ * A destroyed handle (or factor object) also leaves its streams, events and 8 MiB of pinned landing slots for the next handle of
+ * the same device (creating them costs 10-17 ms, which matters at the factorizer seam: one factor object per contour node and
+ * iteration); at most 64 such sets are kept, this call destroys them as well, FEASTHIP_REUSE_STREAMS=0 disables the reuse. */
 int feasthip_trim_memory(void);
 const char* feasthip_last_error(feasthip_handle_t h);   /* h may be NULL: last create() error */
 /* run all work of this handle on an existing hipStream_t (e.g. the caller's) */
