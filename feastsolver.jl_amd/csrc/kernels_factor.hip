@@ -466,7 +466,31 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_reg(const FrontD* __restrict
 #pragma unroll
             for (int q = 0; q < PANEL_RPT; ++q) on[q] = tid + PANEL_NT * q >= sbe && tid + PANEL_NT * q < nrow;
             cz* d0 = Lp + (int64_t)(k0 + sbe) * ld + k0 + tid;
-            for (int jj = 0; jj < nt; ++jj) {
+            // two trailing columns per step: eight loads per thread in flight (the loop is a chain of L2 round trips: 112 columns per
+            // panel; nt is a multiple of 4 except in the last panel of a front)
+            int jj = 0;
+            for (; PANEL_NT <= 512 && jj + 2 <= nt; jj += 2) {      // (1024 threads have 128 registers each: one column per step)
+                cz t[2][PANEL_RPT];
+                cz* dj = d0 + (int64_t)jj * ld;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < PANEL_RPT; ++q) t[h][q] = on[q] ? dj[(int64_t)h * ld + PANEL_NT * q] : cz_make(0, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int c = 0; c < PANEL_SBR; ++c) {
+                        const cz uu = s_u[c][jj + h];
+#pragma unroll
+                        for (int q = 0; q < PANEL_RPT; ++q) cz_msub(t[h][q], v[q][c], uu);
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < PANEL_RPT; ++q)
+                        if (on[q]) dj[(int64_t)h * ld + PANEL_NT * q] = t[h][q];
+            }
+            for (; jj < nt; ++jj) {
                 cz uu[PANEL_SBR], t[PANEL_RPT];
                 cz* dj = d0 + (int64_t)jj * ld;
 #pragma unroll
@@ -496,7 +520,7 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
     // otherwise run their panels five CU-rounds deep.
     if (!generic && max_rows <= PANEL_RPT * 1024) {
         // few workgroups (every one gets a CU of its own anyway): the widest workgroup has the shortest pivot step
-        const int floor_nt = (int64_t)nlist * K <= 256 ? (tall ? 1024 : 256) : 64;
+        const int floor_nt = (int64_t)nlist * K <= 256 ? (tall ? (max_rows <= PANEL_RPT * 512 ? 512 : 1024) : 256) : 64;
 #define FEASTHIP_PANEL_CASE(NT) \
         if (max_rows <= PANEL_RPT * NT && NT >= floor_nt) { \
             hipLaunchKernelGGL(k_panel_reg<NT>, dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
