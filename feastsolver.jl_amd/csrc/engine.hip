@@ -1,6 +1,7 @@
 // See engine.hpp.  Handle life cycle, inputs, ordering + symbolic analysis and launch plans, the gen_feast driver loop.
 // Reference semantics: src/feast.jl:10-80, 89-156; src/utils.jl:69-77, 104-116, 151-179.
 #include "engine_impl.hpp"
+#include <memory>
 
 namespace feasthip {
 
@@ -821,7 +822,12 @@ bool Engine::build_plans() {
 }
 
 static std::mutex g_sym_mu;
-static std::vector<std::pair<uint64_t, Symbolic>> g_sym_cache;      // most recent symbolic analyses (see Engine::analyze)
+struct SymCacheEntry {       // most recent symbolic analyses (see Engine::analyze), with the arena destinations of the terms' entries
+    uint64_t key = 0;
+    Symbolic S;
+    std::vector<std::shared_ptr<const std::vector<int64_t>>> dest;      // per term, filled by the first handle that computes them
+};
+static std::vector<std::shared_ptr<SymCacheEntry>> g_sym_cache;
 
 int Engine::analyze() {
     if (n <= 0 || terms_.empty()) return fail(FEASTHIP_ESTATE, "analyze: no matrices set");
@@ -849,23 +855,13 @@ int Engine::analyze() {
     // per-term host work that runs beside the ordering (CSR copies + their uploads) and beside the launch plans (arena destinations)
     struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, diag = 0; };
     std::vector<TermHost> th;
+    std::shared_ptr<SymCacheEntry> sym_entry;      // the cache entry this analysis came from / went to (sparse terms)
+    std::vector<std::shared_ptr<const std::vector<int64_t>>> dest_ready;    // arena destinations found in it, per term
     std::vector<std::thread> csr_pool, dest_pool;
     struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& t : p) if (t.joinable()) t.join(); } } csr_join{csr_pool}, dest_join{dest_pool};
     if (dense) {
         analyze_dense(n, S);
     } else {
-        std::vector<int64_t> cp(n + 1, 0), ri;
-        for (int j = 0; j < n; ++j) {
-            int64_t c = 1;
-            for (auto& T : terms_) c += T.colptr[j + 1] - T.colptr[j];
-            cp[j + 1] = cp[j] + c;
-        }
-        ri.resize(cp[n]);
-        for (int j = 0; j < n; ++j) {
-            int64_t o = cp[j];
-            ri[o++] = j;
-            for (auto& T : terms_) for (int64_t e = T.colptr[j]; e < T.colptr[j + 1]; ++e) ri[o++] = T.rowval[e];
-        }
         SymbolicOptions opt;
         if (const char* v = getenv("FEASTHIP_RELAX_SMALL")) opt.relax_small = atoi(v);      // tuning knobs
         if (const char* v = getenv("FEASTHIP_RELAX_MID")) opt.relax_mid = atoi(v);
@@ -873,16 +869,20 @@ int Engine::analyze() {
         if (const char* v = getenv("FEASTHIP_ZBIG")) opt.zbig = atof(v);
         if (const char* v = getenv("FEASTHIP_LEAF")) opt.leaf_size = atoi(v);
         const bool trace = getenv("FEASTHIP_ANALYZE_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[feasthip analyze] pattern union                %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        // Ordering + symbolic analysis depend only on the pattern: FEAST is typically run several times on the same
-        // matrices (other contours / spectrum slices, README.md:12 of the reference), so the result is kept in a small
-        // process-wide cache keyed by a hash of the pattern and the options.
+        // Ordering + symbolic analysis (and the arena destination of every entry of every term) depend only on the patterns: FEAST is
+        // typically run several times on the same matrices (other contours / spectrum slices, README.md:12 of the reference; one
+        // factor object per node at the plug-in seam), so they are kept in a small process-wide cache keyed by a hash of the terms'
+        // patterns and the options.
         uint64_t key = 1469598103934665603ull;
         auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
-        mix((uint64_t)n); mix((uint64_t)cp[n]);
-        for (int j = 0; j <= n; ++j) mix((uint64_t)cp[j]);
-        for (int64_t t = 0; t < cp[n]; ++t) mix((uint64_t)ri[t]);
+        mix((uint64_t)n); mix((uint64_t)terms_.size());
+        for (auto& T : terms_) {
+            for (int j = 0; j <= n; ++j) mix((uint64_t)T.colptr[j]);
+            const int64_t nnz = T.colptr[n];
+            for (int64_t t = 0; t < nnz; ++t) mix((uint64_t)T.rowval[t]);
+        }
         mix((uint64_t)opt.leaf_size); mix((uint64_t)opt.relax_small); mix((uint64_t)opt.relax_mid); mix((uint64_t)(opt.zmid * 1e6)); mix((uint64_t)(opt.zbig * 1e6)); mix((uint64_t)opt.ordering);
+        if (trace) fprintf(stderr, "[feasthip analyze] pattern hash                 %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         // CSR copies of the terms for SpMM (a transpose of the caller's CSC arrays) do not depend on the ordering: one host thread
         // per term builds them while the nested dissection leaves most cores idle at its top levels
         if (trace) fprintf(stderr, "[feasthip analyze] + pattern hash               %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -933,23 +933,44 @@ int Engine::analyze() {
                 if (!ok) H.bad = 2;
             });
         if (trace) fprintf(stderr, "[feasthip analyze] + stream sync, CSR threads   %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        bool hit = false;
         {
             std::lock_guard<std::mutex> lk(g_sym_mu);
-            for (auto& c : g_sym_cache) if (c.first == key && c.second.n == n) { S = c.second; hit = true; break; }
+            for (auto& c : g_sym_cache) if (c->key == key && c->S.n == n) { sym_entry = c; break; }
         }
-        if (!hit) {
+        if (sym_entry) S = sym_entry->S;
+        else {
+            // union of the terms' patterns (+ the diagonal), column by column
+            std::vector<int64_t> cp(n + 1, 0), ri;
+            for (int j = 0; j < n; ++j) {
+                int64_t c = 1;
+                for (auto& T : terms_) c += T.colptr[j + 1] - T.colptr[j];
+                cp[j + 1] = cp[j] + c;
+            }
+            ri.resize(cp[n]);
+            for (int j = 0; j < n; ++j) {
+                int64_t o = cp[j];
+                ri[o++] = j;
+                for (auto& T : terms_) for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) ri[o++] = T.rowval[e2];
+            }
             std::string e = analyze_pattern(n, cp.data(), ri.data(), opt, S);
             if (!e.empty()) return fail(FEASTHIP_EARG, "analyze: " + e);
+            sym_entry = std::make_shared<SymCacheEntry>();
+            sym_entry->key = key; sym_entry->S = S; sym_entry->dest.resize(terms_.size());
             std::lock_guard<std::mutex> lk(g_sym_mu);
             if (g_sym_cache.size() >= 4) g_sym_cache.erase(g_sym_cache.begin());
-            g_sym_cache.emplace_back(key, S);
+            g_sym_cache.push_back(sym_entry);
         }
         if (trace) fprintf(stderr, "[feasthip analyze] analyze_pattern total        %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         // arena destination of every entry (a binary search in the supernode's row structure): independent per column, fanned
         // out over host threads per term, beside the launch plans below; joined and uploaded after those
+        dest_ready.assign(terms_.size(), nullptr);
+        {
+            std::lock_guard<std::mutex> lk(g_sym_mu);
+            for (size_t ti = 0; ti < terms_.size() && ti < sym_entry->dest.size(); ++ti)
+                if (sym_entry->dest[ti] && (int64_t)sym_entry->dest[ti]->size() == terms_[ti].colptr[n]) dest_ready[ti] = sym_entry->dest[ti];
+        }
         for (size_t ti = 0; ti < terms_.size(); ++ti)
-            dest_pool.emplace_back([&, ti]() {
+            if (!dest_ready[ti]) dest_pool.emplace_back([&, ti]() {
                 SparseTerm& T = terms_[ti];
                 TermHost& H = th[ti];
                 int64_t nnz = T.colptr[n];
@@ -1083,7 +1104,13 @@ int Engine::analyze() {
             TermHost& H = th[ti];
             if (H.bad == 1) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
             int64_t nnz = T.colptr[n];
-            if (H.bad == 2 || !T.d_dest.upload(H.dest.data(), nnz, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+            if (!dest_ready[ti]) {      // computed here: published for the next analysis of these patterns
+                auto sp2 = std::make_shared<const std::vector<int64_t>>(std::move(H.dest));
+                dest_ready[ti] = sp2;
+                std::lock_guard<std::mutex> lk(g_sym_mu);
+                if (sym_entry && ti < sym_entry->dest.size()) sym_entry->dest[ti] = sp2;
+            }
+            if (H.bad == 2 || !T.d_dest.upload(dest_ready[ti]->data(), nnz, stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
         }
     }
     // numeric arenas
