@@ -178,7 +178,7 @@ bool Engine::take_resources() {
     {
         std::lock_guard<std::mutex> lk(g_res_mu);
         auto& c = res_cache();
-        const std::string sig = res_signature();
+        const std::string& sig = res_sig_;
         size_t i = 0;
         for (; i < c.size(); ++i) if (c[i].device == device_ && c[i].sig == sig) break;
         if (i == c.size()) return false;
@@ -200,7 +200,7 @@ bool Engine::give_resources() {
         if (res_cache().size() >= 64) return false;          // (handles alive at once beyond that are not worth keeping warm)
     }
     HandleResources r;
-    r.device = device_; r.sig = res_signature();
+    r.device = device_; r.sig = res_sig_;          // the configuration the streams were CREATED under (the environment may have changed since)
     r.stream = stream_; r.la = la_stream_; r.fin = fin_stream_; r.rest = rest_stream_;
     r.aux = std::move(aux_streams_); r.up = std::move(up_streams_);
     r.ev_join = std::move(ev_join_); r.ev_chunk = std::move(ev_chunk_); r.ev_la = std::move(ev_la_);
@@ -222,6 +222,7 @@ Engine::Engine(int device) : device_(device) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(FEASTHIP_EHIP, "hipGetDeviceProperties failed"); return; }
     if (std::strstr(prop.gcnArchName, "gfx950") == nullptr) { fail(FEASTHIP_ENOGPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"); return; }
     if (hipSetDevice(device) != hipSuccess) { fail(FEASTHIP_EHIP, "hipSetDevice failed"); return; }
+    res_sig_ = res_signature();
     const bool recycled = take_resources();
     if (!recycled) {
         if (hipStreamCreate(&stream_) != hipSuccess) { fail(FEASTHIP_EHIP, "hipStreamCreate failed"); return; }

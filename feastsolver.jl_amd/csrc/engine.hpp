@@ -211,6 +211,7 @@ private:
     static constexpr int PIN_SLOTS = 8;
     static constexpr size_t PIN_SLOT_BYTES = (size_t)1 << 20;
     char* pin_ = nullptr;
+    std::string res_sig_;                // stream configuration (environment switches) this handle was created under
     bool take_resources();               // streams / events / pinned slots of an earlier handle of this device (engine.hip: HandleResources)
     bool give_resources();
     void* pin_slot(int slot, size_t bytes) { return (pin_ && bytes <= PIN_SLOT_BYTES) ? (void*)(pin_ + (size_t)slot * PIN_SLOT_BYTES) : nullptr; }
