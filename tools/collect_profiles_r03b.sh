@@ -3,7 +3,7 @@
 # serial CPU baseline of the 46^3 configuration beside the GPU work: 64 BLAS threads on the host tripled the launch-bound contour
 # steps of the lines collected there; the counter passes and the CPU line itself are what is kept from part 1).
 set -o pipefail
-O=gpurun_out/r03f; mkdir -p $O
+O=gpurun_out/r03g; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python bench.py > $O/bench_c3_g46.json 2> $O/bench_c3_g46.err || exit 1
 python bench.py --cpu-baseline off --no-fold > $O/bench_c3_g46_no_fold.json 2>> $O/bench.err
