@@ -1,0 +1,70 @@
+"""Randomised differential run: gen_feast on random small / medium pencils (sparse and dense, symmetric and not, real and complex,
+standard and generalized, odd sizes and block widths) against a dense host eigensolve.  Prints one line per case and a summary;
+exit status 1 if any case disagrees.  Usage: python tools/fuzz_feast.py [cases] [seed]"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp, scipy.linalg as sla
+import __graft_entry__ as graft
+pkg = graft.load_package(); wl = importlib.import_module(graft.PKG_NAME + ".workloads")
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+bad = 0
+t_start = time.time()
+for case in range(ncases):
+    n = int(rng.choice([3, 17, 33, 64, 100, 129, 257, 400, 777, 1200, 2000]))
+    sparse = bool(rng.integers(0, 2)) and n >= 17
+    sym = bool(rng.integers(0, 2))
+    cplx = bool(rng.integers(0, 2))
+    gen = bool(rng.integers(0, 2))
+    K = int(rng.choice([4, 8, 16]))
+    if sparse:
+        dens = min(1.0, float(rng.uniform(2.0, 12.0)) / n)
+        S = sp.random(n, n, density=dens, random_state=np.random.RandomState(int(rng.integers(1 << 30))), data_rvs=lambda k: rng.standard_normal(k))
+        if cplx: S = S + 1j * sp.random(n, n, density=dens, random_state=np.random.RandomState(int(rng.integers(1 << 30))), data_rvs=lambda k: rng.standard_normal(k))
+        A = (S + (S.T if not cplx or not sym else S.conj().T)) if sym else (S + 0.3 * S.T)
+        A = (A + sp.diags(np.arange(n) * 0.05)).tocsc()
+        Ad = A.toarray()
+    else:
+        G = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+        Ad = (G + G.conj().T) / 2 if sym else G
+        Ad = Ad / np.sqrt(n) + np.diag(np.arange(n) * (2.0 / n))
+        A = Ad
+    if gen:
+        bd = rng.uniform(0.5, 1.5, n)
+        B = sp.diags(bd).tocsc() if sparse else np.diag(bd)
+        Bd = np.diag(bd)
+    else:
+        B, Bd = None, np.eye(n)
+    lam_all = sla.eigvals(Ad, Bd)
+    # a disc around a random eigenvalue holding 1..6 eigenvalues, with a gap to the next one
+    c = lam_all[int(rng.integers(0, n))]
+    dist = np.sort(np.abs(lam_all - c))
+    kin = int(rng.integers(1, min(6, n) + 1))
+    if kin >= n: kin = n - 1 if n > 1 else 1
+    r = 0.5 * (dist[kin - 1] + dist[kin]) if kin < n else dist[-1] * 1.5 + 0.1
+    if kin < n and (dist[kin] - dist[kin - 1]) < 0.2 * r:
+        continue                                    # eigenvalues within 10 % of the contour on either side: FEAST itself converges slowly or not at
+                                                    # all there with few nodes (the CPU oracle shows the same histories), nothing to compare
+    m0 = min(n, int(kin * rng.uniform(1.5, 3.0)) + 2)
+    X0 = wl.rand_x0(n, m0, int(rng.integers(1 << 30)))
+    con = pkg.circular_contour_trapezoidal(complex(c), float(r), K)
+    info = {}
+    try:
+        lam, V, res = pkg.gen_feast(X0.copy(), A, B, con, iter=40, eps=1e-9, store=bool(rng.integers(0, 2)), info=info) if gen else \
+                      pkg.feast(X0.copy(), A, con, iter=40, eps=1e-9, store=bool(rng.integers(0, 2)), info=info)
+    except Exception as ex:
+        print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} K={K} m0={m0} EXCEPTION {ex}")
+        bad += 1
+        continue
+    ref = lam_all[np.abs(lam_all - c) <= r]
+    ok = len(lam) == len(ref) and (len(ref) == 0 or max(np.abs(lam - x).min() for x in ref) < 1e-6 * max(1.0, abs(c)))
+    if len(lam):
+        Rres = np.linalg.norm(Ad @ V - (Bd @ V) * lam[None, :], axis=0).max()
+        ok = ok and Rres < 1e-6 * max(1.0, np.abs(Ad).max())
+    else:
+        Rres = float("nan")
+    print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} K={K} m0={m0} inside {len(ref)} found {len(lam)} nit {info.get('nit')} "
+          f"res {Rres:.1e} symmetric_path {info.get('symmetric')} {'ok' if ok else 'MISMATCH'}", flush=True)
+    bad += 0 if ok else 1
+print(f"{ncases} cases, {bad} bad, {time.time() - t_start:.0f} s")
+sys.exit(1 if bad else 0)
