@@ -1,6 +1,6 @@
 """Randomised differential run: gen_feast on random small / medium pencils (sparse and dense, symmetric and not, real and complex,
 standard and generalized, odd sizes and block widths) against a dense host eigensolve.  Prints one line per case and a summary;
-exit status 1 if any case disagrees.  Usage: python tools/fuzz_feast.py [cases] [seed]"""
+exit status 1 if any case disagrees.  Usage: python tools/fuzz_feast.py [cases] [seed] [max n]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, scipy.linalg as sla
@@ -8,10 +8,12 @@ import __graft_entry__ as graft
 pkg = graft.load_package(); wl = importlib.import_module(graft.PKG_NAME + ".workloads")
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+sizes = [v for v in (3, 17, 33, 64, 100, 129, 257, 400, 777, 1200, 2000) if v <= nmax]
 bad = 0
 t_start = time.time()
 for case in range(ncases):
-    n = int(rng.choice([3, 17, 33, 64, 100, 129, 257, 400, 777, 1200, 2000]))
+    n = int(rng.choice(sizes))
     sparse = bool(rng.integers(0, 2)) and n >= 17
     sym = bool(rng.integers(0, 2))
     cplx = bool(rng.integers(0, 2))
