@@ -1397,3 +1397,15 @@ print("POISON_OK" if ok else "POISON_DIFF")
 """ % root
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FEASTHIP_POOL_POISON="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "POISON_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("tool,args", [("fuzz_feast.py", ["60", "7", "400"]), ("fuzz_seam.py", ["120", "3"]), ("fuzz_nlfeast.py", ["40", "5"])])
+def test_randomised_differential_runs(gpu, tool, args):
+    """The randomised drivers under tools/ with fixed seeds: feast / gen_feast against a dense host eigensolve, lu / ldiv against a host
+    solve around the block edges, nlfeast against the companion spectrum.  They exit non-zero on the first family of disagreements."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
+    tail = "\n".join(p.stdout.strip().splitlines()[-6:])
+    assert p.returncode == 0, tail + "\n" + p.stderr[-2000:]
+    assert " 0 bad" in tail
