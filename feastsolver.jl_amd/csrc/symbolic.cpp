@@ -63,28 +63,46 @@ Graph symmetrize(int n, const int64_t* colptr, const int64_t* rowidx) {
             for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) tr[pos[rowidx[t]]++] = j;
     }
     g.xadj.assign(n + 1, 0);
-    g.adj.resize((size_t)colptr[n] + (size_t)tp[n]);
-    std::vector<int> own;
-    int64_t len = 0;
-    for (int j = 0; j < n; ++j) {
-        const int64_t c0 = colptr[j], c1 = colptr[j + 1];
-        bool sorted = true;
-        for (int64_t t = c0 + 1; t < c1 && sorted; ++t) sorted = rowidx[t - 1] < rowidx[t];
-        own.resize(c1 - c0);
-        for (int64_t t = c0; t < c1; ++t) own[t - c0] = (int)rowidx[t];
-        if (!sorted) { std::sort(own.begin(), own.end()); own.erase(std::unique(own.begin(), own.end()), own.end()); }
-        const int* a = own.data(); const int* ae = a + own.size();
-        const int* r = tr.data() + tp[j]; const int* re = tr.data() + tp[j + 1];
-        while (a < ae || r < re) {
-            int v;
-            if (r >= re || (a < ae && *a < *r)) v = *a++;
-            else if (a >= ae || *r < *a) v = *r++;
-            else { v = *a; ++a; ++r; }
-            if (v != j && (len == g.xadj[j] || g.adj[len - 1] != v)) g.adj[len++] = v;     // (duplicate entries of a column show up twice in its row)
+    // column ranges on host threads, each into its own list; concatenated in order (the result does not depend on the thread count)
+    const int nth = n >= 20000 ? std::max(1, std::min(8, host_cpu_budget() / 2)) : 1;
+    std::vector<std::vector<int>> part(nth);
+    auto merge_range = [&](int ti) {
+        const int j0 = (int)((int64_t)n * ti / nth), j1 = (int)((int64_t)n * (ti + 1) / nth);
+        std::vector<int>& out = part[ti];
+        out.reserve((size_t)(colptr[j1] - colptr[j0]) + (size_t)(tp[j1] - tp[j0]));
+        std::vector<int> own;
+        for (int j = j0; j < j1; ++j) {
+            const int64_t c0 = colptr[j], c1 = colptr[j + 1];
+            bool sorted = true;
+            for (int64_t t = c0 + 1; t < c1 && sorted; ++t) sorted = rowidx[t - 1] < rowidx[t];
+            own.resize(c1 - c0);
+            for (int64_t t = c0; t < c1; ++t) own[t - c0] = (int)rowidx[t];
+            if (!sorted) { std::sort(own.begin(), own.end()); own.erase(std::unique(own.begin(), own.end()), own.end()); }
+            const int* a = own.data(); const int* ae = a + own.size();
+            const int* r = tr.data() + tp[j]; const int* re = tr.data() + tp[j + 1];
+            const size_t start = out.size();
+            while (a < ae || r < re) {
+                int v;
+                if (r >= re || (a < ae && *a < *r)) v = *a++;
+                else if (a >= ae || *r < *a) v = *r++;
+                else { v = *a; ++a; ++r; }
+                if (v != j && (out.size() == start || out.back() != v)) out.push_back(v);     // (duplicate entries of a column show up twice in its row)
+            }
+            g.xadj[j + 1] = (int64_t)(out.size() - start);       // length for now, offsets below
         }
-        g.xadj[j + 1] = len;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int ti = 1; ti < nth; ++ti) pool.emplace_back(merge_range, ti);
+        merge_range(0);
+        for (auto& th : pool) th.join();
     }
-    g.adj.resize(len);
+    for (int j = 0; j < n; ++j) g.xadj[j + 1] += g.xadj[j];
+    g.adj.resize(g.xadj[n]);
+    {
+        int64_t off = 0;
+        for (int ti = 0; ti < nth; ++ti) { std::copy(part[ti].begin(), part[ti].end(), g.adj.begin() + off); off += (int64_t)part[ti].size(); }
+    }
     return g;
 }
 
@@ -94,11 +112,19 @@ Graph permute_graph(const Graph& g, const std::vector<int>& perm, const std::vec
     h.xadj.assign(g.n + 1, 0);
     h.adj.resize(g.adj.size());
     for (int j = 0; j < g.n; ++j) h.xadj[j + 1] = h.xadj[j] + (g.xadj[perm[j] + 1] - g.xadj[perm[j]]);
-    for (int j = 0; j < g.n; ++j) {
-        int64_t o = h.xadj[j];
-        for (int64_t t = g.xadj[perm[j]]; t < g.xadj[perm[j] + 1]; ++t) h.adj[o++] = iperm[g.adj[t]];
-        std::sort(h.adj.begin() + h.xadj[j], h.adj.begin() + h.xadj[j + 1]);
-    }
+    // columns are independent: ranges of them on host threads (the analysis calls this three times; 4-5 ms each on one core for C3)
+    auto fill = [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j) {
+            int64_t o = h.xadj[j];
+            for (int64_t t = g.xadj[perm[j]]; t < g.xadj[perm[j] + 1]; ++t) h.adj[o++] = iperm[g.adj[t]];
+            std::sort(h.adj.begin() + h.xadj[j], h.adj.begin() + h.xadj[j + 1]);
+        }
+    };
+    const int nth = g.n >= 20000 ? std::max(1, std::min(8, host_cpu_budget() / 2)) : 1;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(fill, (int)((int64_t)g.n * t / nth), (int)((int64_t)g.n * (t + 1) / nth));
+    fill(0, (int)((int64_t)g.n / nth));
+    for (auto& th : pool) th.join();
     return h;
 }
 
