@@ -162,7 +162,7 @@ static void trim_handle_resources() {
     (void)hipGetDevice(&cur);
     for (HandleResources& r : sets) {
         (void)hipSetDevice(r.device);
-        for (hipStream_t s2 : r.up) (void)hipStreamDestroy(s2);
+        for (hipStream_t s2 : r.up) if (s2) (void)hipStreamDestroy(s2);
         for (hipStream_t s2 : r.aux) (void)hipStreamDestroy(s2);
         for (hipStream_t s2 : {r.la, r.rest, r.fin, r.stream}) if (s2) (void)hipStreamDestroy(s2);
         for (auto* v : {&r.ev_join, &r.ev_chunk, &r.ev_la}) for (hipEvent_t e2 : *v) if (e2) (void)hipEventDestroy(e2);
@@ -296,11 +296,11 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     pool_drop_device(device_);       // the cache holds at most what ONE handle used: earlier leftovers go back to the driver now
-    for (hipStream_t s2 : up_streams_) (void)hipStreamSynchronize(s2);
+    for (hipStream_t s2 : up_streams_) if (s2) (void)hipStreamSynchronize(s2);
     for (hipStream_t s2 : aux_streams_) (void)hipStreamSynchronize(s2);
     for (hipStream_t s2 : {la_stream_, rest_stream_, fin_stream_}) if (s2) (void)hipStreamSynchronize(s2);
     if (give_resources()) return;
-    for (hipStream_t s2 : up_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
+    for (hipStream_t s2 : up_streams_) if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipStream_t s2 : aux_streams_) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     for (hipEvent_t e2 : ev_join_) (void)hipEventDestroy(e2);
     for (hipEvent_t e2 : ev_chunk_) (void)hipEventDestroy(e2);
@@ -893,11 +893,7 @@ int Engine::analyze() {
         // term, created once per handle (a stream gets its hardware queue with its first operation: 25-30 ms).
         if (analyzed_once_) HIPCHK(hipStreamSynchronize(stream_));      // (the first analysis of a handle has nothing to wait for)
         analyzed_once_ = true;
-        while (up_streams_.size() < terms_.size()) {
-            hipStream_t us = nullptr;
-            if (hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) return fail(FEASTHIP_EHIP, "analyze: stream creation failed");
-            up_streams_.push_back(us);
-        }
+        if (up_streams_.size() < terms_.size()) up_streams_.resize(terms_.size(), nullptr);      // created by the helper threads themselves (3 ms each)
         for (size_t ti = 0; ti < terms_.size(); ++ti)
             csr_pool.emplace_back([&, ti]() {
                 const SparseTerm& T = terms_[ti];
@@ -927,8 +923,9 @@ int Engine::analyze() {
                 }
                 // ... and uploads them (and the CSC values the factorisation scatters) from this thread, on its own stream
                 SparseTerm& Tw = terms_[ti];
-                hipStream_t us = up_streams_[ti];
                 bool ok = hipSetDevice(device_) == hipSuccess;
+                if (ok && !up_streams_[ti] && hipStreamCreateWithFlags(&up_streams_[ti], hipStreamNonBlocking) != hipSuccess) { up_streams_[ti] = nullptr; ok = false; }
+                hipStream_t us = up_streams_[ti];
                 ok = ok && Tw.d_cscval.upload((const cz*)T.val.data(), nnz, us) && Tw.d_rowptr.upload(H.rp.data(), n + 1, us) &&
                      Tw.d_col.upload(H.col.data(), nnz, us) && Tw.d_val.upload((const cz*)H.v.data(), nnz, us);
                 if (!ok) H.bad = 2;
