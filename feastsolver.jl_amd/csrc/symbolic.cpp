@@ -323,9 +323,11 @@ private:
         }
         auto t_b = std::chrono::steady_clock::now();
         if (ml_async) { tml.join(); if (best_ml.cost < best.cost) best = std::move(best_ml); }
+        else if (m >= ml_min_) multilevel_candidate(verts, id, ml_seed, best);
+        // (until late in round 3 this `else` hung on the trace line below: without FEASTHIP_ANALYZE_TRACE the three top levels computed
+        // their multilevel separator a second time, serially, with the same seed and the same result -- 57 ms of every untraced analysis)
         if (tr_) fprintf(stderr, "[feasthip nd depth %d m=%d] bfs candidates %.1f ms, + wait for multilevel %.1f ms\n", depth, m,
                          std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
-        else if (m >= ml_min_) multilevel_candidate(verts, id, ml_seed, best);
         if (best.s.empty() || best.a.empty() || best.b.empty()) { emit(verts, lo); return; }
         verts.clear(); verts.shrink_to_fit();
         int na = (int)best.a.size(), nb = (int)best.b.size();
