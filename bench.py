@@ -405,7 +405,11 @@ def main():
                        # (ordering + symbolic analysis, the factorisations, and the iterations up to residual < eps)
                        "iterations_to_eps": conv["at"], "eps": w["eps"],
                        "time_to_solution_s": (t_analyze + st["factor_ms"] * 1e-3 + conv["at"] * dt / args.steps) if conv["at"] is not None else None,
-                       "eigenpairs_per_s": (float(ins.sum()) / (t_analyze + st["factor_ms"] * 1e-3 + conv["at"] * dt / args.steps)) if conv["at"] is not None else None},
+                       "eigenpairs_per_s": (float(ins.sum()) / (t_analyze + st["factor_ms"] * 1e-3 + conv["at"] * dt / args.steps)) if conv["at"] is not None else None,
+                       # the same without setup.alloc_s: what the first multi-GB hipMalloc of a process costs depends on what the box's previous
+                       # process left for the driver to scrub (0.001 .. 1.2 s for the same request), not on this library
+                       "time_to_solution_without_alloc_s": (t_analyze - st["alloc_seconds"] + st["factor_ms"] * 1e-3 + conv["at"] * dt / args.steps) if conv["at"] is not None else None,
+                       "eigenpairs_per_s_without_alloc": (float(ins.sum()) / (t_analyze - st["alloc_seconds"] + st["factor_ms"] * 1e-3 + conv["at"] * dt / args.steps)) if conv["at"] is not None else None},
         }
         if world == 1 and args.cpu_baseline != "off":
             h.close()
