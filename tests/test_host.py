@@ -104,6 +104,28 @@ def test_symbolic_quality_3d(lib, wl):
     assert stats[6] < 40      # tree depth stays logarithmic
 
 
+def test_ordering_does_not_depend_on_the_trace_switch(lib, wl, capfd):
+    """FEASTHIP_ANALYZE_TRACE only prints: the ordering and the supernodes are the same with and without it, on a graph large enough
+    for the threaded top levels of the dissection (the switch once decided whether those levels ran their multilevel separator once
+    or twice), and the analysis is reproducible run to run."""
+    A = wl.laplacian_3d(28, 7)          # 21,952 vertices: the asynchronous multilevel path of the top level
+    runs = []
+    for trace in (None, "1", None):
+        old = os.environ.pop("FEASTHIP_ANALYZE_TRACE", None)
+        if trace:
+            os.environ["FEASTHIP_ANALYZE_TRACE"] = trace
+        try:
+            stats, perm, snof, *_ = _probe(lib, A)
+        finally:
+            os.environ.pop("FEASTHIP_ANALYZE_TRACE", None)
+            if old is not None:
+                os.environ["FEASTHIP_ANALYZE_TRACE"] = old
+        runs.append((stats.copy(), perm.copy(), snof.copy()))
+    capfd.readouterr()
+    for st, pm, sn in runs[1:]:
+        assert (st == runs[0][0]).all() and (pm == runs[0][1]).all() and (sn == runs[0][2]).all()
+
+
 def test_small_eig_matches_lapack(lib):
     rng = np.random.default_rng(11)
     for m in (1, 2, 5, 16, 33, 64):
