@@ -359,30 +359,32 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
     const bool trace = n > 50000 && getenv("FEASTHIP_ANALYZE_TRACE");
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* nm) { if (!trace) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[feasthip nd n=%d] %-18s %.1f ms\n", n, nm, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
-    std::vector<WGraph> levels;
+    std::vector<WGraph> coarse;                  // levels 1, 2, ...; level 0 is g0 itself (not copied: 14 MB at the top of C3's dissection)
     std::vector<std::vector<int>> cmaps;
-    levels.push_back(g0);
-    while (levels.back().n > 160 && levels.size() < 40) {
+    auto level = [&](int l) -> const WGraph& { return l == 0 ? g0 : coarse[l - 1]; };
+    int nlev = 1;
+    while (level(nlev - 1).n > 160 && nlev < 40) {
         WGraph c;
         std::vector<int> cmap;
-        if (!coarsen(levels.back(), c, cmap, rng)) break;
-        levels.push_back(std::move(c));
+        if (!coarsen(level(nlev - 1), c, cmap, rng)) break;
+        coarse.push_back(std::move(c));
         cmaps.push_back(std::move(cmap));
+        ++nlev;
     }
     lap("coarsening");
     std::vector<int> part;
     // greedy graph growing from random seeds: the small subgraphs deep in the dissection (most of the calls, each a few hundred
     // vertices) get fewer tries -- their separators bound small fronts, and the tries were most of their cost
     const int trials = getenv("FEASTHIP_IP_TRIALS") ? atoi(getenv("FEASTHIP_IP_TRIALS")) : (n >= 20000 ? 10 : n >= 2000 ? 6 : 4);
-    initial_partition(levels.back(), part, rng, trials);
+    initial_partition(level(nlev - 1), part, rng, trials);
     lap("initial partition");
-    for (int l = (int)levels.size() - 1; l >= 0; --l) {
-        if (l < (int)levels.size() - 1) {
-            std::vector<int> fine(levels[l].n);
-            for (int v = 0; v < levels[l].n; ++v) fine[v] = part[cmaps[l][v]];
+    for (int l = nlev - 1; l >= 0; --l) {
+        if (l < nlev - 1) {
+            std::vector<int> fine(level(l).n);
+            for (int v = 0; v < level(l).n; ++v) fine[v] = part[cmaps[l][v]];
             part.swap(fine);
         }
-        FM fm(levels[l], part);
+        FM fm(level(l), part);
         for (int it = 0; it < 8; ++it) if (!fm.pass(0.54)) break;
     }
     lap("FM refinement");
