@@ -206,6 +206,10 @@ bool Engine::give_resources() {
     r.ev_join = std::move(ev_join_); r.ev_chunk = std::move(ev_chunk_); r.ev_la = std::move(ev_la_);
     r.ev0 = ev0_; r.ev1 = ev1_; r.ev_p0 = ev_p0_; r.ev_p1 = ev_p1_; r.ev_fork = ev_fork_; r.ev_fin = ev_fin_; r.ev_fin_fork = ev_fin_fork_;
     r.pin = pin_; r.warm = streams_warm_;
+    // the kept sets are destroyed when the process exits normally, while the HIP runtime (loaded before this library, so torn down
+    // after its atexit handlers) is still there: tools that finalise at exit (rocprofv3 counter passes) otherwise find live queues
+    static std::once_flag at_exit_once;
+    std::call_once(at_exit_once, [] { std::atexit([] { trim_handle_resources(); }); });
     std::lock_guard<std::mutex> lk(g_res_mu);
     res_cache().push_back(std::move(r));
     stream_ = la_stream_ = fin_stream_ = rest_stream_ = nullptr;
