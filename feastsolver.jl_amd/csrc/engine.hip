@@ -2,6 +2,7 @@
 // Reference semantics: src/feast.jl:10-80, 89-156; src/utils.jl:69-77, 104-116, 151-179.
 #include "engine_impl.hpp"
 #include <memory>
+#include <unistd.h>
 
 namespace feasthip {
 
@@ -147,6 +148,7 @@ struct HandleResources {
     bool warm = false;
 };
 static std::mutex g_res_mu;
+static long g_res_pid = 0;
 static std::vector<HandleResources>& res_cache() { static std::vector<HandleResources>* v = new std::vector<HandleResources>(); return *v; }   // (never destroyed: the HIP runtime may be gone by then)
 static std::string res_signature() {
     std::string s;
@@ -209,7 +211,7 @@ bool Engine::give_resources() {
     // the kept sets are destroyed when the process exits normally, while the HIP runtime (loaded before this library, so torn down
     // after its atexit handlers) is still there: tools that finalise at exit (rocprofv3 counter passes) otherwise find live queues
     static std::once_flag at_exit_once;
-    std::call_once(at_exit_once, [] { std::atexit([] { trim_handle_resources(); }); });
+    std::call_once(at_exit_once, [] { g_res_pid = (long)getpid(); std::atexit([] { if ((long)getpid() == g_res_pid) trim_handle_resources(); }); });      // (not in a forked child: its HIP state is not its own)
     std::lock_guard<std::mutex> lk(g_res_mu);
     res_cache().push_back(std::move(r));
     stream_ = la_stream_ = fin_stream_ = rest_stream_ = nullptr;
