@@ -51,9 +51,10 @@ for case in range(ncases):
     X0 = wl.rand_x0(n, m0, int(rng.integers(1 << 30)))
     con = pkg.circular_contour_trapezoidal(complex(c), float(r), K)
     info = {}
+    mixed = (not gen) and bool(rng.integers(0, 4) == 0)          # feast!'s mixed_prec: complex64 shifted solves, complex128 accumulation
     try:
         lam, V, res = pkg.gen_feast(X0.copy(), A, B, con, iter=40, eps=1e-9, store=bool(rng.integers(0, 2)), info=info) if gen else \
-                      pkg.feast(X0.copy(), A, con, iter=40, eps=1e-9, store=bool(rng.integers(0, 2)), info=info)
+                      pkg.feast(X0.copy(), A, con, iter=40, eps=1e-9, store=bool(rng.integers(0, 2)), mixed_prec=mixed, info=info)
     except Exception as ex:
         print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} K={K} m0={m0} EXCEPTION {ex}")
         bad += 1
@@ -65,7 +66,7 @@ for case in range(ncases):
         ok = ok and Rres < 1e-6 * max(1.0, np.abs(Ad).max())
     else:
         Rres = float("nan")
-    print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} K={K} m0={m0} inside {len(ref)} found {len(lam)} nit {info.get('nit')} "
+    print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} mixed={mixed} K={K} m0={m0} inside {len(ref)} found {len(lam)} nit {info.get('nit')} "
           f"res {Rres:.1e} symmetric_path {info.get('symmetric')} {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
 print(f"{ncases} cases, {bad} bad, {time.time() - t_start:.0f} s")
