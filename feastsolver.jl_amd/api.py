@@ -790,7 +790,9 @@ class HipLU:
         self.info = info          # > 0: number of statically perturbed pivots (LAPACK info convention)
         sym, gr = C.c_int(0), C.c_double(0.0)
         lib.feasthip_fact_info(handle, C.byref(sym), C.byref(gr), None)
-        self.symmetric, self.growth = bool(sym.value), gr.value     # pivot-light elimination (C == C^T, growth-checked) or partial pivoting
+        # path 1: pivot-light elimination of a symmetric matrix (C == C^T, U = D L^T); 2: elimination without interchanges of a matrix that is
+        # Hermitian off its diagonal (L and U apart); 0: partial pivoting.  growth: what the growth check of paths 1 / 2 saw.
+        self.path, self.symmetric, self.growth = sym.value, sym.value == 1, gr.value
 
     def __del__(self):
         try:

@@ -187,7 +187,7 @@ int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     o->perturbed_pivots = e->perturbed; o->local_nodes = e->nodes_local(); o->m0 = e->m0; o->ldw = e->ldw; o->dense = e->dense ? 1 : 0;
     o->factor_units = e->Kloc; o->folded = e->folded() ? 1 : 0; o->solve_bytes_streamed = e->ldw ? e->solve_bytes_streamed() : 0;
     o->proj_ms = e->proj_ms;
-    o->symmetric = e->nopiv_used ? 1 : 0; o->growth = e->growth;
+    o->symmetric = e->nopiv_used ? 1 : e->nopiv_gen_used ? 2 : 0; o->growth = e->growth;
     return 0;
     ENDGUARD(h)
 }
@@ -314,7 +314,7 @@ int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_
 
 int feasthip_fact_info(feasthip_fact_t F, int* symmetric, double* growth, int64_t* perturbed) {
     if (!F || !F->e) return FEASTHIP_EARG;
-    if (symmetric) *symmetric = F->e->nopiv_used ? 1 : 0;
+    if (symmetric) *symmetric = F->e->nopiv_used ? 1 : F->e->nopiv_gen_used ? 2 : 0;
     if (growth) *growth = F->e->growth;
     if (perturbed) *perturbed = F->e->perturbed;
     return 0;

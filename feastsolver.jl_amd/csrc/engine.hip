@@ -252,6 +252,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FWD_SPLITK")) fwd_splitk_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
+    if (const char* v = getenv("FEASTHIP_NOPIV_GEN")) nopiv_gen_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
@@ -369,12 +370,12 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
     terms_.clear();
     terms_.resize(nterms);
     terms_real_ = false;
-    bool real = true, sym = true;
+    bool real = true, sym = true, herm = true;
     // The caller's bytes go to the device as they are; element type, storage order (FEASTHIP_ROW_MAJOR), max |a_ij|, realness and
     // M == M^T (exactly) are dealt with there (k_dense_import): the host touches the matrix once, for the copy.
     DevBuf<int64_t> d_props;
     DevBuf<cz> d_stage;
-    if (!d_props.alloc(3)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
+    if (!d_props.alloc(4)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
     for (int t = 0; t < nterms; ++t) {
         SparseTerm& T = terms_[t];
         T.scale = scale ? zc(scale[2 * t], scale[2 * t + 1]) : zc(1.0);
@@ -391,10 +392,10 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
             if (!d_stage.alloc((nn * esz + 15) / 16)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
             raw = d_stage.p;
         }
-        HIPCHK(hipMemsetAsync(d_props.p, 0, 3 * sizeof(int64_t), stream_));
+        HIPCHK(hipMemsetAsync(d_props.p, 0, 4 * sizeof(int64_t), stream_));
         HIPCHK(hipMemcpyAsync(raw, mats[t], nn * esz, hipMemcpyHostToDevice, stream_));
         launch_dense_import(stream_, raw, ty, row_major, n, T.d_dense.p, reinterpret_cast<unsigned long long*>(d_props.p));
-        int64_t props[3] = {0, 0, 0};
+        int64_t props[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(props, d_props.p, sizeof(props), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipGetLastError());
@@ -403,11 +404,14 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
         T.maxabs = mx;
         if (props[1]) real = false;
         if (props[2]) sym = false;
+        if (props[3]) herm = false;
     }
     for (auto& T : terms_) if (T.scale.imag() != 0.0) real = false;
     terms_real_ = real;
     terms_symmetric_ = sym;
+    terms_hermitian_ = herm;
     nopiv_failed_ = false;
+    nopiv_gen_failed_ = false;
     rebuild_shard();
     return 0;
 }
@@ -463,7 +467,9 @@ int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const
     }
     terms_real_ = real;
     terms_symmetric_ = false;          // decided in analyze(), where the transposes of the terms are built anyway
+    terms_hermitian_ = false;
     nopiv_failed_ = false;
+    nopiv_gen_failed_ = false;
     rebuild_shard();
     return 0;
 }
@@ -860,7 +866,7 @@ int Engine::analyze() {
     }
     struct JoinWarm { std::thread& t; ~JoinWarm() { if (t.joinable()) t.join(); } } join_warm{warm};
     // per-term host work that runs beside the ordering (CSR copies + their uploads) and beside the launch plans (arena destinations)
-    struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, diag = 0; };
+    struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, herm = 0, diag = 0; };
     std::vector<TermHost> th;
     std::shared_ptr<SymCacheEntry> sym_entry;      // the cache entry this analysis came from / went to (sparse terms)
     std::vector<std::shared_ptr<const std::vector<int64_t>>> dest_ready;    // arena destinations found in it, per term
@@ -920,6 +926,15 @@ int Engine::analyze() {
                     for (int j = 0; j <= n && eq; ++j) eq = H.rp[j] == T.colptr[j];
                     for (int64_t e2 = 0; e2 < nnz && eq; ++e2) eq = H.col[e2] == T.rowval[e2] && H.v[e2] == T.val[e2];
                     H.sym = eq ? 1 : 0;
+                    // ... and M == M^H off the diagonal iff they equal them up to conjugation of the values (the diagonal is left out:
+                    // an assembled shifted matrix z I - A, z D - A of a Hermitian pencil has a complex diagonal and is as good a
+                    // candidate for the elimination without interchanges as the pencil's terms; the growth check decides)
+                    bool eqh = true;
+                    for (int j = 0; j <= n && eqh; ++j) eqh = H.rp[j] == T.colptr[j];
+                    for (int j = 0; j < n && eqh; ++j)
+                        for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1] && eqh; ++e2)
+                            eqh = H.col[e2] == T.rowval[e2] && (T.rowval[e2] == j || H.v[e2] == std::conj(T.val[e2]));
+                    H.herm = eqh ? 1 : 0;
                 }
                 {   // entries on the diagonal only: the Rayleigh-Ritz step then scales rows instead of running SpMM products
                     bool dg = !dense;
@@ -1092,7 +1107,8 @@ int Engine::analyze() {
         for (auto& t2 : dest_pool) t2.join();
         for (auto& t2 : csr_pool) t2.join();
         terms_symmetric_ = true;
-        for (TermHost& H : th) if (!H.sym) terms_symmetric_ = false;
+        terms_hermitian_ = true;
+        for (TermHost& H : th) { if (!H.sym) terms_symmetric_ = false; if (!H.herm) terms_hermitian_ = false; }
         for (size_t ti = 0; ti < terms_.size(); ++ti) {
             SparseTerm& T = terms_[ti];
             T.diagonal = th[ti].diag != 0;
@@ -1123,7 +1139,7 @@ int Engine::analyze() {
     ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
          d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
          d_rowperm_.alloc((size_t)Kloc * n) && d_rowinv_.alloc((size_t)Kloc * n) && d_nperturb_.alloc(Kloc) &&
-         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)2 * Kloc) && d_wscr_.alloc((size_t)Kloc * wstride_ * (4 * 1024 + 128)) && d_coef_.alloc((size_t)Kloc * nterms);
+         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)3 * Kloc) && d_wscr_.alloc((size_t)Kloc * wstride_ * (4 * 1024 + 128)) && d_coef_.alloc((size_t)Kloc * nterms);
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
     alloc_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + arena destinations, CSR    %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);

@@ -149,6 +149,7 @@ public:
     Symbolic S;
     int n = 0, nterms = 0, K = 0, Kloc = 0, m0 = 0, ldw = 0;
     bool dense = false;
+    bool nopiv_gen_used = false;          // ... the elimination without interchanges for Hermitian (not symmetric) pencils
     bool nopiv_used = false;              // the last factorisation ran the pivot-light path (symmetric pencil) and passed its growth check
     double growth = 0;                    // max |l_ij| it saw (0 on the pivoted path, where |l_ij| <= 1 by construction)
     double solve_bytes() const;           // algorithmic bytes of one contour step (per contour NODE)
@@ -169,10 +170,13 @@ private:
     std::vector<int> partner_;             // conjugate fold: index of the mirror node of local_[kk], else -1
     bool fold_ = false, fold_enabled_ = true, terms_real_ = false;
     bool analyzed_once_ = false;           // analyze() ran on this handle before (its device buffers may be in use by queued work)
+    bool terms_hermitian_ = false;         // every coefficient matrix equals its conjugate transpose (elimination without interchanges, L and U apart)
+    bool nopiv_gen_enabled_ = true, nopiv_gen_failed_ = false;      // FEASTHIP_NOPIV_GEN=0; set when the growth check rejected it for this handle's matrices
     bool terms_symmetric_ = false;         // every coefficient matrix equals its transpose: T(z) = T(z)^T for all z (pivot-light factorisation)
     bool nopiv_enabled_ = true, nopiv_failed_ = false;   // FEASTHIP_NOPIV=0 / a factorisation whose growth check failed: pivoted path from then on
     double nopiv_max_growth_ = 1024.0;     // largest multiplier |l_ij| the pivot-light path may produce (FEASTHIP_NOPIV_GROWTH)
     bool use_nopiv() const { return terms_symmetric_ && nopiv_enabled_ && !nopiv_failed_; }
+    bool use_nopiv_gen() const { return terms_hermitian_ && !terms_symmetric_ && nopiv_enabled_ && nopiv_gen_enabled_ && !nopiv_gen_failed_; }
     void rebuild_shard();                  // local_ / partner_ / fold_ / Kloc from contour, shard, terms and overrides
     template <class F> std::vector<zc> node_table(F f, int nq = 1) const;   // [q][unit][solve_width] table of f(node, column, q) for the accumulation kernel
     int shard_first_ = 0, shard_stride_ = 1;

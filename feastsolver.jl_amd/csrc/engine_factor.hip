@@ -49,7 +49,7 @@ int Engine::factorize() {
     HIPCHK(hipMemcpyAsync(d_coef_.p, coef.data(), coef.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(d_tiny_.p, tiny.data(), tiny.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemsetAsync(d_nperturb_.p, 0, Kloc * sizeof(int), stream_));
-    HIPCHK(hipMemsetAsync(d_growth_.p, 0, 2 * Kloc * sizeof(int64_t), stream_));
+    HIPCHK(hipMemsetAsync(d_growth_.p, 0, 3 * Kloc * sizeof(int64_t), stream_));
     const int64_t fs = S.fact_size;
     const Tile* tl = d_tiles_.p;
     const int* ls = d_lists_.p;
@@ -58,8 +58,20 @@ int Engine::factorize() {
     // columns (k_diag_grp / k_lscale_grp, U = D L^T), growth-checked afterwards; the trailing matrix and the contribution blocks
     // stay symmetric, so only their lower tile triangle is computed.
     const bool nopiv = use_nopiv();
+    // Hermitian pencil (every coefficient matrix equals its conjugate transpose, but not its transpose): no interchanges either,
+    // with L and U kept apart -- the pivoted schedule with its panel kernel replaced by k_diag32_gen / k_lscale32_gen and its
+    // interchange passes dropped (kernels_factor.hip)
+    const bool gen = !nopiv && use_nopiv_gen();
     const int sym_bits = nopiv ? 2 : 0;        // launch_gemm_nn: skip the U12 updates and the strictly upper tiles of the pivot block
     unsigned long long* growth_dev = reinterpret_cast<unsigned long long*>(d_growth_.p);
+    unsigned long long* umax_dev = gen ? growth_dev + 2 * (size_t)Kloc : nullptr;
+    auto panel = [&](hipStream_t s, FactorStep& st, bool tall, int level_ld) {
+        if (gen) {
+            launch_diag32_gen(s, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, growth_dev, d_wscr_.p, wstride_, Kloc);
+            launch_lscale32_gen(s, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, growth_dev, d_wscr_.p, wstride_, Kloc);
+        } else
+            launch_panel(s, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - st.k0);
+    };
     HIPCHK(hipEventRecord(ev0_, stream_));
     if (dense) {
         std::vector<const cz*> ptrs(nterms);
@@ -101,9 +113,9 @@ int Engine::factorize() {
             }
         } else if (!lookahead) {
             for (FactorStep& st : F.steps) {
-                launch_panel(stream_, dsym_, ls + st.panel.off, st.panel.count, st.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - st.k0);
-                launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
-                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc);
+                panel(stream_, st, tall, level_ld);
+                if (!gen) launch_swap(stream_, dsym_, tl + st.swap.off, st.swap.count, st.k0, d_fact_.p, fs, d_piv_.p, Kloc);
+                launch_trsm_u(stream_, dsym_, tl + st.trsm.off, st.trsm.count, st.k0, d_fact_.p, fs, Kloc, ColSel(), umax_dev);
                 launch_gemm_nn(stream_, dsym_, tl + st.gemm.off, st.gemm.count, st.k0, d_fact_.p, fs, cbp, cbs, Kloc);
             }
         } else {
@@ -141,11 +153,11 @@ int Engine::factorize() {
                 };
                 FactorStep& s0 = F.steps[j0];
                 const int gw = F.steps[j1 - 1].k0 + FACT_NB - k0g;        // group width
-                if (!nopiv) launch_swap(s, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, sel(k0g + gw), gw);
+                if (!nopiv && !gen) launch_swap(s, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, sel(k0g + gw), gw);
                 if (nopiv) {
                     // the group's U rows are already there (D L^T, written with the L columns)
                 } else if (s0.grp.count > 0 && fused_utrsm_) {       // U rows of the whole group in one launch
-                    launch_group_utrsm(s, dsym_, tl + s0.grp.off, s0.grp.count, k0g, gw, d_fact_.p, fs, Kloc, sel(k0g + gw));
+                    launch_group_utrsm(s, dsym_, tl + s0.grp.off, s0.grp.count, k0g, gw, d_fact_.p, fs, Kloc, sel(k0g + gw), umax_dev);
                 } else {
                     for (int j = j0; j < j1; ++j) {
                         FactorStep& sj = F.steps[j];
@@ -155,7 +167,7 @@ int Engine::factorize() {
                             launch_gemm_nn(s, dsym_, tl + s0.gemm0.off, s0.gemm0.count, k0g, d_fact_.p, fs, cbp, cbs, Kloc, c, bw, FACT_NB);
                         }
                         ColSel c = sel(sj.k0 + FACT_NB);
-                        launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                        launch_trsm_u(s, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c, umax_dev);
                     }
                 }
                 // the next group's columns are the first two tile columns right of this group: the short list does
@@ -177,15 +189,15 @@ int Engine::factorize() {
                 }
                 for (int j = j0; j < j1 && !nopiv; ++j) {
                     FactorStep& sj = F.steps[j];
-                    launch_panel(P, dsym_, ls + sj.panel.off, sj.panel.count, sj.k0, d_fact_.p, fs, d_piv_.p, d_tiny_.p, d_nperturb_.p, Kloc, tall, level_ld - sj.k0);
+                    panel(P, sj, tall, level_ld);
                     // inside the group: interchanges on the group's earlier L columns and its remaining columns, U rows and update
                     // of the remaining columns
                     ColSel c;
                     c.llo = k0g; c.lhi = sj.k0; c.clo = 0; c.chi = kend >= INF ? INF : std::max(0, kend - sj.k0 - FACT_NB); c.u12 = 0;
-                    launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
+                    if (!gen) launch_swap(P, dsym_, tl + sj.swap.off, sj.swap.count, sj.k0, d_fact_.p, fs, d_piv_.p, Kloc, c);
                     if (c.chi > 0) {
                         c.llo = c.lhi = 0;
-                        launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c);
+                        launch_trsm_u(P, dsym_, tl + sj.trsm.off, sj.trsm.count, sj.k0, d_fact_.p, fs, Kloc, c, umax_dev);
                         {
                             // columns left in the group fit the first two tile columns unless the groups are wider than 160
                             const Launch& gl = (G - 1) * FACT_NB <= 128 ? sj.gemm_in : sj.gemm;
@@ -259,9 +271,9 @@ int Engine::factorize() {
     }
     HIPCHK(hipEventRecord(ev1_, stream_));
     std::vector<int> np(Kloc);
-    std::vector<int64_t> gr((size_t)2 * Kloc, 0);
+    std::vector<int64_t> gr((size_t)3 * Kloc, 0);
     HIPCHK(hipMemcpyAsync(np.data(), d_nperturb_.p, Kloc * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    if (nopiv) HIPCHK(hipMemcpyAsync(gr.data(), d_growth_.p, 2 * Kloc * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+    if (nopiv || gen) HIPCHK(hipMemcpyAsync(gr.data(), d_growth_.p, 3 * Kloc * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
     float ms = 0;
@@ -269,7 +281,24 @@ int Engine::factorize() {
     perturbed = 0;
     for (int v : np) perturbed += v;
     nopiv_used = nopiv;
+    nopiv_gen_used = gen;
     growth = 0;
+    if (gen) {
+        // max |l_ij|, and max |pivot| and max |u_ij| relative to ||T(z_k)||
+        for (int kk = 0; kk < Kloc; ++kk) {
+            double l, d, u2;
+            std::memcpy(&l, &gr[kk], sizeof(l)); std::memcpy(&d, &gr[(size_t)Kloc + kk], sizeof(d)); std::memcpy(&u2, &gr[(size_t)2 * Kloc + kk], sizeof(u2));
+            growth = std::max(growth, std::max(l, std::max(d, u2) * 2.2e-19 / tiny[kk]));
+        }
+        if (!(growth <= nopiv_max_growth_) || perturbed > 0) {
+            if (getenv("FEASTHIP_FACTOR_TRACE")) fprintf(stderr, "[feasthip factor] elimination without interchanges rejected (growth %.3g, %lld perturbed pivots): refactorising with partial pivoting\n", growth, (long long)perturbed);
+            nopiv_gen_failed_ = true;
+            const double t_first = ms;
+            int r = factorize();
+            factor_ms += t_first;
+            return r;
+        }
+    }
     if (nopiv) {
         // growth = max over the units of max |l_ij| and of max |pivot| / ||T(z_k)|| (tiny[kk] = 2.2e-19 ||T(z_k)||): with
         // U = D L^T the product of the two bounds the element growth of the elimination

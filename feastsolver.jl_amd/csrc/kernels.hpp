@@ -53,11 +53,19 @@ void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 // columns right of the panel with offset in [clo, chi), U12 columns iff u12.  The default selects everything.
 struct ColSel { int llo = 0, lhi = 1 << 30, clo = 0, chi = 1 << 30, u12 = 1; };
 inline ColSel col_right(int clo, int chi) { ColSel c; c.llo = 0; c.lhi = 0; c.clo = clo; c.chi = chi; c.u12 = 0; return c; }
+// elimination without interchanges of a NOT symmetric panel (complex Hermitian pencils): diagonal 32 x 32 block, then the rows below it
+// (tile list: the step's 256-column slices, read as 256-row slices); growth: [K] max |l|, [K] max |pivot|, [K] max |u|
+void launch_diag32_gen(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
+                       const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K);
+void launch_lscale32_gen(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                         unsigned long long* growth, const cz* wscr, int64_t wstride, int K);
 void launch_swap(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                  const int* piv, int K, ColSel cs = ColSel(), int bw = FACT_NB);
-void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs = ColSel());
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs = ColSel(),
+                   unsigned long long* umax = nullptr);      // umax (per node, optional): max |u_ij| written, for the growth check of the eliminations without interchanges
 // U rows of a group of panels (gw <= 128 rows) for 32-column tiles of the columns right of the group
-void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int gw, cz* fact, int64_t fs, int K, ColSel cs);
+void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int gw, cz* fact, int64_t fs, int K, ColSel cs,
+                        unsigned long long* umax = nullptr);
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                     cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0,
                     const cz* cb_child = nullptr, int64_t cbs_child = 0,     // cb_child: fuse the children's extend-add into the contribution block (kind 2)

@@ -75,7 +75,7 @@ void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz
 // element type (Float64 / ComplexF64 / Int64 / ComplexF32) and the storage order (row-major callers: numpy) into the complex128
 // column-major copy the engine keeps, and collects max |a_ij| and "has an imaginary part" on the way; k_dense_symcheck then
 // compares the copy with its transpose.  props: [0] bits of max |a| (non-negative doubles order like their bit patterns),
-// [1] != 0: not real, [2] != 0: not equal to its transpose.  raw == out is allowed for complex128 column-major input.
+// [1] != 0: not real, [2] != 0: not equal to its transpose, [3] != 0: not equal to its conjugate transpose off the diagonal.  raw == out is allowed for complex128 column-major input.
 // (The first version did all of this on one host core before the upload: 1 s per 4096 x 4096 matrix.)
 __global__ __launch_bounds__(256) void k_dense_import(const void* raw, int type, int row_major, int n, cz* out, unsigned long long* props) {
     __shared__ cz tile[32][33];
@@ -116,10 +116,12 @@ __global__ __launch_bounds__(256) void k_dense_symcheck(int n, const cz* __restr
         const int i = bi + tx, j = bj + q;
         if (i < n && j < n && i > j) {
             const cz a = A[i + (int64_t)j * n], b = A[j + (int64_t)i * n];
-            if (!(a.x == b.x && a.y == b.y)) bad = 1;
+            if (!(a.x == b.x && a.y == b.y)) bad |= 1;
+            if (!(a.x == b.x && a.y == -b.y)) bad |= 2;
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(props + 2, 1ull);
+    if (__any(bad & 1) && (threadIdx.x & 63) == 0) atomicOr(props + 2, 1ull);
+    if (__any(bad & 2) && (threadIdx.x & 63) == 0) atomicOr(props + 3, 1ull);
 }
 
 void launch_dense_import(hipStream_t st, const void* raw, int type, int row_major, int n, cz* out, unsigned long long* props) {
@@ -844,6 +846,129 @@ void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 }
 
 // ---------------------------------------------------------------------------
+// Elimination without interchanges for pencils that are NOT symmetric (complex Hermitian A, B: z B - A has a definite
+// "imaginary part" exactly like the real symmetric case, but U != D L^T and T(conj z) != conj(T(z))).  It keeps the schedule and
+// every other kernel of the pivoted path (U rows by k_trsm_u / k_group_utrsm, products by k_gemm_nn, solve-ready conversion from
+// L\U) and replaces its two latency chains: the one-workgroup-per-front panel with its pivot search becomes
+//   k_diag32_gen    the 32 x 32 diagonal block of the panel eliminated in LDS (L\U in place, W = inv(U) to the scratch slot,
+//                   identity pivots), one workgroup per (front, node), and
+//   k_lscale32_gen  the rows below, one per thread over as many workgroups as there are rows: X = A W,
+// and the row interchanges disappear.  Growth check as on the symmetric path (max |l_ij|, max |pivot|, max |u_ij| per node, tiny
+// pivots perturbed and counted); Engine::factorize falls back to partial pivoting when it fails.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_diag32_gen(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0, cz* fact, int64_t fs,
+                                                    int* piv, int npiv, const double* __restrict__ tiny, int* nperturb, unsigned long long* growth,
+                                                    cz* wscr, int64_t wstride, int K) {
+    __shared__ cz A[FACT_NB][FACT_NB + 1];
+    __shared__ cz W[FACT_NB][FACT_NB + 1];
+    __shared__ cz s_pinv;
+    FrontD f = fr[list[blockIdx.x]];
+    const int k = blockIdx.y, tid = threadIdx.x;
+    const int p = f.p, ld = f.p + f.u;
+    const int b = min(FACT_NB, p - k0);
+    cz* D = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;
+    for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+        const int i = e & (FACT_NB - 1), c = e / FACT_NB;
+        A[i][c] = (i < b && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);
+    }
+    const double tiny_k = tiny[k];
+    double lmax = 0.0, dmax = 0.0, umax = 0.0;
+    __syncthreads();
+    for (int j = 0; j < b; ++j) {
+        if (tid == 0) {
+            cz pv = A[j][j];
+            const double pa = cz_abs1(pv);
+            if (!(pa >= tiny_k)) {       // static pivot perturbation (also catches NaN), as in the pivoted kernels
+                pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+                A[j][j] = pv;
+                atomicAdd(nperturb + k, 1);
+            }
+            dmax = fmax(dmax, cz_abs1(pv));
+            s_pinv = cz_inv(pv);
+        }
+        __syncthreads();
+        if (tid > j && tid < b) {
+            const cz l = cz_mul(A[tid][j], s_pinv);
+            A[tid][j] = l;
+            lmax = fmax(lmax, cz_abs1(l));
+        }
+        __syncthreads();
+        for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+            const int i = e & (FACT_NB - 1), c = e / FACT_NB;
+            if (i > j && c > j && i < b && c < b) { cz v = A[i][c]; cz_msub(v, A[i][j], A[j][c]); A[i][c] = v; }
+        }
+        __syncthreads();
+    }
+    // W = inv(U): column c by back substitution, one thread per column
+    if (tid < FACT_NB) {
+        const int c = tid;
+        for (int i = FACT_NB - 1; i >= 0; --i) {
+            cz acc = cz_make(i == c ? 1.0 : 0.0, 0.0);
+            for (int q = i + 1; q <= c; ++q) cz_msub(acc, A[i][q], W[q][c]);
+            W[i][c] = (i <= c && c < b && i < b) ? cz_mul(acc, cz_inv(A[i][i])) : cz_make((i == c) ? 1.0 : 0.0, 0.0);
+        }
+        for (int i = 0; i <= c && c < b; ++i) umax = fmax(umax, cz_abs1(A[i][c]));
+    }
+    __syncthreads();
+    cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
+    for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+        const int i = e & (FACT_NB - 1), c = e / FACT_NB;
+        if (i < b && c < b) D[i + (int64_t)c * ld] = A[i][c];
+        Wt[i + FACT_NB * c] = W[i][c];
+    }
+    if (tid < b) piv[(int64_t)k * npiv + f.c0 + k0 + tid] = k0 + tid;
+    growth_max(growth + k, lmax);
+    growth_max(growth + K + k, dmax);
+    growth_max(growth + 2 * K + k, umax);
+}
+
+// rows below the diagonal block of the panel, one per thread (tile.a counts 256-row slices, the list is the step's column-slice list:
+// the rows below the block are no more than the columns right of it)
+__global__ __launch_bounds__(256) void k_lscale32_gen(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
+                                                      unsigned long long* growth, const cz* __restrict__ wscr, int64_t wstride) {
+    __shared__ cz W[FACT_NB][FACT_NB];       // W[kk][c]
+    Tile t = tiles[blockIdx.x];
+    const int k = blockIdx.y, tid = threadIdx.x;
+    FrontD f = fr[t.f];
+    const int p = f.p, ld = p + f.u;
+    const int b = min(FACT_NB, p - k0);
+    const int r0 = k0 + b + t.a * 256;
+    if (r0 >= ld) return;
+    const cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
+    for (int e = tid; e < FACT_NB * FACT_NB; e += 256) W[e & (FACT_NB - 1)][e / FACT_NB] = Wt[e];      // Wt[i + 32 c] = inv(U)[i][c]
+    __syncthreads();
+    const int r = r0 + tid;
+    double lmax = 0.0;
+    if (r < ld) {
+        cz* row = fact + (int64_t)k * fs + f.lp + r + (int64_t)k0 * ld;
+        cz a[FACT_NB];
+#pragma unroll
+        for (int q = 0; q < FACT_NB; ++q) a[q] = q < b ? row[(int64_t)q * ld] : cz_make(0, 0);
+#pragma unroll 4
+        for (int c = 0; c < FACT_NB; ++c) {
+            if (c >= b) break;
+            cz x = cz_make(0, 0);
+#pragma unroll
+            for (int q = 0; q < FACT_NB; ++q) cz_madd(x, a[q], W[q][c]);       // (W is upper triangular: the entries below its diagonal are zeros)
+            row[(int64_t)c * ld] = x;
+            lmax = fmax(lmax, cz_abs1(x));
+        }
+    }
+    growth_max(growth + k, lmax);
+}
+
+void launch_diag32_gen(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
+                       const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K) {
+    if (nlist <= 0) return;
+    hipLaunchKernelGGL(k_diag32_gen, dim3(nlist, K), dim3(256), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride, K);
+}
+void launch_lscale32_gen(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
+                         unsigned long long* growth, const cz* wscr, int64_t wstride, int K) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_lscale32_gen, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth, wscr, wstride);
+}
+
+// ---------------------------------------------------------------------------
 // apply the panel's row interchanges to every other column of the front
 // ---------------------------------------------------------------------------
 // ColSel picks the columns an elimination step touches in one launch, for the look-ahead schedule of Engine::factorize:
@@ -1009,7 +1134,7 @@ __device__ __forceinline__ void trsm_sweeps(cz (&x)[FACT_NB], const cz* s_l) {
 }
 
 __global__ __launch_bounds__(TRSM_COLS) void k_trsm_u(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
-                                                     ColSel cs) {
+                                                     ColSel cs, unsigned long long* umax) {
     // One thread per column, the column's FACT_NB rows in registers (each thread reads 512 contiguous bytes), L11 broadcast
     // from LDS; the substitution is fully unrolled.  The former version kept the slab in LDS as well (50 KB per 64-thread
     // workgroup: three waves per CU, 50 us per workgroup, 1.7 ms per launch on the wide levels of C3).
@@ -1049,11 +1174,18 @@ __global__ __launch_bounds__(TRSM_COLS) void k_trsm_u(const FrontD* __restrict__
 #pragma unroll
     for (int i = 1; i < FACT_NB; ++i)
         if (i < b) col[i] = x[i];
+    if (umax) {      // elimination without interchanges: the size of the U entries is part of its growth check
+        double m = 0.0;
+#pragma unroll
+        for (int i = 0; i < FACT_NB; ++i) if (i < b) m = fmax(m, cz_abs1(x[i]));
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(umax + k, (unsigned long long)__double_as_longlong(m == m ? m : __longlong_as_double(0x7ff0000000000000ll)));
+    }
 }
 
-void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs) {
+void launch_trsm_u(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs, int K, ColSel cs, unsigned long long* umax) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(TRSM_COLS), 0, st, S.fr, tiles, k0, fact, fs, cs);
+    hipLaunchKernelGGL(k_trsm_u, dim3(ntiles, K), dim3(TRSM_COLS), 0, st, S.fr, tiles, k0, fact, fs, cs, umax);
 }
 
 // ---------------------------------------------------------------------------
@@ -1089,7 +1221,7 @@ __device__ __forceinline__ void group_phase(cz (&x)[GROUP_ROWS / 8], const cz (*
 }
 
 __global__ __launch_bounds__(256) void k_group_utrsm(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, int gw,
-                                                      cz* fact, int64_t fs, ColSel cs) {
+                                                      cz* fact, int64_t fs, ColSel cs, unsigned long long* umax) {
     __shared__ cz sL[32][GROUP_ROWS + 1];
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
@@ -1128,11 +1260,18 @@ __global__ __launch_bounds__(256) void k_group_utrsm(const FrontD* __restrict__ 
         for (int m = 0; m < GROUP_ROWS / 8; ++m)
             if (rsub + 8 * m < b) col[rsub + 8 * m] = x[m];
     }
+    if (umax) {
+        double mx = 0.0;
+#pragma unroll
+        for (int m = 0; m < GROUP_ROWS / 8; ++m) if (mine && rsub + 8 * m < b) mx = fmax(mx, cz_abs1(x[m]));
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+        if (lane == 0 && mx > 0.0) atomicMax(umax + k, (unsigned long long)__double_as_longlong(mx == mx ? mx : __longlong_as_double(0x7ff0000000000000ll)));
+    }
 }
 
-void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int gw, cz* fact, int64_t fs, int K, ColSel cs) {
+void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, int gw, cz* fact, int64_t fs, int K, ColSel cs, unsigned long long* umax) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_group_utrsm, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, gw, fact, fs, cs);
+    hipLaunchKernelGGL(k_group_utrsm, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, gw, fact, fs, cs, umax);
 }
 
 // ---------------------------------------------------------------------------

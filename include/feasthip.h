@@ -237,7 +237,8 @@ int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64
 int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
 int feasthip_fact_free(feasthip_fact_t F);
 /* How F was factorised: *symmetric = 1 if C equals its transpose and the pivot-light elimination passed its growth check
- * (*growth = max |l_ij| it saw), 0 for partial pivoting; *perturbed = statically perturbed pivots.  Any pointer may be NULL. */
+ * (*growth = max |l_ij| it saw), 2 if C is Hermitian off its diagonal and the elimination without interchanges (L, U apart) passed
+ * its own, 0 for partial pivoting; *perturbed = statically perturbed pivots.  Any pointer may be NULL. */
 int feasthip_fact_info(feasthip_fact_t F, int* symmetric, double* growth, int64_t* perturbed);
 
 /* ---- statistics ------------------------------------------------------------ */
@@ -258,7 +259,10 @@ typedef struct {
     int32_t folded;             /* 1 if the conjugate fold is active (feasthip_set_conjugate_fold) */
     double solve_bytes_streamed;/* bytes the sweeps of one contour step move (a folded pair reads its factor once) */
     int32_t symmetric;          /* 1 if the last factorisation took the pivot-light path: every coefficient matrix equals its transpose
-                                 * (complex symmetric T(z)), no row interchanges, growth-checked; 0: partial pivoting inside the fronts */
+                                 * (complex symmetric T(z)), no row interchanges, growth-checked; 2: every coefficient matrix equals its
+                                 * conjugate transpose off the diagonal (Hermitian pencils, and their assembled shifted matrices z D - A):
+                                 * no row interchanges either, L and U kept apart, growth-checked (FEASTHIP_NOPIV_GEN=0 switches it off);
+                                 * 0: partial pivoting inside the fronts */
     int32_t pad_;
     double growth;              /* max |l_ij| of that factorisation (pivot-light path; beyond 1024 the handle refactorises with pivoting) */
     double proj_ms;             /* last feasthip_rr_step: the projection Aq = Q'(AQ) (src/feast.jl:43,118), 8 n m0^2 flops on the f64 matrix cores */

@@ -612,6 +612,84 @@ def test_random_symmetric_sparse_lu(gpu, pkg, n, density):
     assert np.abs(Y - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
 
+def hermitian_path_default():
+    import os
+    return pivot_light_default() and os.environ.get("FEASTHIP_NOPIV_GEN", "1") != "0"
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 100, 129, 257, 700, 1100, 2100])
+def test_hermitian_shifted_matrix_without_interchanges_dense(gpu, pkg, n):
+    """The assembled shifted matrix z I - A of a complex Hermitian A (Hermitian off its diagonal, neither symmetric nor Hermitian
+    itself) is eliminated without row interchanges, L and U apart (path 2), growth-checked; sizes on the panel / group edges."""
+    rng = np.random.default_rng(300 + n)
+    G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    Cm = np.asfortranarray((G + G.conj().T) / (2 * np.sqrt(n)) - (0.3 + 0.4j) * np.eye(n))
+    R = np.asfortranarray(rng.standard_normal((n, 9)) + 1j * rng.standard_normal((n, 9)))
+    F = pkg.lu(Cm)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    path, growth = F.path, F.growth
+    pkg.finalize(F)
+    if n > 1:
+        assert path == (2 if hermitian_path_default() else 0)
+    assert path != 2 or 0.0 < growth < 64.0
+    ref = np.linalg.solve(Cm, R)
+    assert np.abs(Y - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("g", [7, 12, 16])
+def test_hermitian_pencil_without_interchanges_sparse(gpu, pkg, wl, g):
+    """A complex Hermitian pencil (grid Laplacian with random phases on the couplings, diagonal B) through gen_feast: the handle reports
+    path 2, the eigenvalues are real and agree with a dense Hermitian eigensolve, and the pivoted path (FEASTHIP_NOPIV_GEN=0) gives
+    the same ones."""
+    rng = np.random.default_rng(40 + g)
+    w = wl.c3_sparse_generalized(g, 19, 24)
+    A = sp.coo_matrix(w["A"]).astype(np.complex128)
+    up = A.row < A.col
+    data = A.data.copy()
+    data[up] *= np.exp(1j * rng.uniform(-0.4, 0.4, A.nnz)[up])
+    Au = sp.coo_matrix((np.where(up, data, 0), (A.row, A.col)), shape=A.shape).tocsc()
+    Ah = (Au + Au.conj().T + sp.diags(w["A"].diagonal())).tocsc()
+    bd = w["B"].diagonal()
+    lam_ref = np.linalg.eigvalsh(Ah.toarray() / np.sqrt(np.outer(bd, bd)))
+    c, r = complex(lam_ref[4]), float(0.5 * (lam_ref[9] + lam_ref[10]) - lam_ref[4])
+    inside = lam_ref[np.abs(lam_ref - c) <= r]
+    con = pkg.circular_contour_trapezoidal(c, r, 16)
+    out = {}
+    for mode in ("1", "0"):
+        with env_override(FEASTHIP_NOPIV_GEN=mode):
+            info = {}
+            lam, V, res = pkg.gen_feast(w["X0"].copy(), Ah, w["B"], con, iter=30, eps=1e-11, store=True, info=info)
+        out[mode] = (lam, info)
+        assert len(lam) == len(inside) and match_sets(inside, lam) < 1e-9 and np.abs(lam.imag).max() < 1e-10 and res.max() < 1e-10
+    if pivot_light_default():
+        assert out["1"][1]["symmetric"] == 2 and 0.0 < out["1"][1]["growth"] < 64.0
+    assert out["0"][1]["symmetric"] == 0
+    assert match_sets(out["1"][0], out["0"][0]) < 1e-11
+
+
+def test_hermitian_path_falls_back_when_elimination_is_unsafe(gpu, pkg):
+    """Hermitian off the diagonal with leading pivots that vanish: the elimination without interchanges is rejected (perturbed pivots /
+    growth) and the factor object comes from the pivoted path, with the right solution."""
+    rng = np.random.default_rng(9)
+    n = 96
+    G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    Cm = (G + G.conj().T) / 2
+    np.fill_diagonal(Cm, 0.0)
+    Cm[:40, :40] = 0.0                                   # a singular leading block: no elimination without interchanges survives it
+    Cm = np.asfortranarray(Cm + 0j)
+    assert np.linalg.cond(Cm) < 1e6
+    R = np.asfortranarray(rng.standard_normal((n, 4)) + 1j * rng.standard_normal((n, 4)))
+    F = pkg.lu(Cm)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R)
+    path = F.path
+    pkg.finalize(F)
+    assert path == 0
+    ref = np.linalg.solve(Cm, R)
+    assert np.abs(Y - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("shape,extra", [((48, 24, 14), 300), ((90, 70, 3), 0), ((30, 30, 30), 2000), ((48, 24, 14), -300), ((30, 30, 30), -2000)])
 def test_irregular_trees_sparse_lu(gpu, pkg, shape, extra):
     """Elimination trees whose levels mix fronts of very different pivot-block widths (non-cubic grids, random long-range
