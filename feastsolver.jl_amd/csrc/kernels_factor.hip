@@ -856,65 +856,94 @@ void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 // and the row interchanges disappear.  Growth check as on the symmetric path (max |l_ij|, max |pivot|, max |u_ij| per node, tiny
 // pivots perturbed and counted); Engine::factorize falls back to partial pivoting when it fails.
 // ---------------------------------------------------------------------------
+// Thread (i, g) = (tid & 31, tid >> 5) keeps the entries (i, g + 8 s), s < 4, of the block in registers; a step publishes what the
+// next one needs -- the pivot row, the pivot column, the reciprocal of the pivot -- through LDS (two buffers): one barrier per step.
 __global__ __launch_bounds__(256) void k_diag32_gen(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0, cz* fact, int64_t fs,
                                                     int* piv, int npiv, const double* __restrict__ tiny, int* nperturb, unsigned long long* growth,
                                                     cz* wscr, int64_t wstride, int K) {
     __shared__ cz A[FACT_NB][FACT_NB + 1];
     __shared__ cz W[FACT_NB][FACT_NB + 1];
-    __shared__ cz s_pinv;
+    __shared__ cz s_row[2][FACT_NB], s_col[2][FACT_NB], s_pinv[2];
     FrontD f = fr[list[blockIdx.x]];
-    const int k = blockIdx.y, tid = threadIdx.x;
+    const int k = blockIdx.y, tid = threadIdx.x, i = tid & (FACT_NB - 1), g = tid >> 5;
     const int p = f.p, ld = f.p + f.u;
     const int b = min(FACT_NB, p - k0);
     cz* D = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;
-    for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
-        const int i = e & (FACT_NB - 1), c = e / FACT_NB;
-        A[i][c] = (i < b && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);
+    cz v[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const int c = g + 8 * s2;
+        v[s2] = (i < b && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);      // (padding: identity)
     }
     const double tiny_k = tiny[k];
     double lmax = 0.0, dmax = 0.0, umax = 0.0;
-    __syncthreads();
-    for (int j = 0; j < b; ++j) {
-        if (tid == 0) {
-            cz pv = A[j][j];
-            const double pa = cz_abs1(pv);
-            if (!(pa >= tiny_k)) {       // static pivot perturbation (also catches NaN), as in the pivoted kernels
-                pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
-                A[j][j] = pv;
-                atomicAdd(nperturb + k, 1);
+    // what step j needs: row j (entries of the threads with i == j), column j (threads with g == j & 7, slot j >> 3), 1 / pivot
+    auto publish = [&](int j, int buf) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int c = g + 8 * s2;
+            if (i == j) {
+                cz val = v[s2];
+                if (c == j) {
+                    const double pa = cz_abs1(val);
+                    if (!(pa >= tiny_k)) {       // static pivot perturbation (also catches NaN), as in the pivoted kernels
+                        val = (pa > 0.0) ? cz_make(val.x * (tiny_k / pa), val.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+                        v[s2] = val;
+                        if (j < b) atomicAdd(nperturb + k, 1);
+                    }
+                    if (j < b) dmax = fmax(dmax, cz_abs1(val));
+                    s_pinv[buf] = cz_inv_pivot(val);
+                }
+                s_row[buf][c] = val;
             }
-            dmax = fmax(dmax, cz_abs1(pv));
-            s_pinv = cz_inv(pv);
+            if (c == j) s_col[buf][i] = v[s2];
         }
-        __syncthreads();
-        if (tid > j && tid < b) {
-            const cz l = cz_mul(A[tid][j], s_pinv);
-            A[tid][j] = l;
-            lmax = fmax(lmax, cz_abs1(l));
+    };
+    publish(0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < FACT_NB; ++j) {
+        const int buf = j & 1;
+        if (i > j) {
+            const cz l = cz_mul(s_col[buf][i], s_pinv[buf]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int c = g + 8 * s2;
+                if (c == j) { v[s2] = l; if (i < b && j < b) lmax = fmax(lmax, cz_abs1(l)); }
+                else if (c > j) cz_msub(v[s2], l, s_row[buf][c]);
+            }
         }
-        __syncthreads();
-        for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
-            const int i = e & (FACT_NB - 1), c = e / FACT_NB;
-            if (i > j && c > j && i < b && c < b) { cz v = A[i][c]; cz_msub(v, A[i][j], A[j][c]); A[i][c] = v; }
-        }
+        if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
         __syncthreads();
     }
-    // W = inv(U): column c by back substitution, one thread per column
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) A[i][g + 8 * s2] = v[s2];
+    __syncthreads();
+    // W = inv(U): column c by back substitution, one thread per column (the reciprocal pivots once, two partial sums per entry)
+    if (tid < FACT_NB) s_row[0][tid] = cz_inv_pivot(A[tid][tid]);
+    __syncthreads();
     if (tid < FACT_NB) {
         const int c = tid;
-        for (int i = FACT_NB - 1; i >= 0; --i) {
-            cz acc = cz_make(i == c ? 1.0 : 0.0, 0.0);
-            for (int q = i + 1; q <= c; ++q) cz_msub(acc, A[i][q], W[q][c]);
-            W[i][c] = (i <= c && c < b && i < b) ? cz_mul(acc, cz_inv(A[i][i])) : cz_make((i == c) ? 1.0 : 0.0, 0.0);
+        for (int r = FACT_NB - 1; r > c; --r) W[r][c] = cz_make(0.0, 0.0);
+        for (int r = c; r >= 0; --r) {
+            cz acc = cz_make(r == c ? 1.0 : 0.0, 0.0), acc2 = cz_make(0.0, 0.0), acc3 = acc2, acc4 = acc2;
+            int q = r + 1;
+            for (; q + 3 <= c; q += 4) {       // four independent partial sums: the LDS reads of a group are in flight together
+                const cz a0 = A[r][q], a1 = A[r][q + 1], a2 = A[r][q + 2], a3 = A[r][q + 3];
+                const cz w0 = W[q][c], w1 = W[q + 1][c], w2 = W[q + 2][c], w3 = W[q + 3][c];
+                cz_msub(acc, a0, w0); cz_msub(acc2, a1, w1); cz_msub(acc3, a2, w2); cz_msub(acc4, a3, w3);
+            }
+            for (; q <= c; ++q) cz_msub(acc, A[r][q], W[q][c]);
+            W[r][c] = cz_mul(cz_add(cz_add(acc, acc2), cz_add(acc3, acc4)), s_row[0][r]);
         }
-        for (int i = 0; i <= c && c < b; ++i) umax = fmax(umax, cz_abs1(A[i][c]));
+        for (int r = 0; r <= c && c < b; ++r) umax = fmax(umax, cz_abs1(A[r][c]));
     }
     __syncthreads();
     cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
     for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
-        const int i = e & (FACT_NB - 1), c = e / FACT_NB;
-        if (i < b && c < b) D[i + (int64_t)c * ld] = A[i][c];
-        Wt[i + FACT_NB * c] = W[i][c];
+        const int r = e & (FACT_NB - 1), c = e / FACT_NB;
+        if (r < b && c < b) D[r + (int64_t)c * ld] = A[r][c];
+        Wt[r + FACT_NB * c] = W[r][c];
     }
     if (tid < b) piv[(int64_t)k * npiv + f.c0 + k0 + tid] = k0 + tid;
     growth_max(growth + k, lmax);
@@ -922,8 +951,9 @@ __global__ __launch_bounds__(256) void k_diag32_gen(const FrontD* __restrict__ f
     growth_max(growth + 2 * K + k, umax);
 }
 
-// rows below the diagonal block of the panel, one per thread (tile.a counts 256-row slices, the list is the step's column-slice list:
-// the rows below the block are no more than the columns right of it)
+// rows below the diagonal block of the panel: a workgroup takes 64 of them (tile.a counts 256-row slices -- the list is the step's
+// column-slice list, the rows below the block are no more than the columns right of it -- and blockIdx.z the quarter of the slice),
+// wave q of it the columns 8 q .. 8 q + 7 of the result: X = A W with the row's 32 entries in registers and W broadcast from LDS
 __global__ __launch_bounds__(256) void k_lscale32_gen(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0, cz* fact, int64_t fs,
                                                       unsigned long long* growth, const cz* __restrict__ wscr, int64_t wstride) {
     __shared__ cz W[FACT_NB][FACT_NB];       // W[kk][c]
@@ -932,28 +962,34 @@ __global__ __launch_bounds__(256) void k_lscale32_gen(const FrontD* __restrict__
     FrontD f = fr[t.f];
     const int p = f.p, ld = p + f.u;
     const int b = min(FACT_NB, p - k0);
-    const int r0 = k0 + b + t.a * 256;
+    const int r0 = k0 + b + t.a * 256 + blockIdx.z * 64;
     if (r0 >= ld) return;
     const cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
     for (int e = tid; e < FACT_NB * FACT_NB; e += 256) W[e & (FACT_NB - 1)][e / FACT_NB] = Wt[e];      // Wt[i + 32 c] = inv(U)[i][c]
     __syncthreads();
-    const int r = r0 + tid;
+    const int r = r0 + (tid & 63), cq = (tid >> 6) * 8;
     double lmax = 0.0;
     if (r < ld) {
         cz* row = fact + (int64_t)k * fs + f.lp + r + (int64_t)k0 * ld;
-        cz a[FACT_NB];
+        cz x[8];
 #pragma unroll
-        for (int q = 0; q < FACT_NB; ++q) a[q] = q < b ? row[(int64_t)q * ld] : cz_make(0, 0);
-#pragma unroll 4
-        for (int c = 0; c < FACT_NB; ++c) {
-            if (c >= b) break;
-            cz x = cz_make(0, 0);
+        for (int c = 0; c < 8; ++c) x[c] = cz_make(0, 0);
+#pragma unroll 1
+        for (int q0 = 0; q0 < FACT_NB; q0 += 8) {       // (rolled: unrolled, the compiler hoists all 256 LDS reads and spills)
+            cz a8[8];
 #pragma unroll
-            for (int q = 0; q < FACT_NB; ++q) cz_madd(x, a[q], W[q][c]);       // (W is upper triangular: the entries below its diagonal are zeros)
-            row[(int64_t)c * ld] = x;
-            lmax = fmax(lmax, cz_abs1(x));
+            for (int u2 = 0; u2 < 8; ++u2) a8[u2] = q0 + u2 < b ? row[(int64_t)(q0 + u2) * ld] : cz_make(0, 0);
+#pragma unroll
+            for (int u2 = 0; u2 < 8; ++u2)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cz_madd(x[c], a8[u2], W[q0 + u2][cq + c]);       // (W is upper triangular: zeros below its diagonal)
         }
-    }
+        // every wave of the workgroup has read the row before any of them writes its part of it
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (cq + c < b) { row[(int64_t)(cq + c) * ld] = x[c]; lmax = fmax(lmax, cz_abs1(x[c])); }
+    } else __syncthreads();
     growth_max(growth + k, lmax);
 }
 
@@ -965,7 +1001,7 @@ void launch_diag32_gen(hipStream_t st, const DevSym& S, const int* list, int nli
 void launch_lscale32_gen(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                          unsigned long long* growth, const cz* wscr, int64_t wstride, int K) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_lscale32_gen, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth, wscr, wstride);
+    hipLaunchKernelGGL(k_lscale32_gen, dim3(ntiles, K, 4), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth, wscr, wstride);
 }
 
 // ---------------------------------------------------------------------------
