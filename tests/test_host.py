@@ -104,6 +104,18 @@ def test_symbolic_quality_3d(lib, wl):
     assert stats[6] < 40      # tree depth stays logarithmic
 
 
+def test_python_constants_match_the_header(pkg):
+    """element-type tags and the row-major flag of feasthip_set_dense: the Python mirror uses the header's values"""
+    import importlib
+    import __graft_entry__ as graft
+    api = importlib.import_module(graft.PKG_NAME + ".api")
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "feasthip.h")).read()
+    m = re.search(r"enum\s*\{\s*FEASTHIP_F64\s*=\s*(\d+),\s*FEASTHIP_C128\s*=\s*(\d+),\s*FEASTHIP_I64\s*=\s*(\d+),\s*FEASTHIP_C64\s*=\s*(\d+)", hdr)
+    assert m and tuple(int(v) for v in m.groups()) == (api.F64, api.C128, api.I64T, api.C64T)
+    m = re.search(r"#define\s+FEASTHIP_ROW_MAJOR\s+(0x[0-9a-fA-F]+)", hdr)
+    assert m and int(m.group(1), 16) == api.ROW_MAJOR
+
+
 def test_ordering_does_not_depend_on_the_trace_switch(lib, wl, capfd):
     """FEASTHIP_ANALYZE_TRACE only prints: the ordering and the supernodes are the same with and without it, on a graph large enough
     for the threaded top levels of the dissection (the switch once decided whether those levels ran their multilevel separator once
