@@ -856,16 +856,20 @@ void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int n
 // and the row interchanges disappear.  Growth check as on the symmetric path (max |l_ij|, max |pivot|, max |u_ij| per node, tiny
 // pivots perturbed and counted); Engine::factorize falls back to partial pivoting when it fails.
 // ---------------------------------------------------------------------------
-// Thread (i, g) = (tid & 31, tid >> 5) keeps the entries (i, g + 8 s), s < 4, of the block in registers; a step publishes what the
-// next one needs -- the pivot row, the pivot column, the reciprocal of the pivot -- through LDS (two buffers): one barrier per step.
-__global__ __launch_bounds__(256) void k_diag32_gen(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0, cz* fact, int64_t fs,
-                                                    int* piv, int npiv, const double* __restrict__ tiny, int* nperturb, unsigned long long* growth,
-                                                    cz* wscr, int64_t wstride, int K) {
+// Thread (i, g) = (tid & 31, tid >> 5), tid < 256, keeps the entries (i, g + 8 s), s < 4, of the block in registers; a step publishes
+// what the next one needs -- the pivot row, the pivot column, the reciprocal of the pivot -- through LDS (two buffers): one barrier
+// per step.  A fifth wave builds W = inv(U) beside the elimination, one column per step: column j of U is final when step j starts
+// (it is the published pivot column), and W[r][j] = (delta_rj - sum_{q<j} W[r][q] U[q][j]) / U[j][j] needs nothing else.
+constexpr int DIAG32_NT = 320;
+__global__ __launch_bounds__(DIAG32_NT) void k_diag32_gen(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0, cz* fact, int64_t fs,
+                                                          int* piv, int npiv, const double* __restrict__ tiny, int* nperturb, unsigned long long* growth,
+                                                          cz* wscr, int64_t wstride, int K) {
     __shared__ cz A[FACT_NB][FACT_NB + 1];
     __shared__ cz W[FACT_NB][FACT_NB + 1];
     __shared__ cz s_row[2][FACT_NB], s_col[2][FACT_NB], s_pinv[2];
     FrontD f = fr[list[blockIdx.x]];
-    const int k = blockIdx.y, tid = threadIdx.x, i = tid & (FACT_NB - 1), g = tid >> 5;
+    const int k = blockIdx.y, tid = threadIdx.x, i = tid & (FACT_NB - 1), g = (tid >> 5) & 7;
+    const bool elim = tid < 256, winv = tid >= 256 && tid < 256 + FACT_NB;
     const int p = f.p, ld = f.p + f.u;
     const int b = min(FACT_NB, p - k0);
     cz* D = fact + (int64_t)k * fs + f.lp + k0 + (int64_t)k0 * ld;
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(256) void k_diag32_gen(const FrontD* __restrict__ f
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
         const int c = g + 8 * s2;
-        v[s2] = (i < b && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);      // (padding: identity)
+        v[s2] = (elim && i < b && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);      // (padding: identity)
     }
     const double tiny_k = tiny[k];
     double lmax = 0.0, dmax = 0.0, umax = 0.0;
@@ -899,48 +903,46 @@ __global__ __launch_bounds__(256) void k_diag32_gen(const FrontD* __restrict__ f
             if (c == j) s_col[buf][i] = v[s2];
         }
     };
-    publish(0, 0);
+    if (elim) publish(0, 0);
     __syncthreads();
 #pragma unroll 1
     for (int j = 0; j < FACT_NB; ++j) {
         const int buf = j & 1;
-        if (i > j) {
-            const cz l = cz_mul(s_col[buf][i], s_pinv[buf]);
+        if (elim) {
+            if (i > j) {
+                const cz l = cz_mul(s_col[buf][i], s_pinv[buf]);
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const int c = g + 8 * s2;
-                if (c == j) { v[s2] = l; if (i < b && j < b) lmax = fmax(lmax, cz_abs1(l)); }
-                else if (c > j) cz_msub(v[s2], l, s_row[buf][c]);
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int c = g + 8 * s2;
+                    if (c == j) { v[s2] = l; if (i < b && j < b) lmax = fmax(lmax, cz_abs1(l)); }
+                    else if (c > j) cz_msub(v[s2], l, s_row[buf][c]);
+                }
             }
+            if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
+        } else if (winv) {
+            const int r = i;                      // row r of W; its entries left of column j are in W[r][.] already
+            if (r <= j) {
+                cz acc = cz_make(r == j ? 1.0 : 0.0, 0.0), acc2 = cz_make(0.0, 0.0), acc3 = acc2, acc4 = acc2;
+                int q = r;
+                for (; q + 3 < j; q += 4) {       // four independent partial sums: the LDS reads of a group are in flight together
+                    const cz w0 = W[r][q], w1 = W[r][q + 1], w2 = W[r][q + 2], w3 = W[r][q + 3];
+                    const cz u0 = s_col[buf][q], u1 = s_col[buf][q + 1], u2 = s_col[buf][q + 2], u3 = s_col[buf][q + 3];
+                    cz_msub(acc, w0, u0); cz_msub(acc2, w1, u1); cz_msub(acc3, w2, u2); cz_msub(acc4, w3, u3);
+                }
+                for (; q < j; ++q) cz_msub(acc, W[r][q], s_col[buf][q]);
+                W[r][j] = cz_mul(cz_add(cz_add(acc, acc2), cz_add(acc3, acc4)), s_pinv[buf]);
+                if (j < b) umax = fmax(umax, cz_abs1(s_col[buf][r]));
+            } else W[r][j] = cz_make(0.0, 0.0);
         }
-        if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
         __syncthreads();
     }
+    if (elim) {
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) A[i][g + 8 * s2] = v[s2];
-    __syncthreads();
-    // W = inv(U): column c by back substitution, one thread per column (the reciprocal pivots once, two partial sums per entry)
-    if (tid < FACT_NB) s_row[0][tid] = cz_inv_pivot(A[tid][tid]);
-    __syncthreads();
-    if (tid < FACT_NB) {
-        const int c = tid;
-        for (int r = FACT_NB - 1; r > c; --r) W[r][c] = cz_make(0.0, 0.0);
-        for (int r = c; r >= 0; --r) {
-            cz acc = cz_make(r == c ? 1.0 : 0.0, 0.0), acc2 = cz_make(0.0, 0.0), acc3 = acc2, acc4 = acc2;
-            int q = r + 1;
-            for (; q + 3 <= c; q += 4) {       // four independent partial sums: the LDS reads of a group are in flight together
-                const cz a0 = A[r][q], a1 = A[r][q + 1], a2 = A[r][q + 2], a3 = A[r][q + 3];
-                const cz w0 = W[q][c], w1 = W[q + 1][c], w2 = W[q + 2][c], w3 = W[q + 3][c];
-                cz_msub(acc, a0, w0); cz_msub(acc2, a1, w1); cz_msub(acc3, a2, w2); cz_msub(acc4, a3, w3);
-            }
-            for (; q <= c; ++q) cz_msub(acc, A[r][q], W[q][c]);
-            W[r][c] = cz_mul(cz_add(cz_add(acc, acc2), cz_add(acc3, acc4)), s_row[0][r]);
-        }
-        for (int r = 0; r <= c && c < b; ++r) umax = fmax(umax, cz_abs1(A[r][c]));
+        for (int s2 = 0; s2 < 4; ++s2) A[i][g + 8 * s2] = v[s2];
     }
     __syncthreads();
     cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
-    for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+    for (int e = tid; e < FACT_NB * FACT_NB; e += DIAG32_NT) {
         const int r = e & (FACT_NB - 1), c = e / FACT_NB;
         if (r < b && c < b) D[r + (int64_t)c * ld] = A[r][c];
         Wt[r + FACT_NB * c] = W[r][c];
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(256) void k_lscale32_gen(const FrontD* __restrict__
 void launch_diag32_gen(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
                        const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K) {
     if (nlist <= 0) return;
-    hipLaunchKernelGGL(k_diag32_gen, dim3(nlist, K), dim3(256), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride, K);
+    hipLaunchKernelGGL(k_diag32_gen, dim3(nlist, K), dim3(DIAG32_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride, K);
 }
 void launch_lscale32_gen(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                          unsigned long long* growth, const cz* wscr, int64_t wstride, int K) {
