@@ -22,7 +22,7 @@ class Stats(C.Structure):
         ("solve_ms", C.c_double), ("rr_ms", C.c_double), ("solve_bytes", C.c_double), ("solve_flops", C.c_double),
         ("perturbed_pivots", C.c_int64), ("local_nodes", C.c_int32), ("m0", C.c_int32), ("ldw", C.c_int32),
         ("dense", C.c_int32), ("alloc_seconds", C.c_double),
-        ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double), ("symmetric", C.c_int32), ("pad_", C.c_int32), ("growth", C.c_double), ("proj_ms", C.c_double),
+        ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double), ("symmetric", C.c_int32), ("rr_device_sweeps", C.c_int32), ("growth", C.c_double), ("proj_ms", C.c_double),
     ]
 
 
@@ -48,6 +48,7 @@ PROTOTYPES = {
     "feasthip_get_x": (I, [VP, VP]),
     "feasthip_get_block": (I, [VP, I, VP]),
     "feasthip_rr_step": (I, [VP, VP, VP, VP]),
+    "feasthip_small_eig_herm": (I, [VP, I, VP, VP, VP, VP, VP]),
     "feasthip_set_rr_only": (I, [VP, I]),
     "feasthip_contour_step": (I, [VP, I]),
     "feasthip_contour_step_begin": (I, [VP, I, I]),

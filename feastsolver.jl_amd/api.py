@@ -272,6 +272,18 @@ class FeastHandle:
         self._ck(self.lib.feasthip_rr_step(self.h, _vp(lam), _vp(res), _vp(ins)))
         return lam, res, ins.astype(bool)
 
+    def small_eig_herm(self, A, B=None):
+        """feasthip_small_eig_herm: the device's reduced Hermitian(-definite) eigensolver alone (m <= 64).  Returns (lambda ascending,
+        X with X' B X = I, status[8])."""
+        A = np.asfortranarray(A, dtype=np.complex128)
+        m = A.shape[0]
+        Bf = None if B is None else np.asfortranarray(B, dtype=np.complex128)
+        lam = np.zeros(m)
+        X = np.zeros((m, m), dtype=np.complex128, order="F")
+        st = np.zeros(8)
+        self._ck(self.lib.feasthip_small_eig_herm(self.h, m, _vp(A), None if Bf is None else _vp(Bf), _vp(lam), _vp(X), _vp(st)))
+        return lam, X, st
+
     def contour_step(self, refactor=False):
         return self._ck(self.lib.feasthip_contour_step(self.h, 1 if refactor else 0))
 

@@ -98,6 +98,9 @@ int feasthip_set_x(feasthip_handle_t h, const void* X, int64_t n, int m0) { GUAR
 int feasthip_get_x(feasthip_handle_t h, void* X) { GUARD(h) return h->e->get_block(0, X); ENDGUARD(h) }
 int feasthip_get_block(feasthip_handle_t h, int which, void* out) { GUARD(h) return h->e->get_block(which, out); ENDGUARD(h) }
 int feasthip_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside) { GUARD(h) return h->e->rr_step(lambda, res, inside); ENDGUARD(h) }
+int feasthip_small_eig_herm(feasthip_handle_t h, int m, const void* A, const void* B, double* lambda, void* X, double* status) {
+    GUARD(h) return h->e->small_eig_herm(m, A, B, lambda, X, status); ENDGUARD(h)
+}
 int feasthip_set_rr_only(feasthip_handle_t h, int on) { GUARD(h) return h->e->set_rr_only(on); ENDGUARD(h) }
 int feasthip_contour_step(feasthip_handle_t h, int refactor) { GUARD(h) return h->e->contour_step(refactor); ENDGUARD(h) }
 int feasthip_contour_step_begin(feasthip_handle_t h, int refactor, int nchunks) { GUARD(h) return h->e->contour_step_begin(refactor, nchunks); ENDGUARD(h) }
@@ -188,6 +191,7 @@ int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     o->factor_units = e->Kloc; o->folded = e->folded() ? 1 : 0; o->solve_bytes_streamed = e->ldw ? e->solve_bytes_streamed() : 0;
     o->proj_ms = e->proj_ms;
     o->symmetric = e->nopiv_used ? 1 : e->nopiv_gen_used ? 2 : 0; o->growth = e->growth;
+    o->rr_device_sweeps = e->rr_device_sweeps;
     return 0;
     ENDGUARD(h)
 }

@@ -253,6 +253,8 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
     if (const char* v = getenv("FEASTHIP_NOPIV_GEN")) nopiv_gen_enabled_ = atoi(v) != 0;
+    if (const char* v = getenv("FEASTHIP_RR_DEVICE")) rr_device_ = atoi(v) != 0;
+    if (const char* v = getenv("FEASTHIP_RR_COND")) rr_cond_max_ = atof(v);
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
@@ -411,6 +413,7 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
     terms_symmetric_ = sym;
     terms_hermitian_ = herm;
     nopiv_failed_ = false;
+    rr_dev_state_ = 0;
     nopiv_gen_failed_ = false;
     rebuild_shard();
     return 0;
@@ -469,6 +472,7 @@ int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const
     terms_symmetric_ = false;          // decided in analyze(), where the transposes of the terms are built anyway
     terms_hermitian_ = false;
     nopiv_failed_ = false;
+    rr_dev_state_ = 0;
     nopiv_gen_failed_ = false;
     rebuild_shard();
     return 0;
@@ -1189,7 +1193,7 @@ int Engine::alloc_iteration_buffers() {
                             d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * lw))) &&
               d_e0_.alloc((size_t)std::max(1, Kloc) * lw) && d_e1_.alloc((size_t)std::max(1, Kloc) * lw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
               d_lam_.alloc(ldw) && d_gram_scratch_.alloc(gram_scratch_elems(n, ldw)) && d_io_.alloc((size_t)n * std::max(1, m0)) &&
-              d_nrm_.alloc(ldw) && d_nrm_scratch_.alloc(colnorm_scratch_elems(n, ldw));
+              d_nrm_.alloc(ldw) && d_nrm_scratch_.alloc(colnorm_scratch_elems(n, ldw)) && d_rrscr_.alloc(64 * 64) && d_rrstat_.alloc(16 + (size_t)ldw);
     if (ok && mixed_)
         ok = d_W32_.alloc((size_t)Kloc * sblk) && d_Y32_.alloc((size_t)Kloc * sblk) && d_sk32_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * lw) &&
              d_crow32_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * lw) &&

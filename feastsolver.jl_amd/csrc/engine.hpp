@@ -113,6 +113,10 @@ public:
     int set_x(const void* X, int64_t n, int m0);
     int get_block(int which, void* out);
     int rr_step(double* lambda, double* res, uint8_t* inside);
+    // the Hermitian(-definite) Rayleigh-Ritz step without a host round trip (engine_rr.hip); *done = false: the caller takes the host path
+    int rr_step_device(double* lambda, double* res, uint8_t* inside, bool* done);
+    int small_eig_herm(int m, const void* A, const void* B, double* lambda, void* X, double* status);   // the device solver alone (tests)
+    int rr_device_sweeps = 0;             // Jacobi sweeps of the last device-side reduced eigenproblem (0: the host solved it)
     int contour_step(int refactor);
     int contour_step_begin(int refactor, int nchunks);
     int moment_chunk_wait(int c, int64_t* row0, int64_t* rows);
@@ -174,7 +178,7 @@ private:
     bool nopiv_gen_enabled_ = true, nopiv_gen_failed_ = false;      // FEASTHIP_NOPIV_GEN=0; set when the growth check rejected it for this handle's matrices
     bool terms_symmetric_ = false;         // every coefficient matrix equals its transpose: T(z) = T(z)^T for all z (pivot-light factorisation)
     bool nopiv_enabled_ = true, nopiv_failed_ = false;   // FEASTHIP_NOPIV=0 / a factorisation whose growth check failed: pivoted path from then on
-    double nopiv_max_growth_ = 1024.0;     // largest multiplier |l_ij| the pivot-light path may produce (FEASTHIP_NOPIV_GROWTH)
+    double nopiv_max_growth_ = 256.0;      // largest max(1, max |l_ij|) * max(1, max |u_ij| / ||T||) an elimination without interchanges is accepted with (FEASTHIP_NOPIV_GROWTH)
     bool use_nopiv() const { return terms_symmetric_ && nopiv_enabled_ && !nopiv_failed_; }
     bool use_nopiv_gen() const { return terms_hermitian_ && !terms_symmetric_ && nopiv_enabled_ && nopiv_gen_enabled_ && !nopiv_gen_failed_; }
     void rebuild_shard();                  // local_ / partner_ / fold_ / Kloc from contour, shard, terms and overrides
@@ -209,6 +213,11 @@ private:
     std::vector<int64_t> sk_off_, skf_off_;  // per front (or -1): backward / forward split-K scratch rows
     DevBuf<cz> d_e0_, d_e1_, d_small_, d_lam_, d_gram_scratch_, d_io_;
     DevBuf<double> d_nrm_, d_nrm_scratch_;
+    DevBuf<cz> d_rrscr_;                 // device-side reduced eigenproblem: T = R^-1 between the congruence and the back-transform (64 x 64)
+    DevBuf<double> d_rrstat_;            // ... its status words (16: 8 public + phase timings), then the squared column norms of X = Q Xq (ldw)
+    bool rr_device_ = true;              // FEASTHIP_RR_DEVICE=0: reduced eigenproblem always on the host
+    int rr_dev_state_ = 0;               // -1: the projected matrices of this handle's pencil are not Hermitian (host path from then on)
+    double rr_cond_max_ = 8.0;           // largest ||R^-1||_F / sqrt(m) of the column-scaled basis the device path takes without orthonormalising first
 
     // pinned staging slots for the small host <-> device hand-offs of the Rayleigh-Ritz step (Gram matrices, reduced eigenvectors,
     // coefficient tables): pageable memory costs an extra runtime staging copy and 10-20 us per transfer

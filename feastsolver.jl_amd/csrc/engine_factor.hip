@@ -283,13 +283,21 @@ int Engine::factorize() {
     nopiv_used = nopiv;
     nopiv_gen_used = gen;
     growth = 0;
+    // What an elimination without interchanges is accepted on (both paths): the backward error of T = L U is bounded entry by entry
+    // by k eps (|L| |U|)_ij <= k^2 eps max |l| max |u|, so the PRODUCT of the two maxima, relative to ||T(z_k)|| (tiny[kk] =
+    // 2.2e-19 ||T(z_k)||), is what has to stay small -- round 3 tested each factor on its own against 1024, which admitted a backward
+    // error near 1e-7.  growth = max over the units of max(1, max |l_ij|) * max(1, max |u_ij| / ||T||); accepted up to
+    // FEASTHIP_NOPIV_GROWTH (256: a backward error of a few 1e-14 times the usual modest function of the front size, inside the 1e-11
+    // the seam promises) and only without perturbed pivots.  max |u| is measured where the U entries are written (the diagonal-block
+    // kernels' in-block rows and pivots, the transposed U = D L^T rows of k_lscale_grp, k_trsm_u / k_group_utrsm on the Hermitian path).
+    auto growth_of = [&](int kk) {
+        double l, d, u2;
+        std::memcpy(&l, &gr[kk], sizeof(l)); std::memcpy(&d, &gr[(size_t)Kloc + kk], sizeof(d)); std::memcpy(&u2, &gr[(size_t)2 * Kloc + kk], sizeof(u2));
+        const double urel = std::max(d, u2) * 2.2e-19 / tiny[kk];
+        return std::max(1.0, l) * std::max(1.0, urel) * ((l == l && urel == urel) ? 1.0 : std::numeric_limits<double>::infinity());
+    };
     if (gen) {
-        // max |l_ij|, and max |pivot| and max |u_ij| relative to ||T(z_k)||
-        for (int kk = 0; kk < Kloc; ++kk) {
-            double l, d, u2;
-            std::memcpy(&l, &gr[kk], sizeof(l)); std::memcpy(&d, &gr[(size_t)Kloc + kk], sizeof(d)); std::memcpy(&u2, &gr[(size_t)2 * Kloc + kk], sizeof(u2));
-            growth = std::max(growth, std::max(l, std::max(d, u2) * 2.2e-19 / tiny[kk]));
-        }
+        for (int kk = 0; kk < Kloc; ++kk) growth = std::max(growth, growth_of(kk));
         if (!(growth <= nopiv_max_growth_) || perturbed > 0) {
             if (getenv("FEASTHIP_FACTOR_TRACE")) fprintf(stderr, "[feasthip factor] elimination without interchanges rejected (growth %.3g, %lld perturbed pivots): refactorising with partial pivoting\n", growth, (long long)perturbed);
             nopiv_gen_failed_ = true;
@@ -300,13 +308,7 @@ int Engine::factorize() {
         }
     }
     if (nopiv) {
-        // growth = max over the units of max |l_ij| and of max |pivot| / ||T(z_k)|| (tiny[kk] = 2.2e-19 ||T(z_k)||): with
-        // U = D L^T the product of the two bounds the element growth of the elimination
-        for (int kk = 0; kk < Kloc; ++kk) {
-            double l, d;
-            std::memcpy(&l, &gr[kk], sizeof(l)); std::memcpy(&d, &gr[(size_t)Kloc + kk], sizeof(d));
-            growth = std::max(growth, std::max(l, d * 2.2e-19 / tiny[kk]));
-        }
+        for (int kk = 0; kk < Kloc; ++kk) growth = std::max(growth, growth_of(kk));
         // the elimination without interchanges was not harmless (a multiplier beyond the bound, or a pivot that had to be
         // perturbed): this matrix gets partial pivoting, now and on every later factorisation of this handle
         if (!(growth <= nopiv_max_growth_) || perturbed > 0) {

@@ -49,10 +49,13 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
     // D G D with D = diag(G)^-1/2 (each G_ij carries a relative error eps in units of |q_i||q_j| either way),
     // which saves a norm pass, a scaling pass and a host round trip over the n x m block.
     // min_passes = 1 (generalized Rayleigh-Ritz, where Bq = Q'BQ is formed explicitly and any well-conditioned basis of span(Q)
-    // gives the same Ritz pairs): the second pass is dropped when the first Cholesky factor says the scaled block was well
-    // conditioned (ratio of its extreme diagonal entries >= 1e-2: the basis after one pass is orthonormal to 1e-12 or better; in the
-    // steady state of a FEAST run the ratio is 0.5 .. 1).
+    // gives the same Ritz pairs): the second pass is dropped when the scaled block was well conditioned.  Round 3 decided that on
+    // the ratio of the extreme diagonal entries of the first Cholesky factor, which bounds cond(R) only from below (Kahan-type
+    // factors); now on ||R||_F ||R^-1||_F / m = ||R^-1||_F / sqrt(m) <= rr_cond_max_ from the inverse that is formed anyway
+    // (||R||_F^2 = trace of the scaled Gram matrix = m; the quantity is 1 for an orthonormal block and bounds cond_2(R) / sqrt(m)
+    // from above; 1.1 .. 2 in the steady state of a FEAST run).
     int need = 2;
+    bool first_clean = false;
     for (int pass = 0; pass < 6 && need > 0; ++pass) {
         launch_gram(stream_, rows, m, ld, src, src, t.gram, dG);
         void* land = nullptr;
@@ -85,12 +88,7 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
             need = 1;
         } else {
             --need;
-            if (pass == 0 && min_passes <= 1) {
-                double dmin = 1e300, dmax2 = 0;
-                for (int j = 0; j < m; ++j) { const double dj = std::abs(Gc[j + (size_t)j * m]); dmin = std::min(dmin, dj); dmax2 = std::max(dmax2, dj); }
-                if (getenv("FEASTHIP_RR_TRACE")) fprintf(stderr, "[feasthip] CholeskyQR pass 1: diag(R) min/max = %.3e\n", dmin / dmax2);
-                if (dmin >= 1e-2 * dmax2) need = 0;
-            }
+            if (pass == 0 && min_passes <= 1) first_clean = true;
         }
         if (Rtotal) {   // Q_src = Q_dst (R D^-1)  ->  Rt <- (R D^-1) Rt   (only the Beyn step needs the accumulated factor)
             std::vector<zc> Rd(Gc);
@@ -99,6 +97,14 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
             Rt.swap(Rn);
         }
         trtri_upper(m, Gc.data());
+        if (first_clean) {
+            double fro = 0;
+            for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) fro += std::norm(Gc[i + (size_t)j * m]);
+            const double kappa = std::sqrt(fro / m);
+            if (getenv("FEASTHIP_RR_TRACE")) fprintf(stderr, "[feasthip] CholeskyQR pass 1: ||R^-1||_F / sqrt(m) = %.3g\n", kappa);
+            if (kappa <= rr_cond_max_) need = 0;
+            first_clean = false;
+        }
         for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) Tm[i + (size_t)j * m] = Gc[i + (size_t)j * m] / dsc[i];     // T = D^-1 R^-1
         HIPCHK(h2d_async(1, dM, Tm.data(), (size_t)m * m * sizeof(zc)));
         launch_ts_gemm(stream_, rows, m, ld, src, dM, dst);
@@ -199,10 +205,125 @@ void Engine::inside_test(const zc* lam, uint8_t* inside) const {
     }
 }
 
+// The Rayleigh-Ritz step (src/feast.jl:41-50, 117-127) for Hermitian(-definite) pencils without a host round trip: the reference
+// orthonormalises Q, projects and calls LAPACK; any basis of span(Q) gives the same Ritz pairs, so the projection is taken on the RAW
+// filtered block (Ga = Q'AQ, Gb = Q'BQ, three launches) and the whole m0 x m0 problem -- column scaling, Cholesky of Gb, congruence,
+// Jacobi eigensolver, back-transform, ordering -- runs in one workgroup on the device (kernels_small.hip); X = Q Xq, the residual block
+// and the column norms follow on the same stream and the host synchronises ONCE, for lambda, the residual norms and the solver's status
+// words.  The status decides whether the result stands: inputs Hermitian to 1e-13 (Julia's eigen! takes the Hermitian path for exactly
+// Hermitian input; here "up to rounding", as on the host path), Gb positive definite, the column-scaled basis well conditioned
+// (||R^-1||_F / sqrt(m) <= rr_cond_max_: no orthonormalisation was needed), Jacobi converged.  Otherwise *done = false, Q is untouched
+// and rr_step continues on the host path (CholeskyQR2 + smalleig.cpp), exactly as in rounds 1-3.
+int Engine::rr_step_device(double* lambda, double* res, uint8_t* inside, bool* done) {
+    *done = false;
+    const int m = m0;
+    const bool b_is_identity = terms_[1].identity && std::abs(terms_[1].scale + 1.0) == 0.0;
+    const bool b_diag = !b_is_identity && !dense && terms_[1].diagonal && terms_[1].scale == zc(-1.0);
+    cz* dA = d_small_.p;
+    cz* dB = d_small_.p + (size_t)ldw * ldw;
+    cz* dM = d_small_.p + (size_t)2 * ldw * ldw;
+    double* dstat = d_rrstat_.p;
+    double* dnx = d_rrstat_.p + 16;
+    HIPCHK(hipEventRecord(ev0_, stream_));
+    apply_term(0, Qp(), d_R_.p, 1.0, false);                                                  // R = A Q          :42
+    HIPCHK(hipEventRecord(ev_p0_, stream_));
+    launch_gram(stream_, n, m, ldw, Qp(), d_R_.p, d_gram_scratch_.p, dA);                     // Ga = Q' R        :43
+    HIPCHK(hipEventRecord(ev_p1_, stream_));
+    if (b_diag) launch_gram(stream_, n, m, ldw, Qp(), Qp(), d_gram_scratch_.p, dB, terms_[1].d_diag.p);
+    else if (b_is_identity) launch_gram(stream_, n, m, ldw, Qp(), Qp(), d_gram_scratch_.p, dB);
+    else {
+        apply_term(1, Qp(), d_T1_.p, -1.0, false);                                            // B Q              :120
+        launch_gram(stream_, n, m, ldw, Qp(), d_T1_.p, d_gram_scratch_.p, dB);                // Gb               :121
+    }
+    launch_rr_small_herm(stream_, m, dA, dB, dM, d_lam_.p, ldw, dstat, d_rrscr_.p, rr_cond_max_);   // :45, :122
+    launch_ts_gemm(stream_, n, m, ldw, Qp(), dM, d_X_.p);                                     // X = Q Xq         :48
+    const cz* AX;
+    const cz* BX = nullptr;
+    if (dense) {
+        launch_ts_gemm(stream_, n, m, ldw, d_R_.p, dM, d_T2_.p); AX = d_T2_.p;               // A X = (A Q) Xq
+        if (!b_is_identity) { launch_ts_gemm(stream_, n, m, ldw, d_T1_.p, dM, d_MX_.p); BX = d_MX_.p; }
+    } else {
+        launch_ts_gemm(stream_, n, m, ldw, d_R_.p, dM, d_T1_.p); AX = d_T1_.p;
+        if (!b_is_identity && !b_diag) { apply_term(1, d_X_.p, d_T2_.p, -1.0, false); BX = d_T2_.p; }
+    }
+    launch_colnorm2(stream_, n, ldw, d_X_.p, d_nrm_scratch_.p, dnx);
+    // update_R! (src/utils.jl:111-116): columns of X to unit 2-norm, R[:, i] = (A - lam_i B) x_i
+    launch_residual_combine_scaled(stream_, n, ldw, AX, b_is_identity ? d_X_.p : BX, d_lam_.p, d_X_.p, d_R_.p, b_diag ? terms_[1].d_diag.p : nullptr, dnx);
+    launch_colnorm2(stream_, n, ldw, d_R_.p, d_nrm_scratch_.p, d_nrm_.p);                   // residuals! :166-171
+    std::vector<double> nr(ldw), st(16);
+    std::vector<zc> lam(ldw);
+    void *l0 = nullptr, *l1 = nullptr, *l2 = nullptr;
+    HIPCHK(d2h_async(4, nr.data(), d_nrm_.p, ldw * sizeof(double), &l0));
+    HIPCHK(d2h_async(5, lam.data(), d_lam_.p, ldw * sizeof(zc), &l1));
+    HIPCHK(d2h_async(6, st.data(), dstat, 16 * sizeof(double), &l2));
+    HIPCHK(hipEventRecord(ev1_, stream_));
+    HIPCHK(hipEventSynchronize(ev1_));
+    if (l0 != (void*)nr.data()) std::memcpy(nr.data(), l0, ldw * sizeof(double));
+    if (l1 != (void*)lam.data()) std::memcpy(lam.data(), l1, ldw * sizeof(zc));
+    if (l2 != (void*)st.data()) std::memcpy(st.data(), l2, 16 * sizeof(double));
+    const int flags = (int)st[0];
+    if (getenv("FEASTHIP_RR_TRACE"))
+        fprintf(stderr, "[feasthip] reduced eigenproblem on the device (m=%d): flags %d, %d sweeps, ||R^-1||_F/sqrt(m) %.3g, Hermitian defect %.2e, diag(R) min/max %.3g; kernel %.0f (load %.0f, Cholesky %.0f, inverse %.0f, congruence %.0f) + %.0f + %.0f us\n",
+                m, flags, (int)st[1], st[2], st[3], st[4], st[5], st[8], st[9], st[10], st[11], st[6], st[7]);
+    if (flags != 0) {
+        if (flags & 1) rr_dev_state_ = -1;          // not a Hermitian problem: never again on this handle
+        rr_device_sweeps = 0;
+        return 0;
+    }
+    bool finite = true;
+    for (int j = 0; j < m; ++j) if (!std::isfinite(nr[j]) || !std::isfinite(lam[j].real())) finite = false;
+    if (!finite) return 0;
+    rr_device_sweeps = (int)st[1];
+    lam.resize(m);
+    lambda_ = lam;
+    for (int j = 0; j < m; ++j) { lambda[2 * j] = lam[j].real(); lambda[2 * j + 1] = lam[j].imag(); res[j] = std::sqrt(nr[j]); }
+    inside_test(lam.data(), inside);
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    rr_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev_p0_, ev_p1_));
+    proj_ms = ms;
+    *done = true;
+    return 0;
+}
+
+// the device solver alone: lambda ascending, X with X' B X = I (B = NULL: identity), status[8] as in kernels_small.hip
+int Engine::small_eig_herm(int m, const void* A, const void* B, double* lambda, void* X, double* status) {
+    if (m < 1 || m > 64 || !A || !lambda || !X) return fail(FEASTHIP_EARG, "small_eig_herm: 1 <= m <= 64");
+    HIPCHK(hipSetDevice(device_));
+    DevBuf<cz> dA, dB, dX, dl, dscr;
+    DevBuf<double> dst;
+    const int ld = ((m + 15) / 16) * 16;
+    if (!dA.alloc((size_t)m * m) || !dB.alloc((size_t)m * m) || !dX.alloc((size_t)m * m) || !dl.alloc(ld) || !dscr.alloc(64 * 64) || !dst.alloc(16))
+        return fail(FEASTHIP_EHIP, "small_eig_herm: device allocation failed");
+    std::vector<zc> eye;
+    if (!B) { eye.assign((size_t)m * m, zc(0.0)); for (int j = 0; j < m; ++j) eye[j + (size_t)j * m] = 1.0; B = eye.data(); }
+    HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(dB.p, B, (size_t)m * m * sizeof(zc), hipMemcpyHostToDevice, stream_));
+    launch_rr_small_herm(stream_, m, dA.p, dB.p, dX.p, dl.p, ld, dst.p, dscr.p, 1e300);
+    std::vector<zc> lam(ld);
+    double st[8];
+    HIPCHK(hipMemcpyAsync(X, dX.p, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(lam.data(), dl.p, ld * sizeof(zc), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(st, dst.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    for (int j = 0; j < m; ++j) lambda[j] = lam[j].real();
+    if (status) std::memcpy(status, st, sizeof(st));
+    return 0;
+}
+
 int Engine::rr_step(double* lambda, double* res, uint8_t* inside) {
     if (!have_x_) return fail(FEASTHIP_ESTATE, "rr_step: call set_x first");
     if (nterms != 2) return fail(FEASTHIP_ESTATE, "rr_step: linear pencil (2 terms) required");
     HIPCHK(hipSetDevice(device_));
+    if (rr_device_ && rr_dev_state_ >= 0 && m0 <= 64) {
+        bool done = false;
+        int rd = rr_step_device(lambda, res, inside, &done);
+        if (rd) return rd;
+        if (done) return 0;
+    }
+    rr_device_sweeps = 0;
     HIPCHK(hipEventRecord(ev0_, stream_));
     int m = m0;
     // B = -scale_1 * M_1

@@ -161,6 +161,11 @@ void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz
 // nrm2[j] = sum_i |V[i,j]|^2 ; scratch >= colnorm_scratch_elems()
 size_t colnorm_scratch_elems(int n, int ldw);
 void launch_colnorm2(hipStream_t st, int n, int ldw, const cz* V, double* scratch, double* nrm2);
+// kernels_small.hip: the m0 x m0 Hermitian(-definite) reduced eigenproblem in one workgroup (m <= 64), and the residual kernel that
+// normalises the Ritz vectors on the way (update_R!, src/utils.jl:111-116)
+void launch_rr_small_herm(hipStream_t st, int m, const cz* Ga, const cz* Gb, cz* Xq, cz* lam_out, int ldw, double* status, cz* tscratch, double cond_max);
+void launch_residual_combine_scaled(hipStream_t st, int n, int ldw, const cz* AX, const cz* BX, const cz* lam, cz* X, cz* R, const cz* rowscale,
+                                    const double* nrm2);
 void launch_scale_cols(hipStream_t st, int n, int ldw, cz* V, const cz* s);
 // out = alpha*V (+ out)
 void launch_axpby(hipStream_t st, int n, int ldw, cz* out, cz alpha, const cz* V, int accumulate);

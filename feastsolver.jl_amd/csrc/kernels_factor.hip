@@ -577,8 +577,10 @@ constexpr int WSLOT = 4 * 1024 + GRP_W;      // scratch entries per (node, front
 // rows re-read from memory -- the L11 operand of that update are the L entries of ALL rows of block ncb, i.e. also what the other
 // wave of k_diag_grp has just computed, so the caller separates the two passes by a workgroup barrier.
 // Wt: W blocks, element [c][k][j], then the pivots.
-__device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __restrict__ F12, int ld, int p, int k0, int gw, int ncb, bool upd_only,
-                                                 int rbase, int rend, const cz* __restrict__ Wt) {
+struct GrowthLU { double l, u; };       // max |l_ij| and max |u_ij| a substitution wrote
+
+__device__ __forceinline__ GrowthLU grp_substitute(cz* __restrict__ Lp, cz* __restrict__ F12, int ld, int p, int k0, int gw, int ncb, bool upd_only,
+                                                   int rbase, int rend, const cz* __restrict__ Wt) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int row = rbase + li;
     const bool rok = row < rend;
@@ -586,7 +588,7 @@ __device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __rest
     const cz* D0 = Lp + k0 + (int64_t)k0 * ld;          // diagonal block of the group: L11 strictly below, U11 on and above the diagonal
     cz* ucol = (row_c < p) ? Lp + k0 + (int64_t)row_c * ld : F12 + k0 + (int64_t)(row_c - p) * p;
     cz z[8][4];                                          // Z = X D, tile t (16 columns), k-step s: column 16 t + lk + 4 s
-    double lmax = 0.0;
+    double lmax = 0.0, umax = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (c > ncb || (c == ncb && !upd_only) || 32 * c >= gw) break;
@@ -686,10 +688,11 @@ __device__ __forceinline__ double grp_substitute(cz* __restrict__ Lp, cz* __rest
                     Lp[row + (int64_t)(k0 + col) * ld] = x;
                     ucol[col] = zz;                       // U[k0 + col][row] = d_col l_(row, col)
                     lmax = fmax(lmax, fabs(x.x) + fabs(x.y));
+                    umax = fmax(umax, fabs(zz.x) + fabs(zz.y));
                 }
             }
     }
-    return lmax;
+    return GrowthLU{lmax, umax};
 }
 
 // reciprocal of a pivot: 1 / (x + i y) = (x - i y) / (x^2 + y^2) with one hardware reciprocal and two Newton steps (the IEEE
@@ -758,7 +761,9 @@ __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, con
         if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
         __syncthreads();
     }
-    // thread (i, c) holds inv(L)[i][c] = inv(U)[c][i] d_i; a diagonal thread holds the pivot d_i
+    // thread (i, c) holds inv(L)[i][c] = inv(U)[c][i] d_i; a diagonal thread holds the pivot d_i, a thread with c > i the entry U[i][c]
+    if (rok && c0 > i && c0 < b) dmax = fmax(dmax, fabs(a0.x) + fabs(a0.y));
+    if (rok && c1 > i && c1 < b) dmax = fmax(dmax, fabs(a1.x) + fabs(a1.y));
     const cz dinv = sh.dinv[i];
     const cz w0 = cz_mul(e0, dinv), w1 = cz_mul(e1, dinv);
     Wc[c0 * 32 + i] = w0;
@@ -774,7 +779,7 @@ __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, con
 }
 
 // (the substitution's registers and the elimination's are never live together; as a call the two are allocated separately)
-__device__ __attribute__((noinline)) double grp_substitute_call(cz* Lp, cz* F12, int ld, int p, int k0, int gw, int ncb, bool upd_only, int rbase, int rend, const cz* Wt) {
+__device__ __attribute__((noinline)) GrowthLU grp_substitute_call(cz* Lp, cz* F12, int ld, int p, int k0, int gw, int ncb, bool upd_only, int rbase, int rend, const cz* Wt) {
     return grp_substitute(Lp, F12, ld, p, k0, gw, ncb, upd_only, rbase, rend, Wt);
 }
 
@@ -801,7 +806,10 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
         if (c > 0) {
             // rows of block c, 16 per wave, two waves: L entries of the blocks before it; barrier (the update multiplies with the L
             // entries of all 32 rows); update of block (c, c)
-            if (wave < 2) lmax = fmax(lmax, grp_substitute_call(Lp, F12, ld, p, k0, gw, c, false, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt));
+            if (wave < 2) {
+                const GrowthLU g2 = grp_substitute_call(Lp, F12, ld, p, k0, gw, c, false, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt);
+                lmax = fmax(lmax, g2.l); dmax = fmax(dmax, g2.u);
+            }
             __syncthreads();
             if (wave < 2) grp_substitute_call(Lp, F12, ld, p, k0, gw, c, true, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt);
             __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
@@ -829,8 +837,9 @@ __global__ __launch_bounds__(256) void k_lscale_grp(const FrontD* __restrict__ f
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     cz* F12 = fact + (int64_t)k * fs + f.f12;
     const cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
-    const double lm = grp_substitute(Lp, F12, ld, p, k0, gw, nb, false, r0, ld, Wt);
-    growth_max(growth + k, lm);
+    const GrowthLU lm = grp_substitute(Lp, F12, ld, p, k0, gw, nb, false, r0, ld, Wt);
+    growth_max(growth + k, lm.l);
+    growth_max(growth + 2 * gridDim.y + k, lm.u);      // U = D L^T entries as written: what the backward error of the elimination scales with
 }
 
 void launch_diag_grp(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,

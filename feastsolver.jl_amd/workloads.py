@@ -113,6 +113,40 @@ def c3_sparse_generalized(g=46, stencil=19, m0=64, seeds=(3001, 3002), fixture=N
                 X0=rand_x0(n, m0, seeds[1]), iter=20, eps=1e-10, n_inside=int(fixture["n_inside"]))
 
 
+def hermitian_phases(A, seed=3, amplitude=0.3):
+    """A real symmetric sparse matrix with random phases e^{i theta} on the couplings above the diagonal and the conjugate
+    ones below (a gauge field on the same graph): complex Hermitian, same pattern, same diagonal."""
+    C = sp.coo_matrix(A).astype(np.complex128)
+    rng = np.random.default_rng(seed)
+    theta = rng.uniform(-amplitude, amplitude, C.nnz)
+    up = C.row < C.col
+    data = C.data.copy()
+    data[up] *= np.exp(1j * theta[up])
+    Au = sp.coo_matrix((np.where(up, data, 0), (C.row, C.col)), shape=C.shape).tocsc()
+    Ah = (Au + Au.conj().T + sp.diags(A.diagonal())).tocsc()
+    Ah.sort_indices()
+    return Ah
+
+
+def c3_hermitian(g=46, stencil=19, m0=64, seed=3):
+    """The C3 pencil with a complex Hermitian A (`hermitian_phases` of the grid Laplacian), B = the same diagonal, a contour around
+    its ~32 lowest eigenvalues (from the fixture; the real pencil's contour without one): the home ground of FEAST that gets neither the `U = D L^T` elimination nor the conjugate fold.  The expected
+    eigenvalues come from tests/golden/c3_hermitian_g<g>.json (make_hermitian_fixture.py: shift-invert Lanczos on the host)."""
+    w = c3_sparse_generalized(g, stencil, m0)
+    w["A"] = hermitian_phases(w["A"], seed)
+    path = os.path.join(GOLDEN_DIR, f"c3_hermitian_g{g}.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            fx = json.load(f)
+        w["c"], w["r"] = complex(fx["c"], 0.0), float(fx["r"])        # chosen on this pencil's own spectrum (the gauge field lifts it)
+        w["eigs"] = np.array(fx["eigs_inside"])
+        w["n_inside"] = len(w["eigs"])
+        w["eigs_near"] = np.array(fx["eigs_lowest"])
+    else:
+        w["n_inside"] = -1
+    return w
+
+
 def load_mtx(name):
     import scipy.io
     return scipy.io.mmread(os.path.join(GOLDEN_DIR, "data", name))

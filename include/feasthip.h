@@ -109,6 +109,12 @@ int feasthip_get_block(feasthip_handle_t h, int which /*0 X,1 R,2 Q,3 Q1*/, void
  * update_R! (src/utils.jl:111-116); residuals! (:166-171).
  * Outputs: lambda (m0 complex, sorted by (re,im)), res (m0), inside (m0 bytes). */
 int feasthip_rr_step(feasthip_handle_t h, double* lambda, double* res, uint8_t* inside);
+/* The reduced eigenproblem of that step alone (src/feast.jl:45 `eigen!(Aq)`, :122 `eigen!(Aq, Bq)`) as the device solves it for Hermitian
+ * A, Hermitian positive definite B (NULL: identity), 1 <= m <= 64, column-major m x m complex128: lambda (m doubles, ascending), X (m x m,
+ * X' B X = I, A X = B X diag(lambda)), status (8 doubles or NULL: flags {1 not Hermitian, 2 B not positive definite, 4 ill-conditioned,
+ * 8 no convergence}, Jacobi sweeps, ||R^-1||_F / sqrt(m) of the column-scaled Cholesky factor of B, Hermitian defect, min/max diag(R)).
+ * One 1024-thread workgroup, everything in LDS (csrc/kernels_small.hip). */
+int feasthip_small_eig_herm(feasthip_handle_t h, int m, const void* A, const void* B, double* lambda, void* X, double* status);
 
 /* on != 0: this handle runs only the Rayleigh-Ritz half (feasthip_set_x / feasthip_rr_step / feasthip_get_block): no ordering,
  * no symbolic analysis, no factor arenas; factorize / contour_step return FEASTHIP_ESTATE.  For callers that supply their own
@@ -237,7 +243,7 @@ int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64
 int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
 int feasthip_fact_free(feasthip_fact_t F);
 /* How F was factorised: *symmetric = 1 if C equals its transpose and the pivot-light elimination passed its growth check
- * (*growth = max |l_ij| it saw), 2 if C is Hermitian off its diagonal and the elimination without interchanges (L, U apart) passed
+ * (*growth = max(1, max |l_ij|) * max(1, max |u_ij| / ||C||) as it saw them), 2 if C is Hermitian off its diagonal and the elimination without interchanges (L, U apart) passed
  * its own, 0 for partial pivoting; *perturbed = statically perturbed pivots.  Any pointer may be NULL. */
 int feasthip_fact_info(feasthip_fact_t F, int* symmetric, double* growth, int64_t* perturbed);
 
@@ -263,8 +269,9 @@ typedef struct {
                                  * conjugate transpose off the diagonal (Hermitian pencils, and their assembled shifted matrices z D - A):
                                  * no row interchanges either, L and U kept apart, growth-checked (FEASTHIP_NOPIV_GEN=0 switches it off);
                                  * 0: partial pivoting inside the fronts */
-    int32_t pad_;
-    double growth;              /* max |l_ij| of that factorisation (pivot-light path; beyond 1024 the handle refactorises with pivoting) */
+    int32_t rr_device_sweeps;   /* last feasthip_rr_step: Jacobi sweeps of the reduced eigenproblem when it ran on the device (Hermitian(-definite)
+                                 * problem, m0 <= 64, well-conditioned filtered block; FEASTHIP_RR_DEVICE=0 switches it off); 0: host solver */
+    double growth;              /* max(1, max |l_ij|) * max(1, max |u_ij| / ||T||) of that factorisation (paths 1 and 2; beyond 256 the handle refactorises with pivoting) */
     double proj_ms;             /* last feasthip_rr_step: the projection Aq = Q'(AQ) (src/feast.jl:43,118), 8 n m0^2 flops on the f64 matrix cores */
 } feasthip_stats_t;
 int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* out);

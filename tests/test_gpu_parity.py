@@ -82,7 +82,7 @@ def test_seam_dense_symmetric_lu_ldiv(gpu, pkg, n, m0):
     assert np.array_equal(Cm, Cm.T)
     R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
     F = pkg.lu(Cm)
-    assert F.symmetric == pivot_light_default() and F.growth < 1024
+    assert F.symmetric == pivot_light_default() and F.growth <= 256
     Y = np.zeros((n, m0), dtype=np.complex128, order="F")
     pkg.ldiv(Y, F, R)
     pkg.finalize(F)
@@ -540,6 +540,95 @@ def test_system5_nlfeast_first_moments(gpu, pkg, fo, wl):
 
 
 # ---------------------------------------------------------------------------------------
+# the reduced eigenproblem on the device (round 4): src/feast.jl:45, 122
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,definite", [(1, False), (2, True), (3, False), (5, True), (16, True), (17, False), (30, True), (33, True), (48, False), (63, True), (64, True), (64, False)])
+def test_device_reduced_eigensolver(gpu, pkg, m, definite):
+    """The one-workgroup Hermitian(-definite) eigensolver (column scaling, Cholesky, congruence on the matrix cores, cyclic Jacobi in
+    LDS) against LAPACK (scipy.linalg.eigh): eigenvalues to 1e-12 of the spectrum's size, X' B X = I, A X = B X diag(lambda), ascending
+    order; B badly scaled on purpose (the column scaling absorbs it)."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(100 * m + definite)
+    G = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+    A = (G + G.conj().T) / 2
+    B = None
+    if definite:
+        H = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        d = 10.0 ** rng.uniform(-3, 3, m)
+        B = (H @ H.conj().T / m + np.eye(m)) * np.outer(d, d)
+        B = (B + B.conj().T) / 2
+        A = A * np.outer(d, d)
+    ref = sla.eigh(A, B, eigvals_only=True)
+    h = pkg.FeastHandle(0)
+    lam, X, st = h.small_eig_herm(A, B)
+    h.close()
+    Bm = np.eye(m) if B is None else B
+    sc = max(1.0, np.abs(ref).max())
+    assert int(st[0]) == 0, st
+    assert np.all(np.diff(lam) >= 0) and np.abs(lam - ref).max() <= 1e-12 * sc, (np.abs(lam - ref).max(), st)
+    assert np.abs(X.conj().T @ Bm @ X - np.eye(m)).max() <= 1e-11
+    Rr = A @ X - Bm @ X * lam[None, :]
+    assert np.abs(X.conj().T @ Rr).max() <= 1e-11 * sc
+
+
+def test_device_reduced_eigensolver_starts_warm_and_refuses_what_it_cannot_take(gpu, pkg):
+    """A nearly diagonal pencil (the steady state of a FEAST run: Q = rho(B^-1 A) X with X the previous Ritz vectors) converges in at
+    most 3 sweeps where a random one takes 8-9; clustered eigenvalues (multiplicities of a grid Laplacian) converge; a non-Hermitian A,
+    an indefinite B are flagged, not solved."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(5)
+    m = 64
+    E = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)); E = E + E.conj().T
+    F = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)); F = F + F.conj().T
+    h = pkg.FeastHandle(0)
+    A = np.diag(np.sort(rng.standard_normal(m))) + 1e-6 * E
+    B = np.diag(rng.uniform(0.5, 2.0, m)) + 1e-6 * F
+    lam, X, st = h.small_eig_herm(A, B)
+    assert int(st[0]) == 0 and st[1] <= 3 and np.abs(lam - sla.eigh(A, B, eigvals_only=True)).max() <= 1e-13 * 10
+    lam, X, st_cold = h.small_eig_herm(E, None)
+    assert int(st_cold[0]) == 0 and 5 <= st_cold[1] <= 12
+    A = np.diag(np.repeat(np.arange(16.0), 4)) + 1e-3 * E           # 16 clusters of 4
+    lam, X, st = h.small_eig_herm(A, None)
+    assert int(st[0]) == 0 and np.abs(lam - np.linalg.eigvalsh(A)).max() <= 1e-12 * 16
+    assert np.abs(A @ X - X * lam[None, :]).max() <= 1e-11 * 16
+    # refusals
+    N = E.copy(); N[3, 7] += 1e-6
+    assert int(h.small_eig_herm(N, None)[2][0]) & 1
+    Bi = np.eye(m); Bi[5, 5] = -1.0
+    assert int(h.small_eig_herm(E, Bi)[2][0]) & 2
+    h.close()
+
+
+@pytest.mark.parametrize("case", ["c3_g12", "c1", "dense_generalized_diag"])
+def test_rr_device_path_matches_host_path(gpu, pkg, wl, golden, case):
+    """The Rayleigh-Ritz step with the reduced eigenproblem on the device (no orthonormalisation pass, one host synchronisation)
+    against the host path of rounds 1-3 (CholeskyQR2 + smalleig.cpp, FEASTHIP_RR_DEVICE=0): same eigenvalues to 1e-11, same iteration
+    count to +-1, residuals below eps; the device path was really taken (stats.rr_device_sweeps > 0 at the last step)."""
+    if case == "c3_g12":
+        w = wl.c3_sparse_generalized(12, 19, 64)
+    elif case == "c1":
+        w = wl.c1_dense_hermitian(512, 16)
+    else:
+        rng = np.random.default_rng(11)
+        A = rng.standard_normal((300, 300)); A = A + A.T
+        w = dict(A=A, B=np.diag(rng.uniform(0.5, 2.0, 300)), c=0.5 + 0j, r=2.0, nodes=8, m0=40, X0=wl.rand_x0(300, 40, 3), iter=30, eps=1e-11)
+    out = {}
+    for mode in ("1", "0"):
+        with env_override(FEASTHIP_RR_DEVICE=mode):
+            info = {}
+            con = pkg.circular_contour_trapezoidal(w["c"], w["r"], w["nodes"])
+            if w["B"] is None:
+                lam, V, res = pkg.feast(w["X0"].copy(), w["A"], con, iter=w["iter"], eps=w["eps"], store=True, info=info)
+            else:
+                lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, info=info)
+        out[mode] = (lam, res, info)
+        assert len(lam) > 0 and res.max() < w["eps"]
+    assert out["1"][2]["rr_device_sweeps"] > 0 and out["0"][2]["rr_device_sweeps"] == 0
+    assert len(out["1"][0]) == len(out["0"][0]) and match_sets(out["1"][0], out["0"][0]) <= 1e-11 * max(1.0, np.abs(out["0"][0]).max())
+    assert abs(out["1"][2]["nit"] - out["0"][2]["nit"]) <= 1
+
+
+# ---------------------------------------------------------------------------------------
 # properties at sizes the oracle cannot reach quickly
 # ---------------------------------------------------------------------------------------
 def test_large_sparse_solve_residual(gpu, pkg, wl):
@@ -666,6 +755,108 @@ def test_hermitian_pencil_without_interchanges_sparse(gpu, pkg, wl, g):
         assert out["1"][1]["symmetric"] == 2 and 0.0 < out["1"][1]["growth"] < 64.0
     assert out["0"][1]["symmetric"] == 0
     assert match_sets(out["1"][0], out["0"][0]) < 1e-11
+
+
+@pytest.mark.parametrize("g", [22, 24, 26])
+def test_hermitian_factorisation_is_race_free(gpu, pkg, wl, g):
+    """The twin of test_sparse_symmetric_factorisation_is_race_free for the elimination without interchanges of Hermitian pencils
+    (path 2: `k_diag32_gen` with its fifth wave building inv(U) beside the elimination, `k_lscale32_gen`), at the sizes where the
+    symmetric sibling's missing barrier showed: three factorisations per size, each to full accuracy and bit-identical."""
+    A = wl.hermitian_phases(wl.laplacian_3d(g, 19), seed=g)
+    n = A.shape[0]
+    rng = np.random.default_rng(1)
+    Cm = sp.csc_matrix(A - (0.17 + 0.17j) * sp.diags(rng.uniform(0.5, 1.5, n)))
+    R = np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8)))
+    sols = []
+    for rep in range(3):
+        F = pkg.lu(Cm)
+        assert F.path == (2 if hermitian_path_default() else 0)
+        Y = np.zeros_like(R)
+        pkg.ldiv(Y, F, R)
+        pkg.finalize(F)
+        assert np.linalg.norm(Cm @ Y - R) <= 1e-13 * spla.norm(Cm) * np.linalg.norm(Y)
+        sols.append(Y)
+    assert np.array_equal(sols[0], sols[1]) and np.array_equal(sols[0], sols[2])
+
+
+def test_hermitian_c3_full_size_g46(gpu, pkg, wl):
+    """The C3 pencil with a complex Hermitian A (random phases on the couplings, workloads.c3_hermitian) at full size, n = 97,336,
+    16 nodes, m0 = 64: exact count and eigenvalues against a host shift-invert Lanczos of the same seeded pencil
+    (tests/golden/c3_hermitian_g46.json, make_hermitian_fixture.py), real spectrum, true residuals."""
+    w = wl.c3_hermitian(46, 19, 64)
+    assert w["n_inside"] > 0, "fixture tests/golden/c3_hermitian_g46.json is missing"
+    info = {}
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=20, eps=1e-10, store=True, info=info)
+    assert len(lam) == w["n_inside"]
+    assert np.abs(np.sort(lam.real) - np.sort(w["eigs"])).max() <= 1e-10 and np.abs(lam.imag).max() < 1e-10
+    if hermitian_path_default():
+        assert info["symmetric"] == 2 and 0.0 < info["growth"] < 64.0
+    BV = w["B"] @ V
+    r_true = np.linalg.norm(w["A"] @ V - BV * lam[None, :], axis=0) / np.linalg.norm(BV, axis=0)
+    assert r_true.max() < 1e-9 and res.max() < 1e-10
+
+
+def test_process_with_closed_handles_exits_cleanly():
+    """Regression for the exit-time SIGSEGV of round 3: the process-wide cache of streams, events and pinned
+    slots that closed handles leave behind (`HandleResources`) used to be destroyed by a static destructor after the HIP runtime
+    (and, under rocprofv3, the tool) had shut down.  One child process: two handles created, used, closed; a factor object at
+    the seam; then a plain interpreter exit.  The exit code is the check.  Run once, never in a loop."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, __graft_entry__ as g\n"
+        "pkg = g.load_package()\n"
+        "rng = np.random.default_rng(0)\n"
+        "A = rng.standard_normal((96, 96)); A = A + A.T\n"
+        "for rep in range(2):\n"
+        "    h = pkg.FeastHandle(0)\n"
+        "    X = np.asfortranarray(rng.random((96, 8)) + 1j * rng.random((96, 8)))\n"
+        "    lam, V, res = pkg.feast(X, A, nodes=8, iter=3, c=0j, r=1.0, store=True)\n"
+        "    h.close()\n"
+        "F = pkg.lu(A - (0.1 + 0.2j) * np.eye(96)); pkg.finalize(F)\n"
+        "print('child done', flush=True)\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "child done" in out.stdout, out.stderr[-2000:]
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("kind", ["symmetric", "hermitian"])
+def test_moderate_growth_keeps_the_seam_accuracy(gpu, pkg, kind):
+    """Eliminations without interchanges whose growth lies BETWEEN the benign cases (< 64) and the catastrophic ones (1e-14 pivots):
+    an indefinite symmetric / Hermitian matrix with a small definite imaginary shift eps has multipliers and U entries of order 1 / eps
+    each.  Whatever path the growth check picks, the seam's promise ||C Y - R|| <= 1e-11 ||C|| ||Y|| holds; what it accepts has
+    max(1, max |l|) * max(1, max |u| / ||C||) <= 256 (the product is what the backward error scales with -- round 3 bounded each factor
+    by 1024 on its own); the family has members on both sides of the bound."""
+    n = 200
+    seen = []
+    for eps in (3e-2, 1e-2, 3e-3):
+        for seed in (0, 1):
+            rng = np.random.default_rng(seed + n)
+            S = rng.standard_normal((n, n))
+            if kind == "hermitian":
+                S = S + 1j * rng.standard_normal((n, n))
+                Cm = (S + S.conj().T) / np.sqrt(4 * n) + 1j * eps * np.eye(n)
+            else:
+                Cm = (S + S.T) / np.sqrt(2 * n) + 1j * eps * np.eye(n)
+            Cm = np.asfortranarray(Cm.astype(np.complex128))
+            R = np.asfortranarray(rng.standard_normal((n, 6)) + 1j * rng.standard_normal((n, 6)))
+            F = pkg.lu(Cm)
+            Y = np.zeros_like(R)
+            pkg.ldiv(Y, F, R)
+            seen.append((F.path, F.growth))
+            pkg.finalize(F)
+            assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y), (eps, seed, seen[-1])
+    want = 1 if kind == "symmetric" else 2
+    enabled = pivot_light_default() if kind == "symmetric" else hermitian_path_default()
+    if enabled:
+        accepted = [g for pth, g in seen if pth == want]
+        assert all(pth in (0, want) for pth, g in seen)
+        assert accepted and max(accepted) <= 256.0 and max(accepted) > 16.0, seen
+        assert any(pth == 0 for pth, g in seen), seen
+    else:
+        assert all(pth == 0 for pth, g in seen)
 
 
 def test_hermitian_path_falls_back_when_elimination_is_unsafe(gpu, pkg):
