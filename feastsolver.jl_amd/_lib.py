@@ -81,6 +81,7 @@ PROTOTYPES = {
     "feasthip_lu_dense_c64": (I, [I, VP, I64, PVP]),
     "feasthip_lu_csc": (I, [I, I64, VP, VP, VP, I, I, PVP]),
     "feasthip_ldiv": (I, [VP, VP, I64, VP, I64, I]),
+    "feasthip_ldiv_adjoint": (I, [VP, VP, I64, VP, I64, I]),
     "feasthip_fact_free": (I, [VP]),
     "feasthip_fact_info": (I, [VP, C.POINTER(I), C.POINTER(D), C.POINTER(I64)]),
     "feasthip_get_stats": (I, [VP, C.POINTER(Stats)]),

@@ -839,11 +839,13 @@ def lu(Cm, device=0):
     return HipLU(F, n, lib, code)
 
 
-def ldiv(Y, F, R):
-    """left_divider(Y, F, R): Y .= C^-1 R, R untouched (src/feast.jl:62)."""
+def ldiv(Y, F, R, adjoint=False):
+    """left_divider(Y, F, R): Y .= C^-1 R, R untouched (src/feast.jl:62).  adjoint=True: Y .= C^-H R over the same factor object
+    (Julia's `ldiv!(Y, F', R)`; the reference factorises C' again for it, src/feast.jl:185-197)."""
     Rw = np.asfortranarray(R, dtype=np.complex128)
     Yw = Y if (Y.dtype == np.complex128 and Y.flags.f_contiguous) else np.empty(Rw.shape, dtype=np.complex128, order="F")
-    code = F._lib.feasthip_ldiv(F._h, _vp(Yw), Yw.shape[0], _vp(Rw), Rw.shape[0], Rw.shape[1])
+    fn = F._lib.feasthip_ldiv_adjoint if adjoint else F._lib.feasthip_ldiv
+    code = fn(F._h, _vp(Yw), Yw.shape[0], _vp(Rw), Rw.shape[0], Rw.shape[1])
     if code < 0:
         raise _lib.FeastHipError(code, "feasthip_ldiv failed")
     if Yw is not Y:

@@ -316,6 +316,14 @@ int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_
     } catch (...) { return FEASTHIP_EARG; }
 }
 
+int feasthip_ldiv_adjoint(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0) {
+    if (!F || !F->e) return FEASTHIP_EARG;
+    try {
+        std::lock_guard<std::mutex> lk(F->mu);
+        return F->e->ldiv(Y, ldy, R, ldr, m0, 1);
+    } catch (...) { return FEASTHIP_EARG; }
+}
+
 int feasthip_fact_info(feasthip_fact_t F, int* symmetric, double* growth, int64_t* perturbed) {
     if (!F || !F->e) return FEASTHIP_EARG;
     if (symmetric) *symmetric = F->e->nopiv_used ? 1 : F->e->nopiv_gen_used ? 2 : 0;

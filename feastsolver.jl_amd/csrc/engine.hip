@@ -818,6 +818,67 @@ bool Engine::build_plans() {
             L.count = (int)(tiles.size() - L.off);
             L.sl = sl;
         }
+        // ---- adjoint sweeps (kernels.hpp, kinds 8 .. 13): the same blocks, conjugate-transposed, in the reverse order
+        {
+            const int sld = std::max(2, pick_slabs([&](auto&& cb) { for (int s : lv) cb(S.p(s)); }));
+            V.afd.off = (int64_t)tiles.size(); V.afd.sl = sld;
+            for (int s : lv) {
+                int p = S.p(s), NB = solve_nb(s);
+                for (int t = 0; t < cdiv(p, NB); ++t)
+                    for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * sld); ++rt) tiles.push_back({s, 8 | (sld << 8), t, rt});
+            }
+            V.afd.count = (int)(tiles.size() - V.afd.off);
+            V.afe.assign(nsteps, Launch());
+            V.abe.assign(nsteps, Launch());
+            for (int c = 1; c < nsteps; ++c) {         // forward step c: rows of block c, K = c NB
+                Launch& L = V.afe[c];
+                L.off = (int64_t)tiles.size();
+                int sl = pick_slabs([&](auto&& cb) { for (int s : lv) { int NB = solve_nb(s); if (S.p(s) > c * NB) cb(std::min(NB, S.p(s) - c * NB)); } });
+                for (int s : lv) {
+                    int NB = solve_nb(s), p = S.p(s), k0 = c * NB;
+                    if (p <= k0) continue;
+                    for (int a = 0; a < cdiv(std::min(NB, p - k0), 16 * sl); ++a) tiles.push_back({s, 9 | (sl << 8), a, c});
+                }
+                L.count = (int)(tiles.size() - L.off); L.sl = sl;
+            }
+            for (int c = 0; c + 1 < nsteps; ++c) {     // backward step c: rows of block c, K = p - (c + 1) NB
+                Launch& L = V.abe[c];
+                L.off = (int64_t)tiles.size();
+                int sl = pick_slabs([&](auto&& cb) { for (int s : lv) { int NB = solve_nb(s); if (S.p(s) > c * NB + NB) cb(NB); } });
+                for (int s : lv) {
+                    int NB = solve_nb(s), p = S.p(s), k0 = c * NB;
+                    if (p <= k0 + NB) continue;
+                    for (int a = 0; a < cdiv(NB, 16 * sl); ++a) tiles.push_back({s, 13 | (sl << 8), a, c});
+                }
+                L.count = (int)(tiles.size() - L.off); L.sl = sl;
+            }
+            V.af2.off = (int64_t)tiles.size();
+            const int slc = V.f2split ? pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.u(s)); }) : sl2;
+            for (int s : lv) {
+                int p = S.p(s), u = S.u(s), NB = solve_nb(s);
+                for (int a = 0; a < cdiv(u, 16 * slc); ++a) tiles.push_back({s, 10 | (slc << 8), a, 0});
+                for (int t = 0; t < cdiv(p, NB); ++t)
+                    for (int rt = 0; rt < cdiv(std::min(NB, p - t * NB), 16 * slc); ++rt) tiles.push_back({s, 11 | (slc << 8), t, rt});
+            }
+            V.af2.count = (int)(tiles.size() - V.af2.off); V.af2.sl = slc;
+            std::stable_sort(tiles.begin() + V.af2.off, tiles.end(), [&](const Tile& a, const Tile& b) {
+                auto klen = [&](const Tile& t) { return (t.a & 0xff) == 10 ? S.p(t.f) : std::min(solve_nb(t.f), S.p(t.f)); };
+                return klen(a) > klen(b);
+            });
+            V.ab1.off = (int64_t)tiles.size();
+            const int slg = V.b1split ? 4 : pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
+            for (int s : lv) if (S.u(s) > 0) {
+                int p = S.p(s), u = S.u(s);
+                if (V.b1split) {
+                    int Kp = ((cdiv(u, V.b1split)) + 31) & ~31, nparts = cdiv(u, Kp);      // the scratch rows of the primal split (sk_off_) serve here too
+                    for (int q = 0; q < nparts; ++q) for (int a = 0; a < cdiv(p, 64); ++a) tiles.push_back({s, 12 | (slg << 8) | (V.b1split << 16), a, q});
+                } else {
+                    for (int a = 0; a < cdiv(p, 16 * slg); ++a) tiles.push_back({s, 12 | (slg << 8), a, 0});
+                }
+            }
+            V.ab1.count = (int)(tiles.size() - V.ab1.off); V.ab1.sl = slg;
+            std::stable_sort(tiles.begin() + V.ab1.off, tiles.end(), [&](const Tile& a, const Tile& b) { return S.u(a.f) > S.u(b.f); });   // K = u
+        }
         const int sl5 = std::max(2, pick_slabs([&](auto&& cb) { for (int s : lv) cb(S.p(s)); }));
         for (int pass = 0; pass < 2; ++pass) {       // the fronts whose B3 rides with their B1 tile (kind 6) go to their own launch
             Launch& L = pass == 0 ? V.b3 : V.b3s;
@@ -1072,6 +1133,11 @@ int Engine::analyze() {
     if (ebp.empty()) ebp.push_back(0);
     std::vector<int> c0row(n);
     for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
+    {
+        std::vector<int> rid((size_t)Kloc * n);
+        for (int k = 0; k < Kloc; ++k) for (int i = 0; i < n; ++i) rid[(size_t)k * n + i] = i - c0row[i];
+        if (!d_rowid_.upload(rid.data(), rid.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
+    }
     std::vector<int> one(1, 0);
     bool ok = d_fr_.upload(fr.data(), fr.size(), stream_) &&
               d_struct_.upload(S.struct_idx.empty() ? one.data() : S.struct_idx.data(), std::max<size_t>(1, S.struct_idx.size()), stream_) &&
@@ -1268,7 +1334,7 @@ int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int st
     return warn;
 }
 
-int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
+int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_, int adjoint) {
     if (!Y || !R || m0_ <= 0 || ldy < n || ldr < n) return fail(FEASTHIP_EARG, "ldiv: bad arguments");
     if (!factored_) return fail(FEASTHIP_ESTATE, "ldiv: not factorised");
     // unit 0 of the coefficient table must be node 0 itself: under the conjugate fold it would be the upper-half-plane member of
@@ -1287,12 +1353,14 @@ int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_) {
     if (ldr == n) HIPCHK(hipMemcpyAsync(d_io_.p, R, (size_t)n * m0 * sizeof(cz), hipMemcpyHostToDevice, stream_));
     else HIPCHK(hipMemcpy2DAsync(d_io_.p, (size_t)n * sizeof(cz), R, (size_t)ldr * sizeof(cz), (size_t)n * sizeof(cz), m0, hipMemcpyHostToDevice, stream_));
     launch_cm_to_rm(stream_, n, m0, ldw, d_io_.p, n, d_R_.p);
-    int r = solve_all(d_R_.p);
+    if (adjoint && mixed_) return fail(FEASTHIP_ESTATE, "ldiv: the adjoint solve runs in complex128 only");
+    int r = adjoint ? solve_range_adj(stream_, 0, 1, 0, d_R_.p, ldw) : solve_all(d_R_.p);
     if (r) return r;
     std::vector<zc> e0((size_t)Kloc * solve_width(), zc(0.0));
     for (int j = 0; j < ldw; ++j) e0[j] = 1.0;        // node 0 only
     HIPCHK(hipMemcpyAsync(d_e0_.p, e0.data(), e0.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
-    accumulate_solutions(1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    if (adjoint) launch_accumulate(stream_, dsym_, d_X_.p, adj_solution(), (int64_t)n * solve_width(), ldw, solve_width(), 1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
+    else accumulate_solutions(1, d_e0_.p, nullptr, 0, d_T1_.p, nullptr);
     launch_rm_to_cm(stream_, n, m0, ldw, d_T1_.p, d_io_.p, n);
     if (ldy == n) HIPCHK(hipMemcpyAsync(Y, d_io_.p, (size_t)n * m0 * sizeof(cz), hipMemcpyDeviceToHost, stream_));
     else HIPCHK(hipMemcpy2DAsync(Y, (size_t)ldy * sizeof(cz), d_io_.p, (size_t)n * sizeof(cz), (size_t)n * sizeof(cz), m0, hipMemcpyDeviceToHost, stream_));

@@ -52,7 +52,9 @@ struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Laun
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     Launch f2red; int f2split = 0;      // forward L21 products split along K (few nodes per GPU): number of parts, reduction tiles
                     Launch b3s;       // B3 tiles of the fronts whose B1 tile is kind 6 (launched only when the apply kernel does not fuse them)
-                    double asm_rows = 0, pull_rows = 0; };   // children's contribution rows landing in pivot blocks / in contribution rows of this level
+                    double asm_rows = 0, pull_rows = 0;      // children's contribution rows landing in pivot blocks / in contribution rows of this level
+                    // adjoint sweeps (kernels.hpp, tile kinds 8 .. 13): T(z)^H x = r over the same factors
+                    Launch afd; std::vector<Launch> afe; Launch af2; Launch ab1; std::vector<Launch> abe; };
 
 struct SparseTerm {
     std::vector<int64_t> colptr;
@@ -142,7 +144,7 @@ public:
     int nlfeast_moments_run(void* X, int64_t n, int m0, int moments, int iter, double eps, double spurious, double* lambda,
                             double* res, uint8_t* inside, void* Y, int* nit);
     // fine-grained seam: Y = T^-1 R for the single factorised matrix of this engine (node 0)
-    int ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
+    int ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0, int adjoint = 0);
     int estimate_count(const void* X, int64_t n, int m0, double* est);
     int profile_solve(ProfileRow* rows /*[8]*/);
     std::vector<double> prof_detail;   // per launch: class, ms, bytes, flops, tiles, tree depth (filled by profile_solve)
@@ -274,6 +276,11 @@ private:
     void inside_test(const zc* lam, uint8_t* inside) const;
     int solve_all_impl(const cz* rhs, ProfileRow* prof);
     int solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof);
+    // Adjoint sweeps T(z_k)^H x = rhs over the factors of the units kb .. kb + kc - 1; the block vectors of the sweep are the instance
+    // slots slot0 .. slot0 + kc - 1 of W / Y / the contribution arenas.  The solution: adj_solution() (W, or Y when the fronts interchanged rows)
+    int solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs);
+    const cz* adj_solution() const { return (nopiv_used || nopiv_gen_used) ? d_W_.p : d_Y_.p; }
+    DevBuf<int> d_rowid_;                 // identity "row interchanges" (relative index within the supernode) for the adjoint sweeps' gather / assembly
     template <typename T>
     int solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall);
     // mixed precision (feast!'s mixed_prec, src/feast.jl:19-25): complex64 copies of factors and block vectors

@@ -106,6 +106,57 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     return 0;
 }
 
+// Adjoint sweeps: T(z_k)^H x = rhs for the units kb .. kb + kc - 1 over their solve-ready factors (kernels.hpp, tile kinds 8 .. 13).
+// Forward with U^H (a lower triangular factor), backward with L^H; the fronts' row interchanges act on the solution, so the gather and
+// the assembly run with identity interchanges (d_rowid_) and k_accumulate undoes them at the end.  Per level:
+//   forward   assemble -> { Y_b = inv(U_bb)^H W_b } -> steps c = 1 .. S - 1 { Y_c -= (PU_[0,c) c)^H Y_[0,c) } -> { C_I = .. - U12^H Y_J ; W_b = inv(L_bb)^H Y_b }
+//   backward  { W_J -= P21^H W[struct] } (+ split-K reduction) -> steps c = S - 2 .. 0 { W_c -= (P_(c,S) c)^H W_(c,S) }
+int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs) {
+    if (mixed_) return fail(FEASTHIP_ESTATE, "adjoint sweeps run in complex128 only");
+    if (fwd_splitk_) return fail(FEASTHIP_ESTATE, "adjoint sweeps: FEASTHIP_FWD_SPLITK is not supported");
+    const int lw = solve_width();
+    const int64_t fs = S.fact_size, ws = (int64_t)n * lw;
+    cz* crowb[2] = {d_crow_[0].p, d_crow_[1].p};
+    const cz* Fp = d_fact_.p + (int64_t)kb * fs;
+    cz* Wp = d_W_.p + (int64_t)slot0 * ws;
+    cz* Yp = d_Y_.p + (int64_t)slot0 * ws;
+    const int* rid = d_rowid_.p;                 // (every unit's copy is the same identity table)
+    const Tile* tl = d_tiles_.p;
+    launch_gather_rhs(st, dsym_, rhs, ldrhs, lw, Wp, ws, rid, kc);
+    for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep with U^H, leaves to root
+        SolveLevel& V = splan_[d];
+        const int par = d & 1;
+        const int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * lw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * lw;
+        cz* crp = crowb[par] + (int64_t)slot0 * crs;
+        cz* crc = crowb[par ^ 1] + (int64_t)slot0 * crsc;
+        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, lw, crp, crs, crc, crsc, rid, kc, 0, dsym_.asmflag ? rhs : nullptr, ldrhs);
+        launch_apply(st, dsym_, tl + V.afd.off, V.afd.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, nullptr, 0, V.afd.sl);
+        for (size_t c = 1; c < V.afe.size(); ++c) {
+            const Launch& L = V.afe[c];
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, nullptr, 0, L.sl);
+        }
+        launch_apply(st, dsym_, tl + V.af2.off, V.af2.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, crc, crsc, V.af2.sl);
+    }
+    const int64_t sks = std::max<int64_t>(1, sk_rows_) * lw;
+    cz* skp = d_sk_.p + (int64_t)slot0 * sks;
+    // With row interchanges in the fronts (T = P^T L U, T^H = U^H L^H P) a front's finished rows are x_J = P_J^T w_J: they are copied to
+    // their pre-pivot positions in Y (free since the forward sweep ended), which is what the children gather from and what the caller reads.
+    const bool unperm = !(nopiv_used || nopiv_gen_used);
+    cz* Xs = unperm ? Yp : Wp;
+    for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep with L^H, root to leaves
+        SolveLevel& V = splan_[d];
+        launch_apply(st, dsym_, tl + V.ab1.off, V.ab1.count, Fp, fs, Wp, Xs, ws, lw, nullptr, 0, kc, true, skp, sks, nullptr, 0, V.ab1.sl);
+        if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Wp, ws, lw, skp, sks, kc);
+        for (int c = (int)V.abe.size() - 2; c >= 0; --c) {
+            const Launch& L = V.abe[c];
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, lw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, L.sl);
+        }
+        if (unperm) launch_adj_unpermute(st, dsym_, d_lists_.p + fplan_[d].fronts.off, fplan_[d].fronts.count, d_rowperm_.p + (int64_t)kb * n, Wp, Yp, ws, lw, kc);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // Q0 (Q1) = sum_k T_k .* e0[k,:] (e1[k,:]) over the solution blocks of the last sweep (fp64 accumulation in either precision)
 void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0, int nrows) {
     const int lw = solve_width();

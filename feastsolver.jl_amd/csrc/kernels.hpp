@@ -106,6 +106,16 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 //   3 B1  backward, pivot rows:                                        Y_J -= U12 W[struct]    (K = u, gathered; final x lives in W)
 //   4 B2  backward, rows above diagonal block c:                       Y_r -= PU_rc Y_c
 //   5 B3  backward, diagonal super block b, row tile c:                W_b  = inv(U_bb) Y_b
+// Adjoint sweeps, T(z)^H x = r over the SAME solve-ready factors (round 4; T(conj z) = T(z)^H for Hermitian pencils, and the left systems
+// (A - z B)^H of dual_gen_feast!, src/feast.jl:185-197, 241).  U^-1 = F E_0 .. E_{S-1} and L^-1 = F' E'_{S-2} .. E'_0 in terms of the block
+// operations above; the adjoint sweeps apply the conjugate transposes of the same blocks in the reverse order, every operand read as
+// conj(slab)^T (ApplyGeom::trans):
+//   8  AF-D forward, diagonal super block b, row tile c:               Y_b  = inv(U_bb)^H W_b            (first step of a front)
+//   9  AF-E forward step c >= 1, rows of block c:                      Y_c -= (PU_[0,c) c)^H Y_[0,c)     (K = c NB, growing)
+//   10 AF-C forward, contribution rows:                                C_I  = sum_children C_child[I] - U12^H Y_J   (K = p)
+//   11 AB-D diagonal super block b, row tile c:                        W_b  = inv(L_bb)^H Y_b            (same launch as kind 10)
+//   12 AB-G backward, pivot rows:                                      W_J -= P21^H W[struct]            (K = u, gathered; split like kind 3)
+//   13 AB-E backward step c, rows of block c:                          W_c -= (P_(c,S) c)^H W_(c,S)      (descending c; final x in W)
 // max_slabs: an upper bound of the tile heights of this launch in 16-row slabs (4, 2 or 1).  Launches whose tiles all have
 // at most 32 rows run a k_apply2 instance that needs fewer registers and keeps three workgroups per CU instead of two.
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
@@ -142,8 +152,11 @@ void launch_splitk_reduce_fwd(hipStream_t st, const DevSym& S, const Tile* tiles
 // Q0 (and Q1) = sum_k T_k .* e0[k,:] (e1[k,:]),  T_k = mode ? X - W_k : W_k, rows scattered to original order;
 // lds = leading dimension of W and of the coefficient tables (2 ldw: conjugate fold, see k_accumulate)
 // row0 / nrows: the rows of Q (original order) this launch produces; nrows < 0 = all from row0
+// add: += instead of =
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int lds, int K,
-                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0 = 0, int nrows = -1);
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0 = 0, int nrows = -1, int add = 0);
+// adjoint sweeps on factors with row interchanges: X[c0 + rowperm[i]] = W[c0 + i] for the pivot rows of the listed fronts (see kernels_solve.hip)
+void launch_adj_unpermute(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* rowperm, const cz* W, cz* X, int64_t ws, int ld, int K);
 
 // ---- Rayleigh-Ritz block ------------------------------------------------------
 void launch_spmm_csr(hipStream_t st, int n, const int64_t* rowptr, const int* col, const cz* val, const cz* V, int ldw,

@@ -172,7 +172,8 @@ template <typename T>
 struct ApplyGeomT {
     const T* A;          // factor slab, column-major
     int64_t lda;
-    int rbase, rend, Kd, k0, mask;          // mask 1: unit lower (F2b), 2: upper incl. diagonal (B3)
+    int rbase, rend, Kd, k0, mask;          // mask 1: unit lower (F2b), 2: upper incl. diagonal (B3), 3: lower incl. diagonal, 4: unit upper (adjoint sweeps)
+    int trans;                              // 1: the operand is the conjugate transpose of the slab: element (row r, k) = conj(A[k + r lda]) (adjoint sweeps)
     const T* Vk;         // block vector the V rows come from (this node)
     const int* sidx;     // struct_idx of the front (gather kinds)
     int vrow0;           // first V row (contiguous kinds)
@@ -204,7 +205,7 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
     const T* Lp = fact + (int64_t)k * fs + f.lp;
     T* Wk = W + (int64_t)k * ws;
     T* Yk = Y + (int64_t)k * ws;
-    g.k0 = 0; g.mask = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0; g.pull = nullptr; g.npull = 0; g.pullbase = nullptr;
+    g.k0 = 0; g.mask = 0; g.trans = 0; g.vrow0 = 0; g.lda = ld; g.mode = 0; g.pull = nullptr; g.npull = 0; g.pullbase = nullptr;
     g.fuse = 0; g.D = nullptr; g.dld = 0; g.dp = 0; g.xout = nullptr;
     g.sidx = struct_idx + f.sptr;
     g.out = Yk; g.orow_shift = f.c0;
@@ -235,9 +236,42 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
         }
     }
     else if (kind == 4) { g.k0 = t.c * NB; int b = min(NB, p - g.k0); g.rbase = t.b * th; g.rend = g.k0; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; }
-    else {                  // upper inverse: row tile c only needs the columns from its first row on
+    else if (kind == 5) {   // upper inverse: row tile c only needs the columns from its first row on
         int kb = t.b * NB, b = min(NB, p - kb), ks = t.c * th;
         g.rbase = kb + ks; g.rend = kb + b; g.k0 = kb + ks; g.A = Lp + (int64_t)g.k0 * ld; g.Kd = b - ks; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 2; g.mode = 1; g.out = Wk;
+    }
+    // ---- adjoint sweeps: T(z)^H x = r over the SAME solve-ready factors (kernels.hpp, kinds 8 .. 13).  Every operand is the conjugate
+    //      transpose of a slab the primal sweeps read: element (output row r, k) = conj(slab[k + r lda]).
+    else if (kind == 8) {   // forward: z_b = inv(U_bb)^H w_b, lower incl. diagonal: row tile c needs the columns up to its last row
+        g.k0 = t.b * NB; int b = min(NB, p - g.k0); g.rbase = g.k0 + t.c * th; g.rend = g.k0 + b; g.A = Lp + g.k0; g.trans = 1;
+        g.Kd = min(b, t.c * th + th); g.Vk = Wk; g.vrow0 = f.c0 + g.k0; g.mask = 3; g.mode = 1;
+    }
+    else if (kind == 9) {   // forward step c >= 1, rows of block c: z_c -= (PU_[0, k0), c)^H z_[0, k0)
+        int kc0 = t.c * NB, b = min(NB, p - kc0); g.rbase = kc0 + t.b * th; g.rend = kc0 + b; g.A = Lp; g.trans = 1; g.Kd = kc0; g.Vk = Yk; g.vrow0 = f.c0;
+    }
+    else if (kind == 10) {  // forward, contribution rows: C_I = sum_children C_child[I] - U12^H z_J   (K = p)
+        g.rbase = p + t.b * th; g.rend = ld; g.A = fact + (int64_t)k * fs + f.f12 - (int64_t)p * p; g.lda = p; g.trans = 1; g.Kd = p; g.Vk = Yk; g.vrow0 = f.c0;
+        g.out = crow + (int64_t)k * crs + f.crow * (int64_t)ldw; g.orow_shift = -p; g.mode = 2;
+        if (f.cmap >= 0) { g.mode = 3; g.pull = cmap + f.cmap; g.npull = f.nchild; g.pullbase = crow_child + (int64_t)k * crs_child; }
+    }
+    else if (kind == 11) {  // t_b = inv(L_bb)^H z_b, unit upper: row tile c needs the columns from its first row on
+        int kb = t.b * NB, b = min(NB, p - kb), ks = t.c * th;
+        g.rbase = kb + ks; g.rend = kb + b; g.k0 = kb + ks; g.A = Lp + g.k0; g.trans = 1; g.Kd = b - ks; g.Vk = Yk; g.vrow0 = f.c0 + g.k0; g.mask = 4; g.mode = 1; g.out = Wk;
+    }
+    else if (kind == 12) {  // backward, pivot rows: W_J -= P21^H W[struct]   (K = u, gathered)
+        // (the gathered rows are the ancestors' solution at its PRE-pivot positions: the Y argument of the launch -- the unpermuted copy
+        // of k_adj_unpermute, or W itself when the factorisation made no interchanges)
+        g.rbase = t.b * th; g.rend = p; g.A = Lp + p; g.trans = 1; g.Kd = u; g.Vk = Yk; g.out = Wk;
+        if (nsplit > 0) {
+            int Kp = (((u + nsplit - 1) / nsplit) + 31) & ~31;
+            int kbeg = t.c * Kp;
+            g.A += kbeg; g.sidx += kbeg; g.Kd = min(Kp, u - kbeg);
+            g.out = skbuf + (int64_t)k * sks + (f.sk_off + (int64_t)t.c * p) * ldw; g.orow_shift = 0; g.mode = 2;
+        }
+    }
+    else {                  // kind 13, backward step c, rows of block c: W_c -= (P_[k0 + b, p), c)^H W_[k0 + b, p)
+        int kc0 = t.c * NB, b = min(NB, p - kc0); g.rbase = kc0 + t.b * th; g.rend = kc0 + b; g.A = Lp + (kc0 + b); g.trans = 1; g.Kd = p - kc0 - b;
+        g.Vk = Wk; g.vrow0 = f.c0 + kc0 + b; g.out = Wk;
     }
     return min(th, g.rend - g.rbase);
 }
@@ -304,11 +338,14 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
     const bool aok_all = g.rbase + slab * 16 + 16 <= g.rend;        // wave-uniform: the whole slab has rows
     const int adiag = arow - g.k0;
     const int Kd = g.Kd, nks = (Kd + 3) >> 2;
-    const int lo_keep = (g.mask == 2) ? adiag : 0;                  // keep gk in [lo_keep, hi_keep)
-    const int hi_keep = (g.mask == 1) ? adiag : 0x7fffffff;
-    const int unit_at = (g.mask == 1 && aok) ? adiag : -1;
-    const T* Ap = g.A + min(arow, g.rend - 1);
-    const int lda = (int)g.lda;       // a panel's leading dimension fits 31 bits: one v_mad_i64_i32 per address
+    const int lo_keep = (g.mask == 2) ? adiag : (g.mask == 4) ? adiag + 1 : 0;      // keep gk in [lo_keep, hi_keep)
+    const int hi_keep = (g.mask == 1) ? adiag : (g.mask == 3) ? adiag + 1 : 0x7fffffff;
+    const int unit_at = ((g.mask == 1 || g.mask == 4) && aok) ? adiag : -1;
+    // adjoint sweeps (g.trans): the operand element of (row, k) sits at A[k + row lda] and enters conjugated; the lanes of a row
+    // group then read 64 contiguous bytes of a column per k-step, consecutive k-steps the next 64
+    const int lda = g.trans ? 1 : (int)g.lda;       // address step per k.  A panel's leading dimension fits 31 bits: one v_mad_i64_i32 per address
+    const T* Ap = g.A + (int64_t)min(arow, g.rend - 1) * (g.trans ? g.lda : 1);
+    const real cjs = g.trans ? (real)-1 : (real)1;
     // Column of lane li in column tile q.  complex128: 16 consecutive columns per tile, one 16-byte load per lane and tile.
     // complex64: two tiles share a 32-column span, lane li owning the columns 2 li (even tile) and 2 li + 1 (odd tile), so that one
     // 16-byte load (store) per lane serves both -- the complex64 sweeps are bound by the number of vector memory instructions,
@@ -378,7 +415,7 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
         const bool keep = aok && gk < Kd && gk >= lo_keep && gk < hi_keep;
         a.x = keep ? a.x : (gk == unit_at ? (real)1 : (real)0);
         a.y = keep ? a.y : (real)0;
-        const real as = a.x + a.y;
+        const real as = a.x + cjs * a.y;       // conj(a) v by the 3M scheme: t2 accumulates +a.y v.y, t3 (a.x - a.y)(v.x + v.y); the epilogue takes the signs
         // 3M complex product, see apply_body
 #if FEASTHIP_A2_ABLATE & 4
 #pragma unroll
@@ -426,7 +463,7 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
 #endif
             __builtin_amdgcn_sched_barrier(0);
             const T a = ar[j % A2_DA];
-            const real as = a.x + a.y;
+            const real as = a.x + cjs * a.y;
 #if FEASTHIP_A2_ABLATE & 4
 #pragma unroll
             for (int q = 0; q < NS; ++q) { t1[q][0] += a.x * vr[j % A2_DV][q].x; t2[q][0] += a.y * vr[j % A2_DV][q].y; t3[q][0] += as; }
@@ -502,7 +539,7 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
         T o[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            const real cr = t1[q][r] - t2[q][r], ci = t3[q][r] - t1[q][r] - t2[q][r];
+            const real cr = t1[q][r] - cjs * t2[q][r], ci = t3[q][r] - t1[q][r] - cjs * t2[q][r];
             if (g.mode == 1 || g.mode == 2) { o[q].x = sgn * cr; o[q].y = sgn * ci; }
             else { o[q].x = old[r][q].x - cr; o[q].y = old[r][q].y - ci; }
         }
@@ -733,19 +770,20 @@ void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, in
 // Fixed summation order over k: run-to-run reproducible (src/feast.jl:68-70, src/nlfeast.jl:56-59).
 // Conjugate fold (lds = 2 ldw): unit k carries two contour nodes; columns [ldw, 2 ldw) of W_k hold T(z_k)^-1 conj(R),
 // whose conjugate is the solution of the node conj(z_k); its coefficients are columns [ldw, 2 ldw) of e0 / e1.
+// add: Q0 (Q1) += instead of = (a second launch over the adjoint instances of an adjoint-folded step)
 template <typename T>
 __global__ void k_accumulate(const int* __restrict__ iperm, int row0, int nrows, const cz* __restrict__ X, const T* __restrict__ W,
                              int64_t ws, int ldw, int lds, int K, const cz* __restrict__ e0, const cz* __restrict__ e1, int mode,
-                             cz* Q0, cz* Q1) {
+                             cz* Q0, cz* Q1, int add) {
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (r >= nrows) return;
     int64_t old = row0 + r;            // rows [row0, row0 + nrows) of Q in ORIGINAL order (a contiguous chunk for the all-reduce)
-    int i = iperm[old];
+    const int i = iperm[old];
     const bool fold = lds > ldw;
     for (int j = lane; j < ldw; j += 64) {
         cz x = mode ? X[old * ldw + j] : cz_make(0, 0);
-        cz q0 = cz_make(0, 0), q1 = cz_make(0, 0);
+        cz q0 = add ? Q0[old * ldw + j] : cz_make(0, 0), q1 = (add && Q1) ? Q1[old * ldw + j] : cz_make(0, 0);
         for (int k = 0; k < K; ++k) {
             T wt = W[(int64_t)k * ws + (int64_t)i * lds + j];
             cz w = cz_make(wt.x, wt.y);                 // accumulation is always fp64 (src/feast.jl:68-70)
@@ -766,16 +804,39 @@ __global__ void k_accumulate(const int* __restrict__ iperm, int row0, int nrows,
 }
 
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W, int64_t ws, int ldw, int lds, int K,
-                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0, int nrows) {
+                       const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0, int nrows, int add) {
     if (nrows < 0) nrows = S.n - row0;
     if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_accumulate<cz>, dim3((nrows + 3) / 4), dim3(256), 0, st, S.iperm, row0, nrows, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
+    hipLaunchKernelGGL(k_accumulate<cz>, dim3((nrows + 3) / 4), dim3(256), 0, st, S.iperm, row0, nrows, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1, add);
+}
+
+// Adjoint sweeps on factors with row interchanges: T = P^T L U gives T^H = U^H L^H P, so the interchanges of a front act on its part
+// of the SOLUTION, x_J = P_J^T w_J.  One workgroup per (front, unit) writes the finished pivot rows of W into X at their pre-pivot
+// positions (row c0 + rowperm[i] <- row c0 + i); the children's gathers and the accumulation then read X.
+template <typename T>
+__global__ __launch_bounds__(256) void k_adj_unpermute(const FrontD* __restrict__ fr, const int* __restrict__ list, const int* __restrict__ rowperm, int n,
+                                                       const T* __restrict__ W, T* X, int64_t ws, int ld) {
+    const FrontD f = fr[list[blockIdx.x]];
+    const int k = blockIdx.y;
+    const int* rp = rowperm + (int64_t)k * n + f.c0;
+    const T* Wk = W + (int64_t)k * ws + (int64_t)f.c0 * ld;
+    T* Xk = X + (int64_t)k * ws + (int64_t)f.c0 * ld;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < f.p; i += 4) {
+        const int o = rp[i];
+        for (int j = lane; j < ld; j += 64) Xk[(int64_t)o * ld + j] = Wk[(int64_t)i * ld + j];
+    }
+}
+
+void launch_adj_unpermute(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* rowperm, const cz* W, cz* X, int64_t ws, int ld, int K) {
+    if (nlist <= 0) return;
+    hipLaunchKernelGGL(k_adj_unpermute<cz>, dim3(nlist, K), dim3(256), 0, st, S.fr, list, rowperm, S.n, W, X, ws, ld);
 }
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0, int nrows) {
     if (nrows < 0) nrows = S.n - row0;
     if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_accumulate<cf>, dim3((nrows + 3) / 4), dim3(256), 0, st, S.iperm, row0, nrows, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1);
+    hipLaunchKernelGGL(k_accumulate<cf>, dim3((nrows + 3) / 4), dim3(256), 0, st, S.iperm, row0, nrows, X, W, ws, ldw, lds, K, e0, e1, mode, Q0, Q1, 0);
 }
 
 }  // namespace feasthip

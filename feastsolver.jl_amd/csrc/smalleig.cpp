@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace feasthip {
 namespace {
@@ -182,8 +185,12 @@ int eig_general(int m, zc* A, zc* lam, zc* V) {
     if (m <= 0) return 0;
     Planes T(m), Z(m);
     T.load(A);
+    static const bool trace = getenv("FEASTHIP_EIG_TRACE") != nullptr;
+    auto tp0 = std::chrono::steady_clock::now();
     hessenberg(T, Z);
+    auto tp1 = std::chrono::steady_clock::now();
     int info = hqr_schur(T, Z);
+    auto tp2 = std::chrono::steady_clock::now();
     if (info) return info;
     double tn = 0;
     for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) tn = std::max(tn, std::fabs(T.r(j)[i]) + std::fabs(T.i(j)[i]));
@@ -215,6 +222,10 @@ int eig_general(int m, zc* A, zc* lam, zc* V) {
         for (int i = 0; i < m; ++i) nr += wr[i] * wr[i] + wi[i] * wi[i];
         nr = 1.0 / std::sqrt(nr);
         for (int i = 0; i < m; ++i) vecs[i + (size_t)k * m] = zc(wr[i] * nr, wi[i] * nr);
+    }
+    if (trace) {
+        auto msf = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[feasthip eig] m=%d: Hessenberg %.3f, QR iteration %.3f, eigenvectors %.3f ms\n", m, msf(tp0, tp1), msf(tp1, tp2), msf(tp2, std::chrono::steady_clock::now()));
     }
     std::vector<int> order(m);
     std::iota(order.begin(), order.end(), 0);

@@ -241,6 +241,9 @@ int feasthip_lu_dense_c64(int device_id, const void* C, int64_t n, feasthip_fact
 int feasthip_lu_csc(int device_id, int64_t n, const int64_t* colptr, const int64_t* rowval,
                     const void* nzval, int type, int index_base, feasthip_fact_t* F);
 int feasthip_ldiv(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
+/* Y = C^-H R over the SAME factor object (Julia: `ldiv!(Y, F', R)`): the adjoint sweeps U^H, L^H of round 4.  The reference factorises
+ * the adjoint matrices a second time (`lfacts`, src/feast.jl:185-197, used at :241); a caller of this seam need not.  complex128 only. */
+int feasthip_ldiv_adjoint(feasthip_fact_t F, void* Y, int64_t ldy, const void* R, int64_t ldr, int m0);
 int feasthip_fact_free(feasthip_fact_t F);
 /* How F was factorised: *symmetric = 1 if C equals its transpose and the pivot-light elimination passed its growth check
  * (*growth = max(1, max |l_ij|) * max(1, max |u_ij| / ||C||) as it saw them), 2 if C is Hermitian off its diagonal and the elimination without interchanges (L, U apart) passed

@@ -629,6 +629,71 @@ def test_rr_device_path_matches_host_path(gpu, pkg, wl, golden, case):
 
 
 # ---------------------------------------------------------------------------------------
+# adjoint sweeps over the same factors (round 4): src/feast.jl:185-197, 241
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,n,m0", [("dense", 1, 1), ("dense", 5, 3), ("dense", 64, 64), ("dense", 100, 20), ("dense", 129, 7), ("dense", 257, 64), ("dense", 300, 100),
+                                       ("dense", 700, 37), ("dense", 1100, 8), ("dense", 2100, 4), ("dense", 193, 7), ("dense", 385, 3), ("dense", 513, 2),
+                                       ("dense", 1025, 5), ("dense", 1537, 3), ("symmetric", 300, 9), ("symmetric", 1100, 5), ("hermitian", 257, 9),
+                                       ("hermitian", 1100, 5)])
+def test_seam_adjoint_ldiv_dense(gpu, pkg, kind, n, m0):
+    """Y = C^-H R from the factor object of C (feasthip_ldiv_adjoint: forward with U^H, backward with L^H over the same solve-ready
+    factors, the fronts' row interchanges undone on the solution): against a host solve with C^H, to the seam's backward error, on
+    every factorisation path (partial pivoting, U = D L^T, no interchanges with L and U apart) and at sizes on every super-block edge."""
+    rng = np.random.default_rng(n * 13 + m0)
+    G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    if kind == "dense":
+        Cm = G
+    elif kind == "symmetric":
+        S = rng.standard_normal((n, n)); H = rng.standard_normal((n, n))
+        Cm = (S + S.T) + 1j * (H @ H.T / n + 0.5 * np.eye(n))
+    else:
+        Cm = (G + G.conj().T) / (2 * np.sqrt(n)) - (0.3 + 0.4j) * np.eye(n)
+    Cm = np.asfortranarray(Cm.astype(np.complex128))
+    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
+    F = pkg.lu(Cm)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R, adjoint=True)
+    Y2 = np.zeros_like(R)
+    pkg.ldiv(Y2, F, R)                                   # the primal solve still works on the same object afterwards
+    path = F.path
+    pkg.finalize(F)
+    Ch = Cm.conj().T
+    assert np.linalg.norm(Ch @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y), path
+    assert np.linalg.norm(Cm @ Y2 - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y2)
+
+
+@pytest.mark.parametrize("case", ["grid3d_19", "grid2d", "random_unsym", "hermitian_grid", "grid3d_big"])
+@pytest.mark.parametrize("m0", [1, 20, 64])
+def test_seam_adjoint_ldiv_sparse(gpu, pkg, wl, case, m0):
+    """The adjoint solve on multifrontal factors (children's contribution rows, gathered ancestor rows, split-K tiles at the top of
+    a big tree), unsymmetric values with real pivoting included."""
+    rng = np.random.default_rng(7)
+    if case == "grid3d_19":
+        A = wl.laplacian_3d(9, 19).astype(np.complex128)
+    elif case == "grid2d":
+        g = 20
+        T = sp.diags([-np.ones(g - 1), 2 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
+        A = sp.csc_matrix(sp.kron(sp.identity(g), T) + sp.kron(T, sp.identity(g))).astype(np.complex128)
+    elif case == "random_unsym":
+        A = (sp.random(400, 400, density=0.01, random_state=5, format="csc") * (1.0 + 0.5j) + sp.identity(400, format="csc") * 0.3).astype(np.complex128)
+    elif case == "hermitian_grid":
+        A = wl.hermitian_phases(wl.laplacian_3d(10, 19), seed=4)
+    else:
+        if m0 != 20:
+            pytest.skip("one block width is enough at this size")
+        A = wl.laplacian_3d(24, 19).astype(np.complex128)
+    n = A.shape[0]
+    Cm = sp.csc_matrix(A - (0.4 + 0.3j) * sp.diags(rng.uniform(0.5, 1.5, n)))
+    R = np.asfortranarray(rng.standard_normal((n, m0)) + 1j * rng.standard_normal((n, m0)))
+    F = pkg.lu(Cm)
+    Y = np.zeros_like(R)
+    pkg.ldiv(Y, F, R, adjoint=True)
+    pkg.finalize(F)
+    Ch = sp.csc_matrix(Cm.conj().T)
+    assert np.linalg.norm(Ch @ Y - R) <= 1e-11 * spla.norm(Cm) * np.linalg.norm(Y)
+
+
+# ---------------------------------------------------------------------------------------
 # properties at sizes the oracle cannot reach quickly
 # ---------------------------------------------------------------------------------------
 def test_large_sparse_solve_residual(gpu, pkg, wl):
