@@ -12,6 +12,7 @@ X is overwritten in place (the `!` convention); return values are the reference'
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -572,11 +573,18 @@ def dual_gen_feast(Xr, Xl, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0,
     z = np.asarray(contour.nodes, dtype=np.complex128)
     w = np.asarray(contour.weights, dtype=np.complex128)
     import copy
+    doubled = os.environ.get("FEASTHIP_DUAL_DOUBLED", "0") == "1"       # rounds 2-3: the adjoint matrices factorised as K more nodes
     dual_contour = copy.copy(contour)
-    dual_contour.nodes, dual_contour.weights = np.concatenate([z, z.conj()]), np.concatenate([w, w.conj()])
-    table = np.zeros((2 * K, 4), dtype=np.complex128)
-    table[:K, 0], table[:K, 1] = 1.0, z                        # A - z_k B          (scales 1, -1)
-    table[K:, 2], table[K:, 3] = 1.0, z.conj()                 # A' - conj(z_k) B'  (the reference's lfacts, :185-197)
+    if doubled:
+        dual_contour.nodes, dual_contour.weights = np.concatenate([z, z.conj()]), np.concatenate([w, w.conj()])
+        table = np.zeros((2 * K, 4), dtype=np.complex128)
+        table[:K, 0], table[:K, 1] = 1.0, z                        # A - z_k B          (scales 1, -1)
+        table[K:, 2], table[K:, 3] = 1.0, z.conj()                 # A' - conj(z_k) B'  (the reference's lfacts, :185-197)
+    else:
+        # K factorisations of A - z_k B; the left systems (A - z_k B)' y = r (lfacts, :185-197, :241) are adjoint sweeps over the same
+        # factors (the terms A', B' stay for the left residual A' y - conj(lam) B' y, :214)
+        table = np.zeros((K, 4), dtype=np.complex128)
+        table[:, 0], table[:, 1] = 1.0, z
     h = FeastHandle(device)
     try:
         h.set_terms([A, B, _adjoint(A), _adjoint(B)], scales=[1.0, -1.0, 1.0, -1.0])

@@ -13,7 +13,7 @@ namespace feasthip {
 // handles left on its device is returned to the driver first (pool_drop_device), then its own blocks are cached -- other
 // allocators of the process (torch, RCCL, the caller's hipMalloc) never face more idle memory than the last solver run used.
 // feasthip_trim_memory() returns the cached blocks to the driver; so does an allocation that fails.  FEASTHIP_POOL_GB caps the
-// cache (default 48; 0 switches it off), FEASTHIP_POOL_POISON=1 fills a recycled block with 0xFF bytes before it is handed out
+// cache (default 96, a third of the 288 GB part: dual_gen_feast on C3 holds 55 GB; 0 switches it off), FEASTHIP_POOL_POISON=1 fills a recycled block with 0xFF bytes before it is handed out
 // (NaN patterns: a dependence on what a previous problem left in a block then shows in the tests).
 namespace {
 struct CachedBlock { int dev; void* p; size_t bytes; };
@@ -21,7 +21,7 @@ std::mutex g_pool_mu;
 std::vector<CachedBlock> g_pool;
 constexpr size_t POOL_MIN_BYTES = (size_t)64 << 20;
 size_t pool_limit_bytes() {
-    static const size_t lim = [] { const char* e = getenv("FEASTHIP_POOL_GB"); return (size_t)((e ? atof(e) : 48.0) * 1073741824.0); }();
+    static const size_t lim = [] { const char* e = getenv("FEASTHIP_POOL_GB"); return (size_t)((e ? atof(e) : 96.0) * 1073741824.0); }();
     return lim;
 }
 bool pool_poison() {
@@ -253,6 +253,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
     if (const char* v = getenv("FEASTHIP_NOPIV_GEN")) nopiv_gen_enabled_ = atoi(v) != 0;
+    if (const char* v = getenv("FEASTHIP_ADJ_FOLD")) adj_fold_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_RR_DEVICE")) rr_device_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_RR_COND")) rr_cond_max_ = atof(v);
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
@@ -372,12 +373,12 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
     terms_.clear();
     terms_.resize(nterms);
     terms_real_ = false;
-    bool real = true, sym = true, herm = true;
+    bool real = true, sym = true, herm = true, hdiag = true;
     // The caller's bytes go to the device as they are; element type, storage order (FEASTHIP_ROW_MAJOR), max |a_ij|, realness and
     // M == M^T (exactly) are dealt with there (k_dense_import): the host touches the matrix once, for the copy.
     DevBuf<int64_t> d_props;
     DevBuf<cz> d_stage;
-    if (!d_props.alloc(4)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
+    if (!d_props.alloc(5)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
     for (int t = 0; t < nterms; ++t) {
         SparseTerm& T = terms_[t];
         T.scale = scale ? zc(scale[2 * t], scale[2 * t + 1]) : zc(1.0);
@@ -394,10 +395,10 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
             if (!d_stage.alloc((nn * esz + 15) / 16)) return fail(FEASTHIP_EHIP, "set_dense: device allocation failed");
             raw = d_stage.p;
         }
-        HIPCHK(hipMemsetAsync(d_props.p, 0, 4 * sizeof(int64_t), stream_));
+        HIPCHK(hipMemsetAsync(d_props.p, 0, 5 * sizeof(int64_t), stream_));
         HIPCHK(hipMemcpyAsync(raw, mats[t], nn * esz, hipMemcpyHostToDevice, stream_));
         launch_dense_import(stream_, raw, ty, row_major, n, T.d_dense.p, reinterpret_cast<unsigned long long*>(d_props.p));
-        int64_t props[4] = {0, 0, 0, 0};
+        int64_t props[5] = {0, 0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(props, d_props.p, sizeof(props), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipGetLastError());
@@ -407,11 +408,13 @@ int Engine::set_dense(int64_t n_, int nterms_, const void* const* mats, const in
         if (props[1]) real = false;
         if (props[2]) sym = false;
         if (props[3]) herm = false;
+        if (props[4]) hdiag = false;
     }
     for (auto& T : terms_) if (T.scale.imag() != 0.0) real = false;
     terms_real_ = real;
     terms_symmetric_ = sym;
     terms_hermitian_ = herm;
+    terms_herm_exact_ = herm && hdiag;
     nopiv_failed_ = false;
     rr_dev_state_ = 0;
     nopiv_gen_failed_ = false;
@@ -471,6 +474,7 @@ int Engine::set_csc(int64_t n_, int nterms_, const int64_t* const* colptr, const
     terms_real_ = real;
     terms_symmetric_ = false;          // decided in analyze(), where the transposes of the terms are built anyway
     terms_hermitian_ = false;
+    terms_herm_exact_ = false;
     nopiv_failed_ = false;
     rr_dev_state_ = 0;
     nopiv_gen_failed_ = false;
@@ -547,11 +551,18 @@ bool plan_node_shard(const std::vector<zc>& nodes, int first, int stride, bool f
 // local_ / partner_ / fold_ / Kloc from the contour, the shard, the terms and the per-node overrides (plan_node_shard, engine.hpp)
 void Engine::rebuild_shard() {
     std::vector<int> loc, par;
-    const bool allowed = fold_enabled_ && terms_real_ && !terms_.empty() && node_coef_.empty() && coef_fn_ == nullptr;
-    const bool can = plan_node_shard(nodes_, shard_first_, shard_stride_, allowed, loc, par);
-    if (loc.size() != local_.size() || can != fold_) { analyzed_ = false; have_x_ = false; }
-    if (loc != local_ || par != partner_ || can != fold_) factored_ = false;
-    local_.swap(loc); partner_.swap(par); fold_ = can;
+    const bool base = fold_enabled_ && !terms_.empty() && node_coef_.empty() && coef_fn_ == nullptr;
+    bool scales_real = true;
+    for (const SparseTerm& T : terms_) if (T.scale.imag() != 0.0) scales_real = false;
+    const bool allow_conj = base && terms_real_;
+    // the adjoint fold: Hermitian coefficient matrices that are not real (real ones take the conjugate fold: one sweep of twice the width
+    // instead of two); complex128 sweeps only
+    const bool allow_adj = base && !terms_real_ && adj_fold_enabled_ && terms_herm_exact_ && scales_real && !mixed_;
+    const bool can = plan_node_shard(nodes_, shard_first_, shard_stride_, allow_conj || allow_adj, loc, par);
+    const bool nf = can && allow_conj, na = can && !allow_conj && allow_adj;
+    if (loc.size() != local_.size() || nf != fold_ || na != adj_fold_) { analyzed_ = false; have_x_ = false; }
+    if (loc != local_ || par != partner_ || nf != fold_ || na != adj_fold_) factored_ = false;
+    local_.swap(loc); partner_.swap(par); fold_ = nf; adj_fold_ = na;
     Kloc = (int)local_.size();
 }
 
@@ -931,7 +942,7 @@ int Engine::analyze() {
     }
     struct JoinWarm { std::thread& t; ~JoinWarm() { if (t.joinable()) t.join(); } } join_warm{warm};
     // per-term host work that runs beside the ordering (CSR copies + their uploads) and beside the launch plans (arena destinations)
-    struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, herm = 0, diag = 0; };
+    struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, herm = 0, diag = 0, hreal = 0; };
     std::vector<TermHost> th;
     std::shared_ptr<SymCacheEntry> sym_entry;      // the cache entry this analysis came from / went to (sparse terms)
     std::vector<std::shared_ptr<const std::vector<int64_t>>> dest_ready;    // arena destinations found in it, per term
@@ -1000,6 +1011,10 @@ int Engine::analyze() {
                         for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1] && eqh; ++e2)
                             eqh = H.col[e2] == T.rowval[e2] && (T.rowval[e2] == j || H.v[e2] == std::conj(T.val[e2]));
                     H.herm = eqh ? 1 : 0;
+                    bool dreal = true;      // a real diagonal on top of that: the matrix IS Hermitian (adjoint fold)
+                    for (int j = 0; j < n && dreal; ++j)
+                        for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) if (T.rowval[e2] == j && T.val[e2].imag() != 0.0) { dreal = false; break; }
+                    H.hreal = dreal ? 1 : 0;
                 }
                 {   // entries on the diagonal only: the Rayleigh-Ritz step then scales rows instead of running SpMM products
                     bool dg = !dense;
@@ -1131,6 +1146,17 @@ int Engine::analyze() {
         }
     }
     if (ebp.empty()) ebp.push_back(0);
+    if (!dense) {
+        // the CSR threads (long finished: they ran beside the ordering) also compared every term with its transposes: whether the
+        // adjoint fold applies, and with it the number of units of this handle, is known before anything is sized by it
+        for (auto& t2 : csr_pool) if (t2.joinable()) t2.join();
+        terms_symmetric_ = true;
+        terms_hermitian_ = true;
+        terms_herm_exact_ = true;
+        for (TermHost& H : th) { if (!H.sym) terms_symmetric_ = false; if (!H.herm) terms_hermitian_ = false; if (!H.herm || !H.hreal) terms_herm_exact_ = false; }
+        rebuild_shard();
+        if (Kloc <= 0) return fail(FEASTHIP_ESTATE, "analyze: no contour nodes on this shard");
+    }
     std::vector<int> c0row(n);
     for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
     {
@@ -1174,11 +1200,8 @@ int Engine::analyze() {
     }
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (!dense) {
-        for (auto& t2 : dest_pool) t2.join();
-        for (auto& t2 : csr_pool) t2.join();
-        terms_symmetric_ = true;
-        terms_hermitian_ = true;
-        for (TermHost& H : th) { if (!H.sym) terms_symmetric_ = false; if (!H.herm) terms_hermitian_ = false; }
+        for (auto& t2 : dest_pool) if (t2.joinable()) t2.join();
+        for (auto& t2 : csr_pool) if (t2.joinable()) t2.join();
         for (size_t ti = 0; ti < terms_.size(); ++ti) {
             SparseTerm& T = terms_[ti];
             T.diagonal = th[ti].diag != 0;
@@ -1254,10 +1277,10 @@ int Engine::alloc_iteration_buffers() {
     const size_t lw = (size_t)solve_width(), sblk = (size_t)n * lw;      // per-unit solve blocks (twice as wide with the conjugate fold)
     bool ok = d_X_.alloc(blk) && d_R_.alloc(blk) && (q_ext_ ? (q_ext_bytes_ >= 2 * blk * sizeof(cz)) : d_Q_.alloc(2 * blk)) && d_T1_.alloc(blk) && d_T2_.alloc(blk) &&
               d_MX_.alloc(blk * std::max(2, nterms)) &&
-              (rr_only_ || (d_W_.alloc((size_t)Kloc * sblk) && d_Y_.alloc((size_t)Kloc * sblk) && d_sk_.alloc((size_t)Kloc * std::max<int64_t>(1, sk_rows_) * lw) &&
-                            d_crow_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[0]) * lw) &&
-                            d_crow_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.crow_size[1]) * lw))) &&
-              d_e0_.alloc((size_t)std::max(1, Kloc) * lw) && d_e1_.alloc((size_t)std::max(1, Kloc) * lw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
+              (rr_only_ || (d_W_.alloc((size_t)ninst() * sblk) && d_Y_.alloc((size_t)ninst() * sblk) && d_sk_.alloc((size_t)ninst() * std::max<int64_t>(1, sk_rows_) * lw) &&
+                            d_crow_[0].alloc((size_t)ninst() * std::max<int64_t>(1, S.crow_size[0]) * lw) &&
+                            d_crow_[1].alloc((size_t)ninst() * std::max<int64_t>(1, S.crow_size[1]) * lw))) &&
+              d_e0_.alloc((size_t)std::max(1, ninst()) * lw) && d_e1_.alloc((size_t)std::max(1, ninst()) * lw) && d_small_.alloc((size_t)8 * ldw * ldw) &&
               d_lam_.alloc(ldw) && d_gram_scratch_.alloc(gram_scratch_elems(n, ldw)) && d_io_.alloc((size_t)n * std::max(1, m0)) &&
               d_nrm_.alloc(ldw) && d_nrm_scratch_.alloc(colnorm_scratch_elems(n, ldw)) && d_rrscr_.alloc(64 * 64) && d_rrstat_.alloc(16 + (size_t)ldw);
     if (ok && mixed_)
@@ -1269,7 +1292,7 @@ int Engine::alloc_iteration_buffers() {
 }
 
 int Engine::set_precision(int mixed) {
-    if ((mixed != 0) != mixed_) { mixed_ = mixed != 0; factored_ = false; have_x_ = false; }
+    if ((mixed != 0) != mixed_) { mixed_ = mixed != 0; factored_ = false; have_x_ = false; rebuild_shard(); }
     return 0;
 }
 
@@ -1339,7 +1362,7 @@ int Engine::ldiv(void* Y, int64_t ldy, const void* R, int64_t ldr, int m0_, int 
     if (!factored_) return fail(FEASTHIP_ESTATE, "ldiv: not factorised");
     // unit 0 of the coefficient table must be node 0 itself: under the conjugate fold it would be the upper-half-plane member of
     // the first pair (possibly the mirror image of node 0), and the solve would silently be the one at conj(z_0)
-    if (fold_ || Kloc != 1) return fail(FEASTHIP_ESTATE, "ldiv: factor handles hold exactly one unfolded node");
+    if (fold_ || adj_fold_ || dual_adj_ || Kloc != 1) return fail(FEASTHIP_ESTATE, "ldiv: factor handles hold exactly one unfolded node");
     HIPCHK(hipSetDevice(device_));
     if (m0_ != m0 || !have_x_) {
         m0 = m0_;

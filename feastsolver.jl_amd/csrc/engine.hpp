@@ -161,7 +161,14 @@ public:
     double solve_bytes() const;           // algorithmic bytes of one contour step (per contour NODE)
     double solve_bytes_streamed() const;  // what the sweeps actually stream (folded pairs read their factor once)
     double solve_flops() const;
-    int nodes_local() const { return Kloc * (fold_ ? 2 : 1); }
+    int nodes_local() const { return Kloc * ((fold_ || adj_fold_) ? 2 : 1); }
+    // Adjoint fold (round 4): a pencil / polynomial with HERMITIAN coefficient matrices (and real scales) satisfies T(conj z) = T(z)^H, so
+    // a contour node and its mirror image share one factorisation here too; the mirror system is solved by the adjoint sweeps (U^H, L^H)
+    // over the same factors, with the right-hand side as it is.  Chosen where the conjugate fold does not apply (complex matrices).
+    bool adj_folded() const { return adj_fold_; }
+    // solve instances: units, plus one adjoint instance per unit under the adjoint fold and in dual_gen_feast (block vectors W / Y,
+    // contribution arenas and coefficient tables are sized and indexed by instance: [0, Kloc) primal, [Kloc, 2 Kloc) adjoint)
+    int ninst() const { return Kloc * ((adj_fold_ || dual_adj_) ? 2 : 1); }
 
 private:
     int device_;
@@ -175,6 +182,9 @@ private:
     std::vector<int> local_;               // indices of local nodes (conjugate fold: the member of each local pair that is factorised)
     std::vector<int> partner_;             // conjugate fold: index of the mirror node of local_[kk], else -1
     bool fold_ = false, fold_enabled_ = true, terms_real_ = false;
+    bool adj_fold_ = false, adj_fold_enabled_ = true;   // FEASTHIP_ADJ_FOLD=0
+    bool terms_herm_exact_ = false;        // every coefficient matrix equals its conjugate transpose INCLUDING a real diagonal
+    bool dual_adj_ = false;                // dual_gen_feast with K factorisations: the left systems are adjoint sweeps
     bool analyzed_once_ = false;           // analyze() ran on this handle before (its device buffers may be in use by queued work)
     bool terms_hermitian_ = false;         // every coefficient matrix equals its conjugate transpose (elimination without interchanges, L and U apart)
     bool nopiv_gen_enabled_ = true, nopiv_gen_failed_ = false;      // FEASTHIP_NOPIV_GEN=0; set when the growth check rejected it for this handle's matrices

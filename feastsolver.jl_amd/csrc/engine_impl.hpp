@@ -25,13 +25,14 @@ static inline cz to_cz(zc v) { return cz_make(v.real(), v.imag()); }
 // conjugate fold a unit carries two nodes and the mirror node's coefficients occupy columns [ldw, 2 ldw).
 template <class F>
 std::vector<zc> Engine::node_table(F f, int nq) const {
-    const int lw = solve_width();
-    std::vector<zc> e((size_t)nq * Kloc * lw, zc(0.0));
+    const int lw = solve_width(), ni = ninst();       // adjoint fold: the mirror node's coefficients are the rows of the adjoint instances
+    std::vector<zc> e((size_t)nq * ni * lw, zc(0.0));
     for (int q = 0; q < nq; ++q)
         for (int kk = 0; kk < Kloc; ++kk)
             for (int j = 0; j < m0; ++j) {
-                e[((size_t)q * Kloc + kk) * lw + j] = f(local_[kk], j, q);
-                if (fold_) e[((size_t)q * Kloc + kk) * lw + ldw + j] = f(partner_[kk], j, q);
+                e[((size_t)q * ni + kk) * lw + j] = f(local_[kk], j, q);
+                if (fold_) e[((size_t)q * ni + kk) * lw + ldw + j] = f(partner_[kk], j, q);
+                if (adj_fold_) e[((size_t)q * ni + Kloc + kk) * lw + j] = f(partner_[kk], j, q);
             }
     return e;
 }

@@ -193,7 +193,7 @@ int Engine::nlm_alloc(int moments) {
     ldM_ = ((M + 15) / 16) * 16;
     size_t blk = (size_t)n * ldw, hrows = (size_t)mm_ * n, tall = hrows * ldM_, wide = (size_t)n * ldM_;
     bool ok = d_Qm_.alloc(2 * (size_t)mm_ * blk) && d_H0_.alloc(tall) && d_H1_.alloc(tall) && d_Ht_.alloc(tall) && d_Ym_.alloc(wide) &&
-              d_Rm_.alloc(wide) && d_MXm_.alloc(wide * std::max(2, nterms)) && d_em_.alloc(2 * (size_t)mm_ * Kloc * solve_width()) &&
+              d_Rm_.alloc(wide) && d_MXm_.alloc(wide * std::max(2, nterms)) && d_em_.alloc(2 * (size_t)mm_ * ninst() * solve_width()) &&
               d_smallM_.alloc((size_t)8 * ldM_ * ldM_) && d_lamM_.alloc(ldM_) && d_gramM_.alloc(gram_scratch_elems((int)hrows, ldM_)) &&
               d_nrmM_.alloc(ldM_) && d_nrmMs_.alloc(colnorm_scratch_elems((int)hrows, ldM_)) && d_colidx_.alloc(ldM_);
     if (!ok) return fail(FEASTHIP_EHIP, "out of device memory for the moment buffers");
@@ -213,7 +213,7 @@ int Engine::nlm_contour_step(int first) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(first ? d_X_.p : d_R_.p);
     if (r) return r;
-    size_t blk = (size_t)n * ldw, eb = (size_t)Kloc * solve_width();
+    size_t blk = (size_t)n * ldw, eb = (size_t)ninst() * solve_width();
     for (int q = 0; q < L; q += 2)      // two moments per pass over the K solution blocks
         accumulate_solutions(Kloc, d_em_.p + q * eb, d_em_.p + (q + 1) * eb, first ? 0 : 1, d_Qm_.p + q * blk, d_Qm_.p + (q + 1) * blk);
     HIPCHK(hipEventRecord(ev1_, stream_));
@@ -460,6 +460,45 @@ int Engine::nlfeast_moments_run(void* X, int64_t n_, int m0_, int moments, int i
 // residual uses conj(lam) (A' y = conj(lam) B' y), and left Ritz vectors are paired with the right ones by eigenvalue.
 // ---------------------------------------------------------------------------
 int Engine::dual_contour_step() {
+    if (dual_adj_) {
+        // round 4: K factorisations of A - z_k B; the left systems (A - z_k B)^H y = Rl (the reference's lfacts, src/feast.jl:185-197, 241)
+        // are adjoint sweeps over the same factors, instances K .. 2 K - 1, beside the primal sweeps on a second stream
+        const size_t blk = (size_t)n * ldw;
+        std::vector<zc> e((size_t)2 * Kloc * ldw, zc(0.0));
+        for (int kk = 0; kk < Kloc; ++kk) {
+            const zc z = nodes_[local_[kk]], w = weights_[local_[kk]];
+            for (int j = 0; j < m0; ++j) {
+                e[(size_t)kk * ldw + j] = w / (z - lambda_[j]);                                            // :226
+                e[(size_t)(Kloc + kk) * ldw + j] = std::conj(w) / (std::conj(z) - std::conj(lambda_[j]));     // :236
+            }
+        }
+        HIPCHK(hipMemcpyAsync(d_e0_.p, e.data(), e.size() * sizeof(zc), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        HIPCHK(hipEventRecord(ev0_, stream_));
+        hipStream_t sa = aux_streams_.size() >= 2 ? aux_streams_[0] : stream_, sb = aux_streams_.size() >= 2 ? aux_streams_[1] : stream_;
+        if (sa != stream_) {
+            HIPCHK(hipEventRecord(ev_fork_, stream_));
+            HIPCHK(hipStreamWaitEvent(sa, ev_fork_, 0));
+            HIPCHK(hipStreamWaitEvent(sb, ev_fork_, 0));
+        }
+        int r = solve_range(sa, 0, Kloc, d_R_.p, nullptr);
+        if (r == 0) r = solve_range_adj(sb, 0, Kloc, Kloc, d_Rl_.p, ldw);
+        if (r) return r;
+        if (sa != stream_) {
+            HIPCHK(hipEventRecord(ev_join_[0], sa)); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0));
+            HIPCHK(hipEventRecord(ev_join_[1], sb)); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[1], 0));
+        }
+        launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)blk, ldw, ldw, Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr);                      // :232-234
+        launch_accumulate(stream_, dsym_, d_Xl_.p, adj_solution() + (size_t)Kloc * blk, (int64_t)blk, ldw, ldw, Kloc, d_e0_.p + (size_t)Kloc * ldw, nullptr, 1,
+                          Qp() + blk, nullptr);                                                                                          // :242-244
+        HIPCHK(hipEventRecord(ev1_, stream_));
+        HIPCHK(hipEventSynchronize(ev1_));
+        HIPCHK(hipGetLastError());
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+        solve_ms = ms;
+        return 0;
+    }
     const int Kh = Kloc / 2;
     size_t blk = (size_t)n * ldw;
     std::vector<zc> e((size_t)Kloc * ldw, zc(0.0));
@@ -591,9 +630,15 @@ int Engine::dual_rr_step(double* lambda, double* resr, double* resl, uint8_t* in
 
 int Engine::dual_run(void* Xr, void* Xl, int64_t n_, int m0_, int iter, double eps, int store, double* lambda, double* resr,
                      double* resl, uint8_t* inside, int* nit_out) {
-    if (nterms != 4 || (K & 1) || node_coef_.empty() || shard_stride_ != 1 || mixed_)
-        return fail(FEASTHIP_ESTATE, "dual_gen_feast: needs the terms {A, B, A', B'}, 2K nodes with a node coefficient table, one GPU, fp64");
+    if (nterms != 4 || node_coef_.empty() || shard_stride_ != 1 || mixed_)
+        return fail(FEASTHIP_ESTATE, "dual_gen_feast: needs the terms {A, B, A', B'} with a node coefficient table, one GPU, fp64");
     if (!Xl) return fail(FEASTHIP_EARG, "dual_gen_feast: null Xl");
+    // Two layouts of the node table.  Round 4: K nodes, every row (f_A, f_B, 0, 0): K factorisations, the left systems are adjoint sweeps
+    // over them.  Rounds 2-3: 2 K nodes, rows K .. 2 K - 1 = (0, 0, f_A', f_B'): the adjoint matrices factorised as K more nodes.
+    bool no_adjoint_terms = true;
+    for (int k = 0; k < K; ++k) if (node_coef_[(size_t)k * 4 + 2] != zc(0.0) || node_coef_[(size_t)k * 4 + 3] != zc(0.0)) no_adjoint_terms = false;
+    if (!no_adjoint_terms && (K & 1)) return fail(FEASTHIP_ESTATE, "dual_gen_feast: the doubled layout needs 2K nodes");
+    if (no_adjoint_terms != dual_adj_) { dual_adj_ = no_adjoint_terms; have_x_ = false; }
     int r = set_x(Xr, n_, m0_);
     if (r) return r;
     size_t blk = (size_t)n * ldw;

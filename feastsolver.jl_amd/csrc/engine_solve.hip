@@ -162,6 +162,9 @@ void Engine::accumulate_solutions(int K_, const cz* e0, const cz* e1, int mode, 
     const int lw = solve_width();
     if (mixed_) launch_accumulate(stream_, dsym_, d_X_.p, d_W32_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1, row0, nrows);
     else launch_accumulate(stream_, dsym_, d_X_.p, d_W_.p, (int64_t)n * lw, ldw, lw, K_, e0, e1, mode, Q0, Q1, row0, nrows);
+    if (adj_fold_ && K_ == Kloc)       // the mirror nodes: solutions of the adjoint instances, their rows of the coefficient tables, added
+        launch_accumulate(stream_, dsym_, d_X_.p, adj_solution() + (int64_t)Kloc * n * lw, (int64_t)n * lw, ldw, lw, Kloc, e0 + (size_t)Kloc * lw,
+                          e1 ? e1 + (size_t)Kloc * lw : nullptr, mode, Q0, Q1, row0, nrows, 1);
 }
 
 // Node groups that run on their own streams.  Two groups overlap the launch tails and the latency-bound small
@@ -177,6 +180,24 @@ int Engine::stream_groups() const {
 int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
     if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
     int ns = stream_groups();
+    if (adj_fold_) {
+        // every unit is solved twice over its one factorisation: T(z_k) y = rhs by the primal sweeps, T(conj z_k) y = T(z_k)^H y = rhs
+        // by the adjoint ones (instances Kloc .. 2 Kloc - 1), on two streams when the handle has them
+        hipStream_t sa = (!prof && aux_streams_.size() >= 2) ? aux_streams_[0] : stream_, sb = (!prof && aux_streams_.size() >= 2) ? aux_streams_[1] : stream_;
+        if (sa != stream_) {
+            HIPCHK(hipEventRecord(ev_fork_, stream_));
+            HIPCHK(hipStreamWaitEvent(sa, ev_fork_, 0));
+            HIPCHK(hipStreamWaitEvent(sb, ev_fork_, 0));
+        }
+        int r = solve_range(sa, 0, Kloc, rhs, prof);
+        if (r == 0) r = solve_range_adj(sb, 0, Kloc, Kloc, rhs, ldw);
+        if (r) return r;
+        if (sa != stream_) {
+            HIPCHK(hipEventRecord(ev_join_[0], sa)); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0));
+            HIPCHK(hipEventRecord(ev_join_[1], sb)); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[1], 0));
+        }
+        return 0;
+    }
     if (prof || ns <= 1) return solve_range(stream_, 0, Kloc, rhs, prof);
     // The nodes are independent: split them over a few streams so that the tails and the latency-bound small
     // launches of one group overlap with the large launches of another.

@@ -75,7 +75,7 @@ void launch_dense_assemble(hipStream_t st, cz* fact, int64_t fs, int n, const cz
 // element type (Float64 / ComplexF64 / Int64 / ComplexF32) and the storage order (row-major callers: numpy) into the complex128
 // column-major copy the engine keeps, and collects max |a_ij| and "has an imaginary part" on the way; k_dense_symcheck then
 // compares the copy with its transpose.  props: [0] bits of max |a| (non-negative doubles order like their bit patterns),
-// [1] != 0: not real, [2] != 0: not equal to its transpose, [3] != 0: not equal to its conjugate transpose off the diagonal.  raw == out is allowed for complex128 column-major input.
+// [1] != 0: not real, [2] != 0: not equal to its transpose, [3] != 0: not equal to its conjugate transpose off the diagonal, [4] != 0: a diagonal entry with an imaginary part.  raw == out is allowed for complex128 column-major input.
 // (The first version did all of this on one host core before the upload: 1 s per 4096 x 4096 matrix.)
 __global__ __launch_bounds__(256) void k_dense_import(const void* raw, int type, int row_major, int n, cz* out, unsigned long long* props) {
     __shared__ cz tile[32][33];
@@ -119,9 +119,11 @@ __global__ __launch_bounds__(256) void k_dense_symcheck(int n, const cz* __restr
             if (!(a.x == b.x && a.y == b.y)) bad |= 1;
             if (!(a.x == b.x && a.y == -b.y)) bad |= 2;
         }
+        if (i < n && i == j && A[i + (int64_t)j * n].y != 0.0) bad |= 4;
     }
     if (__any(bad & 1) && (threadIdx.x & 63) == 0) atomicOr(props + 2, 1ull);
     if (__any(bad & 2) && (threadIdx.x & 63) == 0) atomicOr(props + 3, 1ull);
+    if (__any(bad & 4) && (threadIdx.x & 63) == 0) atomicOr(props + 4, 1ull);
 }
 
 void launch_dense_import(hipStream_t st, const void* raw, int type, int row_major, int n, cz* out, unsigned long long* props) {

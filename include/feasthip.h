@@ -265,7 +265,8 @@ typedef struct {
     double alloc_seconds;       /* hipMalloc of the factor / contribution arenas at the end of feasthip_analyze (the driver may
                                  * have to scrub tens of GB freed by a previous process: 0.03 .. 2 s for the same request) */
     int32_t factor_units;       /* factorisations held: local_nodes, or local_nodes / 2 with the conjugate fold */
-    int32_t folded;             /* 1 if the conjugate fold is active (feasthip_set_conjugate_fold) */
+    int32_t folded;             /* 1 if the conjugate fold is active (feasthip_set_conjugate_fold); 2: the adjoint fold (Hermitian, not real, coefficient
+                                 * matrices: T(conj z) = T(z)^H, the mirror node of a unit is solved by the adjoint sweeps over the unit's factors) */
     double solve_bytes_streamed;/* bytes the sweeps of one contour step move (a folded pair reads its factor once) */
     int32_t symmetric;          /* 1 if the last factorisation took the pivot-light path: every coefficient matrix equals its transpose
                                  * (complex symmetric T(z)), no row interchanges, growth-checked; 2: every coefficient matrix equals its

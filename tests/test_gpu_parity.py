@@ -393,6 +393,7 @@ def test_dual_gen_feast_dense(gpu, pkg, wl, golden):
     Xr, Xl = wl.rand_x0(256, 32, 8001), wl.rand_x0(256, 32, 8002)
     info = {}
     lam, xr, xl, res = pkg.dual_gen_feast(Xr, Xl, w["A"], w["B"], nodes=16, iter=20, c=w["c"], r=w["r"], eps=1e-11, store=True, info=info)
+    assert info["factor_units"] == 16          # round 4: the left systems are adjoint sweeps over the 16 factorisations (32 until round 3)
     assert len(lam) == 12 and match_sets(lam, c2n(g["lam"])) < 1e-9 and match_sets(c2n(g["lam"]), lam) < 1e-9
     assert res.max() < 1e-11 and abs(info["nit"] - g["history"][-1][0]) <= 1
     A, B = w["A"], w["B"]
@@ -406,7 +407,8 @@ def test_dual_gen_feast_dense(gpu, pkg, wl, golden):
 
 def test_dual_gen_feast_sparse_nonsymmetric(gpu, pkg, wl):
     """sparse, structurally symmetric but non-Hermitian (convection-diffusion on a 10^3 grid), store=false: the adjoint
-    systems are factorised as extra nodes from the terms A', B'."""
+    systems are adjoint sweeps over the pivoted factors of A - z_k B (round 4); the doubled layout of rounds 2-3 (the adjoint matrices
+    factorised as K more nodes, FEASTHIP_DUAL_DOUBLED=1) gives the same eigenvalues."""
     g = 10
     L = wl.laplacian_3d(g, 7)
     n = g ** 3
@@ -422,10 +424,16 @@ def test_dual_gen_feast_sparse_nonsymmetric(gpu, pkg, wl):
     c, r = 0.8 + 0j, 0.5 * (dist[k - 1] + dist[k])
     inside_ref = ev[np.abs(ev - c) <= r]
     Xr, Xl = wl.rand_x0(n, 32, 31), wl.rand_x0(n, 32, 32)
-    lam, xr, xl, res = pkg.dual_gen_feast(Xr, Xl, A, B, nodes=16, iter=25, c=c, r=r, eps=1e-11, store=False)
+    info = {}
+    lam, xr, xl, res = pkg.dual_gen_feast(Xr, Xl, A, B, nodes=16, iter=25, c=c, r=r, eps=1e-11, store=False, info=info)
+    assert info["factor_units"] == 16
     assert len(lam) == k and match_sets(lam, inside_ref) < 1e-9 and match_sets(inside_ref, lam) < 1e-9 and res.max() < 1e-11
     for i in range(len(lam)):
         assert np.linalg.norm(xl[:, i].conj() @ A - lam[i] * (xl[:, i].conj() @ B)) < 1e-9
+    with env_override(FEASTHIP_DUAL_DOUBLED="1"):
+        info2 = {}
+        lam2, _, _, res2 = pkg.dual_gen_feast(wl.rand_x0(n, 32, 31), wl.rand_x0(n, 32, 32), A, B, nodes=16, iter=25, c=c, r=r, eps=1e-11, store=False, info=info2)
+    assert info2["factor_units"] == 32 and len(lam2) == k and match_sets(lam2, lam) < 1e-9
 
 
 # ---------------------------------------------------------------------------------------
@@ -1458,6 +1466,43 @@ def test_conjugate_fold_matches_one_factorisation_per_node(gpu, pkg, wl):
     # more ranks than pairs: every rank falls back to single nodes, consistently
     parts = [_moment(pkg, w, con, True, (r, 16)) for r in (0, 5, 15)]
     assert all(p[1]["folded"] == 0 and p[1]["local_nodes"] == 1 for p in parts)
+
+
+@pytest.mark.parametrize("kind", ["sparse", "sparse_pivoted", "dense"])
+def test_adjoint_fold_matches_one_factorisation_per_node(gpu, pkg, wl, kind):
+    """Complex Hermitian pencil + mirror-symmetric contour: T(conj z) = T(z)^H, so a node pair shares ONE factorisation and the mirror
+    system is solved by the adjoint sweeps (U^H, L^H) over it.  The moment equals the one from 16 separate factorisations to 1e-12,
+    with half the factorisations (stats.folded == 2); shards deal out pairs and still add up to the full moment; with partial pivoting
+    forced (FEASTHIP_NOPIV_GEN=0) the fronts' row interchanges are undone on the adjoint solutions."""
+    rng = np.random.default_rng(21)
+    if kind == "dense":
+        n = 300
+        G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        H = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        A = (G + G.conj().T) / np.sqrt(4 * n)
+        B = H @ H.conj().T / n + np.eye(n)
+        B = (B + B.conj().T) / 2
+        w = dict(A=A, B=B, X0=wl.rand_x0(n, 24, 5))
+        con = pkg.circular_contour_trapezoidal(0.1 + 0j, 0.3, 16)
+    else:
+        w = wl.c3_sparse_generalized(12, 19, 64)
+        w["A"] = wl.hermitian_phases(w["A"], seed=12)
+        con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    with env_override(FEASTHIP_NOPIV_GEN="0" if kind == "sparse_pivoted" else "1"):
+        q1, s1 = _moment(pkg, w, con, True)
+        q0, s0 = _moment(pkg, w, con, False)
+        assert s1["folded"] == 2 and s1["factor_units"] == 8 and s1["local_nodes"] == 16
+        assert s0["folded"] == 0 and s0["factor_units"] == 16 and s0["local_nodes"] == 16
+        assert np.abs(q1 - q0).max() <= 1e-12 * np.abs(q0).max()
+        parts = [_moment(pkg, w, con, True, (r, 4)) for r in range(4)]
+        assert all(p[1]["factor_units"] == 2 and p[1]["local_nodes"] == 4 for p in parts)
+        assert np.abs(sum(p[0] for p in parts) - q1).max() <= 1e-12 * np.abs(q1).max()
+    if kind == "sparse_pivoted":
+        assert s1["symmetric"] == 0
+    # the fold is taken only where it is exact: a complex SYMMETRIC (not Hermitian) pencil has neither fold
+    if kind == "dense":
+        w2 = dict(A=w["A"] + 0.05j * np.eye(300), B=w["B"], X0=w["X0"])
+        assert _moment(pkg, w2, con, True)[1]["folded"] == 0
 
 
 def test_conjugate_fold_only_where_it_is_exact(gpu, pkg, wl):

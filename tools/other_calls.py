@@ -24,4 +24,4 @@ con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
 timed("contour_estimate_eig C3 (n=97,336, 16 nodes, 64 samples)", lambda: pkg.contour_estimate_eig(w["A"], con, w["B"], samples=64, seed=1))
 info = {}
 timed("dual_gen_feast C3 (right + left subspaces)", lambda: pkg.dual_gen_feast(w["X0"].copy(), w["X0"].copy(), w["A"], w["B"], con, iter=20, eps=1e-10, store=True, info=info))
-print("   iterations", info.get("nit"))
+print("   iterations", info.get("nit"), {k: info.get(k) for k in ("factor_units", "factor_ms", "solve_ms", "rr_ms", "analyze_seconds", "alloc_seconds", "symmetric", "folded")})
