@@ -12,7 +12,7 @@ from .contour import (CircularContour, RectangularContour, circular_contour_gaus
                       circular_contour_trapezoidal, in_contour, rectangular_contour_gauss,
                       rectangular_contour_trapezoidal)
 from ._lib import FeastHipError, library_path, load_library
-from .api import (FeastHandle, HipLU, PolynomialNEP, SplitNEP, contour_estimate_eig, dual_gen_feast, feast, finalize, gen_feast, ldiv, lu, mmread, mmwrite, nlfeast, nlfeast_moments, trim_memory)
+from .api import (FeastHandle, HipLU, comm_unique_id, PolynomialNEP, SplitNEP, contour_estimate_eig, dual_gen_feast, feast, finalize, gen_feast, ldiv, lu, mmread, mmwrite, nlfeast, nlfeast_moments, trim_memory)
 
 __all__ = [
     "CircularContour", "RectangularContour", "circular_contour_gauss", "circular_contour_trapezoidal",

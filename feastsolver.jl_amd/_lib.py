@@ -47,6 +47,9 @@ PROTOTYPES = {
     "feasthip_set_x": (I, [VP, VP, I64, I]),
     "feasthip_get_x": (I, [VP, VP]),
     "feasthip_get_block": (I, [VP, I, VP]),
+    "feasthip_comm_unique_id": (I, [VP]),
+    "feasthip_comm_init": (I, [VP, VP, I, I]),
+    "feasthip_comm_destroy": (I, [VP]),
     "feasthip_rr_step": (I, [VP, VP, VP, VP]),
     "feasthip_small_eig_herm": (I, [VP, I, VP, VP, VP, VP, VP]),
     "feasthip_set_rr_only": (I, [VP, I]),

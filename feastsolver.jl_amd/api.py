@@ -291,6 +291,15 @@ class FeastHandle:
     def set_rr_only(self, on=True):
         self._ck(self.lib.feasthip_set_rr_only(self.h, 1 if on else 0))
 
+    def comm_init(self, uid, rank, world):
+        """feasthip_comm_init: join the RCCL communicator drawn by `comm_unique_id()` on rank 0; the contour steps of this handle then
+        return with the moment summed over the ranks (include/feasthip.h)."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(uid))
+        self._ck(self.lib.feasthip_comm_init(self.h, C.cast(buf, C.c_void_p), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.feasthip_comm_destroy(self.h))
+
     def contour_step_begin(self, refactor=False, nchunks=1):
         """feasthip_contour_step_begin: the step enqueued, the moment produced in `nchunks` row ranges (multi-GPU driver)."""
         return self._ck(self.lib.feasthip_contour_step_begin(self.h, 1 if refactor else 0, int(nchunks)))
@@ -526,6 +535,17 @@ def trim_memory():
     """Return the library's cache of released device blocks to the driver (feasthip_trim_memory): handles that are closed
     leave their large buffers (factor arena, block vectors) for the next handle of the process."""
     _lib.load_library().feasthip_trim_memory()
+
+
+def comm_unique_id():
+    """feasthip_comm_unique_id: 128 bytes (RCCL's ncclUniqueId) for rank 0 to hand to the other ranks."""
+    lib = _lib.load_library()
+    buf = (C.c_char * 128)()
+    code = lib.feasthip_comm_unique_id(C.cast(buf, C.c_void_p))
+    if code != 0:
+        msg = lib.feasthip_last_error(None)
+        raise _lib.FeastHipError(code, msg.decode() if msg else "feasthip_comm_unique_id failed")
+    return bytes(buf)
 
 
 def mmread(path):

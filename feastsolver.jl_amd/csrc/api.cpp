@@ -177,6 +177,18 @@ int feasthip_estimate_count(feasthip_handle_t h, const void* X, int64_t n, int m
     GUARD(h) return h->e->estimate_count(X, n, m0, est); ENDGUARD(h)
 }
 
+int feasthip_comm_unique_id(void* id128) {
+    if (!id128) return FEASTHIP_EARG;
+    try {
+        std::string e;
+        int r = Engine::comm_unique_id(id128, e);
+        if (r) { std::lock_guard<std::mutex> lk(g_mu); g_create_error = e; }
+        return r;
+    } catch (...) { return FEASTHIP_EARG; }
+}
+int feasthip_comm_init(feasthip_handle_t h, const void* id128, int rank, int world) { GUARD(h) return h->e->comm_init(id128, rank, world); ENDGUARD(h) }
+int feasthip_comm_destroy(feasthip_handle_t h) { GUARD(h) return h->e->comm_destroy(); ENDGUARD(h) }
+
 int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     GUARD(h)
     if (!o) return FEASTHIP_EARG;

@@ -305,6 +305,10 @@ Engine::Engine(int device) : device_(device) {
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    (void)comm_destroy();
+    if (comm_stream_) { (void)hipStreamSynchronize(comm_stream_); (void)hipStreamDestroy(comm_stream_); comm_stream_ = nullptr; }
+    if (ev_comm0_) { (void)hipEventDestroy(ev_comm0_); ev_comm0_ = nullptr; }
+    if (ev_comm1_) { (void)hipEventDestroy(ev_comm1_); ev_comm1_ = nullptr; }
     pool_drop_device(device_);       // the cache holds at most what ONE handle used: earlier leftovers go back to the driver now
     for (hipStream_t s2 : up_streams_) if (s2) (void)hipStreamSynchronize(s2);
     for (hipStream_t s2 : aux_streams_) (void)hipStreamSynchronize(s2);

@@ -122,7 +122,17 @@ public:
     int contour_step(int refactor);
     int contour_step_begin(int refactor, int nchunks);
     int moment_chunk_wait(int c, int64_t* row0, int64_t* rows);
+    int comm_allreduce_rows(int row0, int rows);
     int contour_step_end();
+    // RCCL inside the library (round 4): with a communicator on the handle every range of the moment is all-reduced (sum) over the
+    // ranks on the library's own communication stream, behind the event of that range's accumulation -- stream-ordered, no host wait --
+    // and contour_step / contour_step_end return with the SUMMED moment in place.  The functions are resolved from librccl.so.1 at the
+    // first use (dlopen: the library carries no link-time dependency on RCCL, and shares the copy a host process already loaded).
+    static int comm_unique_id(void* id128, std::string& err);
+    int comm_init(const void* id128, int rank, int world);
+    int comm_destroy();
+    bool has_comm() const { return comm_ != nullptr; }
+    double allreduce_ms = 0;              // last contour step: first all-reduce enqueued .. last one finished (HIP events on the communication stream)
     int nl_contour_step(int first);
     int nl_rr_step(double* lambda, double* res, uint8_t* inside, int external_residual = 0);
     int nl_orthonormalize_x();
@@ -319,6 +329,10 @@ private:
     std::vector<hipStream_t> up_streams_;  // analyze(): one upload stream per term (helper threads)
     std::vector<hipEvent_t> ev_join_;
     std::vector<hipEvent_t> ev_chunk_;   // contour_step_begin: one per row range of the moment
+    void* comm_ = nullptr;               // ncclComm_t
+    int comm_rank_ = 0, comm_world_ = 1;
+    hipStream_t comm_stream_ = nullptr;
+    hipEvent_t ev_comm0_ = nullptr, ev_comm1_ = nullptr;
     std::vector<int> chunk_rows_;
     bool step_open_ = false;
     bool rr_only_ = false;               // feasthip_set_rr_only: only the Rayleigh-Ritz half runs on this handle

@@ -261,13 +261,24 @@ int Engine::contour_step_begin(int refactor, int nchunks) {
     HIPCHK(hipEventRecord(ev0_, stream_));
     int r = solve_all(d_R_.p);                                                                // :61-66
     if (r) return r;
+    if (comm_ && comm_world_ > 1 && nchunks < 4) nchunks = 4;      // ranges to overlap the all-reduce of one with the accumulation of the next
     nchunks = std::max(1, std::min(nchunks, std::min(64, n)));
     while ((int)ev_chunk_.size() < nchunks) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_chunk_.push_back(e); }
     chunk_rows_.assign(nchunks + 1, 0);
     for (int c = 0; c <= nchunks; ++c) chunk_rows_[c] = (int)((int64_t)n * c / nchunks);
     for (int c = 0; c < nchunks; ++c) {
         accumulate_solutions(Kloc, d_e0_.p, nullptr, 1, Qp(), nullptr, chunk_rows_[c], chunk_rows_[c + 1] - chunk_rows_[c]);     // :68-70
-        if (nchunks > 1) HIPCHK(hipEventRecord(ev_chunk_[c], stream_));
+        if (nchunks > 1 || comm_) HIPCHK(hipEventRecord(ev_chunk_[c], stream_));
+        if (comm_) {      // sum over the ranks, in place, behind this range's accumulation (src/feast.jl:59-71: the node loop is what is sharded)
+            HIPCHK(hipStreamWaitEvent(comm_stream_, ev_chunk_[c], 0));
+            if (c == 0) HIPCHK(hipEventRecord(ev_comm0_, comm_stream_));
+            int r2 = comm_allreduce_rows(chunk_rows_[c], chunk_rows_[c + 1] - chunk_rows_[c]);
+            if (r2) return r2;
+        }
+    }
+    if (comm_) {
+        HIPCHK(hipEventRecord(ev_comm1_, comm_stream_));
+        HIPCHK(hipStreamWaitEvent(stream_, ev_comm1_, 0));
     }
     HIPCHK(hipEventRecord(ev1_, stream_));
     step_open_ = true;
@@ -294,6 +305,7 @@ int Engine::contour_step_end() {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
     solve_ms = ms;
+    if (comm_) { HIPCHK(hipEventElapsedTime(&ms, ev_comm0_, ev_comm1_)); allreduce_ms = ms; }
     return 0;
 }
 

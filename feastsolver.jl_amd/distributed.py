@@ -61,8 +61,9 @@ class MomentReducer:
     overlap=True: the library produces the moment in `chunks` contiguous row ranges (feasthip_contour_step_begin); as soon as
     a range is final its all-reduce is issued (async), so the collective of range c runs while the ranges after it are still
     being accumulated, and only the last range's collective is exposed.  overlap=False: contour step, then one all-reduce of
-    the whole n x ldw block.  Either way the result is the same sum in the same order per element (the collective is
-    element-wise), so both settings are bit-identical for a given backend.
+    the whole n x ldw block.  Either way every element is the sum of the same partial moments; the ORDER in which a ring or tree
+    collective adds them may depend on the element's offset and the buffer size, so the two settings agree to rounding (a few ulp of
+    the moment: what the tests against the single-process fixture bound at 1e-10), not bit by bit.
     `q` is the torch tensor handed to feasthip_set_q_buffer (float64 view of the complex128 moment)."""
 
     def __init__(self, handle, q, n, ldw, overlap=True, chunks=4, group=None):
@@ -101,9 +102,35 @@ class MomentReducer:
         return t_done
 
 
-def gen_feast_distributed(X, A, B, contour, *, iter=10, eps=1e-12, store=True, device=None, group=None, info=None, overlap=True):
+class LibraryReducer:
+    """The same step with the collective INSIDE the library (feasthip_comm_init, round 4): rank 0 draws RCCL's unique id, torch.distributed
+    only carries those 128 bytes to the other ranks (any backend: it is host data), every rank joins the communicator, and from then on
+    feasthip_contour_step returns with the summed moment -- the all-reduce of a row range is enqueued on the library's communication
+    stream behind the event of that range's accumulation, without a host wait (MomentReducer waits on the host per range and enqueues
+    on torch's stream).  What a Julia host would use (julia/FEASTHip.jl); executed with one rank only so far."""
+
+    def __init__(self, handle, group=None):
+        import torch.distributed as dist
+        from . import api
+        self.h = handle
+        live = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if live else 0
+        world = dist.get_world_size(group) if live else 1
+        box = [api.comm_unique_id() if rank == 0 else None]
+        if live and world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        handle.comm_init(box[0], rank, world)
+
+    def contour_step_and_reduce(self, refactor=False):
+        import time
+        self.h.contour_step(refactor)
+        return time.perf_counter()
+
+
+def gen_feast_distributed(X, A, B, contour, *, iter=10, eps=1e-12, store=True, device=None, group=None, info=None, overlap=True, reduce="torch"):
     """gen_feast! (src/feast.jl:89-156) with the node loop sharded over the ranks of `group`.
-    Every rank passes the same X, A, B, contour and receives the same result.  B=None: feast!."""
+    Every rank passes the same X, A, B, contour and receives the same result.  B=None: feast!.
+    reduce: "torch" (torch.distributed all-reduce of the moment, MomentReducer) or "library" (RCCL inside libfeasthip, LibraryReducer)."""
     import torch
     import torch.distributed as dist
     from . import api
@@ -128,7 +155,7 @@ def gen_feast_distributed(X, A, B, contour, *, iter=10, eps=1e-12, store=True, d
         if store:
             h.factorize()
         h.set_x(np.asfortranarray(X, dtype=np.complex128))
-        red = MomentReducer(h, q, n, ldw, overlap=overlap, group=group)
+        red = LibraryReducer(h, group=group) if reduce == "library" else MomentReducer(h, q, n, ldw, overlap=overlap, group=group)
         nit = 0
         for nit in range(iter + 1):                                   # src/feast.jl:40
             lam, res, ins = h.rr_step()

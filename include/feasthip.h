@@ -39,7 +39,8 @@ enum {
     FEASTHIP_ESTATE = -4,    /* call order (e.g. solve before factorize) */
     FEASTHIP_EHIP = -5,      /* HIP runtime failure */
     FEASTHIP_ENOGPU = -6,    /* no gfx950 device: the product path has NO CPU fallback */
-    FEASTHIP_ENUM = -7       /* numerical breakdown (Cholesky of a Gram matrix, small eigensolver) */
+    FEASTHIP_ENUM = -7,      /* numerical breakdown (Cholesky of a Gram matrix, small eigensolver) */
+    FEASTHIP_ECOMM = -8      /* RCCL failure (librccl.so.1 not found, communicator or collective error) */
 };
 
 /* element type tags for matrix values */
@@ -91,6 +92,18 @@ int feasthip_set_contour(feasthip_handle_t h, int K, const double* nodes, const 
                          int region_kind, const double* region);
 /* Multi-GPU sharding: this handle owns nodes k = first, first+stride, ... */
 int feasthip_set_node_shard(feasthip_handle_t h, int first, int stride);
+/* The one collective of the path inside the library (round 4): one process per GPU, every process a handle with its node shard;
+ * rank 0 draws an id (128 bytes, RCCL's ncclUniqueId) and hands it to the others by whatever channel the host program has (Julia:
+ * Distributed / MPI.jl; Python: torch.distributed, a file, a socket), every rank then joins with feasthip_comm_init.  From then on
+ * feasthip_contour_step (and _begin / _end; feasthip_feast_run with it) sums every row range of the moment Q = sum_k w_k ...
+ * (src/feast.jl:57-72: the node loop :59-71 is what is sharded) over the ranks -- ncclAllReduce(sum, float64) on the library's own
+ * communication stream behind the event of that range's accumulation, no host wait in between -- and returns with the summed moment
+ * in place on every rank, so that the replicated Rayleigh-Ritz step needs no broadcast.  RCCL is loaded with dlopen("librccl.so.1") at
+ * the first of these calls (FEASTHIP_ECOMM if it cannot be).  world = 1 is allowed (a one-rank communicator: the sum is the identity).
+ * NOTE: executed with one rank only so far; no multi-GPU node was available to any round of this build. */
+int feasthip_comm_unique_id(void* id128);
+int feasthip_comm_init(feasthip_handle_t h, const void* id128, int rank, int world);
+int feasthip_comm_destroy(feasthip_handle_t h);
 
 /* ---- factorizer seam: facts[k] = factorizer(T(z_k))  (src/feast.jl:28-38, 104-114;
  *      src/nlfeast.jl:17-28).  analyze = ordering + symbolic (once per pattern),

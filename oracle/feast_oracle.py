@@ -145,9 +145,14 @@ class _DenseLU:
 
 
 class _SparseLU:
-    def __init__(self, C):
+    """SuperLU through scipy (the reference: UMFPACK through Julia's `lu`).  `permc_spec`: SuperLU's column ordering -- scipy's default
+    COLAMD, or MMD_AT_PLUS_A, the closest SuperLU setting to the symmetric strategy UMFPACK picks for patterns like the grid
+    Laplacians of the benchmark (2-3 x fewer factor entries there; bench.py times both and reports the faster)."""
+
+    def __init__(self, C, permc_spec=None):
         self.dtype = np.complex64 if C.dtype == np.complex64 else np.complex128
-        self.f = spla.splu(sp.csc_matrix(C, dtype=self.dtype))
+        self.f = spla.splu(sp.csc_matrix(C, dtype=self.dtype), **({} if permc_spec is None else {"permc_spec": permc_spec}))
+        self.nnz_lu = int(self.f.L.nnz + self.f.U.nnz)
 
     def solve(self, R):
         return self.f.solve(np.ascontiguousarray(R, dtype=self.dtype))
@@ -156,6 +161,11 @@ class _SparseLU:
 def lu(C):
     """default ``factorizer`` (Julia ``lu``: LAPACK zgetrf / UMFPACK)."""
     return _SparseLU(C) if sp.issparse(C) else _DenseLU(C)
+
+
+def lu_mmd(C):
+    """``factorizer`` with SuperLU's MMD(A^T + A) column ordering for sparse C (see _SparseLU)."""
+    return _SparseLU(C, "MMD_AT_PLUS_A") if sp.issparse(C) else _DenseLU(C)
 
 
 def ldiv(Y, F, R):

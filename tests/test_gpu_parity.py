@@ -1173,6 +1173,36 @@ def test_zero_diagonal_is_never_silently_wrong(gpu, pkg):
     pkg.finalize(F)
 
 
+def test_library_rccl_world1(gpu, pkg, wl, golden):
+    """RCCL inside the library (feasthip_comm_unique_id / _comm_init): with a one-rank communicator the contour step sums the moment
+    over "the ranks" on the library's communication stream -- row range by row range behind the accumulation events -- and the result
+    is the moment of a handle without a communicator, bit by bit; a whole gen_feast through distributed.LibraryReducer reproduces the
+    single-process fixture.  (More than one rank has never run anywhere: no multi-GPU node was available to this build.)"""
+    w = wl.c3_sparse_generalized(12, 19, 64)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    qs = []
+    for with_comm in (False, True):
+        h = pkg.FeastHandle(0)
+        h.set_terms([w["A"], w["B"]], [1.0, -1.0])
+        h.set_contour(con)
+        if with_comm:
+            h.comm_init(pkg.comm_unique_id(), 0, 1)
+        h.factorize(); h.set_x(w["X0"]); h.rr_step(); h.contour_step()
+        qs.append(h.get_block(2).copy())
+        lam, res, ins = h.rr_step()
+        if with_comm:
+            h.comm_destroy()
+            h.contour_step()                                  # and the handle works on without one
+        h.close()
+    assert np.array_equal(qs[0], qs[1])
+    import importlib
+    import __graft_entry__ as graft
+    dmod = importlib.import_module(graft.PKG_NAME + ".distributed")
+    g = golden["c3_g12_s19"]
+    lam, V, res = dmod.gen_feast_distributed(w["X0"].copy(), w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, device=0, reduce="library")
+    assert len(lam) == len(g["lam"]) and np.abs(np.sort(lam.real) - np.sort(c2n(g["lam"]).real)).max() <= 1e-10
+
+
 def test_distributed_driver_rccl_world1(gpu, pkg, wl, golden):
     """distributed.py end to end on the GPU with backend nccl (= RCCL) and one rank: node sharding,
     external moment buffer (torch tensor), all-reduce between the two halves of each iteration."""
