@@ -45,11 +45,14 @@ def parse_args():
     ap.add_argument("--nodes", type=int, default=16)
     ap.add_argument("--cpu-baseline", choices=["auto", "off", "full"], default="auto",
                     help="auto: bounded 24^3 sample of the same pencil family (about 20 s of host work); full: additionally the "
-                         "metric's own 46^3 configuration (minutes; writes profiles/r03_cpu_baseline_c3_g46.json when --record)")
+                         "metric's own 46^3 configuration (minutes; writes profiles/r04_cpu_baseline_c3_g46.json when --record)")
     ap.add_argument("--cpu-grid", type=int, default=24)
-    ap.add_argument("--cpu-orderings", default="COLAMD,MMD_AT_PLUS_A",
-                    help="SuperLU column orderings the CPU baseline times (the faster one is reported).  With --cpu-baseline full an ordering "
-                         "left out here is taken from the committed record of an earlier run of the same pool, and labelled so")
+    ap.add_argument("--cpu-orderings", default="COLAMD",
+                    help="SuperLU column orderings the CPU baseline times (the faster one is reported): COLAMD, MMD_AT_PLUS_A or both, comma "
+                         "separated.  Round 4 timed both on the 24^3 sample (GPU box: 20.9 s vs 53.5 s per factorisation, "
+                         "profiles/r04_bench_c3_g46.json) and on 46^3 (profiles/r04_cpu_baseline_c3_g46.json): COLAMD is the faster one on this "
+                         "pencil family, so the default run times only it.  With --cpu-baseline full an ordering left out here is taken "
+                         "from the committed record of an earlier run of the same pool, and labelled so")
     ap.add_argument("--record", action="store_true", help="with --cpu-baseline full: write the measured line under profiles/")
     ap.add_argument("--no-fold", action="store_true",
                     help="factorise every contour node separately (the conjugate fold of real pencils off): the reference's literal schedule")
@@ -99,7 +102,7 @@ def cpu_node_body(fo, w, grid_desc, orderings=None):
     import numpy as np
     import scipy.sparse as sp
     if orderings is None:
-        orderings = [("COLAMD", fo.lu), ("MMD_AT_PLUS_A", fo.lu_mmd)]
+        orderings = [("COLAMD", fo.lu)]
     A = sp.csc_matrix(w["A"], dtype=np.complex128)
     B = sp.csc_matrix(w["B"], dtype=np.complex128)
     con = fo.circular_contour_trapezoidal(w["c"], w["r"], 16)
@@ -162,7 +165,7 @@ def cpu_baseline(pkg, wl, fo, args):
     g = args.cpu_grid
     w = wl.c3_sparse_generalized(g, args.stencil, 64)
     all_ord = {"COLAMD": fo.lu, "MMD_AT_PLUS_A": fo.lu_mmd}
-    s = cpu_node_body(fo, w, f"{g}^3")
+    s = cpu_node_body(fo, w, f"{g}^3", [(nm, all_ord[nm]) for nm in args.cpu_orderings.split(",") if nm in all_ord] or None)
     # the HIP path on the very same sample, for an apples-to-apples ratio
     h = pkg.FeastHandle(0)
     h.set_terms([w["A"], w["B"]], [1.0, -1.0])
@@ -180,7 +183,7 @@ def cpu_baseline(pkg, wl, fo, args):
         "value": s["iterations_per_s"], "unit": "iterations/s", "cores": 1, "blas_threads": blas_threads(), "kind": "port",
         "ordering": s["ordering"], "orderings": s["orderings"],
         "sample": f"same pencil family on a {g}^3 grid (n={s['n']}), 16 nodes, m0=64: one node factorised "
-                  f"(SuperLU with the faster of its COLAMD and MMD(A^T+A) column orderings: {s['ordering']}, {s['nnz_LU']} factor entries, "
+                  f"(SuperLU, column ordering {s['ordering']} -- the faster of COLAMD and MMD(A^T+A) on this family, profiles/r04_cpu_baseline_c3_g46.json --, {s['nnz_LU']} factor entries, "
                   f"{s['t_factor_node_s']:.2f} s, setup) and block-solved ({s['t_solve_node_s']:.3f} s), RR block once ({s['t_rr_s']:.3f} s); "
                   f"iteration = 16 x node + RR; SuperLU is serial like the reference's UMFPACK solves (cores = 1: the node loop of "
                   f"src/feast.jl:134-148 is serial; the dense RR products use blas_threads)",
@@ -239,7 +242,7 @@ def roofline(args, st, st2, prof, detail, levels, world):
     tf = step_flops / t / 1e12
     gbs = step_bytes / t / 1e9
     traffic = tsrc = None
-    for nm in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for nm in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", nm)
         if os.path.exists(tpath) and args.grid == 46 and args.stencil == 19 and world == 1 and not args.mixed_prec and not args.no_fold:
             per_step = json.load(open(tpath)).get("traffic_bytes_per_contour_step")

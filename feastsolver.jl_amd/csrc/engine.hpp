@@ -239,6 +239,7 @@ private:
     DevBuf<double> d_rrstat_;            // ... its status words (16: 8 public + phase timings), then the squared column norms of X = Q Xq (ldw)
     bool rr_device_ = true;              // FEASTHIP_RR_DEVICE=0: reduced eigenproblem always on the host
     int rr_dev_state_ = 0;               // -1: the projected matrices of this handle's pencil are not Hermitian (host path from then on)
+    double rr_cond_pass2_ = 1e3;         // host path, generalized problem: the second CholeskyQR pass is dropped below this value of the same quantity
     double rr_cond_max_ = 8.0;           // largest ||R^-1||_F / sqrt(m) of the column-scaled basis the device path takes without orthonormalising first
 
     // pinned staging slots for the small host <-> device hand-offs of the Rayleigh-Ritz step (Gram matrices, reduced eigenvectors,

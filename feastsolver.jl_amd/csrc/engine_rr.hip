@@ -51,9 +51,10 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
     // min_passes = 1 (generalized Rayleigh-Ritz, where Bq = Q'BQ is formed explicitly and any well-conditioned basis of span(Q)
     // gives the same Ritz pairs): the second pass is dropped when the scaled block was well conditioned.  Round 3 decided that on
     // the ratio of the extreme diagonal entries of the first Cholesky factor, which bounds cond(R) only from below (Kahan-type
-    // factors); now on ||R||_F ||R^-1||_F / m = ||R^-1||_F / sqrt(m) <= rr_cond_max_ from the inverse that is formed anyway
+    // factors); now on ||R||_F ||R^-1||_F / m = ||R^-1||_F / sqrt(m) <= rr_cond_pass2_ (1e3) from the inverse that is formed anyway
     // (||R||_F^2 = trace of the scaled Gram matrix = m; the quantity is 1 for an orthonormal block and bounds cond_2(R) / sqrt(m)
-    // from above; 1.1 .. 2 in the steady state of a FEAST run).
+    // from above; 1.1 .. 2 in the steady state of a FEAST run, 1e2 .. 1e4 on the first filtered block of a random start).  The
+    // basis after one pass is then orthonormal to eps * 1e6 m or better, and the reduced pencil (Q'AQ, Q'BQ) is formed with it.
     int need = 2;
     bool first_clean = false;
     for (int pass = 0; pass < 6 && need > 0; ++pass) {
@@ -102,7 +103,7 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
             for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) fro += std::norm(Gc[i + (size_t)j * m]);
             const double kappa = std::sqrt(fro / m);
             if (getenv("FEASTHIP_RR_TRACE")) fprintf(stderr, "[feasthip] CholeskyQR pass 1: ||R^-1||_F / sqrt(m) = %.3g\n", kappa);
-            if (kappa <= rr_cond_max_) need = 0;
+            if (kappa <= rr_cond_pass2_) need = 0;
             first_clean = false;
         }
         for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) Tm[i + (size_t)j * m] = Gc[i + (size_t)j * m] / dsc[i];     // T = D^-1 R^-1
