@@ -229,11 +229,13 @@ int feasthip_nlm_finish(feasthip_handle_t h, const void* R, const double* res_in
 int feasthip_nlm_get_y(feasthip_handle_t h, void* Y);
 
 /* ---- dual_gen_feast!(Xr, Xl, A, B, contour; iter, eps, store)  src/feast.jl:158-257: right AND left
- * eigenvectors.  Set-up: terms {A, B, A', B'} with scales {1, -1, 1, -1} (feasthip_set_dense/_csc), a contour of 2K
- * entries {z_1..z_K, conj(z_1)..conj(z_K)} / {w_1..w_K, conj(w_1)..conj(w_K)} and the 2K x 4 node coefficient table
- * {(1, z_k, 0, 0)} U {(0, 0, 1, conj(z_k))}: the adjoint systems (A - z_k B)' the reference factorises separately
- * (lfacts, :185-197) are K more nodes of the same batched factorisation.  Xr, Xl n x m0 in/out; lambda, resr, resl, inside
- * have m0 entries (resl may be NULL); the caller filters with `inside` (:256). */
+ * eigenvectors.  Set-up: terms {A, B, A', B'} with scales {1, -1, 1, -1} (feasthip_set_dense/_csc; A', B' serve the left residual
+ * A' y - conj(lam) B' y, :214), the contour's K nodes and the K x 4 node coefficient table {(1, z_k, 0, 0)}: K factorisations of
+ * A - z_k B; the adjoint systems (A - z_k B)' y = r that the reference factorises separately (lfacts, :185-197, used at :241) are
+ * solved by the adjoint sweeps over the SAME factors (round 4).  The layout of rounds 2-3 is still accepted: a contour of 2K entries
+ * {z; conj(z)} / {w; conj(w)} with the 2K x 4 table {(1, z_k, 0, 0)} U {(0, 0, 1, conj(z_k))}, i.e. the adjoint matrices factorised
+ * as K more nodes (twice the factor memory).  Xr, Xl n x m0 in/out; lambda, resr, resl, inside have m0 entries (resl may be NULL);
+ * the caller filters with `inside` (:256). */
 int feasthip_dual_feast_run(feasthip_handle_t h, void* Xr, void* Xl, int64_t n, int m0, int iter, double eps, int store,
                             double* lambda, double* resr, double* resl, uint8_t* inside, int* nit);
 

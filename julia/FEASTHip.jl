@@ -100,6 +100,18 @@ function ldiv!(Y::Matrix{ComplexF32}, F::HipLU, R::Matrix{ComplexF64})
 end
 ldiv!(Y::AbstractMatrix, F::HipLU, R::AbstractMatrix) = (Y .= ldiv!(Matrix{ComplexF64}(undef, size(R)), F, Matrix{ComplexF64}(R)); Y)
 
+"left_divider(Y, F', R): Y .= C' \\ R over the SAME factor object -- forward with U', backward with L' (feasthip_ldiv_adjoint).  The
+reference factorises the adjoint matrices a second time (`lfacts`, src/feast.jl:185-197) and solves with them at :241; with
+`factorizer=hiplu` a caller can keep ONE factor per node and write `ldiv!(temp, facts[i]', Rl)`."
+function ldiv!(Y::Matrix{ComplexF64}, Fa::Adjoint{<:Any,HipLU}, R::Matrix{ComplexF64})
+    F = parent(Fa)
+    code = GC.@preserve Y R ccall((:feasthip_ldiv_adjoint, lib), Cint,
+        (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Ptr{ComplexF64}, Int64, Cint),
+        F.handle, Y, stride(Y, 2), R, stride(R, 2), size(R, 2))
+    code < 0 && throw(FeastHipError(code, "feasthip_ldiv_adjoint"))
+    Y
+end
+
 "FEASTSolver.finalize!(F::HipLU): the overload of src/utils.jl:173 that releases the device memory (src/feast.jl:75,151)"
 function finalize!(F::HipLU)
     F.handle == C_NULL || ccall((:feasthip_fact_free, lib), Cint, (Ptr{Cvoid},), F.handle)
@@ -296,6 +308,137 @@ function nlfeast_moments!(T::PolynomialNEP, X::AbstractMatrix{ComplexF64}, nodes
     end
     _unstage!(X, Xw)
     Λ, Y, res
+end
+
+# ---- dual_gen_feast!, contour_estimate_eig (SURVEY 8f rank 3) -------------------------------------------------------------
+"dual_gen_feast!(Xr, Xl, A, B, contour; iter, debug, store, ϵ, factorizer, left_divider)   src/feast.jl:165-257: right and left
+eigenvectors.  K factorisations of A - z_k B; the left systems (A - z_k B)' y = r (the reference's `lfacts`, :185-197, :241) are
+adjoint sweeps over the same factors.  Returns (Λ[inside], Xr[:, inside], Xl[:, inside], resr[inside]) like the reference (:256)."
+function dual_gen_feast!(Xr::AbstractMatrix, Xl::AbstractMatrix, A::AbstractMatrix, B, contour::Contour;
+                         iter::Integer=10, debug=false, store=false, ϵ=1e-12, factorizer=lu, left_divider=ldiv!, device::Integer=0)
+    _default_plugins(factorizer, left_divider) ||
+        return FEASTSolver.dual_gen_feast!(Xr, Xl, A, B, contour; iter=iter, debug=debug, store=store, ϵ=ϵ, factorizer=factorizer, left_divider=left_divider)
+    N, m₀ = size(Xl)
+    size(A, 1) != size(A, 2) && error("Incorrect dimensions of A, must be square")     # src/feast.jl:169-170
+    size(A, 1) != N && error("Incorrect dimensions of X, must match A")                # :171-172
+    Bm = B isa UniformScaling ? nothing : B
+    Xrw, Xlw = _stage(Xr), _stage(Xl)
+    z = ComplexF64.(contour.nodes)
+    K = length(z)
+    table = zeros(ComplexF64, 4, K)                                                    # row-major K x 4 for the C side: (1, z_k, 0, 0)
+    table[1, :] .= 1.0; table[2, :] .= z
+    Λ, resr, resl, inside, nit = zeros(ComplexF64, m₀), zeros(m₀), zeros(m₀), zeros(UInt8, m₀), Ref{Cint}(0)
+    with_handle(device) do h
+        set_terms!(h, N, Any[A, Bm, copy(A'), Bm === nothing ? nothing : copy(Bm')], ComplexF64[1.0, -1.0, 1.0, -1.0])
+        set_contour!(h, contour)
+        check(h, ccall((:feasthip_set_node_coefficients, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Cint, Cint), h, table, K, 4))
+        GC.@preserve Xrw Xlw check(h, ccall((:feasthip_dual_feast_run, lib), Cint,
+            (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int64, Cint, Cint, Float64, Cint, Ptr{ComplexF64}, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}),
+            h, Xrw, Xlw, N, m₀, iter, ϵ, store ? 1 : 0, Λ, resr, resl, inside, nit))
+    end
+    _unstage!(Xr, Xrw); _unstage!(Xl, Xlw)
+    in_c = inside .!= 0
+    any(in_c) || println("no eigenvalues found in contour!")                           # src/feast.jl:255
+    Λ[in_c], Xrw[:, in_c], Xlw[:, in_c], resr[in_c]
+end
+dual_gen_feast!(Xr::AbstractMatrix, Xl::AbstractMatrix, A::AbstractMatrix, B::AbstractMatrix;
+                nodes::Integer=8, iter::Integer=10, c=complex(0.0, 0.0), r=1.0, kw...) =                    # src/feast.jl:158-163
+    dual_gen_feast!(Xr, Xl, A, B, circular_contour_trapezoidal(c, r, nodes); iter=iter, kw...)
+
+"contour_estimate_eig(A, contour, B=I; samples, ...)   src/stochastic.jl:2-33: stochastic estimate of the number of eigenvalues inside
+the contour, est = real(Σ_k w_k tr(X'(z_k B - A)⁻¹X)) / samples with a Gaussian block X drawn here like the reference (:14-15)."
+function contour_estimate_eig(A::AbstractMatrix, contour::Contour, B=I; samples::Integer=min(100, size(A, 1)), ϵ=1e-12, debug=false,
+                              mixed_prec=false, factorizer=lu, left_divider=ldiv!, device::Integer=0)
+    _default_plugins(factorizer, left_divider) ||
+        return FEASTSolver.contour_estimate_eig(A, contour, B; samples=samples, ϵ=ϵ, debug=debug, mixed_prec=mixed_prec, factorizer=factorizer, left_divider=left_divider)
+    N = size(A, 1)
+    X = randn(ComplexF64, N, samples)
+    est = Ref{Float64}(0.0)
+    with_handle(device) do h
+        set_terms!(h, N, Any[A, B isa UniformScaling ? nothing : B], ComplexF64[1.0, -1.0])
+        set_contour!(h, contour)
+        mixed_prec && check(h, ccall((:feasthip_set_precision, lib), Cint, (Ptr{Cvoid}, Cint), h, 1))
+        GC.@preserve X check(h, ccall((:feasthip_estimate_count, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Ref{Float64}), h, X, N, samples, est))
+    end
+    est[]
+end
+
+# ---- nlfeast_moments! for an opaque closure T (test/gun.jl:36, test/fiber.jl:33, string.jl:33) -----------------------------
+"nlfeast_moments!(T, X, nodes, iter; c, r, ϵ, moments, spurious)   src/nlfeast.jl:173-318 for ANY closure z -> matrix: T(z_k) of every
+node goes to the device once (one term per node, identity coefficient table), the loop runs here with the phase calls and the
+residual block R[:,i] = T(λ_i) y_i, res_i = ‖R_i‖ / ‖T(λ_i)‖_F is formed on the host exactly like update_R_moments!
+(src/utils.jl:118-134).  Returns (Λ, Y, res) for all moments·m₀ candidates, sorted by residual."
+function nlfeast_moments!(T::Function, X::AbstractMatrix{ComplexF64}, nodes::Integer, iter::Integer;
+                          c=complex(0.0, 0.0), r=1.0, debug=false, ϵ=10e-12, moments::Integer=2, store=true, spurious=1e-5, device::Integer=0)
+    N, m₀ = size(X)
+    M = moments * m₀
+    contour = circular_contour_trapezoidal(c, r, nodes)
+    Xw = _stage(X)
+    Λ, res, inside = zeros(ComplexF64, M), zeros(M), zeros(UInt8, M)
+    Y, R = zeros(ComplexF64, N, M), zeros(ComplexF64, N, M)
+    with_handle(device) do h
+        set_terms!(h, N, Any[T(z) for z in contour.nodes], ones(ComplexF64, nodes))
+        set_contour!(h, contour)
+        eye = Matrix{ComplexF64}(I, nodes, nodes)
+        check(h, ccall((:feasthip_set_node_coefficients, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Cint, Cint), h, eye, nodes, nodes))
+        GC.@preserve Xw check(h, ccall((:feasthip_nlm_begin, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint, Cint), h, Xw, N, m₀, moments))
+        for nit in 0:iter                                                               # src/nlfeast.jl:200
+            check(h, ccall((:feasthip_nlm_contour_step, lib), Cint, (Ptr{Cvoid}, Cint), h, nit == 0 ? 1 : 0))
+            check(h, ccall((:feasthip_nlm_candidates, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{ComplexF64}), h, Λ, Y))
+            resin = zeros(M)
+            for i in 1:M                                                                # update_R_moments!  src/utils.jl:118-123
+                isfinite(real(Λ[i])) || (resin[i] = Inf; continue)
+                Tl = T(Λ[i])
+                R[:, i] = Tl * Y[:, i]
+                resin[i] = norm(R[:, i]) / norm(Tl)
+            end
+            check(h, ccall((:feasthip_nlm_finish, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8}),
+                           h, R, resin, Λ, res, inside))
+            in_c = inside .!= 0
+            any(in_c) && maximum(res[in_c]) < ϵ && break                                # src/nlfeast.jl:299-302
+        end
+        check(h, ccall((:feasthip_nlm_get_y, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), h, Y))
+        check(h, ccall((:feasthip_nl_finalize_x, lib), Cint, (Ptr{Cvoid},), h))
+        check(h, ccall((:feasthip_get_x, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), h, Xw))
+    end
+    _unstage!(X, Xw)
+    Λ, Y, res
+end
+
+# ---- multi-GPU: one process per GPU, the all-reduce inside the library (include/feasthip.h: feasthip_comm_*) -------------------
+"128 bytes (RCCL's ncclUniqueId) drawn on rank 0; hand them to the other ranks by whatever the host program uses (Distributed, MPI.jl)."
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(C_NULL, ccall((:feasthip_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
+    id
+end
+
+"gen_feast! with the node loop (src/feast.jl:134-148) sharded over `world` processes, one GPU each: every rank passes the same X, A, B,
+contour and the id of rank 0 and receives the same result.  Rank g owns every world-th unit with its factorisations; the moment Q is
+summed over the ranks by RCCL inside feasthip_contour_step; the Rayleigh-Ritz step (:117-127) runs redundantly on every rank."
+function gen_feast_distributed!(X::AbstractMatrix, A::AbstractMatrix, B, contour::Contour, id::Vector{UInt8}, rank::Integer, world::Integer;
+                                iter::Integer=10, ϵ=1e-12, store=true, device::Integer=0)
+    N, m₀ = size(X)
+    Xw = _stage(X)
+    Λ, res, inside = zeros(ComplexF64, m₀), zeros(m₀), zeros(UInt8, m₀)
+    with_handle(device) do h
+        set_terms!(h, N, Any[A, B isa UniformScaling ? nothing : B], ComplexF64[1.0, -1.0])
+        set_contour!(h, contour)
+        check(h, ccall((:feasthip_set_node_shard, lib), Cint, (Ptr{Cvoid}, Cint, Cint), h, rank, world))
+        check(h, ccall((:feasthip_comm_init, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), h, id, rank, world))
+        store && check(h, ccall((:feasthip_factorize, lib), Cint, (Ptr{Cvoid},), h))
+        GC.@preserve Xw check(h, ccall((:feasthip_set_x, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Cint), h, Xw, N, m₀))
+        for nit in 0:iter                                                               # src/feast.jl:116
+            check(h, ccall((:feasthip_rr_step, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}, Ptr{UInt8}), h, Λ, res, inside))
+            in_c = inside .!= 0
+            any(in_c) && maximum(res[in_c]) < ϵ && break                                # :129-132
+            nit < iter && check(h, ccall((:feasthip_contour_step, lib), Cint, (Ptr{Cvoid}, Cint), h, store ? 0 : 1))   # :133-148 + the sum over the ranks
+        end
+        check(h, ccall((:feasthip_get_x, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), h, Xw))
+    end
+    _unstage!(X, Xw)
+    in_c = inside .!= 0
+    Λ[in_c], Xw[:, in_c], res[in_c]
 end
 
 end # module

@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick loop: selected tests + the bench line with the Rayleigh-Ritz trace
+# quick loop of round 4: selected GPU tests + the bench line with the Rayleigh-Ritz trace (usage: gpurun -- bash tools/r04/gpu_quick.sh <tag> "<pytest -k expression>")
 tag=${1:-r04q}; sel=${2:-"device_reduced or rr_device_path"}
 out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 600 python -m pytest tests -m gpu -q -k "$sel" > $out/tests.log 2>&1; echo "tests rc=$?"; tail -4 $out/tests.log
