@@ -1236,7 +1236,9 @@ int Engine::analyze() {
     ok = d_fact_.alloc((size_t)Kloc * S.fact_size) && d_cb_[0].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[0])) &&
          d_cb_[1].alloc((size_t)Kloc * std::max<int64_t>(1, S.cb_size[1])) && d_piv_.alloc((size_t)Kloc * n) &&
          d_rowperm_.alloc((size_t)Kloc * n) && d_rowinv_.alloc((size_t)Kloc * n) && d_nperturb_.alloc(Kloc) &&
-         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)3 * Kloc) && d_wscr_.alloc((size_t)Kloc * wstride_ * (4 * 1024 + 128)) && d_coef_.alloc((size_t)Kloc * nterms);
+         d_tiny_.alloc(Kloc) && d_growth_.alloc((size_t)3 * Kloc) && d_coef_.alloc((size_t)Kloc * nterms);
+    // (d_wscr_, the scratch of the eliminations without interchanges -- 67.6 KB per unit and front of the widest tree level: 0.35 GB on
+    // C3, tens of GB on a wide 2-D mesh -- is allocated by factorize() when one of those paths is taken, not here)
     if (!ok) return fail(FEASTHIP_EHIP, "analyze: out of device memory for the factor arenas");
     alloc_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + arena destinations, CSR    %.1f ms (cumulative)\n[feasthip analyze] arena allocation (hipMalloc)  %.1f ms\n", analyze_seconds * 1e3, alloc_seconds * 1e3);

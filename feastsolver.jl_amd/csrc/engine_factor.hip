@@ -62,6 +62,15 @@ int Engine::factorize() {
     // with L and U kept apart -- the pivoted schedule with its panel kernel replaced by k_diag32_gen / k_lscale32_gen and its
     // interchange passes dropped (kernels_factor.hip)
     const bool gen = !nopiv && use_nopiv_gen();
+    if (nopiv || gen) {
+        const size_t need = (size_t)Kloc * wstride_ * (4 * 1024 + 128);
+        if (d_wscr_.n < need && !d_wscr_.alloc(need)) {
+            // no room for the scratch of the elimination without interchanges: this handle keeps partial pivoting
+            (void)hipGetLastError();
+            if (nopiv) nopiv_failed_ = true; else nopiv_gen_failed_ = true;
+            return factorize();
+        }
+    }
     const int sym_bits = nopiv ? 2 : 0;        // launch_gemm_nn: skip the U12 updates and the strictly upper tiles of the pivot block
     unsigned long long* growth_dev = reinterpret_cast<unsigned long long*>(d_growth_.p);
     unsigned long long* umax_dev = gen ? growth_dev + 2 * (size_t)Kloc : nullptr;
