@@ -248,6 +248,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_NB256_MINP")) nb256_min_p_ = std::max(129, atoi(v));      // tuning knobs: 1 << 30 keeps the 128-column blocks
     if (const char* v = getenv("FEASTHIP_FUSE_B3")) fuse_b3_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
+    if (const char* v = getenv("FEASTHIP_NB1024_MINP")) nb1024_min_p_ = std::max(513, atoi(v));
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
     if (const char* v = getenv("FEASTHIP_FWD_SPLITK")) fwd_splitk_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
@@ -692,7 +693,7 @@ bool Engine::build_plans() {
         }
         F.scale.count = (int)(tiles.size() - F.scale.off);
         // coupling into 256- and 512-column super blocks (kernels.hpp: launch_couple_outer / launch_couple_level)
-        for (int lvl = 0; lvl < 2; ++lvl) {
+        for (int lvl = 0; lvl < 3; ++lvl) {
             const int half = SOLVE_NB << lvl;
             F.outer[lvl].off = (int64_t)tiles.size();
             for (int s : lv) if (solve_nb(s) >= 2 * half) {

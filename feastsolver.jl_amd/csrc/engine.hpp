@@ -48,7 +48,7 @@ struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp;
 struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm;
                      Launch cbgemm_sym;     // symmetric pencils: the tiles on and below the diagonal of the contribution block only (mirrored on store)
                      Launch fronts; Launch binv, couple, scale;
-                     Launch outer[2], inner[2]; };      // coupling of 128 -> 256 ([0]) and 256 -> 512 ([1]) super blocks (launch_couple_outer / _level)
+                     Launch outer[3], inner[3]; };      // coupling of 128 -> 256 ([0]), 256 -> 512 ([1]) and 512 -> 1024 ([2]) super blocks (launch_couple_outer / _level)
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     Launch f2red; int f2split = 0;      // forward L21 products split along K (few nodes per GPU): number of parts, reduction tiles
                     Launch b3s;       // B3 tiles of the fronts whose B1 tile is kind 6 (launched only when the apply kernel does not fuse them)
@@ -325,7 +325,10 @@ private:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)
     int short_k_max_p_ = 96;          // levels whose fronts have at most this many pivot columns use 32-row substitution tiles
     int nb256_min_p_ = 193, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
-    int solve_nb(int s) const { int p = S.p(s); return p >= nb512_min_p_ ? 512 : p >= nb256_min_p_ ? 256 : 128; }
+    int nb1024_min_p_ = 1 << 30;      // ... 1024-column ones: built and tested in round 4 (FEASTHIP_NB1024_MINP=2048: the root of C3, p = 3174, gets 4 instead of 7
+                                      // blocks, 59 instead of 65 launches per sweep pair) and OFF by default: contour step 16.12 -> 16.09 ms at 16 nodes for + 4.5 ms
+                                      // of factorisation (one more coupling level): the root's chain is throughput-bound there, not latency-bound
+    int solve_nb(int s) const { int p = S.p(s); return p >= nb1024_min_p_ ? 1024 : p >= nb512_min_p_ ? 512 : p >= nb256_min_p_ ? 256 : 128; }
     std::vector<hipStream_t> aux_streams_;
     std::vector<hipStream_t> up_streams_;  // analyze(): one upload stream per term (helper threads)
     std::vector<hipEvent_t> ev_join_;

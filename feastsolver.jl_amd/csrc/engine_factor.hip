@@ -242,7 +242,7 @@ int Engine::factorize() {
         else launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
-        for (int lvl = 0; lvl < 2; ++lvl) {       // 256- and 512-column super blocks of the fronts with many pivot columns
+        for (int lvl = 0; lvl < 3; ++lvl) {       // 256-, 512- and 1024-column super blocks of the fronts with many pivot columns
             launch_couple_outer(fin, dsym_, tl + F.outer[lvl].off, F.outer[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
             launch_couple_level(fin, dsym_, tl + F.inner[lvl].off, F.inner[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
         }

@@ -1823,7 +1823,8 @@ void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // vector units: a few hundred workgroups of < 20 us per tree level.
 __global__ __launch_bounds__(256) void k_couple_level(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int half,
                                                       cz* fact, int64_t fs) {
-    __shared__ cz Ss[256][17];          // half <= 256
+    extern __shared__ cz couple_lds[];      // half x 17 entries (launch_couple_level)
+    cz (*Ss)[17] = reinterpret_cast<cz (*)[17]>(couple_lds);
     Tile t = tiles[blockIdx.x];
     const int k = blockIdx.y;
     FrontD f = fr[t.f];
@@ -1870,7 +1871,9 @@ __global__ __launch_bounds__(256) void k_couple_level(const FrontD* __restrict__
 
 void launch_couple_level(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_couple_level, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, half, fact, fs);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_couple_level, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 17 * (int)sizeof(cz)); attr_set = true; }
+    hipLaunchKernelGGL(k_couple_level, dim3(ntiles, K), dim3(256), (size_t)half * 17 * sizeof(cz), st, S.fr, tiles, half, fact, fs);
 }
 
 // ---------------------------------------------------------------------------

@@ -50,10 +50,11 @@ def match_sets(a, b):
 # ---------------------------------------------------------------------------------------
 # 257..700: look-ahead with whole and partial panel groups; 1100 / 2100: 512- and 1024-thread register panels;
 # 4200: the first panels are taller than 4 x 1024 rows (generic panel kernel), the later ones are not;
-# 192..385 / 513..1537: the edges of the 256- and 512-column solve super blocks (whole, partial and single-block tails)
+# 192..385 / 513..1537: the edges of the 256- and 512-column solve super blocks (whole, partial and single-block tails);
+# 2047..3100: 1024-column super blocks (round 4: fronts of 2048 pivot columns and more), three whole blocks + a tail at 3100
 @pytest.mark.parametrize("n,m0", [(1, 1), (5, 3), (33, 16), (64, 64), (100, 20), (257, 64), (300, 100), (700, 37), (1100, 8), (2100, 4),
                                   (4200, 3), (192, 5), (193, 7), (200, 64), (384, 9), (385, 3), (513, 2), (640, 17), (1023, 3), (1024, 2),
-                                  (1025, 5), (1537, 3)])
+                                  (1025, 5), (1537, 3), (2047, 2), (2049, 2), (3100, 5)])
 def test_seam_dense_lu_ldiv(gpu, pkg, n, m0):
     rng = np.random.default_rng(n * 1000 + m0)
     Cm = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))      # needs real pivoting
@@ -70,7 +71,7 @@ def test_seam_dense_lu_ldiv(gpu, pkg, n, m0):
 
 
 @pytest.mark.parametrize("n,m0", [(1, 1), (5, 3), (31, 4), (32, 4), (33, 16), (64, 64), (100, 20), (129, 7), (257, 64), (300, 100), (700, 37), (1100, 8),
-                                  (2100, 4), (193, 7), (385, 3), (513, 2), (1025, 5), (1537, 3)])
+                                  (2100, 4), (193, 7), (385, 3), (513, 2), (1025, 5), (1537, 3), (2049, 2), (3100, 3)])
 def test_seam_dense_symmetric_lu_ldiv(gpu, pkg, n, m0):
     """Complex SYMMETRIC C (C = C^T, not Hermitian) with a definite imaginary part -- the shape of FEAST's shifted matrices
     z B - A for real symmetric A, B -- takes the elimination without interchanges (F.symmetric, U = D L^T) at every size on a
@@ -641,7 +642,7 @@ def test_rr_device_path_matches_host_path(gpu, pkg, wl, golden, case):
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind,n,m0", [("dense", 1, 1), ("dense", 5, 3), ("dense", 64, 64), ("dense", 100, 20), ("dense", 129, 7), ("dense", 257, 64), ("dense", 300, 100),
                                        ("dense", 700, 37), ("dense", 1100, 8), ("dense", 2100, 4), ("dense", 193, 7), ("dense", 385, 3), ("dense", 513, 2),
-                                       ("dense", 1025, 5), ("dense", 1537, 3), ("symmetric", 300, 9), ("symmetric", 1100, 5), ("hermitian", 257, 9),
+                                       ("dense", 1025, 5), ("dense", 1537, 3), ("dense", 2049, 2), ("dense", 3100, 3), ("symmetric", 2100, 3), ("symmetric", 300, 9), ("symmetric", 1100, 5), ("hermitian", 257, 9),
                                        ("hermitian", 1100, 5)])
 def test_seam_adjoint_ldiv_dense(gpu, pkg, kind, n, m0):
     """Y = C^-H R from the factor object of C (feasthip_ldiv_adjoint: forward with U^H, backward with L^H over the same solve-ready
@@ -1108,6 +1109,23 @@ def test_c2_full_size_dense4096(gpu, pkg, wl):
     # no inside eigenvalue was missed: the stochastic count estimate of the same contour agrees with the count
     est = pkg.contour_estimate_eig(w["A"], pkg.circular_contour_trapezoidal(w["c"], w["r"], 16), B=w["B"], samples=64, seed=7)
     assert abs(est - len(lam)) <= 0.35 * len(lam) + 3
+
+
+@pytest.mark.parametrize("n", [2049, 3100])
+def test_optional_1024_column_super_blocks(gpu, pkg, n):
+    """FEASTHIP_NB1024_MINP=2048 (off by default: measured neutral on the sweep, + 5 % on the factorisation): fronts of 2048 pivot
+    columns and more get 1024-column solve super blocks (a third coupling level); primal and adjoint solves keep the seam's accuracy."""
+    rng = np.random.default_rng(n)
+    Cm = np.asfortranarray(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    R = np.asfortranarray(rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3)))
+    with env_override(FEASTHIP_NB1024_MINP="2048"):
+        F = pkg.lu(Cm)
+        Y = np.zeros_like(R); Ya = np.zeros_like(R)
+        pkg.ldiv(Y, F, R)
+        pkg.ldiv(Ya, F, R, adjoint=True)
+        pkg.finalize(F)
+    assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y)
+    assert np.linalg.norm(Cm.conj().T @ Ya - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Ya)
 
 
 @pytest.mark.parametrize("m0", [100, 128])
