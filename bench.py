@@ -425,7 +425,8 @@ def main():
                 "n": n, "nnz_A": int(w["A"].nnz), "nodes": args.nodes, "m0": args.m0, "nodes_per_gpu": st["local_nodes"],
                 "conjugate_fold": bool(st["folded"]), "factorisations_per_gpu": st["factor_units"],
                 "nnz_L": st["nnz_l"], "nnz_U": st["nnz_u"], "supernodes": st["nsuper"], "max_front": st["max_front"],
-                "backend": (backend if use_dist else None), "allreduce_overlap": bool(reducer is not None and reducer.overlap),
+                "backend": (backend if use_dist else None), "allreduce_overlap": bool(reducer is not None and getattr(reducer, "overlap", True)),
+                "reduce": (args.reduce if use_dist else None),
                 "symmetric_factorisation": bool(st.get("symmetric", 0)),
             },
             "roofline": roofline(args, st, st2, prof, detail, levels, world),

@@ -1338,6 +1338,26 @@ def test_custom_factorizer_is_called_per_node(gpu, pkg, wl, golden, store):
     assert calls["lu"] == K
 
 
+@pytest.mark.parametrize("reduce", ["torch", "library"])
+def test_bench_rccl_path_with_one_rank(gpu, reduce):
+    """bench.py's multi-GPU code path on the one GPU of this box (FEASTHIP_FORCE_DIST=1: process group over RCCL with a single rank):
+    external moment buffer + torch all-reduce, and the collective inside the library (--reduce library); the line is complete and
+    the run converges to the single-process result."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(FEASTHIP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547" if reduce == "torch" else "29548")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--grid", "12", "--cpu-baseline", "off",
+                        "--reduce", reduce], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl" and line["config"]["reduce"] == reduce
+    assert line["result"]["inside"] == line["result"]["expected_inside"] and line["result"]["max_res_inside"] < 1e-10
+
+
 def test_bench_self_launch_two_ranks(gpu):
     """`python bench.py --gpus 2` started plainly (no torch.distributed.run, no RANK / WORLD_SIZE) starts its two ranks itself.
     On this one-GPU box the ranks share the card and sum the moment through gloo (bench.py --backend auto); the line must say
