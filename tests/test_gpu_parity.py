@@ -1573,6 +1573,50 @@ def test_adjoint_fold_matches_one_factorisation_per_node(gpu, pkg, wl, kind):
         assert _moment(pkg, w2, con, True)[1]["folded"] == 0
 
 
+def test_adjoint_fold_in_the_other_callers(gpu, pkg, fo, wl):
+    """The adjoint fold (Hermitian coefficient matrices: T(conj z) = T(z)^H) goes through solve_all / accumulate_solutions, which every
+    caller shares: nlfeast! on a Hermitian quadratic NEP (two moment tables), nlfeast_moments!, and contour_estimate_eig on a Hermitian
+    pencil give the same results with the fold (8 factorisations) as without (16, FEASTHIP_ADJ_FOLD=0)."""
+    rng = np.random.default_rng(31)
+    n = 80
+    def herm(scale):
+        G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return scale * (G + G.conj().T) / np.sqrt(4 * n)
+    M0, M1, M2 = herm(1.0) - 0.2 * np.eye(n), herm(0.3), np.eye(n) + herm(0.1)
+    Ms = [M0, M1, M2]
+    X0 = wl.rand_x0(n, 24, 9)              # 9 eigenvalues of this quadratic lie in |z| <= 0.3 (companion spectrum)
+    outs, outm = [], []
+    for fold in ("1", "0"):
+        with env_override(FEASTHIP_ADJ_FOLD=fold):
+            info = {}
+            lam, X, res = pkg.nlfeast(pkg.PolynomialNEP(Ms), X0.copy(), 16, 10, c=0j, r=0.3, eps=1e-13, info=info)
+            assert info["folded"] == (2 if fold == "1" else 0) and info["factor_units"] == (8 if fold == "1" else 16)
+            outs.append((lam.copy(), res.copy()))
+            lamm, Ym, resm = pkg.nlfeast_moments(pkg.PolynomialNEP(Ms), wl.rand_x0(n, 12, 9), 16, 8, c=0j, r=0.3, eps=1e-13, moments=2)
+            outm.append((lamm.copy(), resm.copy()))
+    for (l1, r1), (l0, r0) in (outs, outm):
+        i1 = (np.abs(l1) <= 0.3) & (r1 < 1e-8)
+        i0 = (np.abs(l0) <= 0.3) & (r0 < 1e-8)
+        assert i0.sum() == 9 and i1.sum() == 9
+        assert match_sets(l1[i1], l0[i0]) < 1e-8 and match_sets(l0[i0], l1[i1]) < 1e-8
+    # every converged value is an eigenvalue of the quadratic: T(lam) singular
+    l1, r1 = outs[0]
+    for lv in l1[(np.abs(l1) <= 0.3) & (r1 < 1e-10)]:
+        T = M0 + lv * M1 + lv * lv * M2
+        assert np.linalg.svd(T, compute_uv=False)[-1] < 1e-8 * np.linalg.norm(T)
+    # contour_estimate_eig on a Hermitian pencil
+    w = wl.c3_sparse_generalized(8, 19, 16)
+    Ah = wl.hermitian_phases(w["A"], seed=2)
+    Xs = (rng.standard_normal((512, 24)) + 1j * rng.standard_normal((512, 24))) / np.sqrt(2.0)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    est = []
+    for fold in ("1", "0"):
+        with env_override(FEASTHIP_ADJ_FOLD=fold):
+            est.append(pkg.contour_estimate_eig(Ah, con, w["B"], X=Xs))
+    ref = fo.contour_estimate_eig(Ah.astype(np.complex128), fo.circular_contour_trapezoidal(w["c"], w["r"], 16), w["B"].astype(np.complex128), X=Xs)
+    assert abs(est[0] - est[1]) < 1e-9 * max(1.0, abs(ref)) and abs(est[0] - ref) < 1e-9 * max(1.0, abs(ref))
+
+
 def test_conjugate_fold_only_where_it_is_exact(gpu, pkg, wl):
     """No fold for complex matrices, for a contour that is not mirror-symmetric, or with a node on the real axis."""
     w = wl.c3_sparse_generalized(8, 19, 16)
