@@ -1164,11 +1164,9 @@ int Engine::analyze() {
     }
     std::vector<int> c0row(n);
     for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
-    {
-        std::vector<int> rid((size_t)Kloc * n);
-        for (int k = 0; k < Kloc; ++k) for (int i = 0; i < n; ++i) rid[(size_t)k * n + i] = i - c0row[i];
-        if (!d_rowid_.upload(rid.data(), rid.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
-    }
+    std::vector<int> rid((size_t)Kloc * n);          // (function scope: the asynchronous upload reads it until the stream is synchronised below)
+    for (int k = 0; k < Kloc; ++k) for (int i = 0; i < n; ++i) rid[(size_t)k * n + i] = i - c0row[i];
+    if (!d_rowid_.upload(rid.data(), rid.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     std::vector<int> one(1, 0);
     bool ok = d_fr_.upload(fr.data(), fr.size(), stream_) &&
               d_struct_.upload(S.struct_idx.empty() ? one.data() : S.struct_idx.data(), std::max<size_t>(1, S.struct_idx.size()), stream_) &&

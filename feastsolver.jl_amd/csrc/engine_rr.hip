@@ -255,7 +255,7 @@ int Engine::rr_step_device(double* lambda, double* res, uint8_t* inside, bool* d
     std::vector<zc> lam(ldw);
     void *l0 = nullptr, *l1 = nullptr, *l2 = nullptr;
     HIPCHK(d2h_async(4, nr.data(), d_nrm_.p, ldw * sizeof(double), &l0));
-    HIPCHK(d2h_async(5, lam.data(), d_lam_.p, ldw * sizeof(zc), &l1));
+    HIPCHK(d2h_async(7, lam.data(), d_lam_.p, ldw * sizeof(zc), &l1));      // (slot 5 carries the coefficient table of the contour step)
     HIPCHK(d2h_async(6, st.data(), dstat, 16 * sizeof(double), &l2));
     HIPCHK(hipEventRecord(ev1_, stream_));
     HIPCHK(hipEventSynchronize(ev1_));
