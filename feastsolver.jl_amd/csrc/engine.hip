@@ -912,6 +912,7 @@ bool Engine::build_plans() {
     }
     if (tiles.empty()) tiles.push_back({0, 0, 0, 0});
     if (lists.empty()) lists.push_back(0);
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze]   launch plans: %zu tiles (%.1f MB)\n", tiles.size(), tiles.size() * sizeof(Tile) / 1048576.0);
     return d_tiles_.upload(tiles.data(), tiles.size(), stream_) && d_lists_.upload(lists.data(), lists.size(), stream_);
 }
 
@@ -1174,7 +1175,9 @@ int Engine::analyze() {
               d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
               d_perm_.upload(S.perm.data(), n, stream_) && d_iperm_.upload(S.iperm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
               d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_);
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + front records, index uploads  %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
+    if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + launch plans (build + upload) %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     for (int s = 0; s < S.nsuper; ++s) { fr[s].sk_off = sk_off_[s]; fr[s].skf_off = skf_off_[s]; }
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
