@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--record", action="store_true", help="with --cpu-baseline full: write the measured line under profiles/")
     ap.add_argument("--no-fold", action="store_true",
                     help="factorise every contour node separately (the conjugate fold of real pencils off): the reference's literal schedule")
+    ap.add_argument("--fold", choices=["auto", "on", "off"], default="auto",
+                    help="conjugate fold (one factorisation per node pair, 128-column units).  auto: on with one rank, off with several -- with "
+                         "<= 4 units per rank the steady-state sweep is 4-8 %% faster on single nodes (two 64-column units instead of one of 128: "
+                         "profiles/r04_per_rank_load_single_gpu.txt) at twice the factorisations, and iterations/s is a steady-state metric")
     ap.add_argument("--mixed-prec", action="store_true",
                     help="secondary measurement: complex64 shifted solves with complex128 accumulation (feast!'s mixed_prec); not the headline number")
     ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
@@ -351,7 +355,8 @@ def main():
     h.set_terms([w["A"], w["B"]], [1.0, -1.0])
     h.set_contour(con)
     h.set_node_shard(rank, world)
-    if args.no_fold:
+    fold_on = (not args.no_fold) and (args.fold == "on" or (args.fold == "auto" and world == 1))
+    if not fold_on:
         h.set_conjugate_fold(False)
     if args.mixed_prec:
         h.set_precision(True)
