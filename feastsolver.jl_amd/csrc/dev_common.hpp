@@ -25,9 +25,16 @@ struct FrontD {
     int64_t cmap;             // offset into the contribution-row pull map (u x nchild ints), or -1 without children
     int64_t ebp;              // as a child: offset into the extend-add break points (first contribution row that lands at or
                               // beyond parent row 64 b, b = 0 .. ceil(ld_parent / 64)), or -1 for a root
+    int64_t pmap;             // offset into DevSym::pmap, the pull map of the pivot rows (p x nchild ints), or -1 without children
 };
 
 struct Tile { int f, a, b, c; };
+// Work split of one launch_apply launch over the 8 XCDs (workgroup b runs on XCD b % 8): XCD x owns the tiles [off[x], off[x + 1]) of
+// the launch's list for every node and column group; the grid is padded to cmax = the largest part (the spare workgroups exit at once).
+// The parts are cut by the planner (Engine::build_plans) for equal estimated time, not for equal tile counts.  perm >= 0: the parts index
+// DevSym::xperm + perm (tile numbers of the launch, dealt to the XCDs) instead of the list itself, whose order -- longest tiles first --
+// is the one a single XCD sweeping a whole node wants.
+struct XcdParts { int off[9]; int cmax; int perm; };
 
 __host__ __device__ inline cz cz_make(double x, double y) { cz r; r.x = x; r.y = y; return r; }
 __host__ __device__ inline cz cz_mul(cz a, cz b) { return cz_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }

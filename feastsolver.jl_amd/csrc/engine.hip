@@ -249,6 +249,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FUSE_B3")) fuse_b3_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NB512_MINP")) nb512_min_p_ = std::max(257, atoi(v));
     if (const char* v = getenv("FEASTHIP_NB1024_MINP")) nb1024_min_p_ = std::max(513, atoi(v));
+    if (const char* v = getenv("FEASTHIP_XCD_BALANCE")) xcd_balance_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
     if (const char* v = getenv("FEASTHIP_FWD_SPLITK")) fwd_splitk_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
@@ -910,6 +911,92 @@ bool Engine::build_plans() {
             L.count = (int)(tiles.size() - L.off);
         }
     }
+    // ---- split of every block-substitution launch over the 8 XCDs (dev_common.hpp: XcdParts).  A workgroup's XCD is fixed by its index,
+    // so the parts are cut here for equal estimated time: a tile costs a start-up plus its K extent times the 16-row slabs a wave
+    // walks (host mirror of decode_tile).  Launches of many small fronts are cut contiguously at front boundaries (neighbouring fronts,
+    // and a front's tiles in consecutive launches, stay on one XCD's L2); launches with few, long tiles (top of the tree, or the sorted
+    // lists of the L21 / U12 products when few nodes are left on this GPU) are dealt longest-first to the least loaded XCD.
+    {
+        const double xcd_c0 = getenv("FEASTHIP_XCD_C0") ? atof(getenv("FEASTHIP_XCD_C0")) : 64.0, xcd_thr = getenv("FEASTHIP_XCD_THR") ? atof(getenv("FEASTHIP_XCD_THR")) : 64.0;
+        auto tile_cost = [&](const Tile& t) -> double {
+            const int kind = t.a & 0xff, slv = (t.a >> 8) & 0xff, th = slv ? 16 * slv : 64, nsplit = t.a >> 16;
+            const int p = S.p(t.f), u = S.u(t.f), NB = solve_nb(t.f);
+            int Kd = 0, rows = th;
+            auto part = [&](int len) { if (!nsplit) return len; int Kp = (cdiv(len, nsplit) + 31) & ~31; return std::max(0, std::min(Kp, len - t.c * Kp)); };
+            switch (kind) {
+                case 0: { int k0 = t.c * NB, b = std::min(NB, p - k0); Kd = b; rows = p - (k0 + b + t.b * th); } break;
+                case 1: Kd = part(p); rows = u - t.b * th; break;
+                case 2: case 8: { int k0 = t.b * NB, b = std::min(NB, p - k0); Kd = std::min(b, t.c * th + th); rows = b - t.c * th; } break;
+                case 3: case 6: case 12: Kd = part(u); rows = p - t.b * th; break;
+                case 4: { int k0 = t.c * NB; Kd = std::min(NB, p - k0); rows = k0 - t.b * th; } break;
+                case 5: case 11: { int kb = t.b * NB, b = std::min(NB, p - kb), ks = t.c * th; Kd = b - ks; rows = b - ks; } break;
+                case 9: { int kc0 = t.c * NB, b = std::min(NB, p - kc0); Kd = kc0; rows = b - t.b * th; } break;
+                case 10: Kd = p; rows = u - t.b * th; break;
+                default: { int kc0 = t.c * NB, b = std::min(NB, p - kc0); Kd = p - kc0 - b; rows = b - t.b * th; } break;     // 13
+            }
+            rows = std::max(1, std::min(rows, th));
+            const int ns = rows <= 16 ? 1 : rows <= 32 ? 2 : 4;
+            return xcd_c0 + (double)std::max(0, Kd) * ns + (kind == 6 ? 2.0 * p : 0.0);
+        };
+        std::vector<double> w;
+        std::vector<int> order, bin, xperm;
+        auto balance = [&](Launch& L) {
+            const int nt = L.count;
+            for (int x = 0; x <= 8; ++x) L.xp.off[x] = (int)((int64_t)nt * x / 8);
+            L.xp.cmax = cdiv(nt, 8); L.xp.perm = -1;
+            if (nt <= 0 || !xcd_balance_) return;
+            const Tile* tl = tiles.data() + L.off;
+            w.resize(nt);
+            double total = 0, gmax = 0, gcur = 0;
+            for (int i = 0; i < nt; ++i) {
+                w[i] = tile_cost(tl[i]); total += w[i];
+                const bool same = i > 0 && tl[i].f == tl[i - 1].f && (tl[i].a & 0xff) == (tl[i - 1].a & 0xff);
+                gcur = same ? gcur + w[i] : w[i];
+                gmax = std::max(gmax, gcur);
+            }
+            const double target = total / 8;
+            if (gmax * xcd_thr <= target) {          // many small groups: contiguous parts, cut where the running cost passes x / 8 of the total
+                double cum = 0; int x = 0, i = 0;
+                L.xp.off[0] = 0;
+                while (i < nt) {
+                    int e = i + 1; double g = w[i];
+                    while (e < nt && tl[e].f == tl[i].f && (tl[e].a & 0xff) == (tl[i].a & 0xff)) g += w[e++];
+                    while (x < 7 && cum + 0.5 * g > (x + 1) * target) L.xp.off[++x] = i;
+                    cum += g; i = e;
+                }
+                while (x < 8) L.xp.off[++x] = nt;
+            } else {                            // longest first to the least loaded XCD
+                order.resize(nt); bin.assign(nt, 0);
+                for (int i = 0; i < nt; ++i) order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a] > w[b]; });
+                double load[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i : order) {
+                    int best = 0;
+                    for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+                    bin[i] = best; load[best] += w[i]; ++cnt[best];
+                }
+                L.xp.off[0] = 0;
+                for (int x = 0; x < 8; ++x) L.xp.off[x + 1] = L.xp.off[x] + cnt[x];
+                int pos[8];
+                for (int x = 0; x < 8; ++x) pos[x] = L.xp.off[x];
+                L.xp.perm = (int)xperm.size();
+                xperm.resize(xperm.size() + nt);
+                for (int i : order) xperm[L.xp.perm + pos[bin[i]]++] = i;
+            }
+            L.xp.cmax = 0;
+            for (int x = 0; x < 8; ++x) L.xp.cmax = std::max(L.xp.cmax, L.xp.off[x + 1] - L.xp.off[x]);
+        };
+        for (SolveLevel& V : splan_) {
+            for (Launch& L : V.f1) balance(L);
+            for (Launch& L : V.b2) balance(L);
+            for (Launch& L : V.afe) balance(L);
+            for (Launch& L : V.abe) balance(L);
+            balance(V.f2); balance(V.b1); balance(V.b3); balance(V.b3s); balance(V.afd); balance(V.af2); balance(V.ab1);
+        }
+        if (xperm.empty()) xperm.push_back(0);
+        if (!d_xperm_.upload(xperm.data(), xperm.size(), stream_)) return false;
+        dsym_.xperm = d_xperm_.p;
+    }
     if (tiles.empty()) tiles.push_back({0, 0, 0, 0});
     if (lists.empty()) lists.push_back(0);
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze]   launch plans: %zu tiles (%.1f MB)\n", tiles.size(), tiles.size() * sizeof(Tile) / 1048576.0);
@@ -1136,6 +1223,25 @@ int Engine::analyze() {
         }
     }
     if (cmap.empty()) cmap.push_back(-1);
+    // ... and the same for the pivot rows (rel < p): the forward sweep's assembly adds, row by row, the children's rows in child order
+    std::vector<int> pmap;
+    for (int s = 0; s < S.nsuper; ++s) {
+        int nch = fr[s].nchild, p = fr[s].p;
+        fr[s].pmap = -1;
+        if (nch == 0) continue;
+        fr[s].pmap = (int64_t)pmap.size();
+        size_t base = pmap.size();
+        pmap.resize(base + (size_t)p * nch, -1);
+        for (int c = 0; c < nch; ++c) {
+            int gch = S.child_idx[S.child_ptr[s] + c];
+            int ug = S.u(gch);
+            for (int i = 0; i < ug; ++i) {
+                int dst = S.rel[S.struct_ptr[gch] + i];
+                if (dst < p) pmap[base + (size_t)dst * nch + c] = (int)(S.crow_off[gch] + i);
+            }
+        }
+    }
+    if (pmap.empty()) pmap.push_back(-1);
     // extend-add break points: for a child g of parent s, ebp[b] = number of contribution rows of g that land before parent
     // row 64 b (rel is ascending), so a 64 x 64 parent tile finds its slice of the child's block without searching
     std::vector<int> ebp;
@@ -1174,34 +1280,34 @@ int Engine::analyze() {
               d_rel_.upload(S.rel.empty() ? one.data() : S.rel.data(), std::max<size_t>(1, S.rel.size()), stream_) &&
               d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
               d_perm_.upload(S.perm.data(), n, stream_) && d_iperm_.upload(S.iperm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
-              d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_);
+              d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_) &&
+              d_pmap_.upload(pmap.data(), pmap.size(), stream_);
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + front records, index uploads  %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + launch plans (build + upload) %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     for (int s = 0; s < S.nsuper; ++s) { fr[s].sk_off = sk_off_[s]; fr[s].skf_off = skf_off_[s]; }
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
-    dsym_.perm = d_perm_.p; dsym_.iperm = d_iperm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.n = n;
-    dsym_.asmflag = nullptr; dsym_.relfirst = nullptr;
+    dsym_.perm = d_perm_.p; dsym_.iperm = d_iperm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.pmap = d_pmap_.p; dsym_.n = n;
+    dsym_.asmflag = nullptr;
     {
-        // fused right-hand-side gather: pivot rows that receive contributions of children, and the first contribution to each
-        // (children in the order k_fwd_assemble visits them)
+        // fused right-hand-side gather: the pivot rows that receive contributions of children are written by k_fwd_assemble
         static const bool fuse_gather = [] { const char* e = getenv("FEASTHIP_FUSE_GATHER"); return e ? atoi(e) != 0 : true; }();
         if (fuse_gather && !dense && !S.rel.empty()) {
-            std::vector<int> asmflag(n, 0), relfirst(S.rel.size(), 0);
+            std::vector<int> asmflag(n, 0);
             for (int s2 = 0; s2 < S.nsuper; ++s2) {
                 const int p = S.p(s2), c0 = S.sn_start[s2];
                 for (int64_t c = S.child_ptr[s2]; c < S.child_ptr[s2 + 1]; ++c) {
                     const int g2 = S.child_idx[c], ug = S.u(g2);
                     for (int i = 0; i < ug; ++i) {
                         const int dst = S.rel[S.struct_ptr[g2] + i];
-                        if (dst < p && !asmflag[c0 + dst]) { asmflag[c0 + dst] = 1; relfirst[S.struct_ptr[g2] + i] = 1; }
+                        if (dst < p) asmflag[c0 + dst] = 1;
                     }
                 }
             }
-            if (!d_asmflag_.upload(asmflag.data(), asmflag.size(), stream_) || !d_relfirst_.upload(relfirst.data(), relfirst.size(), stream_))
+            if (!d_asmflag_.upload(asmflag.data(), asmflag.size(), stream_))
                 return fail(FEASTHIP_EHIP, "analyze: device upload failed");
-            dsym_.asmflag = d_asmflag_.p; dsym_.relfirst = d_relfirst_.p;
+            dsym_.asmflag = d_asmflag_.p;
         }
     }
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + plans, uploads             %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

@@ -41,6 +41,7 @@ struct Launch {        // a slice of the tile / list buffers
     double bytes = 0, flops = 0;   // algorithmic bytes / real flops of this launch for ONE contour node
     double vrows = 0;              // block-vector rows read or written by the in-block steps (one node)
     int sl = 4;                    // tile height of the launch in 16-row slabs (launch_apply: max_slabs)
+    XcdParts xp = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, -1};     // launch_apply launches: the tiles of each XCD (dev_common.hpp; filled by build_plans)
 };
 
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp;
@@ -215,9 +216,11 @@ private:
     // device symbolic
     DevBuf<FrontD> d_fr_;
     DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_iperm_, d_c0row_, d_cmap_, d_ebp_;
-    DevBuf<int> d_asmflag_, d_relfirst_;  // fused right-hand-side gather (kernels.hpp: DevSym::asmflag / relfirst; FEASTHIP_FUSE_GATHER=0 turns it off)
+    DevBuf<int> d_asmflag_;     // fused right-hand-side gather (kernels.hpp: DevSym::asmflag; FEASTHIP_FUSE_GATHER=0 turns it off)
     DevBuf<Tile> d_tiles_;
     DevBuf<int> d_lists_;
+    DevBuf<int> d_xperm_;       // XcdParts::perm
+    DevBuf<int> d_pmap_;        // DevSym::pmap
     std::vector<FactorLevel> fplan_;
     std::vector<SolveLevel> splan_;
     DevSym dsym_;
@@ -323,6 +326,7 @@ private:
     bool fwd_splitk_ = false;         // FEASTHIP_FWD_SPLITK=1: split the long forward L21 products along K when few nodes are left on this GPU.
                                       // Measured at one unit per GPU (C3): the split launches gain 10-40 us each, their reductions cost 50-80 us:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)
+    bool xcd_balance_ = true;         // FEASTHIP_XCD_BALANCE=0: equal tile counts per XCD in every block-substitution launch (build_plans)
     int short_k_max_p_ = 96;          // levels whose fronts have at most this many pivot columns use 32-row substitution tiles
     int nb256_min_p_ = 193, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
     int nb1024_min_p_ = 1 << 30;      // ... 1024-column ones: built and tested in round 4 (FEASTHIP_NB1024_MINP=2048: the root of C3, p = 3174, gets 4 instead of 7

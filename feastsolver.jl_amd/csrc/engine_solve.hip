@@ -50,14 +50,14 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         int par = d & 1;
         int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
         begin();
-        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs,
-                            (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, rinv, kc, 0, dsym_.asmflag ? rhs : nullptr, ldrhs);
+        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, ldw, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, rinv, kc,
+                            dsym_.asmflag ? rhs : nullptr, ldrhs);
         if (V.assemble.count) end(1, 3.0 * V.asm_rows * rowb * kc, 0);
         double lvl_rows = 0;
         for (int s : S.levels[d]) lvl_rows += S.p(s) + S.u(s);
         for (Launch& L : V.f1) {
             begin();
-            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false, nullptr, 0, nullptr, 0, L.sl);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false, nullptr, 0, nullptr, 0, L.sl, &L.xp);
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, L.vrows), stat_flops(L)); }
         }
         begin();
@@ -65,7 +65,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         // epilogue of the F2a tiles (kind 1), so there is no second assembly pass
         const int64_t sksf = std::max<int64_t>(1, sk_rows_) * ldw;
         launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
-                     V.f2split ? skall + (int64_t)kb * sksf : nullptr, V.f2split ? sksf : 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2.sl);
+                     V.f2split ? skall + (int64_t)kb * sksf : nullptr, V.f2split ? sksf : 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2.sl, &V.f2.xp);
         if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows + V.pull_rows), stat_flops(V.f2)); }
         if (V.f2split) {
             begin();
@@ -83,7 +83,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         for (int s : S.levels[d]) { lvl_p += S.p(s); lvl_u += S.u(s); }
         begin();
         int64_t sks = std::max<int64_t>(1, sk_rows_) * ldw;
-        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, skall + (int64_t)kb * sks, sks, nullptr, 0, V.b1.sl);
+        launch_apply(st, dsym_, tl + V.b1.off, V.b1.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, true, skall + (int64_t)kb * sks, sks, nullptr, 0, V.b1.sl, &V.b1.xp);
         if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Yp, ws, ldw, skall + (int64_t)kb * sks, sks, kc);
         if (V.b1.count) {
             Launch b1s = V.b1;          // the kind-6 tiles carry their fronts' B3 products
@@ -94,11 +94,11 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         for (int c = (int)V.b2.size() - 1; c >= 1; --c) {
             Launch& L = V.b2[c];
             begin();
-            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, L.sl);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, L.sl, &L.xp);
             if (L.count) { cur_tiles = L.count; end(3, stat_bytes(L, L.vrows), stat_flops(L)); }
         }
         begin();
-        launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, V.b3.sl);
+        launch_apply(st, dsym_, tl + V.b3.off, V.b3.count, Fp, fs, Wp, Yp, ws, ldw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, V.b3.sl, &V.b3.xp);
         if (V.b3.count) { cur_tiles = V.b3.count; end(3, stat_bytes(V.b3, V.b3.vrows), stat_flops(V.b3)); }
     }
     if (prof) { (void)hipEventDestroy(pa); (void)hipEventDestroy(pb); }
@@ -129,13 +129,13 @@ int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz*
         const int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * lw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * lw;
         cz* crp = crowb[par] + (int64_t)slot0 * crs;
         cz* crc = crowb[par ^ 1] + (int64_t)slot0 * crsc;
-        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, lw, crp, crs, crc, crsc, rid, kc, 0, dsym_.asmflag ? rhs : nullptr, ldrhs);
-        launch_apply(st, dsym_, tl + V.afd.off, V.afd.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, nullptr, 0, V.afd.sl);
+        launch_fwd_assemble(st, dsym_, tl + V.assemble.off, V.assemble.count, Wp, ws, lw, crc, crsc, rid, kc, dsym_.asmflag ? rhs : nullptr, ldrhs);
+        launch_apply(st, dsym_, tl + V.afd.off, V.afd.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, nullptr, 0, V.afd.sl, &V.afd.xp);
         for (size_t c = 1; c < V.afe.size(); ++c) {
             const Launch& L = V.afe[c];
-            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, nullptr, 0, L.sl);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, nullptr, 0, L.sl, &L.xp);
         }
-        launch_apply(st, dsym_, tl + V.af2.off, V.af2.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, crc, crsc, V.af2.sl);
+        launch_apply(st, dsym_, tl + V.af2.off, V.af2.count, Fp, fs, Wp, Yp, ws, lw, crp, crs, kc, false, nullptr, 0, crc, crsc, V.af2.sl, &V.af2.xp);
     }
     const int64_t sks = std::max<int64_t>(1, sk_rows_) * lw;
     cz* skp = d_sk_.p + (int64_t)slot0 * sks;
@@ -145,11 +145,11 @@ int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz*
     cz* Xs = unperm ? Yp : Wp;
     for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep with L^H, root to leaves
         SolveLevel& V = splan_[d];
-        launch_apply(st, dsym_, tl + V.ab1.off, V.ab1.count, Fp, fs, Wp, Xs, ws, lw, nullptr, 0, kc, true, skp, sks, nullptr, 0, V.ab1.sl);
+        launch_apply(st, dsym_, tl + V.ab1.off, V.ab1.count, Fp, fs, Wp, Xs, ws, lw, nullptr, 0, kc, true, skp, sks, nullptr, 0, V.ab1.sl, &V.ab1.xp);
         if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Wp, ws, lw, skp, sks, kc);
         for (int c = (int)V.abe.size() - 2; c >= 0; --c) {
             const Launch& L = V.abe[c];
-            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, lw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, L.sl);
+            launch_apply(st, dsym_, tl + L.off, L.count, Fp, fs, Wp, Yp, ws, lw, nullptr, 0, kc, false, nullptr, 0, nullptr, 0, L.sl, &L.xp);
         }
         if (unperm) launch_adj_unpermute(st, dsym_, d_lists_.p + fplan_[d].fronts.off, fplan_[d].fronts.count, d_rowperm_.p + (int64_t)kb * n, Wp, Yp, ws, lw, kc);
     }

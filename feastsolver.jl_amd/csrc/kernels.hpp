@@ -22,10 +22,11 @@ struct DevSym {          // device copies of the symbolic structure
     const int* c0_of_row;  // first column of the supernode owning (new) row i
     const int* cmap;       // per front with children: [contribution row][child slot] -> row in the children's arena, or -1
     const int* ebp;        // extend-add break points, see FrontD::ebp
+    const int* pmap;       // per front with children: [pivot row][child slot] -> row in the children's arena, or -1 (k_fwd_assemble)
+    const int* xperm;      // dealt tile orders of the block-substitution launches (dev_common.hpp: XcdParts::perm)
     // fused right-hand-side gather (nullptr: off): rows of the block vectors that receive contributions of children are not
-    // written by k_gather_rhs but by the first contribution in k_fwd_assemble (W = R + contribution instead of W += contribution)
+    // written by k_gather_rhs but by k_fwd_assemble (W = R + contributions instead of W += contributions)
     const int* asmflag;    // [n] by pre-pivot (new) row: 1 = some child contributes to this pivot row
-    const int* relfirst;   // parallel to rel: 1 = this child row is the first contribution to its destination
     int n;
 };
 
@@ -95,8 +96,7 @@ void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, 
                        const int* rowperm, int K);
 // (src, ldsrc: the right-hand side the sweep started from, for the rows k_gather_rhs left to the first contribution)
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
-                         cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase, const cz* src = nullptr, int ldsrc = 0);
+                         const cz* crow_child, int64_t crs_child, const int* rowinv, int K, const cz* src = nullptr, int ldsrc = 0);
 // Block substitution on the solve-ready factors: every tile is out (-)= A * V on the f64 matrix cores.
 // Tile.a = kind, Tile.b = row tile (or diagonal block), Tile.c = step block index:
 //   0 F1  forward, rows of the pivot block below diagonal block c:   W_r -= P_rc W_c
@@ -120,18 +120,19 @@ void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int
 // at most 32 rows run a k_apply2 instance that needs fewer registers and keeps three workgroups per CU instead of two.
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather = false,
-                  cz* skbuf = nullptr, int64_t sks = 0, const cz* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4);
+                  cz* skbuf = nullptr, int64_t sks = 0, const cz* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4,
+                  const XcdParts* xp = nullptr);
 // Tile kind 6 = the B1 tile of a front whose pivot block fits one row tile; k_apply2 multiplies it by the front's upper inverse in
 // the same workgroup (so the front has no separate B3 tile).
 // complex64 twins for the mixed-precision solve path (same tiles, same plans)
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather = false,
-                  cf* skbuf = nullptr, int64_t sks = 0, const cf* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4);
+                  cf* skbuf = nullptr, int64_t sks = 0, const cf* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4,
+                  const XcdParts* xp = nullptr);
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cf* W, int64_t ws,
                        const int* rowperm, int K);
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
-                         cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase, const cz* src = nullptr, int ldsrc = 0);
+                         const cf* crow_child, int64_t crs_child, const int* rowinv, int K, const cz* src = nullptr, int ldsrc = 0);
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* Y, int64_t ws, int ldw,
                           const cf* skbuf, int64_t sks, int K);
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,

@@ -76,89 +76,93 @@ void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, 
     hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 255) / 256, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm, S.asmflag);
 }
 
-// Forward sweep, assembly of the children's contribution rows into the parent:
-// rows that map into the pivot block go to W (at their pivoted position), the
-// rest into the parent's own contribution rows.  A workgroup owns 64 destination
-// rows and pulls from the children in a fixed order (deterministic, no atomics).
+// Forward sweep, assembly of the children's contribution rows into the pivot rows of the parent (the rest of a child's rows is pulled
+// into the parent's own contribution rows by the epilogue of the kind-1 tiles).  Destination-major: a wave owns 16 pivot rows and adds
+// to each of them the children's rows that land on it, in child order (deterministic, no atomics), through the host-built pull map
+// DevSym::pmap -- one read and one write of the destination row whatever the number of children, no index chain per child, no
+// workgroup barrier.  (Rounds 1-3 went child by child through front record -> break points -> rel -> row: the same sums in the same
+// order, 40 us per launch with one node on the GPU where this one takes 25.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_fwd_assemble(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
-                                                      const int* __restrict__ rel, const int* __restrict__ child_idx,
-                                                      const int* __restrict__ ebp, T* W, int64_t ws, int ldw, T* crp, int64_t crsp,
-                                                      const T* __restrict__ crc, int64_t crsc,
-                                                      const int* __restrict__ rowinv, int n, int phase,
-                                                      const int* __restrict__ relfirst, const int* __restrict__ perm,
-                                                      const cz* __restrict__ src, int ldsrc) {
-    Tile t = tiles[blockIdx.x];
-    int k = blockIdx.y;
-    FrontD f = fr[t.f];
-    int p = f.p, r0 = t.a * 64;
-    // phase 0: destinations inside the pivot block (before the front is solved);
-    // phase 1: destinations among the contribution rows (after F2a has written them)
-    if (phase == 0 ? (r0 >= p) : (r0 + 64 <= p)) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                                                       const int* __restrict__ pmap, T* W, int64_t ws, int ldw,
+                                                       const T* __restrict__ crc, int64_t crsc, const int* __restrict__ rowinv, int n,
+                                                       const int* __restrict__ perm, const cz* __restrict__ src, int ldsrc) {
+    const Tile t = tiles[blockIdx.x];
+    const int k = blockIdx.y;
+    const FrontD f = fr[t.f];
+    const int p = f.p, nc = f.nchild, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rw = t.a * 64 + wave * 16;            // first row of this wave
+    if (rw >= p) return;
     T* const Wk = W + (int64_t)k * ws;
-    T* const Ck = crp + (int64_t)k * crsp;
-    for (int ci = 0; ci < f.nchild; ++ci) {
-        FrontD g = fr[child_idx[f.child_ptr + ci]];
-        const int* rc = rel + g.sptr;
-        const int ia = ebp[g.ebp + t.a], ib = ebp[g.ebp + t.a + 1];        // the child's rows that land in parent rows [r0, r0 + 64): at most 64
-        const int cnt = ib - ia;
-        // lane l resolves the destination of the child's row ia + l (two dependent index loads, all rows at once); the waves
-        // then add four rows per step with every load of the step in flight together
-        int drow = -1;                                                       // >= 0: row of W;  <= -2: -(row of the parent's contribution arena) - 2
-        int frow = -1;                                                       // >= 0: first contribution to the row, which starts from this row of src (fused gather)
-        if (lane < cnt) {
-            const int dst = rc[ia + lane];
-            if ((dst < p) == (phase == 0)) {
-                drow = dst < p ? f.c0 + rowinv[(int64_t)k * n + f.c0 + dst] : -((int)f.crow + dst - p) - 2;
-                if (relfirst && dst < p && relfirst[g.sptr + ia + lane]) frow = perm[f.c0 + dst];
-            }
-        }
-        const T* s0 = crc + (int64_t)k * crsc + (int64_t)(g.crow + ia) * ldw;
-        for (int base = wave * 4; base < cnt; base += 16) {
+    const T* const Ck = crc + (int64_t)k * crsc;
+    const int* const pm = pmap + f.pmap;
+    // lane l < 16: where row rw + l of the pivot block lives in W (after this node's row interchanges), and the row of the right-hand
+    // side it starts from when the gather is fused (rows that receive contributions are not written by k_gather_rhs)
+    int drow = 0, frow = 0;
+    if (lane < 16 && rw + lane < p) {
+        drow = f.c0 + rowinv[(int64_t)k * n + f.c0 + rw + lane];
+        if (src) frow = perm[f.c0 + rw + lane];
+    }
+    const int lu = lane >> 4, ls = lane & 15;       // lane = (row of the group of four, child slot)
+    for (int q = 0; q < 16 && rw + q < p; q += 4) {
+        unsigned started = 0;                       // rows of this group that already hold a sum (more than 16 children)
+        for (int s0 = 0; s0 < nc; s0 += 16) {
+            const int ns = min(16, nc - s0);
+            const int mv = (ls < ns && rw + q + lu < p) ? pm[(int64_t)(rw + q + lu) * nc + s0 + ls] : -1;
+            const unsigned long long hasm = __ballot(mv >= 0);
+            if (hasm == 0ull) continue;
             T* d[4];
-            const T* sp[4];
             const cz* fp[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int l = min(base + u, cnt - 1);
-                const int dr = __builtin_amdgcn_readlane(drow, l);
-                const int fr2 = __builtin_amdgcn_readlane(frow, l);
-                d[u] = (base + u < cnt && dr != -1) ? (dr >= 0 ? Wk + (int64_t)dr * ldw : Ck + (int64_t)(-dr - 2) * ldw) : nullptr;
-                sp[u] = s0 + (int64_t)l * ldw;
-                fp[u] = (d[u] && fr2 >= 0) ? src + (int64_t)fr2 * ldsrc : nullptr;
+                const bool has = ((hasm >> (16 * u)) & 0xffffull) != 0ull;
+                const int dr = __builtin_amdgcn_readlane(drow, q + u), fr2 = __builtin_amdgcn_readlane(frow, q + u);
+                d[u] = has ? Wk + (int64_t)dr * ldw : nullptr;
+                fp[u] = (has && src && !((started >> u) & 1u)) ? src + (int64_t)fr2 * ldsrc : nullptr;
+                if (has) started |= 1u << u;
             }
             for (int j = lane; j < ldw; j += 64) {
-                T a[4], b[4];
                 const int js = j < ldsrc ? j : j - ldsrc;          // columns ldsrc .. of a folded block vector: conj(src)
+                T a[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    b[u] = sp[u][j];
                     if (fp[u]) { const cz v = fp[u][js]; a[u] = el_make<T>(v.x, j < ldsrc ? v.y : -v.y); }
-                    else a[u] = (d[u] ? d[u] : sp[u])[j];
+                    else if (d[u]) a[u] = d[u][j];
+                }
+                for (int s = 0; s < ns; s += 2) {
+                    T b[4][2];
+                    int ix[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ix[u][h] = (s + h < ns) ? __builtin_amdgcn_readlane(mv, 16 * u + min(s + h, 15)) : -1;
+                            if (ix[u][h] >= 0) b[u][h] = Ck[(int64_t)ix[u][h] * ldw + j];
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (ix[u][h] >= 0) { a[u].x += b[u][h].x; a[u].y += b[u][h].y; }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (d[u]) { a[u].x += b[u].x; a[u].y += b[u].y; d[u][j] = a[u]; }
+                for (int u = 0; u < 4; ++u) if (d[u]) d[u][j] = a[u];
             }
         }
-        __syncthreads();
     }
 }
 
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
-                         cz* crow_parent, int64_t crs_parent, const cz* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase, const cz* src, int ldsrc) {
+                         const cz* crow_child, int64_t crs_child, const int* rowinv, int K, const cz* src, int ldsrc) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, S.ebp, W, ws, ldw,
-                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase, src ? S.relfirst : nullptr, S.perm, src, ldsrc);
+    hipLaunchKernelGGL(k_fwd_assemble<cz>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.pmap, W, ws, ldw, crow_child, crs_child, rowinv, S.n,
+                       S.perm, src, ldsrc);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
-                         cf* crow_parent, int64_t crs_parent, const cf* crow_child, int64_t crs_child,
-                         const int* rowinv, int K, int phase, const cz* src, int ldsrc) {
+                         const cf* crow_child, int64_t crs_child, const int* rowinv, int K, const cz* src, int ldsrc) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.rel, S.child_idx, S.ebp, W, ws, ldw,
-                       crow_parent, crs_parent, crow_child, crs_child, rowinv, S.n, phase, src ? S.relfirst : nullptr, S.perm, src, ldsrc);
+    hipLaunchKernelGGL(k_fwd_assemble<cf>, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, S.pmap, W, ws, ldw, crow_child, crs_child, rowinv, S.n,
+                       S.perm, src, ldsrc);
 }
 
 // ---------------------------------------------------------------------------
@@ -276,22 +280,16 @@ __device__ __forceinline__ int decode_tile(ApplyGeomT<T>& g, const FrontD& f, co
     return min(th, g.rend - g.rbase);
 }
 
-// node-major item mapping with a contiguous range per XCD (see k_apply)
-__device__ __forceinline__ int xcd_item() {
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-}
-
 template <typename T>
 static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const T* fact, int64_t fs,
                           T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, int K, bool gather, T* skbuf, int64_t sks,
-                          const T* crow_child, int64_t crs_child, int max_slabs);
+                          const T* crow_child, int64_t crs_child, int max_slabs, const XcdParts* xpp);
 
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cz* fact, int64_t fs,
                   cz* W, cz* Y, int64_t ws, int ldw, cz* crow, int64_t crs, int K, bool gather, cz* skbuf, int64_t sks,
-                  const cz* crow_child, int64_t crs_child, int max_slabs) {
+                  const cz* crow_child, int64_t crs_child, int max_slabs, const XcdParts* xp) {
     if (ntiles <= 0) return;
-    launch_apply2<cz>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs);
+    launch_apply2<cz>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs, xp);
 }
 
 // ---------------------------------------------------------------------------
@@ -625,10 +623,16 @@ template <typename T, bool GATHER, int NSMAX>
 __global__ __launch_bounds__(256, NSMAX == 4 ? 2 : 3) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                 const int* __restrict__ struct_idx, const T* __restrict__ fact, int64_t fs,
                                                 T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, T* skbuf, int64_t sks,
-                                                int ntiles, int ncg, const int* __restrict__ cmap, const T* __restrict__ crow_child, int64_t crs_child) {
-    const int item0 = xcd_item(), item = item0 / ncg;      // same work mapping as k_apply
-    Tile t = tiles[item % ntiles];
-    int k = item / ntiles, cg = (item0 % ncg) * LDS_COLS;
+                                                XcdParts xp, const int* __restrict__ xperm, int lanes, int ncg, const int* __restrict__ cmap, const T* __restrict__ crow_child, int64_t crs_child) {
+    // Workgroup b runs on XCD b % 8.  The XCDs form `lanes` groups of 8 / lanes: group l takes the nodes l, l + lanes, ... whole, and its
+    // XCDs the 8 / lanes parts of every launch list (dev_common.hpp: XcdParts, `lanes` adjacent parts merged), node-major, the column
+    // groups of a tile next to each other (the second one finds the factor slab in the XCD's L2).  lanes = gcd(nodes, 8): with 8 nodes
+    // every XCD sweeps whole nodes (no block-vector row is shared between L2s), with one node every XCD takes an eighth of each list.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, P = 8 / lanes, lane = xcd / P, q = xcd - lane * P;
+    const int lo = xp.off[q * lanes], cnt = xp.off[(q + 1) * lanes] - lo, per = xp.cmax * ncg;
+    const int ki = slot / per, rem = slot - ki * per, j = rem / ncg, cg = (rem - j * ncg) * LDS_COLS, k = lane + ki * lanes;
+    if (j >= cnt) return;
+    Tile t = tiles[xp.perm >= 0 ? xperm[xp.perm + lo + j] : lo + j];
     FrontD f = fr[t.f];
     ApplyGeomT<T> g;
     int trows = decode_tile<T>(g, f, t, k, struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, cmap, crow_child, crs_child);
@@ -641,10 +645,18 @@ __global__ __launch_bounds__(256, NSMAX == 4 ? 2 : 3) void k_apply2(const FrontD
 template <typename T>
 static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const T* fact, int64_t fs,
                           T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, int K, bool gather, T* skbuf, int64_t sks,
-                          const T* crow_child, int64_t crs_child, int max_slabs) {
+                          const T* crow_child, int64_t crs_child, int max_slabs, const XcdParts* xpp) {
     const int ncg = (ldw + LDS_COLS - 1) / LDS_COLS;
-    dim3 g(ntiles * K * ncg);
-#define FEASTHIP_A2(G, N) hipLaunchKernelGGL((k_apply2<T, G, N>), g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, ntiles, ncg, S.cmap, crow_child, crs_child)
+    XcdParts xp;
+    if (xpp && xpp->off[8] == ntiles) xp = *xpp;
+    else { for (int x = 0; x <= 8; ++x) xp.off[x] = (int)((int64_t)ntiles * x / 8); xp.perm = -1; }     // no plan: equal counts
+    int lanes = 8;
+    while (K % lanes) lanes >>= 1;          // gcd(K, 8)
+    if (lanes == 8) xp.perm = -1;           // whole nodes per XCD: the list's own order
+    xp.cmax = 0;
+    for (int q = 0; q < 8 / lanes; ++q) xp.cmax = std::max(xp.cmax, xp.off[(q + 1) * lanes] - xp.off[q * lanes]);
+    dim3 g(8 * xp.cmax * (K / lanes) * ncg);
+#define FEASTHIP_A2(G, N) hipLaunchKernelGGL((k_apply2<T, G, N>), g, dim3(256), 0, st, S.fr, tiles, S.struct_idx, fact, fs, W, Y, ws, ldw, crow, crs, skbuf, sks, xp, S.xperm, lanes, ncg, S.cmap, crow_child, crs_child)
     if (max_slabs <= 2) { if (gather) FEASTHIP_A2(true, 2); else FEASTHIP_A2(false, 2); }
     else { if (gather) FEASTHIP_A2(true, 4); else FEASTHIP_A2(false, 4); }
 #undef FEASTHIP_A2
@@ -654,9 +666,9 @@ static void launch_apply2(hipStream_t st, const DevSym& S, const Tile* tiles, in
 // Mixed precision (feast!'s mixed_prec, src/feast.jl:19-25): the complex64 instance of k_apply2 (v_mfma_f32_16x16x4_f32, paired 16-byte lanes)
 void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, const cf* fact, int64_t fs,
                   cf* W, cf* Y, int64_t ws, int ldw, cf* crow, int64_t crs, int K, bool gather, cf* skbuf, int64_t sks,
-                  const cf* crow_child, int64_t crs_child, int max_slabs) {
+                  const cf* crow_child, int64_t crs_child, int max_slabs, const XcdParts* xp) {
     if (ntiles <= 0) return;
-    launch_apply2<cf>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs);
+    launch_apply2<cf>(st, S, tiles, ntiles, fact, fs, W, Y, ws, ldw, crow, crs, K, gather, skbuf, sks, crow_child, crs_child, max_slabs, xp);
 }
 
 __global__ void k_to_f32(int64_t total, const cz* __restrict__ in, cf* out) {
