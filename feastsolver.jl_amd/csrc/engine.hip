@@ -1004,10 +1004,18 @@ bool Engine::build_plans() {
 }
 
 static std::mutex g_sym_mu;
+// Structure of the CSR copy of a term (the transpose of the caller's CSC arrays) and where every CSC entry lands in it: a later analysis of
+// the same patterns uploads these and lets the device permute the values (k_permute_vals) instead of transposing on the host again.
+struct CsrPattern {
+    std::vector<int64_t> rp;
+    std::vector<int> col, q;        // q[e]: position of CSC entry e in the CSR arrays
+    bool same = false;              // the CSR arrays equal the CSC arrays: a symmetric pattern with sorted indices
+};
 struct SymCacheEntry {       // most recent symbolic analyses (see Engine::analyze), with the arena destinations of the terms' entries
     uint64_t key = 0;
     Symbolic S;
     std::vector<std::shared_ptr<const std::vector<int64_t>>> dest;      // per term, filled by the first handle that computes them
+    std::vector<std::shared_ptr<const CsrPattern>> csr;                 // per term: the CSR copy's structure (SpMM), likewise
 };
 static std::vector<std::shared_ptr<SymCacheEntry>> g_sym_cache;
 
@@ -1035,7 +1043,7 @@ int Engine::analyze() {
     }
     struct JoinWarm { std::thread& t; ~JoinWarm() { if (t.joinable()) t.join(); } } join_warm{warm};
     // per-term host work that runs beside the ordering (CSR copies + their uploads) and beside the launch plans (arena destinations)
-    struct TermHost { std::vector<int64_t> dest, rp; std::vector<int> col; std::vector<zc> v; char bad = 0, bad_dest = 0, sym = 0, herm = 0, diag = 0, hreal = 0; };
+    struct TermHost { std::vector<int64_t> dest; std::shared_ptr<const CsrPattern> pat; char bad = 0, bad_dest = 0, sym = 0, herm = 0, diag = 0, hreal = 0; };
     std::vector<TermHost> th;
     std::shared_ptr<SymCacheEntry> sym_entry;      // the cache entry this analysis came from / went to (sparse terms)
     std::vector<std::shared_ptr<const std::vector<int64_t>>> dest_ready;    // arena destinations found in it, per term
@@ -1069,6 +1077,14 @@ int Engine::analyze() {
         // per term builds them while the nested dissection leaves most cores idle at its top levels
         if (trace) fprintf(stderr, "[feasthip analyze] + pattern hash               %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         th.resize(terms_.size());
+        for (auto& T : terms_) if (T.colptr[n] >= ((int64_t)1 << 31)) return fail(FEASTHIP_EARG, "analyze: more than 2^31 - 1 entries in one term");
+        {
+            std::lock_guard<std::mutex> lk(g_sym_mu);
+            for (auto& c : g_sym_cache) if (c->key == key && c->S.n == n) { sym_entry = c; break; }
+            if (sym_entry)
+                for (size_t ti = 0; ti < terms_.size() && ti < sym_entry->csr.size(); ++ti)
+                    if (sym_entry->csr[ti] && (int64_t)sym_entry->csr[ti]->q.size() == terms_[ti].colptr[n]) th[ti].pat = sym_entry->csr[ti];
+        }
         // The helper threads overwrite device buffers a previous analysis of this handle may still be using (DevBuf::alloc keeps a
         // buffer that is large enough): everything queued on the handle's stream has to be through first.  One upload stream per
         // term, created once per handle (a stream gets its hardware queue with its first operation: 25-30 ms).
@@ -1080,29 +1096,41 @@ int Engine::analyze() {
                 const SparseTerm& T = terms_[ti];
                 TermHost& H = th[ti];
                 const int64_t nnz = T.colptr[n];
-                H.rp.assign(n + 1, 0);
-                for (int64_t e2 = 0; e2 < nnz; ++e2) H.rp[T.rowval[e2] + 1]++;
-                for (int i = 0; i < n; ++i) H.rp[i + 1] += H.rp[i];
-                H.col.resize(nnz);
-                H.v.resize(nnz);
-                std::vector<int64_t> pos(H.rp.begin(), H.rp.end() - 1);
-                for (int j = 0; j < n; ++j)
-                    for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; H.col[q] = j; H.v[q] = T.val[e2]; }
+                // the structure of the CSR copy and the position q[e] of every CSC entry in it: from the cache entry of these patterns
+                // (H.pat, set above) or built here and published after the analysis
+                std::shared_ptr<const CsrPattern> pat = H.pat;
+                if (!pat) {
+                    auto np = std::make_shared<CsrPattern>();
+                    np->rp.assign(n + 1, 0);
+                    for (int64_t e2 = 0; e2 < nnz; ++e2) np->rp[T.rowval[e2] + 1]++;
+                    for (int i = 0; i < n; ++i) np->rp[i + 1] += np->rp[i];
+                    np->col.resize(nnz);
+                    np->q.resize(nnz);
+                    std::vector<int64_t> pos(np->rp.begin(), np->rp.end() - 1);
+                    for (int j = 0; j < n; ++j)
+                        for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) { int64_t q = pos[T.rowval[e2]]++; np->col[q] = j; np->q[e2] = (int)q; }
+                    bool same = true;
+                    for (int j = 0; j <= n && same; ++j) same = np->rp[j] == T.colptr[j];
+                    for (int64_t e2 = 0; e2 < nnz && same; ++e2) same = np->col[e2] == T.rowval[e2];
+                    np->same = same;
+                    pat = np;
+                    H.pat = np;
+                }
+                const int* const q = pat->q.data();
                 // The CSR arrays of M are the CSC arrays of M^T with sorted indices: M == M^T iff they equal the caller's CSC arrays
-                // (unsorted caller indices compare unequal and merely keep the pivoted factorisation).
+                // (unsorted caller indices compare unequal and merely keep the pivoted factorisation): the same structure, and the value
+                // of every entry equal to the one at its transposed position
                 {
-                    bool eq = true;
-                    for (int j = 0; j <= n && eq; ++j) eq = H.rp[j] == T.colptr[j];
-                    for (int64_t e2 = 0; e2 < nnz && eq; ++e2) eq = H.col[e2] == T.rowval[e2] && H.v[e2] == T.val[e2];
+                    bool eq = pat->same;
+                    for (int64_t e2 = 0; e2 < nnz && eq; ++e2) eq = T.val[q[e2]] == T.val[e2];
                     H.sym = eq ? 1 : 0;
                     // ... and M == M^H off the diagonal iff they equal them up to conjugation of the values (the diagonal is left out:
                     // an assembled shifted matrix z I - A, z D - A of a Hermitian pencil has a complex diagonal and is as good a
                     // candidate for the elimination without interchanges as the pencil's terms; the growth check decides)
-                    bool eqh = true;
-                    for (int j = 0; j <= n && eqh; ++j) eqh = H.rp[j] == T.colptr[j];
+                    bool eqh = pat->same;
                     for (int j = 0; j < n && eqh; ++j)
                         for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1] && eqh; ++e2)
-                            eqh = H.col[e2] == T.rowval[e2] && (T.rowval[e2] == j || H.v[e2] == std::conj(T.val[e2]));
+                            eqh = T.rowval[e2] == j || T.val[q[e2]] == std::conj(T.val[e2]);
                     H.herm = eqh ? 1 : 0;
                     bool dreal = true;      // a real diagonal on top of that: the matrix IS Hermitian (adjoint fold)
                     for (int j = 0; j < n && dreal; ++j)
@@ -1120,15 +1148,14 @@ int Engine::analyze() {
                 bool ok = hipSetDevice(device_) == hipSuccess;
                 if (ok && !up_streams_[ti] && hipStreamCreateWithFlags(&up_streams_[ti], hipStreamNonBlocking) != hipSuccess) { up_streams_[ti] = nullptr; ok = false; }
                 hipStream_t us = up_streams_[ti];
-                ok = ok && Tw.d_cscval.upload((const cz*)T.val.data(), nnz, us) && Tw.d_rowptr.upload(H.rp.data(), n + 1, us) &&
-                     Tw.d_col.upload(H.col.data(), nnz, us) && Tw.d_val.upload((const cz*)H.v.data(), nnz, us);
+                // (the values in CSR order are a permutation of the CSC values the factorisation scatters: made on the device)
+                ok = ok && Tw.d_cscval.upload((const cz*)T.val.data(), nnz, us) && Tw.d_rowptr.upload(pat->rp.data(), n + 1, us) &&
+                     Tw.d_col.upload(pat->col.data(), nnz, us) && Tw.d_csrq.upload(q, nnz, us) && Tw.d_val.alloc(nnz);
+                if (ok && nnz > 0) { launch_permute_vals(us, nnz, Tw.d_csrq.p, Tw.d_cscval.p, Tw.d_val.p); ok = hipGetLastError() == hipSuccess; }
+                ok = ok && hipStreamSynchronize(us) == hipSuccess;      // the handle's own streams read these buffers after the join
                 if (!ok) H.bad = 2;
             });
         if (trace) fprintf(stderr, "[feasthip analyze] + stream sync, CSR threads   %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        {
-            std::lock_guard<std::mutex> lk(g_sym_mu);
-            for (auto& c : g_sym_cache) if (c->key == key && c->S.n == n) { sym_entry = c; break; }
-        }
         if (sym_entry) S = sym_entry->S;
         else {
             // union of the terms' patterns (+ the diagonal), column by column
@@ -1329,6 +1356,11 @@ int Engine::analyze() {
             TermHost& H = th[ti];
             if (H.bad == 1) return fail(FEASTHIP_EARG, "analyze: internal, entry outside the symbolic structure");
             int64_t nnz = T.colptr[n];
+            if (H.pat && sym_entry) {   // the CSR structure, likewise
+                std::lock_guard<std::mutex> lk(g_sym_mu);
+                if (sym_entry->csr.size() < terms_.size()) sym_entry->csr.resize(terms_.size());
+                if (!sym_entry->csr[ti]) sym_entry->csr[ti] = H.pat;
+            }
             if (!dest_ready[ti]) {      // computed here: published for the next analysis of these patterns
                 auto sp2 = std::make_shared<const std::vector<int64_t>>(std::move(H.dest));
                 dest_ready[ti] = sp2;

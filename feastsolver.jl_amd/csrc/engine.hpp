@@ -70,6 +70,7 @@ struct SparseTerm {
     DevBuf<cz> d_val;
     DevBuf<int64_t> d_dest;     // arena destination of each CSC entry
     DevBuf<cz> d_cscval;
+    DevBuf<int> d_csrq;         // position of every CSC entry in the CSR arrays (d_val = d_cscval permuted, k_permute_vals)
     DevBuf<cz> d_dense;         // dense column-major copy (dense path)
     bool diagonal = false;      // sparse term with entries on the diagonal only (a lumped mass matrix, Diagonal(...) in the reference's tests)
     DevBuf<cz> d_diag;          // ... its diagonal (n entries, zeros where no entry is stored)

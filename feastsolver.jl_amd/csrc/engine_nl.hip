@@ -228,6 +228,7 @@ int Engine::nlm_contour_step(int first) {
 // Hankel matrices, thin SVD of the first through its orthonormal basis, reduced eigenproblem, candidate
 // vectors Y = U[1:N,:] vecs, update_R_moments! (src/utils.jl:118-134).  On return lam/res (moments*m0) are
 // sorted by residual, d_Ym_/d_Rm_ hold the sorted candidates, d_X_/d_R_ the m0 best.
+extern std::string g_ortho_diag;
 // Part 1: candidates.  Hankel matrices, rank-revealing basis, reduced eigenproblem; on return d_Ym_ holds the
 // column-normalised candidate vectors, lam their eigenvalues (NaN beyond the numerical rank nlm_rank_).
 int Engine::nlm_candidates(std::vector<zc>& lam) {
@@ -244,7 +245,26 @@ int Engine::nlm_candidates(std::vector<zc>& lam) {
     if (r) return r;
     int rk = 0;
     for (int j = 0; j < M; ++j) rk += keepc[j] ? 1 : 0;
-    if (rk == 0) return fail(FEASTHIP_ENUM, "nlfeast_moments: the moment matrix is numerically zero");
+    if (rk == 0) {
+        // diagnostics of a failure that must not happen with a regular T(z_k): what the moments, the subspace and the residual block hold
+        auto stats = [&](const cz* dptr, size_t count, const char* name, std::string& out) {
+            std::vector<zc> hbuf(count);
+            if (hipMemcpy(hbuf.data(), dptr, count * sizeof(zc), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+            size_t bad = 0; double mx = 0;
+            for (const zc& v : hbuf) { if (!std::isfinite(v.real()) || !std::isfinite(v.imag())) ++bad; else mx = std::max(mx, std::abs(v)); }
+            char line[160];
+            snprintf(line, sizeof line, " %s: max |.| %.3e, %zu non-finite of %zu;", name, mx, bad, count);
+            out += line;
+        };
+        std::string d;
+        stats(d_Qm_.p, (size_t)2 * mm_ * n * ldw, "moments", d);
+        stats(d_X_.p, (size_t)n * ldw, "X", d);
+        stats(d_R_.p, (size_t)n * ldw, "R", d);
+        stats(d_em_.p, (size_t)2 * mm_ * ninst() * solve_width(), "weights", d);
+        stats(d_W_.p, (size_t)ninst() * n * solve_width(), "solutions", d);
+        stats(d_H0_.p, (size_t)hrows * ld, "basis", d);
+        return fail(FEASTHIP_ENUM, "nlfeast_moments: the moment matrix is numerically zero (" + d + " orthonormalisation:" + g_ortho_diag + ")");
+    }
     std::vector<zc> Ur((size_t)M * M), Vr((size_t)M * M), G1((size_t)M * M), T((size_t)M * M), vec((size_t)M * M, zc(0.0));
     std::vector<double> sv(M);
     jacobi_svd(M, Rr.data(), Ur.data(), sv.data(), Vr.data());               // singular values descending: the first rk are the numerical range

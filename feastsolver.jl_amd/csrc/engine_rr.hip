@@ -123,7 +123,9 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
 // decided on cancellation noise), orthonormalises them and projects them out of the others explicitly; columns
 // whose explicitly formed remainder is below 1e-13 of their original norm are dropped (zeroed).  On return
 // Q_in = Q_out * Rtot, kept columns of Q_out are orthonormal, dropped ones (keep[j] = 0) are zero.
+std::string g_ortho_diag;          // what the last orthonormalize_rr saw, pass by pass (error messages)
 int Engine::orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rtot, std::vector<uint8_t>& keep) {
+    std::string& ortho_diag_ = g_ortho_diag;
     const int m = t.m, rows = t.rows, ld = t.ld;
     std::vector<double> nr;
     int r = col_norms(t, Q, nr);
@@ -131,6 +133,12 @@ int Engine::orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rt
     std::vector<zc> sc(ld, zc(0.0));
     Rtot.assign((size_t)m * m, zc(0.0));
     keep.assign(m, 1);
+    ortho_diag_.clear();
+    {
+        char line[200]; double mn = 1e300, mx = 0;
+        for (int j = 0; j < m; ++j) { mn = std::min(mn, nr[j]); mx = std::max(mx, nr[j]); }
+        snprintf(line, sizeof line, " column norms %.3e .. %.3e;", mn, mx); ortho_diag_ += line;
+    }
     for (int j = 0; j < m; ++j) {
         if (!std::isfinite(nr[j])) return fail(FEASTHIP_ENUM, "orthonormalize: non-finite column in the subspace");
         if (nr[j] > 0.0) { sc[j] = 1.0 / nr[j]; Rtot[j + (size_t)j * m] = nr[j]; } else keep[j] = 0;
@@ -146,6 +154,7 @@ int Engine::orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rt
         launch_gram(stream_, rows, m, ld, Q, Q, t.gram, dG);
         HIPCHK(hipMemcpyAsync(G.data(), dG, (size_t)m * m * sizeof(zc), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
+        for (const zc& v : G) if (!std::isfinite(v.real()) || !std::isfinite(v.imag())) return fail(FEASTHIP_ENUM, "orthonormalize: non-finite Gram matrix of the subspace (" + ortho_diag_ + ")");
         for (int j = 0; j < m; ++j) for (int i = 0; i < j; ++i) { zc a = 0.5 * (G[i + (size_t)j * m] + std::conj(G[j + (size_t)i * m])); G[i + (size_t)j * m] = a; G[j + (size_t)i * m] = std::conj(a); }
         W = G;
         std::vector<double> d0(m);
@@ -172,6 +181,12 @@ int Engine::orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rt
         }
         int ra = (int)acc.size(), ndef = 0;
         for (int j = 0; j < m; ++j) if (state[j] == 0) ++ndef;   // deferred: projected now, decided on the next pass
+        {
+            char line[200]; double mn = 1e300, mx = -1e300; int nonfinite = 0;
+            for (int j = 0; j < m; ++j) { if (!std::isfinite(d0[j])) ++nonfinite; else { mn = std::min(mn, d0[j]); mx = std::max(mx, d0[j]); } }
+            snprintf(line, sizeof line, " pass %d: diag(G) %.3e .. %.3e (%d non-finite), %d accepted, %d deferred, defect %.2e;", pass, mn, mx, nonfinite, ra, ndef, defect);
+            ortho_diag_ += line;
+        }
         // R11 (ra x ra, upper triangular in acceptance order) and its inverse
         R11.assign((size_t)ra * ra, zc(0.0));
         for (int tt = 0; tt < ra; ++tt) for (int s2 = tt; s2 < ra; ++s2) R11[tt + (size_t)s2 * ra] = rowsR[tt][acc[s2]];

@@ -160,6 +160,8 @@ void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cz* W
 void launch_adj_unpermute(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* rowperm, const cz* W, cz* X, int64_t ws, int ld, int K);
 
 // ---- Rayleigh-Ritz block ------------------------------------------------------
+// out[q[e]] = in[e]: the values of a term in CSR order from its CSC values (Engine::analyze)
+void launch_permute_vals(hipStream_t st, int64_t nnz, const int* q, const cz* in, cz* out);
 void launch_spmm_csr(hipStream_t st, int n, const int64_t* rowptr, const int* col, const cz* val, const cz* V, int ldw,
                      cz* out, cz alpha, int accumulate);
 // out(row-major n x ldw) (+)= alpha * A(col-major n x n) * V

@@ -16,6 +16,14 @@ __device__ inline void cmfma3(d4& cr, d4& ci, double ar, double ai, double br, d
     ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
 }
 
+__global__ void k_permute_vals(int64_t nnz, const int* __restrict__ q, const cz* __restrict__ in, cz* __restrict__ out) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < nnz) out[q[e]] = in[e];
+}
+void launch_permute_vals(hipStream_t st, int64_t nnz, const int* q, const cz* in, cz* out) {
+    hipLaunchKernelGGL(k_permute_vals, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, q, in, out);
+}
+
 // CSR SpMM: one wave per matrix row, one lane per block-vector column; the CSR
 // (rowptr, col, val) arrays are read coalesced by the wave, the gathered V rows are
 // whole contiguous lines.
@@ -386,7 +394,10 @@ __global__ __launch_bounds__(256, 2) void k_ts_gemm(int n, int m, int ldw, const
     const int tid = threadIdx.x;
     const int cg = blockIdx.y * 64, ntiles = (n + 63) / 64;
     for (int kc = 0; kc < m; kc += TS_KMAX) {
-        const int klen = min(TS_KMAX, m - kc), krows = (klen + 3) & ~3;
+        // the tile loops walk 16, 32 or 64 rows of M: all of them are staged, the ones beyond klen as zeros.  (Until round 4 only
+        // (klen + 3) & ~3 rows were: for m <= 12 the loop of 16 multiplied the masked -- zero -- entries of V with whatever LDS held
+        // beyond the staged rows, and 0 x NaN is NaN: the intermittent all-NaN subspaces of the 8-column moment blocks.)
+        const int klen = min(TS_KMAX, m - kc), krows = klen <= 16 ? 16 : klen <= 32 ? 32 : 64;
         __syncthreads();
         for (int idx = tid; idx < krows * 64; idx += 256) {
             int k = idx >> 6, c = idx & 63;
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_ts_gemm(int n, int m, int ldw, const
 
 void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz* M, cz* out) {
     const int ntiles = (n + 63) / 64, ncg = (ldw + 63) / 64;
-    const int krows = (std::min(m, TS_KMAX) + 3) & ~3;
+    const int kmax = std::min(m, TS_KMAX), krows = kmax <= 16 ? 16 : kmax <= 32 ? 32 : 64;      // rows of M a tile loop walks (k_ts_gemm)
     const size_t lds = (size_t)krows * 64 * sizeof(cz);                 // 64 KB for m = 64: two workgroups per CU
     const int per_cu = 2;
     const int wgs = std::max(1, std::min(ntiles, 256 * per_cu / std::max(1, ncg) ));

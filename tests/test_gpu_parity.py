@@ -318,6 +318,28 @@ def test_c4_butterfly_nlfeast(gpu, pkg, wl, golden):
         assert abs(np.linalg.norm(Tl @ Xo[:, j]) / np.linalg.norm(Tl) - res[j]) < 1e-12
 
 
+def test_narrow_blocks_after_nan_left_in_lds(gpu, pkg, wl, golden):
+    """k_ts_gemm (X = Q Xq, src/feast.jl:48, and every basis update of the rank-revealing orthonormalisation) walks 16, 32 or 64 rows
+    of the small matrix in LDS; until round 4 only (m + 3) & ~3 of them were staged, and the masked (zero) entries of the tall block
+    met whatever the LDS held beyond: 0 x NaN = NaN, an all-NaN subspace reported as "the moment matrix is numerically zero"
+    (intermittent: LDS usually holds finite leftovers).  Leave NaN in the LDS of every CU first, then run the 8-column moment case
+    and a 24-column linear one."""
+    import torch
+    a = torch.full((2048, 2048), float("nan"), device="cuda", dtype=torch.float64)
+    assert not torch.isfinite((a @ a).sum()).item() and not torch.isfinite(torch.softmax(a, 1).sum()).item()
+    del a
+    g = golden["moments_deficient_quadratic"]
+    T = pkg.PolynomialNEP(wl.deficient_quadratic_coeffs())
+    X = wl.rand_x0(g["n"], g["m0"], g["seed"])
+    c = complex(*g["c"])
+    lam, Y, res = pkg.nlfeast_moments(T, X, g["nodes"], g["iter"], c=c, r=g["r"], eps=g["eps"], moments=g["moments"])
+    ins = (np.abs(lam - c) <= g["r"]) & (res < 1e-9)
+    assert match_sets(lam[ins], c2n(g["lam_inside"])) < 1e-10
+    w = wl.c3_sparse_generalized(8, 19, 24)
+    lam2, X2, res2 = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=8, iter=20, c=w["c"], r=w["r"], eps=1e-10)
+    assert np.all(np.isfinite(lam2)) and np.all(np.isfinite(res2)) and len(lam2) > 0 and res2.max() < 1e-9
+
+
 @pytest.mark.parametrize("case,comp_key", [("moments_deficient_quadratic", "deficient_quadratic"),
                                            ("moments_butterfly", "c4_butterfly"), ("moments_system5", "system5")])
 def test_nlfeast_moments_parity(gpu, pkg, fo, wl, golden, case, comp_key):
