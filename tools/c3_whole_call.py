@@ -9,7 +9,7 @@ w = wl.c3_sparse_generalized(46, 19, 64)
 con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
 for rep in range(4):
     info = {}
-    X = w["X0"].copy()
+    X = w["X0"].copy(order="F")         # column-major like the reference's Matrix{ComplexF64} (a C-ordered block costs two more 100 MB copies per call: 35 ms)
     t0 = time.perf_counter()
     lam, V, res = pkg.gen_feast(X, w["A"], w["B"], con, iter=w["iter"], eps=w["eps"], store=True, info=info)
     dt = time.perf_counter() - t0
