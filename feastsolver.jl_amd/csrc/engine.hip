@@ -1158,18 +1158,34 @@ int Engine::analyze() {
         if (trace) fprintf(stderr, "[feasthip analyze] + stream sync, CSR threads   %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (sym_entry) S = sym_entry->S;
         else {
-            // union of the terms' patterns (+ the diagonal), column by column
+            // union of the terms' patterns (+ the diagonal), column by column, every column sorted and free of duplicates (a symmetric
+            // union then is its own transpose: analyze_pattern's fast path), column ranges on host threads
             std::vector<int64_t> cp(n + 1, 0), ri;
-            for (int j = 0; j < n; ++j) {
-                int64_t c = 1;
-                for (auto& T : terms_) c += T.colptr[j + 1] - T.colptr[j];
-                cp[j + 1] = cp[j] + c;
-            }
-            ri.resize(cp[n]);
-            for (int j = 0; j < n; ++j) {
-                int64_t o = cp[j];
-                ri[o++] = j;
-                for (auto& T : terms_) for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) ri[o++] = T.rowval[e2];
+            {
+                const int nth = n >= 20000 ? std::max(1, std::min(8, host_cpu_budget() / 2)) : 1;
+                std::vector<std::vector<int64_t>> part(nth);
+                auto build = [&](int ti) {
+                    const int j0 = (int)((int64_t)n * ti / nth), j1 = (int)((int64_t)n * (ti + 1) / nth);
+                    std::vector<int64_t>& out = part[ti];
+                    std::vector<int64_t> colrows;
+                    for (int j = j0; j < j1; ++j) {
+                        colrows.clear();
+                        colrows.push_back(j);
+                        for (auto& T : terms_) for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1]; ++e2) colrows.push_back(T.rowval[e2]);
+                        std::sort(colrows.begin(), colrows.end());
+                        colrows.erase(std::unique(colrows.begin(), colrows.end()), colrows.end());
+                        cp[j + 1] = (int64_t)colrows.size();
+                        out.insert(out.end(), colrows.begin(), colrows.end());
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (int ti = 1; ti < nth; ++ti) pool.emplace_back(build, ti);
+                build(0);
+                for (auto& t2 : pool) t2.join();
+                for (int j = 0; j < n; ++j) cp[j + 1] += cp[j];
+                ri.resize(cp[n]);
+                int64_t off = 0;
+                for (int ti = 0; ti < nth; ++ti) { std::copy(part[ti].begin(), part[ti].end(), ri.begin() + off); off += (int64_t)part[ti].size(); }
             }
             std::string e = analyze_pattern(n, cp.data(), ri.data(), opt, S);
             if (!e.empty()) return fail(FEASTHIP_EARG, "analyze: " + e);

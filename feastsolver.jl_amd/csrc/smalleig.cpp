@@ -110,6 +110,7 @@ inline void rot_cols(int lo, int hi, double c, double sr, double si, double* __r
 // Single-shift complex QR on an upper Hessenberg matrix; H becomes the Schur form T, Z the Schur vectors.
 // H is kept TRANSPOSED (Ht(j, i) = H(i, j)) so that the row rotations, the longer of the two updates of H, run over
 // contiguous memory like the rotations of Z; only the short column part (rows 0..k+2) is strided.
+constexpr int QR_GRP = 8;
 int hqr_schur(Planes& H, Planes& Z) {
     const int m = H.m;
     Planes T(m);
@@ -145,25 +146,71 @@ int hqr_schur(Planes& H, Planes& Z) {
         }
         ++its;
         zc x = h(l, l) - s, y = h(l + 1, l);
-        for (int k = l; k < ihi; ++k) {
-            // Givens G = [c sn; -conj(sn) c] with G [x;y] = [r;0]
-            double ax = std::abs(x), ay = std::abs(y), c;
-            zc sn;
-            if (ay == 0.0) { c = 1.0; sn = 0.0; }
-            else if (ax == 0.0) { c = 0.0; sn = std::conj(y) / ay; }
-            else { double nr = pythag(ax, ay); c = ax / nr; sn = (x / ax) * std::conj(y) / nr; }
-            int j0 = std::max(l, k - 1);
-            // rows k, k+1 of H = columns k, k+1 of T:  [h0; h1] <- [c h0 + sn h1; -conj(sn) h0 + c h1]
-            rot_cols(j0, m, c, sn.real(), -sn.imag(), T.r(k), T.i(k), T.r(k + 1), T.i(k + 1));
-            if (k > l) hset(k + 1, k - 1, 0.0);
-            int i1 = std::min(k + 2, ihi);
-            for (int i = 0; i <= i1; ++i) {         // columns k, k+1 of H (rows of T, strided)
-                zc h0 = h(i, k), h1 = h(i, k + 1);
-                hset(i, k, c * h0 + std::conj(sn) * h1);
-                hset(i, k + 1, -sn * h0 + c * h1);
+        // The rotations of a sweep are generated in groups of QR_GRP.  Each one is applied at once to its two rows (contiguous in T) and to
+        // the few entries of its two columns the next rotations read (rows k0 - 1 .. k + 2); the rows above the group take the whole group
+        // in one visit -- QR_GRP + 1 neighbouring entries of a T column loaded once, rotated QR_GRP times in registers, stored once --
+        // instead of one strided visit per rotation (the strided part was 45 % of the iteration for m = 128).  The same rotations reach every entry
+        // in the same order; QR iteration 9.8 -> 7.7 ms for m = 128 random, 5.8 -> 4.7 nearly diagonal, m = 64 unchanged (build host).
+        const int grp = (ihi - l >= 80) ? QR_GRP : 1;       // short windows (and m = 64 altogether: measured 7 % slower grouped) keep one visit per rotation
+        for (int k0 = l; k0 < ihi; k0 += grp) {
+            const int ng = std::min(grp, ihi - k0);
+            double gc[QR_GRP], gsr[QR_GRP], gsi[QR_GRP];
+            const int near0 = grp == 1 ? 0 : std::max(0, k0 - 1);          // first row handled rotation by rotation
+            for (int q = 0; q < ng; ++q) {
+                const int k = k0 + q;
+                // Givens G = [c sn; -conj(sn) c] with G [x;y] = [r;0]
+                double ax = std::abs(x), ay = std::abs(y), c;
+                zc sn;
+                if (ay == 0.0) { c = 1.0; sn = 0.0; }
+                else if (ax == 0.0) { c = 0.0; sn = std::conj(y) / ay; }
+                else { double nr = pythag(ax, ay); c = ax / nr; sn = (x / ax) * std::conj(y) / nr; }
+                gc[q] = c; gsr[q] = sn.real(); gsi[q] = sn.imag();
+                int j0 = std::max(l, k - 1);
+                // rows k, k+1 of H = columns k, k+1 of T:  [h0; h1] <- [c h0 + sn h1; -conj(sn) h0 + c h1]
+                rot_cols(j0, m, c, sn.real(), -sn.imag(), T.r(k), T.i(k), T.r(k + 1), T.i(k + 1));
+                if (k > l) hset(k + 1, k - 1, 0.0);
+                int i1 = std::min(k + 2, ihi);
+                for (int i = near0; i <= i1; ++i) {         // columns k, k+1 of H, rows near the diagonal (strided in T)
+                    zc h0 = h(i, k), h1 = h(i, k + 1);
+                    hset(i, k, c * h0 + std::conj(sn) * h1);
+                    hset(i, k + 1, -sn * h0 + c * h1);
+                }
+                rot_cols(0, m, c, sn.real(), sn.imag(), Z.r(k), Z.i(k), Z.r(k + 1), Z.i(k + 1));
+                if (k + 1 < ihi) { x = h(k + 1, k); y = h(k + 2, k); }
             }
-            rot_cols(0, m, c, sn.real(), sn.imag(), Z.r(k), Z.i(k), Z.r(k + 1), Z.i(k + 1));
-            if (k + 1 < ihi) { x = h(k + 1, k); y = h(k + 2, k); }
+            // rows 0 .. near0 - 1: columns k0 .. k0 + ng of H = entries k0 .. k0 + ng of column i of T; four rows per pass (independent
+            // chains of dependent rotations: the loads and the arithmetic of one hide the latencies of the others)
+            {
+                int i = 0;
+                for (; i + 4 <= near0; i += 4) {
+                    double* tr[4]; double* ti[4]; double ar[4], ai[4];
+                    for (int u = 0; u < 4; ++u) { tr[u] = T.re.data() + (size_t)(i + u) * m + k0; ti[u] = T.im.data() + (size_t)(i + u) * m + k0; ar[u] = tr[u][0]; ai[u] = ti[u][0]; }
+                    for (int q = 0; q < ng; ++q) {
+                        const double c = gc[q], sr = gsr[q], si = gsi[q];
+                        for (int u = 0; u < 4; ++u) {
+                            const double br = tr[u][q + 1], bi = ti[u][q + 1];
+                            tr[u][q] = c * ar[u] + (sr * br + si * bi);
+                            ti[u][q] = c * ai[u] + (sr * bi - si * br);
+                            const double nr = c * br - (sr * ar[u] - si * ai[u]), ni = c * bi - (sr * ai[u] + si * ar[u]);
+                            ar[u] = nr; ai[u] = ni;
+                        }
+                    }
+                    for (int u = 0; u < 4; ++u) { tr[u][ng] = ar[u]; ti[u][ng] = ai[u]; }
+                }
+                for (; i < near0; ++i) {
+                    double* tr = T.re.data() + (size_t)i * m + k0;
+                    double* ti = T.im.data() + (size_t)i * m + k0;
+                    double ar = tr[0], ai = ti[0];
+                    for (int q = 0; q < ng; ++q) {
+                        const double c = gc[q], sr = gsr[q], si = gsi[q], br = tr[q + 1], bi = ti[q + 1];
+                        tr[q] = c * ar + (sr * br + si * bi);
+                        ti[q] = c * ai + (sr * bi - si * br);
+                        const double nr = c * br - (sr * ar - si * ai), ni = c * bi - (sr * ai + si * ar);
+                        ar = nr; ai = ni;
+                    }
+                    tr[ng] = ar; ti[ng] = ai;
+                }
+            }
         }
     }
     for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { H.re[i + (size_t)j * m] = T.re[j + (size_t)i * m]; H.im[i + (size_t)j * m] = T.im[j + (size_t)i * m]; }
