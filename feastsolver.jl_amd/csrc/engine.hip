@@ -940,6 +940,7 @@ bool Engine::build_plans() {
         };
         std::vector<double> w;
         std::vector<int> order, bin, xperm;
+        bool plans_ok = true;
         auto balance = [&](Launch& L) {
             const int nt = L.count;
             for (int x = 0; x <= 8; ++x) L.xp.off[x] = (int)((int64_t)nt * x / 8);
@@ -985,6 +986,14 @@ bool Engine::build_plans() {
             }
             L.xp.cmax = 0;
             for (int x = 0; x < 8; ++x) L.xp.cmax = std::max(L.xp.cmax, L.xp.off[x + 1] - L.xp.off[x]);
+            // every tile in exactly one part (a wrong split would silently skip or repeat work): checked here, once per analysis
+            bool fine = L.xp.off[0] == 0 && L.xp.off[8] == nt;
+            for (int x = 0; x < 8 && fine; ++x) fine = L.xp.off[x] <= L.xp.off[x + 1];
+            if (fine && L.xp.perm >= 0) {
+                bin.assign(nt, 0);
+                for (int i = 0; i < nt && fine; ++i) { const int t2 = xperm[L.xp.perm + i]; fine = t2 >= 0 && t2 < nt && !bin[t2]; if (fine) bin[t2] = 1; }
+            }
+            if (!fine) plans_ok = false;
         };
         for (SolveLevel& V : splan_) {
             for (Launch& L : V.f1) balance(L);
@@ -993,6 +1002,7 @@ bool Engine::build_plans() {
             for (Launch& L : V.abe) balance(L);
             balance(V.f2); balance(V.b1); balance(V.b3); balance(V.b3s); balance(V.afd); balance(V.af2); balance(V.ab1);
         }
+        if (!plans_ok) { err = "build_plans: internal, a launch list is not split into disjoint parts"; return false; }
         if (xperm.empty()) xperm.push_back(0);
         if (!d_xperm_.upload(xperm.data(), xperm.size(), stream_)) return false;
         dsym_.xperm = d_xperm_.p;
@@ -1326,7 +1336,8 @@ int Engine::analyze() {
               d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_) &&
               d_pmap_.upload(pmap.data(), pmap.size(), stream_);
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + front records, index uploads  %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, "analyze: device upload of the symbolic structure failed");
+    err.clear();
+    if (!ok || !build_plans()) return fail(FEASTHIP_EHIP, err.empty() ? std::string("analyze: device upload of the symbolic structure failed") : "analyze: " + err);
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + launch plans (build + upload) %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     for (int s = 0; s < S.nsuper; ++s) { fr[s].sk_off = sk_off_[s]; fr[s].skf_off = skf_off_[s]; }
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");

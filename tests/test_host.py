@@ -104,6 +104,25 @@ def test_symbolic_quality_3d(lib, wl):
     assert stats[6] < 40      # tree depth stays logarithmic
 
 
+def test_symmetric_fast_path_gives_the_general_path_s_graph(lib, wl):
+    """analyze_pattern takes the adjacency of a structurally symmetric pattern with ascending row indices straight from the pattern
+    (no transposition); the general path (here: the same columns with their row indices reversed, which only costs it a sort) must see
+    the same graph: same ordering, same supernodes, same fill.  Above 20,000 vertices both paths run on host threads."""
+    for g in (9, 28):
+        A = sp.csc_matrix(wl.laplacian_3d(g, 19))
+        A.sort_indices()
+        s1, p1, sn1, cp, ri = _probe(lib, A)
+        B = A.copy()
+        for j in range(B.shape[0]):
+            B.indices[B.indptr[j]:B.indptr[j + 1]] = B.indices[B.indptr[j]:B.indptr[j + 1]][::-1].copy()
+        B.has_sorted_indices = False
+        n = B.shape[0]
+        cpb = np.ascontiguousarray(B.indptr, dtype=np.int64); rib = np.ascontiguousarray(B.indices, dtype=np.int64)
+        s2 = np.zeros(8, dtype=np.int64); p2 = np.zeros(n, dtype=np.int32); sn2 = np.zeros(n, dtype=np.int32)
+        assert lib.feasthip_symbolic_probe(n, cpb.ctypes.data, rib.ctypes.data, 0, 0, s2.ctypes.data, p2.ctypes.data, sn2.ctypes.data, None) == 0
+        assert np.array_equal(s1, s2) and np.array_equal(p1, p2) and np.array_equal(sn1, sn2)
+
+
 def test_python_constants_match_the_header(pkg):
     """element-type tags and the row-major flag of feasthip_set_dense: the Python mirror uses the header's values"""
     import importlib
