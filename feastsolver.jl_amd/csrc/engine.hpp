@@ -329,7 +329,9 @@ private:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)
     bool xcd_balance_ = true;         // FEASTHIP_XCD_BALANCE=0: equal tile counts per XCD in every block-substitution launch (build_plans)
     int short_k_max_p_ = 96;          // levels whose fronts have at most this many pivot columns use 32-row substitution tiles
-    int nb256_min_p_ = 193, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
+    int nb256_min_p_ = 129, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
+                                      // (256 from 129 on, 193 until round 4: a level whose widest front has 132 pivot columns no longer pays an in-block
+                                      // step forward and one backward for it: 65 -> 61 launches per sweep pair on C3, contour step -0.2 %, one unit per GPU -1.5 %)
     int nb1024_min_p_ = 1 << 30;      // ... 1024-column ones: built and tested in round 4 (FEASTHIP_NB1024_MINP=2048: the root of C3, p = 3174, gets 4 instead of 7
                                       // blocks, 59 instead of 65 launches per sweep pair) and OFF by default: contour step 16.12 -> 16.09 ms at 16 nodes for + 4.5 ms
                                       // of factorisation (one more coupling level): the root's chain is throughput-bound there, not latency-bound

@@ -50,10 +50,11 @@ def match_sets(a, b):
 # ---------------------------------------------------------------------------------------
 # 257..700: look-ahead with whole and partial panel groups; 1100 / 2100: 512- and 1024-thread register panels;
 # 4200: the first panels are taller than 4 x 1024 rows (generic panel kernel), the later ones are not;
-# 192..385 / 513..1537: the edges of the 256- and 512-column solve super blocks (whole, partial and single-block tails);
+# 129..385 / 513..1537: the edges of the 256- and 512-column solve super blocks (whole, partial and single-block tails; 256-column blocks
+# start at 129 pivot columns since round 4: a front of 132 no longer costs its tree level two extra launches);
 # 2047..3100: 1024-column super blocks (round 4: fronts of 2048 pivot columns and more), three whole blocks + a tail at 3100
 @pytest.mark.parametrize("n,m0", [(1, 1), (5, 3), (33, 16), (64, 64), (100, 20), (257, 64), (300, 100), (700, 37), (1100, 8), (2100, 4),
-                                  (4200, 3), (192, 5), (193, 7), (200, 64), (384, 9), (385, 3), (513, 2), (640, 17), (1023, 3), (1024, 2),
+                                  (4200, 3), (129, 3), (130, 64), (161, 5), (192, 5), (193, 7), (200, 64), (384, 9), (385, 3), (513, 2), (640, 17), (1023, 3), (1024, 2),
                                   (1025, 5), (1537, 3), (2047, 2), (2049, 2), (3100, 5)])
 def test_seam_dense_lu_ldiv(gpu, pkg, n, m0):
     rng = np.random.default_rng(n * 1000 + m0)
