@@ -339,6 +339,16 @@ def test_narrow_blocks_after_nan_left_in_lds(gpu, pkg, wl, golden):
     w = wl.c3_sparse_generalized(8, 19, 24)
     lam2, X2, res2 = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], nodes=8, iter=20, c=w["c"], r=w["r"], eps=1e-10)
     assert np.all(np.isfinite(lam2)) and np.all(np.isfinite(res2)) and len(lam2) > 0 and res2.max() < 1e-9
+    # ... and the other LDS users at sizes that leave part of their staging areas unused: dense pivoted and symmetric factorisations
+    # (panel, interchange, triangular-inverse and coupling kernels), the one-workgroup eigensolver, the quartic NEP
+    test_seam_dense_lu_ldiv(gpu, pkg, 130, 7)
+    test_seam_dense_lu_ldiv(gpu, pkg, 37, 3)
+    test_seam_dense_symmetric_lu_ldiv(gpu, pkg, 129, 7)
+    test_device_reduced_eigensolver(gpu, pkg, 24, 1)
+    wb = wl.c4_butterfly()
+    lam3, X3, res3 = pkg.nlfeast(pkg.PolynomialNEP(wb["coeffs"]), wb["X0"].copy(), 16, 10, c=wb["c"], r=wb["r"], eps=wb["eps"], spurious=wb["spurious"])
+    ins = np.abs(lam3 - wb["c"]) <= wb["r"]
+    assert ins.sum() == 13 and res3[ins].max() < 1e-10
 
 
 @pytest.mark.parametrize("case,comp_key", [("moments_deficient_quadratic", "deficient_quadratic"),
