@@ -159,7 +159,7 @@ def test_ordering_does_not_depend_on_the_trace_switch(lib, wl, capfd):
 
 def test_small_eig_matches_lapack(lib):
     rng = np.random.default_rng(11)
-    for m in (1, 2, 5, 16, 33, 64):
+    for m in (1, 2, 5, 16, 33, 64, 81, 100, 128):      # from 80 on the QR iteration applies the column rotations in groups of 8
         A = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
         B = np.eye(m) + 0.2 * (rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
         for Bm in (None, B):
