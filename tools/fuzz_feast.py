@@ -12,7 +12,12 @@ nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 sizes = [v for v in (3, 17, 33, 64, 100, 129, 257, 400, 777, 1200, 2000) if v <= nmax]
 bad = 0
 t_start = time.time()
+_nan = None
+if os.environ.get("FUZZ_LDS_NAN"):      # leave NaN in the LDS of every CU before each case (stale-LDS reads: tests/test_gpu_parity.py, test_narrow_blocks_...)
+    import torch
+    _nan = torch.full((2048, 2048), float("nan"), device="cuda", dtype=torch.float64)
 for case in range(ncases):
+    if _nan is not None: (_nan @ _nan).sum().item(); torch.softmax(_nan, 1).sum().item()
     n = int(rng.choice(sizes))
     sparse = bool(rng.integers(0, 2)) and n >= 17
     sym = bool(rng.integers(0, 2))

@@ -9,7 +9,12 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 bad = 0
 t0 = time.time()
+_nan = None
+if os.environ.get("FUZZ_LDS_NAN"):      # leave NaN in the LDS of every CU before each case (stale-LDS reads: tests/test_gpu_parity.py, test_narrow_blocks_...)
+    import torch
+    _nan = torch.full((2048, 2048), float("nan"), device="cuda", dtype=torch.float64)
 for case in range(ncases):
+    if _nan is not None: (_nan @ _nan).sum().item(); torch.softmax(_nan, 1).sum().item()
     n = int(rng.choice([8, 20, 33, 64, 100, 150]))
     deg = int(rng.choice([2, 3]))
     sparse = bool(rng.integers(0, 2)) and n >= 20

@@ -10,7 +10,12 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 edges = [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 385, 511, 512, 513, 640, 767, 769, 1023, 1025, 1300]
 bad = 0
 t0 = time.time()
+_nan = None
+if os.environ.get("FUZZ_LDS_NAN"):      # leave NaN in the LDS of every CU before each case (stale-LDS reads: tests/test_gpu_parity.py, test_narrow_blocks_...)
+    import torch
+    _nan = torch.full((2048, 2048), float("nan"), device="cuda", dtype=torch.float64)
 for case in range(ncases):
+    if _nan is not None: (_nan @ _nan).sum().item(); torch.softmax(_nan, 1).sum().item()
     n = int(rng.choice(edges)) if rng.integers(0, 3) else int(rng.integers(1, 1500))
     sparse = bool(rng.integers(0, 2))
     sym = bool(rng.integers(0, 2))

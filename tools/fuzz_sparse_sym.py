@@ -9,7 +9,12 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 21)
 bad = 0
 t0 = time.time()
+_nan = None
+if os.environ.get("FUZZ_LDS_NAN"):      # leave NaN in the LDS of every CU before each case (stale-LDS reads: tests/test_gpu_parity.py, test_narrow_blocks_...)
+    import torch
+    _nan = torch.full((2048, 2048), float("nan"), device="cuda", dtype=torch.float64)
 for case in range(ncases):
+    if _nan is not None: (_nan @ _nan).sum().item(); torch.softmax(_nan, 1).sum().item()
     n = int(rng.integers(2000, 60000))
     offs = sorted(set([1] + [int(v) for v in rng.integers(2, max(3, int(n ** 0.67)), size=int(rng.integers(1, 4)))]))
     diags = [rng.standard_normal(n - o) for o in offs]
