@@ -228,7 +228,7 @@ int Engine::nlm_contour_step(int first) {
 // Hankel matrices, thin SVD of the first through its orthonormal basis, reduced eigenproblem, candidate
 // vectors Y = U[1:N,:] vecs, update_R_moments! (src/utils.jl:118-134).  On return lam/res (moments*m0) are
 // sorted by residual, d_Ym_/d_Rm_ hold the sorted candidates, d_X_/d_R_ the m0 best.
-extern std::string g_ortho_diag;
+extern thread_local std::string g_ortho_diag;
 // Part 1: candidates.  Hankel matrices, rank-revealing basis, reduced eigenproblem; on return d_Ym_ holds the
 // column-normalised candidate vectors, lam their eigenvalues (NaN beyond the numerical rank nlm_rank_).
 int Engine::nlm_candidates(std::vector<zc>& lam) {

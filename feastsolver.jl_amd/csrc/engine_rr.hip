@@ -123,7 +123,7 @@ int Engine::orthonormalize(const Tall& t, cz* Q, cz* tmp, std::vector<zc>* Rtota
 // decided on cancellation noise), orthonormalises them and projects them out of the others explicitly; columns
 // whose explicitly formed remainder is below 1e-13 of their original norm are dropped (zeroed).  On return
 // Q_in = Q_out * Rtot, kept columns of Q_out are orthonormal, dropped ones (keep[j] = 0) are zero.
-std::string g_ortho_diag;          // what the last orthonormalize_rr saw, pass by pass (error messages)
+thread_local std::string g_ortho_diag;          // what this thread's last orthonormalize_rr saw, pass by pass (error messages)
 int Engine::orthonormalize_rr(const Tall& t, cz* Q, cz* tmp, std::vector<zc>& Rtot, std::vector<uint8_t>& keep) {
     std::string& ortho_diag_ = g_ortho_diag;
     const int m = t.m, rows = t.rows, ld = t.ld;
