@@ -593,7 +593,9 @@ def dual_gen_feast(Xr, Xl, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0,
     z = np.asarray(contour.nodes, dtype=np.complex128)
     w = np.asarray(contour.weights, dtype=np.complex128)
     import copy
-    doubled = os.environ.get("FEASTHIP_DUAL_DOUBLED", "0") == "1"       # rounds 2-3: the adjoint matrices factorised as K more nodes
+    # rounds 2-3: the adjoint matrices factorised as K more nodes; also the layout under FEASTHIP_FWD_SPLITK=1, whose forward plans the
+    # adjoint sweeps cannot walk (engine_solve.hip: solve_range_adj)
+    doubled = os.environ.get("FEASTHIP_DUAL_DOUBLED", "0") == "1" or os.environ.get("FEASTHIP_FWD_SPLITK", "0") not in ("", "0")
     dual_contour = copy.copy(contour)
     if doubled:
         dual_contour.nodes, dual_contour.weights = np.concatenate([z, z.conj()]), np.concatenate([w, w.conj()])

@@ -32,8 +32,15 @@ const RcclApi* rccl(std::string& err) {
     if (!g_rccl.err.empty()) { err = g_rccl.err; return nullptr; }
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;
-    for (const char* nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
-    if (!lib) { g_rccl.err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); err = g_rccl.err; return nullptr; }
+    const char* only = getenv("FEASTHIP_RCCL_LIB");      // a specific library (or, in the tests, a name that does not exist)
+    if (only && *only) lib = dlopen(only, RTLD_NOW | RTLD_LOCAL);
+    else for (const char* nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+    if (!lib) {
+        const char* de = dlerror();      // one call: dlerror() clears the message it returns
+        g_rccl.err = std::string("RCCL not found (dlopen librccl.so.1): ") + (de ? de : "");
+        err = g_rccl.err;
+        return nullptr;
+    }
     g_rccl.get_unique_id = (fn_get_unique_id)dlsym(lib, "ncclGetUniqueId");
     g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(lib, "ncclCommInitRank");
     g_rccl.comm_destroy = (fn_comm_destroy)dlsym(lib, "ncclCommDestroy");

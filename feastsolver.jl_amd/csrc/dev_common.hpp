@@ -1,9 +1,18 @@
 // Shared host/device definitions for the gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 
 namespace feasthip {
+
+// Function attributes (dynamic LDS above 64 KB) are per device: true the first time the calling thread's current device asks.
+inline bool first_on_this_device(std::atomic<uint64_t>& seen) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    return !(seen.fetch_or(bit) & bit);
+}
 
 typedef double2 cz;                                             // complex128 (re, im)
 typedef float2 cf;                                              // complex64, mixed-precision solve path

@@ -563,7 +563,7 @@ void Engine::rebuild_shard() {
     const bool allow_conj = base && terms_real_;
     // the adjoint fold: Hermitian coefficient matrices that are not real (real ones take the conjugate fold: one sweep of twice the width
     // instead of two); complex128 sweeps only
-    const bool allow_adj = base && !terms_real_ && adj_fold_enabled_ && terms_herm_exact_ && scales_real && !mixed_;
+    const bool allow_adj = base && !terms_real_ && adj_fold_enabled_ && terms_herm_exact_ && scales_real && !mixed_ && !fwd_splitk_;   // (the adjoint sweeps have no forward split-K form)
     const bool can = plan_node_shard(nodes_, shard_first_, shard_stride_, allow_conj || allow_adj, loc, par);
     const bool nf = can && allow_conj, na = can && !allow_conj && allow_adj;
     if (loc.size() != local_.size() || nf != fold_ || na != adj_fold_) { analyzed_ = false; have_x_ = false; }

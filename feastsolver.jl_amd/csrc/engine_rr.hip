@@ -251,7 +251,10 @@ int Engine::rr_step_device(double* lambda, double* res, uint8_t* inside, bool* d
         apply_term(1, Qp(), d_T1_.p, -1.0, false);                                            // B Q              :120
         launch_gram(stream_, n, m, ldw, Qp(), d_T1_.p, d_gram_scratch_.p, dB);                // Gb               :121
     }
+    // status words start as NaN: a launch the runtime rejected (or a kernel that never wrote them) must not read as "flags 0, done"
+    HIPCHK(hipMemsetAsync(dstat, 0xFF, 16 * sizeof(double), stream_));
     launch_rr_small_herm(stream_, m, dA, dB, dM, d_lam_.p, ldw, dstat, d_rrscr_.p, rr_cond_max_);   // :45, :122
+    HIPCHK(hipGetLastError());
     launch_ts_gemm(stream_, n, m, ldw, Qp(), dM, d_X_.p);                                     // X = Q Xq         :48
     const cz* AX;
     const cz* BX = nullptr;
@@ -277,7 +280,7 @@ int Engine::rr_step_device(double* lambda, double* res, uint8_t* inside, bool* d
     if (l0 != (void*)nr.data()) std::memcpy(nr.data(), l0, ldw * sizeof(double));
     if (l1 != (void*)lam.data()) std::memcpy(lam.data(), l1, ldw * sizeof(zc));
     if (l2 != (void*)st.data()) std::memcpy(st.data(), l2, 16 * sizeof(double));
-    const int flags = (int)st[0];
+    const int flags = std::isfinite(st[0]) ? (int)st[0] : -2;      // -2: the kernel did not report (sentinel still there)
     if (getenv("FEASTHIP_RR_TRACE"))
         fprintf(stderr, "[feasthip] reduced eigenproblem on the device (m=%d): flags %d, %d sweeps, ||R^-1||_F/sqrt(m) %.3g, Hermitian defect %.2e, diag(R) min/max %.3g; kernel %.0f (load %.0f, Cholesky %.0f, inverse %.0f, congruence %.0f) + %.0f + %.0f us\n",
                 m, flags, (int)st[1], st[2], st[3], st[4], st[5], st[8], st[9], st[10], st[11], st[6], st[7]);

@@ -1871,8 +1871,8 @@ __global__ __launch_bounds__(256) void k_couple_level(const FrontD* __restrict__
 
 void launch_couple_level(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K) {
     if (ntiles <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_couple_level, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 17 * (int)sizeof(cz)); attr_set = true; }
+    static std::atomic<uint64_t> attr_seen{0};
+    if (first_on_this_device(attr_seen)) { (void)hipFuncSetAttribute((const void*)k_couple_level, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 17 * (int)sizeof(cz)); }
     hipLaunchKernelGGL(k_couple_level, dim3(ntiles, K), dim3(256), (size_t)half * 17 * sizeof(cz), st, S.fr, tiles, half, fact, fs);
 }
 

@@ -417,8 +417,8 @@ void launch_ts_gemm(hipStream_t st, int n, int m, int ldw, const cz* V, const cz
     const size_t lds = (size_t)krows * 64 * sizeof(cz);                 // 64 KB for m = 64: two workgroups per CU
     const int per_cu = 2;
     const int wgs = std::max(1, std::min(ntiles, 256 * per_cu / std::max(1, ncg) ));
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ts_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, TS_KMAX * 64 * (int)sizeof(cz)); attr_set = true; }
+    static std::atomic<uint64_t> attr_seen{0};
+    if (first_on_this_device(attr_seen)) { (void)hipFuncSetAttribute((const void*)k_ts_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, TS_KMAX * 64 * (int)sizeof(cz)); }
     hipLaunchKernelGGL(k_ts_gemm, dim3(wgs, ncg), dim3(256), lds, st, n, m, ldw, V, M, out);
 }
 

@@ -431,8 +431,8 @@ size_t rr_small_lds_bytes() { return (size_t)2 * SM_N * SM_LD * sizeof(cz) + siz
 
 // Xq: m x m column-major; lam_out: ldw entries (zero beyond m); status: 8 doubles; tscratch: 64 x 64 entries
 void launch_rr_small_herm(hipStream_t st, int m, const cz* Ga, const cz* Gb, cz* Xq, cz* lam_out, int ldw, double* status, cz* tscratch, double cond_max) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rr_small_herm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rr_small_lds_bytes()); attr_set = true; }
+    static std::atomic<uint64_t> attr_seen{0};
+    if (first_on_this_device(attr_seen)) { (void)hipFuncSetAttribute((const void*)k_rr_small_herm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rr_small_lds_bytes()); }
     hipLaunchKernelGGL(k_rr_small_herm, dim3(1), dim3(SM_NT), rr_small_lds_bytes(), st, m, Ga, Gb, Xq, lam_out, ldw, status, tscratch, cond_max);
 }
 

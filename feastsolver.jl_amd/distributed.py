@@ -118,7 +118,11 @@ class LibraryReducer:
         world = dist.get_world_size(group) if live else 1
         box = [api.comm_unique_id() if rank == 0 else None]
         if live and world > 1:
-            dist.broadcast_object_list(box, src=0, group=group)
+            # src is a GLOBAL rank: the first member of a sub-group need not be global rank 0
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+        if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != 128:
+            raise RuntimeError("LibraryReducer: the RCCL unique id did not arrive (128 bytes expected)")
         handle.comm_init(box[0], rank, world)
 
     def contour_step_and_reduce(self, refactor=False):

@@ -1240,6 +1240,13 @@ def test_library_rccl_world1(gpu, pkg, wl, golden):
             h.comm_init(pkg.comm_unique_id(), 0, 1)
         h.factorize(); h.set_x(w["X0"]); h.rr_step(); h.contour_step()
         qs.append(h.get_block(2).copy())
+        if with_comm:
+            # the chunked form every rank of a larger world runs (>= 4 row ranges, per-range events, the communication stream waiting on
+            # each, in-place all-reduce at row offsets): same block, so the same moment, bit by bit (round-4 ADVICE: it had never executed)
+            h.contour_step_begin(False, 4)
+            assert [h.moment_chunk_wait(c)[0] for c in range(4)] == [w["X0"].shape[0] * c // 4 for c in range(4)]
+            h.contour_step_end()
+            assert np.array_equal(h.get_block(2), qs[0])
         lam, res, ins = h.rr_step()
         if with_comm:
             h.comm_destroy()
@@ -1648,6 +1655,24 @@ def test_adjoint_fold_in_the_other_callers(gpu, pkg, fo, wl):
             est.append(pkg.contour_estimate_eig(Ah, con, w["B"], X=Xs))
     ref = fo.contour_estimate_eig(Ah.astype(np.complex128), fo.circular_contour_trapezoidal(w["c"], w["r"], 16), w["B"].astype(np.complex128), X=Xs)
     assert abs(est[0] - est[1]) < 1e-9 * max(1.0, abs(ref)) and abs(est[0] - ref) < 1e-9 * max(1.0, abs(ref))
+
+
+def test_forward_splitk_knob_excludes_the_adjoint_sweeps(gpu, pkg, wl):
+    """FEASTHIP_FWD_SPLITK=1 (documented switch, off by default) has no adjoint form: a Hermitian pencil then takes one factorisation per
+    node (no adjoint fold) and dual_gen_feast the doubled layout, with the same results (round-4 ADVICE: it used to fail with ESTATE)."""
+    w = wl.c3_sparse_generalized(12, 19, 64)
+    w["A"] = wl.hermitian_phases(w["A"], seed=12)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16)
+    q1, s1 = _moment(pkg, w, con, True)
+    with env_override(FEASTHIP_FWD_SPLITK="1"):
+        q0, s0 = _moment(pkg, w, con, True)
+        assert s0["folded"] == 0 and s0["factor_units"] == 16 and s1["folded"] == 2
+        assert np.abs(q1 - q0).max() <= 1e-12 * np.abs(q0).max()
+        w2 = wl.c2_dense_generalized(256, 32, n_inside=12)
+        info = {}
+        lam, _, _, res = pkg.dual_gen_feast(wl.rand_x0(256, 32, 8001), wl.rand_x0(256, 32, 8002), w2["A"], w2["B"], nodes=16, iter=20,
+                                            c=w2["c"], r=w2["r"], eps=1e-11, store=True, info=info)
+        assert info["factor_units"] == 32 and len(lam) == 12 and res.max() < 1e-11
 
 
 def test_conjugate_fold_only_where_it_is_exact(gpu, pkg, wl):

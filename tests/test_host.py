@@ -269,3 +269,17 @@ def test_matrixmarket_io_matches_scipy(pkg, wl, tmp_path):
         assert back.shape == mat.shape and abs(back - sp.csc_matrix(mat, dtype=np.complex128)).max() < 1e-15
     with pytest.raises(ValueError):
         pkg.mmread(str(tmp_path / "missing.mtx"))
+
+
+def test_missing_rccl_library_is_a_status_not_a_crash(pkg):
+    """feasthip_comm_unique_id on a host whose RCCL cannot be loaded returns FEASTHIP_ECOMM (-8, include/feasthip.h:43) with a message (the round-4 code called
+    dlerror() twice and ran strlen(NULL)).  Child process: the library caches the outcome of its first lookup."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; p = g.load_package()\n"
+            "try:\n    p.comm_unique_id(); print('NOERROR')\n"
+            "except p.FeastHipError as e:\n    print('CODE', e.code, str(e))\n") % ROOT
+    env = dict(os.environ, FEASTHIP_RCCL_LIB="libdoes_not_exist_feasthip.so.9")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "CODE -8" in out.stdout and "RCCL not found" in out.stdout, out.stdout

@@ -3,7 +3,7 @@ with the 8 / 4 / 2 / 1 factorisation units a rank holds at N = 1 / 2 / 4 / 8 (C3
 units are node pairs, 128 columns wide) and without it (single nodes, 64 columns: twice the factorisations, faster sweeps at few units).
 NOTE on the Rayleigh-Ritz column: a shard's moment is a PARTIAL sum here (no other ranks to add theirs), so the subspace of this emulation
 does not converge and the device eigensolver runs cold (5 Jacobi sweeps, 0.5 ms) at N > 1; with the all-reduce every rank sees the N = 1
-moment and the N = 1 time (tools/r04/rr_after_idle.py)."""
+moment and the N = 1 time."""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

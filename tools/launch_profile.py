@@ -24,7 +24,7 @@ print("other launches", len(cl), "ms", cl[:, 1].sum())
 print("all launches sorted by time (top 40):")
 for i in np.argsort(-d[:, 1])[:40]: print(f"  class {int(d[i,0])} {d[i,1]*1e3:8.1f} us tiles {int(d[i,4])}")
 print("launches < 50us:", len(small), "total ms", small[:, 1].sum(), "GF", small[:, 3].sum() / 1e9)
-print("launch sequence (class ms tiles GB GB/s TF/s):")
+print("launch sequence (class us tiles GB TB/s TF/s):")
 for i in range(len(d)):
     c, ms, by, fl, ti, dep = d[i]
-    print(f"  {i:3d} d{int(dep):2d} c{int(c)} {ms*1e3:8.1f}us tiles {int(ti):6d}  {by/1e9:7.3f} GB {by/ms/1e9 if ms>0 else 0:7.1f} GB/s {fl/ms/1e9 if ms>0 else 0:6.1f} TF")
+    print(f"  {i:3d} d{int(dep):2d} c{int(c)} {ms*1e3:8.1f}us tiles {int(ti):6d}  {by/1e9:7.3f} GB {by/ms/1e9 if ms>0 else 0:7.2f} TB/s {fl/ms/1e9 if ms>0 else 0:6.1f} TF")
