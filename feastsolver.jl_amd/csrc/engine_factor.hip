@@ -93,6 +93,7 @@ int Engine::factorize() {
             launch_scatter(stream_, d_fact_.p, fs, terms_[t].d_dest.p, terms_[t].d_cscval.p, terms_[t].colptr[n], d_coef_.p, nterms, t, Kloc);
     }
     bool fin_used = false;
+    const bool skip_conversion = getenv("FEASTHIP_PROBE_SKIP_CONVERSION") != nullptr;
     // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
     const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
     std::vector<hipEvent_t> tev;
@@ -236,6 +237,12 @@ int Engine::factorize() {
         // level's own panels, which nothing above reads (parents take the contribution blocks): it runs on a side stream
         // next to the factorisation of the levels above.  It must follow the Schur-complement product, which reads L21 / U12.
         hipStream_t fin = (finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_) ? fin_stream_ : stream_;
+        if (skip_conversion) {      // timing probe: how much of the solve-ready conversion a factorisation exposes (the factors are left unusable)
+            if (!fuse)
+                launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
+                                  std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
+            continue;
+        }
         if (fin != stream_) { HIPCHK(hipEventRecord(ev_fin_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fin_fork_, 0)); fin_used = true; }
         launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
         if (nopiv) launch_couple32(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);      // the 32 x 32 inverses are in place already
@@ -330,7 +337,7 @@ int Engine::factorize() {
         }
     }
     factor_ms = ms;
-    factored_ = true;
+    factored_ = !skip_conversion;
     return perturbed > 0 ? (int)std::min<int64_t>(perturbed, 0x7fffffff) : 0;
 }
 

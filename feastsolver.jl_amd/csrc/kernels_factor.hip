@@ -9,6 +9,14 @@
 
 namespace feasthip {
 
+// Development aid (tools/diag_phases.py): wall-clock stamps (100 MHz) of workgroup (0, 0) of the group kernels at their phase boundaries,
+// taken only while g_prof_on is set through feasthip_debug_prof -- one scalar load per stamp otherwise.
+__device__ unsigned long long g_prof[64];
+__device__ int g_prof_on;
+__device__ __forceinline__ void prof_stamp(int slot) {
+    if (g_prof_on && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_prof[slot] = wall_clock64();
+}
+
 __device__ inline int lower_bound_dev(const int* a, int n, int v) {
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
@@ -722,32 +730,42 @@ struct LuShared {
     cz col[2][FACT_NB], row[2][FACT_NB], erow[2][FACT_NB], pinv[2], dinv[FACT_NB];
 };
 
+template <int NQ = 16>      // NQ = threads / 32: thread (i, q) keeps the columns q, q + NQ, .. of row i (2 entries with 512 threads, 4 with 256)
 __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, const int b, const double tiny_k, LuShared& sh, cz* __restrict__ Wc,
-                                           cz* __restrict__ dout, double& lmax, double& dmax, int& npert) {
-    const int i = threadIdx.x & 31, q = threadIdx.x >> 5, c0 = q, c1 = q + 16;
+                                           cz* __restrict__ dout, double& lmax, double& dmax, int& npert, cz* Wlds = nullptr, cz* dlds = nullptr) {
+    constexpr int NC = FACT_NB / NQ;
+    const int i = threadIdx.x & 31, q = threadIdx.x >> 5;
     const bool rok = i < b;
-    cz a0 = (rok && c0 < b) ? D[i + (int64_t)c0 * ld] : cz_make(i == c0 ? 1.0 : 0.0, 0.0);
-    cz a1 = (rok && c1 < b) ? D[i + (int64_t)c1 * ld] : cz_make(i == c1 ? 1.0 : 0.0, 0.0);
-    cz e0 = cz_make(i == c0 ? 1.0 : 0.0, 0.0), e1 = cz_make(i == c1 ? 1.0 : 0.0, 0.0);
+    cz a[NC], e[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int cm = q + NQ * m;
+        a[m] = (rok && cm < b) ? D[i + (int64_t)cm * ld] : cz_make(i == cm ? 1.0 : 0.0, 0.0);
+        e[m] = cz_make(i == cm ? 1.0 : 0.0, 0.0);
+    }
     auto publish = [&](int jn, int nbuf) {       // what step jn reads: column jn, row jn of both matrices, the pivot's reciprocal
-        if (c0 == jn) sh.col[nbuf][i] = a0;
-        if (c1 == jn) sh.col[nbuf][i] = a1;
+        const bool mine = (jn % NQ) == q;          // this thread holds column jn (in slot jn / NQ)
+#pragma unroll
+        for (int m = 0; m < NC; ++m) if (mine && jn / NQ == m) sh.col[nbuf][i] = a[m];
         if (i == jn) {
-            if (c0 == jn || c1 == jn) {
-                cz pv = (c0 == jn) ? a0 : a1;
+            if (mine) {
+                cz pv = a[0];
+#pragma unroll
+                for (int m = 1; m < NC; ++m) if (jn / NQ == m) pv = a[m];
                 const double pa = fabs(pv.x) + fabs(pv.y);
                 if (jn < b) dmax = fmax(dmax, pa);
                 if (!(pa >= tiny_k)) {            // static pivot perturbation (also catches NaN), as in k_panel_reg
                     pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
-                    if (c0 == jn) a0 = pv; else a1 = pv;
+#pragma unroll
+                    for (int m = 0; m < NC; ++m) if (jn / NQ == m) a[m] = pv;
                     if (jn < b) ++npert;
                 }
                 const cz pin = cz_inv_pivot(pv);
                 sh.pinv[nbuf] = pin;
                 sh.dinv[jn] = pin;
             }
-            sh.row[nbuf][c0] = a0; sh.row[nbuf][c1] = a1;
-            sh.erow[nbuf][c0] = e0; sh.erow[nbuf][c1] = e1;
+#pragma unroll
+            for (int m = 0; m < NC; ++m) { sh.row[nbuf][q + NQ * m] = a[m]; sh.erow[nbuf][q + NQ * m] = e[m]; }
         }
     };
     publish(0, 0);
@@ -757,26 +775,30 @@ __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, con
         const int buf = j & 1;
         if (i > j) {
             const cz l = cz_mul(sh.col[buf][i], sh.pinv[buf]);
-            if (c0 > j) cz_msub(a0, l, sh.row[buf][c0]); else { cz_msub(e0, l, sh.erow[buf][c0]); if (c0 == j) { a0 = l; lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } }
-            if (c1 > j) cz_msub(a1, l, sh.row[buf][c1]); else { cz_msub(e1, l, sh.erow[buf][c1]); if (c1 == j) { a1 = l; lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } }
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                const int cm = q + NQ * m;
+                if (cm > j) cz_msub(a[m], l, sh.row[buf][cm]);
+                else { cz_msub(e[m], l, sh.erow[buf][cm]); if (cm == j) { a[m] = l; lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } }
+            }
         }
         if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
         __syncthreads();
     }
     // thread (i, c) holds inv(L)[i][c] = inv(U)[c][i] d_i; a diagonal thread holds the pivot d_i, a thread with c > i the entry U[i][c]
-    if (rok && c0 > i && c0 < b) dmax = fmax(dmax, fabs(a0.x) + fabs(a0.y));
-    if (rok && c1 > i && c1 < b) dmax = fmax(dmax, fabs(a1.x) + fabs(a1.y));
     const cz dinv = sh.dinv[i];
-    const cz w0 = cz_mul(e0, dinv), w1 = cz_mul(e1, dinv);
-    Wc[c0 * 32 + i] = w0;
-    Wc[c1 * 32 + i] = w1;
-    if (c0 == i) dout[i] = a0;
-    if (c1 == i) dout[i] = a1;
-    if (rok) {
-        if (c0 < i) D[i + (int64_t)c0 * ld] = e0;              // inv(L)[i][c0]           (c0 < i < b)
-        if (c0 <= i) D[c0 + (int64_t)i * ld] = w0;             // inv(U)[c0][i]
-        if (c1 < i) D[i + (int64_t)c1 * ld] = e1;
-        if (c1 <= i) D[c1 + (int64_t)i * ld] = w1;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int cm = q + NQ * m;
+        if (rok && cm > i && cm < b) dmax = fmax(dmax, fabs(a[m].x) + fabs(a[m].y));
+        const cz w = cz_mul(e[m], dinv);
+        Wc[cm * 32 + i] = w;
+        if (Wlds) Wlds[cm * 32 + i] = w;          // (k_diag_grp2 keeps W_c and the pivots in LDS for the blocks to come)
+        if (cm == i) { dout[i] = a[m]; if (dlds) dlds[i] = a[m]; }
+        if (rok) {
+            if (cm < i) D[i + (int64_t)cm * ld] = e[m];            // inv(L)[i][cm]           (cm < i < b)
+            if (cm <= i) D[cm + (int64_t)i * ld] = w;              // inv(U)[cm][i]
+        }
     }
 }
 
@@ -803,6 +825,7 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
     const double tiny_k = tiny[k];
     double lmax = 0.0, dmax = 0.0;
     int npert = 0;
+    prof_stamp(0);
     for (int c = 0; c < nb; ++c) {
         const int b = min(FACT_NB, gw - FACT_NB * c);
         if (c > 0) {
@@ -813,12 +836,196 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
                 lmax = fmax(lmax, g2.l); dmax = fmax(dmax, g2.u);
             }
             __syncthreads();
+            prof_stamp(1 + 4 * c + 1);
             if (wave < 2) grp_substitute_call(Lp, F12, ld, p, k0, gw, c, true, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt);
             __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
         }
+        prof_stamp(1 + 4 * c + 2);
         lu32_block(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
         if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
         __syncthreads();                       // W_c, L\U of block c: visible to the next block's substitution
+        prof_stamp(1 + 4 * c + 3);
+    }
+    if (npert > 0) atomicAdd(nperturb + k, npert);
+    growth_max(growth + gridDim.y + k, dmax);
+    growth_max(growth + k, lmax);
+}
+
+// A wave-uniform value the compiler may not look through: address arithmetic that uses it stays behind this point instead of being hoisted to
+// the kernel entry (the unrolled block rows of k_diag_grp2 have some 200 distinct 64-bit addresses: hoisted, they alone spill)
+__device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
+
+// 3M product chain of the staged kernels: acc(16 x 32 of the wave's rows) += Z-or-Y (registers, k-step s = 4 tp + sidx) x A^T with the
+// A operand A[kk][16 tl + li] read from LDS one k-step ahead of its matrix-core instructions; the scheduling barrier keeps the compiler
+// from hoisting every LDS read of the unrolled chain to its top (hundreds of live registers, spilled)
+template <int NS>
+__device__ __forceinline__ void lds_chain(const cz* __restrict__ A, const cz (*zsrc)[4], int li, int lk, d4 (&t1)[2], d4 (&t2)[2], d4 (&t3)[2]) {
+    cz an[2], ac[2];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) ac[tl] = A[lk * 32 + 16 * tl + li];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+        if (s2 + 1 < NS) {
+            const int kn = 16 * ((s2 + 1) >> 2) + lk + 4 * ((s2 + 1) & 3);
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) an[tl] = A[kn * 32 + 16 * tl + li];
+        }
+        const cz zb = zsrc[s2 >> 2][s2 & 3];
+        const double zs = zb.x + zb.y;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            t1[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[tl].x, zb.x, t1[tl], 0, 0, 0);
+            t2[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[tl].y, zb.y, t2[tl], 0, 0, 0);
+            t3[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[tl].x + ac[tl].y, zs, t3[tl], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) ac[tl] = an[tl];
+    }
+}
+
+// k_diag_grp with everything the blocks share kept in LDS (round 5): the L rows of the finished blocks ([kk][jj] per block row, 96 KB
+// for a full group), W_0 .. W_2 (48 KB) and the pivots.  k_diag_grp's substitutions read those from global memory inside their
+// matrix-core chains and its update pass re-reads the L entries it has just written -- a dozen dependent round trips per 32-column
+// block, 190-270 us per group on the big fronts with the trailing product of the other stream next to it.  Here a block row costs
+// one round trip for its own A entries; Z = L D stays in the registers of the wave from the substitution to the update.  Same
+// products in the same order as k_diag_grp: bit-identical factors.
+constexpr int DG2_LROW_OFF[4] = {0, 0, 32 * 32, 32 * 32 + 64 * 32};       // element offsets of the block rows 1, 2, 3 ([kk][32] each, kk < 32 r)
+constexpr int DG2_L_ELEMS = (32 + 64 + 96) * 32, DG2_W_ELEMS = 3 * 1024;
+constexpr size_t DG2_LDS_BYTES = (size_t)(DG2_L_ELEMS + DG2_W_ELEMS + GRP_W) * sizeof(cz) + sizeof(LuShared);
+
+constexpr int DIAG2_NT = 256;      // four waves: the two that work on a block row have 512 registers each
+__global__ __launch_bounds__(DIAG2_NT) void k_diag_grp2(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
+                                                       cz* fact, int64_t fs, int* piv, int npiv, const double* __restrict__ tiny, int* nperturb,
+                                                       unsigned long long* growth, cz* wscr, int64_t wstride) {
+    extern __shared__ cz dg2_lds[];
+    cz* Lrows = dg2_lds;
+    cz* Wb = dg2_lds + DG2_L_ELEMS;
+    cz* Dsh = Wb + DG2_W_ELEMS;
+    LuShared& sh = *reinterpret_cast<LuShared*>(Dsh + GRP_W);
+    __builtin_amdgcn_s_setprio(3);
+    const FrontD f = fr[list[blockIdx.x]];
+    const int k = blockIdx.y;
+    const int p = f.p, ld = f.p + f.u;
+    const int gw = min(GRP_W, p - k0), nb = (gw + FACT_NB - 1) / FACT_NB;
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const double tiny_k = tiny[k];
+    double lmax = 0.0, dmax = 0.0;
+    int npert = 0;
+    auto block_row = [&](auto cc_) {
+        constexpr int c = decltype(cc_)::value;
+        // rows 16 wave .. 16 wave + 15 of block c (waves 0 and 1): L entries of the blocks before it, then -- after a barrier: the
+        // operand are the L entries of all 32 rows -- the Schur update of block (c, c).  The other waves only keep the barriers.
+        const int b = min(FACT_NB, gw - FACT_NB * c);
+        const int rloc = 16 * wave + li;                          // row within the block
+        const bool work = wave < 2, rok = work && rloc < b;
+        const int row = k0 + FACT_NB * c + min(rloc, b - 1);
+        cz* Lc = Lrows + DG2_LROW_OFF[c];
+        cz z[2 * c][4];
+        cz yd[2][4];                                              // the rows' entries of block (c, c)
+        auto load_cols = [&](int cc, cz (&out)[2][4], int ldl) {          // the rows' entries of column block cc (zero beyond the rows / columns of a ragged group)
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int col = 32 * cc + 16 * tl + lk + 4 * sidx;
+                    const cz v = Lp[row + (int64_t)(k0 + min(col, gw - 1)) * ldl];
+                    const bool keep = rok && col < gw;
+                    out[tl][sidx] = cz_make(keep ? v.x : 0.0, keep ? v.y : 0.0);
+                }
+        };
+        if (work) {
+            cz ycur[2][4];
+            load_cols(0, ycur, opaque_uniform(ld));
+            auto substage = [&](auto cc_) {
+                constexpr int cc = decltype(cc_)::value;
+                const int ldl = opaque_uniform(ld);
+                cz* ucol = Lp + k0 + (int64_t)row * ldl;         // (rows of the diagonal block are pivot rows: row < p)
+                cz ynext[2][4];
+                load_cols(cc + 1, ynext, ldl);                          // (column block c itself after the last one: the entries the update works on)
+                if constexpr (cc > 0) {
+                    d4 t1[2], t2[2], t3[2];
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) { t1[tl] = (d4){0, 0, 0, 0}; t2[tl] = (d4){0, 0, 0, 0}; t3[tl] = (d4){0, 0, 0, 0}; }
+                    const cz* Lcc = Lrows + DG2_LROW_OFF[cc];
+                    lds_chain<8 * cc>(Lcc, z, li, lk, t1, t2, t3);
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx) {
+                            ycur[tl][sidx].x -= t1[tl][sidx] - t2[tl][sidx];
+                            ycur[tl][sidx].y -= t3[tl][sidx] - t1[tl][sidx] - t2[tl][sidx];
+                        }
+                }
+                d4 u1[2], u2[2], u3[2];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) { u1[tl] = (d4){0, 0, 0, 0}; u2[tl] = (d4){0, 0, 0, 0}; u3[tl] = (d4){0, 0, 0, 0}; }
+                const cz* Wc = Wb + cc * 1024;
+                lds_chain<8>(Wc, ycur, li, lk, u1, u2, u3);
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        const int col = 32 * cc + 16 * tl + lk + 4 * sidx;        // (< 32 c <= gw)
+                        const cz x = cz_make(u1[tl][sidx] - u2[tl][sidx], u3[tl][sidx] - u1[tl][sidx] - u2[tl][sidx]);
+                        const cz zz = cz_mul(x, Dsh[col]);
+                        z[2 * cc + tl][sidx] = zz;
+                        Lc[col * 32 + 16 * wave + li] = x;                         // (zero for the rows beyond a ragged last block)
+                        if (rok) {
+                            Lp[row + (int64_t)(k0 + col) * ldl] = x;
+                            ucol[col] = zz;                                        // U[k0 + col][row] = d_col l_(row, col)
+                            lmax = fmax(lmax, fabs(x.x) + fabs(x.y));
+                            dmax = fmax(dmax, fabs(zz.x) + fabs(zz.y));
+                        }
+                    }
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) ycur[tl][sidx] = ynext[tl][sidx];
+            };
+            substage(std::integral_constant<int, 0>{});
+            if constexpr (c > 1) substage(std::integral_constant<int, 1>{});
+            if constexpr (c > 2) substage(std::integral_constant<int, 2>{});
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) yd[tl][sidx] = ycur[tl][sidx];
+        }
+        __syncthreads();
+        prof_stamp(1 + 4 * c + 1);
+        if (work) {
+            d4 t1[2], t2[2], t3[2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) { t1[tl] = (d4){0, 0, 0, 0}; t2[tl] = (d4){0, 0, 0, 0}; t3[tl] = (d4){0, 0, 0, 0}; }
+            lds_chain<8 * c>(Lc, z, li, lk, t1, t2, t3);
+            const int ldl = opaque_uniform(ld);
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int col = 32 * c + 16 * tl + lk + 4 * sidx;
+                    const cz v = cz_make(yd[tl][sidx].x - (t1[tl][sidx] - t2[tl][sidx]), yd[tl][sidx].y - (t3[tl][sidx] - t1[tl][sidx] - t2[tl][sidx]));
+                    if (rok && col < gw) Lp[row + (int64_t)(k0 + col) * ldl] = v;
+                }
+        }
+        __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
+    };
+    prof_stamp(0);
+    for (int c = 0; c < nb; ++c) {
+        const int b = min(FACT_NB, gw - FACT_NB * c);
+        if (c == 1) block_row(std::integral_constant<int, 1>{});
+        else if (c == 2) block_row(std::integral_constant<int, 2>{});
+        else if (c == 3) block_row(std::integral_constant<int, 3>{});
+        prof_stamp(1 + 4 * c + 2);
+        const int ldl = opaque_uniform(ld);
+        lu32_block<DIAG2_NT / 32>(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ldl, ldl, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax,
+                                  npert, c < 3 ? Wb + c * 1024 : nullptr, Dsh + FACT_NB * c);
+        if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
+        __syncthreads();                   // W_c, the pivots and L\U of block c: visible to the next block row
+        prof_stamp(1 + 4 * c + 3);
     }
     if (npert > 0) atomicAdd(nperturb + k, npert);
     growth_max(growth + gridDim.y + k, dmax);
@@ -844,16 +1051,165 @@ __global__ __launch_bounds__(256) void k_lscale_grp(const FrontD* __restrict__ f
     growth_max(growth + 2 * gridDim.y + k, lm.u);      // U = D L^T entries as written: what the backward error of the elimination scales with
 }
 
+// The same substitution with its shared operands staged in LDS (round 5).  k_lscale_grp reads the group's L11 entries and the W
+// blocks straight from global memory inside its MFMA chain: a dozen dependent round trips per wave, each of which costs several
+// microseconds next to the trailing product of the other stream -- 170-380 us per launch on the big fronts of C3 for 13 us of
+// matrix-core work per wave.  Here a workgroup (4 waves x 16 rows) stages, per 32-column block c, the block row c of L11 (32 x 32 c)
+// and W_c once, with all of the stage's global loads (those and the waves' own A rows) issued together before the barrier: ONE
+// round trip per block.  Same products in the same order as grp_substitute: bit-identical L and U.
+constexpr int LS2_LROWS = GRP_W - FACT_NB;       // k extent of the largest staged L11 block row (96)
+__global__ __launch_bounds__(256, 2) void k_lscale_grp2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles, int k0,
+                                                        cz* fact, int64_t fs, unsigned long long* growth, const cz* __restrict__ wscr, int64_t wstride) {
+    __shared__ cz Ls[LS2_LROWS * FACT_NB];       // [kk][jj]: L11[32 c + jj][kk], kk < 32 c
+    __shared__ cz Ws[FACT_NB * FACT_NB];         // [kk][j]:  W_c
+    __shared__ cz Ds[GRP_W];                     // pivots d_col (zero beyond gw)
+    const Tile t = tiles[blockIdx.x];
+    const int k = blockIdx.y;
+    const FrontD f = fr[t.f];
+    const int p = f.p, ld = p + f.u;
+    const int gw = min(GRP_W, p - k0), nb = (gw + FACT_NB - 1) / FACT_NB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int rbase = k0 + gw + t.a * 64 + 16 * wave, rend = ld;
+    __builtin_amdgcn_s_setprio(2);
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* F12 = fact + (int64_t)k * fs + f.f12;
+    const cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
+    const cz* D0 = Lp + k0 + (int64_t)k0 * ld;
+    const int row = rbase + li;
+    const bool rok = row < rend;                 // (a wave without rows still takes part in the barriers)
+    const int row_c = max(k0, min(row, rend - 1));
+    cz* ucol = (row_c < p) ? Lp + k0 + (int64_t)row_c * ld : F12 + k0 + (int64_t)(row_c - p) * p;
+    if (tid < GRP_W) Ds[tid] = tid < gw ? Wt[4096 + tid] : cz_make(0, 0);
+    cz z[6][4];
+    double lmax = 0.0, umax = 0.0;
+    auto stage = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        // every global load of the stage: the wave's A rows of block c, W_c, the block row c of L11
+        cz y[2][4], wpre[4], lpre[c > 0 ? 4 * c : 1];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int col = 32 * c + 16 * tl + lk + 4 * sidx;
+                y[tl][sidx] = Lp[row_c + (int64_t)(k0 + min(col, gw - 1)) * ld];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wpre[q] = Wt[c * 1024 + tid + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 4 * c; ++q) {
+            const int idx = tid + 256 * q, kk = idx >> 5, jj = idx & 31;
+            lpre[q] = D0[min(32 * c + jj, gw - 1) + (int64_t)kk * ld];
+        }
+        __syncthreads();                          // the previous stage's reads of Ls / Ws are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Ws[tid + 256 * q] = wpre[q];
+#pragma unroll
+        for (int q = 0; q < 4 * c; ++q) {
+            const int idx = tid + 256 * q, jj = idx & 31;
+            Ls[idx] = (32 * c + jj < gw) ? lpre[q] : cz_make(0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int col = 32 * c + 16 * tl + lk + 4 * sidx;
+                const bool keep = rok && col < gw;
+                y[tl][sidx].x = keep ? y[tl][sidx].x : 0.0; y[tl][sidx].y = keep ? y[tl][sidx].y : 0.0;
+            }
+        if constexpr (c > 0) {
+            d4 t1[2], t2[2], t3[2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) { t1[tl] = (d4){0, 0, 0, 0}; t2[tl] = (d4){0, 0, 0, 0}; t3[tl] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+            for (int tp = 0; tp < 2 * c; ++tp)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int kk = 16 * tp + lk + 4 * sidx;
+                    const cz zb = z[tp][sidx];
+                    const double zs = zb.x + zb.y;
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        const cz a = Ls[kk * 32 + 16 * tl + li];
+                        t1[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, zb.x, t1[tl], 0, 0, 0);
+                        t2[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, zb.y, t2[tl], 0, 0, 0);
+                        t3[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, zs, t3[tl], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    y[tl][sidx].x -= t1[tl][sidx] - t2[tl][sidx];
+                    y[tl][sidx].y -= t3[tl][sidx] - t1[tl][sidx] - t2[tl][sidx];
+                }
+        }
+        d4 u1[2], u2[2], u3[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) { u1[tl] = (d4){0, 0, 0, 0}; u2[tl] = (d4){0, 0, 0, 0}; u3[tl] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int kk = 16 * ts + lk + 4 * sidx;
+                const cz yb = y[ts][sidx];
+                const double ys = yb.x + yb.y;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const cz a = Ws[kk * 32 + 16 * tl + li];
+                    u1[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, yb.x, u1[tl], 0, 0, 0);
+                    u2[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, yb.y, u2[tl], 0, 0, 0);
+                    u3[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, ys, u3[tl], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int col = 32 * c + 16 * tl + lk + 4 * sidx;
+                const bool cok = col < gw;
+                const cz x = cz_make(u1[tl][sidx] - u2[tl][sidx], u3[tl][sidx] - u1[tl][sidx] - u2[tl][sidx]);
+                const cz zz = cz_mul(x, Ds[col]);
+                if constexpr (c < 3) z[2 * c + tl][sidx] = zz;
+                if (rok && cok) {
+                    Lp[row + (int64_t)(k0 + col) * ld] = x;
+                    ucol[col] = zz;                       // U[k0 + col][row] = d_col l_(row, col)
+                    lmax = fmax(lmax, fabs(x.x) + fabs(x.y));
+                    umax = fmax(umax, fabs(zz.x) + fabs(zz.y));
+                }
+            }
+    };
+    stage(std::integral_constant<int, 0>{});
+    if (nb > 1) stage(std::integral_constant<int, 1>{});
+    if (nb > 2) stage(std::integral_constant<int, 2>{});
+    if (nb > 3) stage(std::integral_constant<int, 3>{});
+    growth_max(growth + k, lmax);
+    growth_max(growth + 2 * gridDim.y + k, umax);
+}
+
 void launch_diag_grp(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
                      const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K) {
     if (nlist <= 0) return;
+    // FEASTHIP_DIAG2=1: the LDS-resident variant.  Its substitutions and updates take 33 us per group instead of 57 (and do not slow down
+    // next to the other stream's product), but its 256-thread elimination of the 32 x 32 blocks takes 53 us per block against 20 with 512
+    // threads (tools/diag_phases.py), and with 512 threads the two working waves spill: off until the block elimination is rewritten.
+    const char* e2 = getenv("FEASTHIP_DIAG2");                 // read per launch (tests switch it)
+    if (e2 && atoi(e2) == 1) {
+        static std::atomic<uint64_t> attr_seen{0};
+        if (first_on_this_device(attr_seen)) (void)hipFuncSetAttribute((const void*)k_diag_grp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DG2_LDS_BYTES);
+        hipLaunchKernelGGL(k_diag_grp2, dim3(nlist, K), dim3(DIAG2_NT), DG2_LDS_BYTES, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
+        return;
+    }
     hipLaunchKernelGGL(k_diag_grp, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
 }
 
 void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                        unsigned long long* growth, const cz* wscr, int64_t wstride, int K) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_lscale_grp, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth, wscr, wstride);
+    const char* e2 = getenv("FEASTHIP_LSCALE2");               // 0: the round-3 kernel (operands from global memory); read per launch (tests switch it)
+    const bool staged = !(e2 && atoi(e2) == 0);
+    if (staged) hipLaunchKernelGGL(k_lscale_grp2, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth, wscr, wstride);
+    else hipLaunchKernelGGL(k_lscale_grp, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, k0, fact, fs, growth, wscr, wstride);
 }
 
 // ---------------------------------------------------------------------------
@@ -1917,3 +2273,10 @@ void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist,
 }
 
 }  // namespace feasthip
+
+// not part of include/feasthip.h: development hook (see g_prof above).  on >= 0 sets the switch; out (64 values) receives the stamps.
+extern "C" int feasthip_debug_prof(int on, unsigned long long* out) {
+    if (on >= 0 && hipMemcpyToSymbol(HIP_SYMBOL(feasthip::g_prof_on), &on, sizeof(int)) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(feasthip::g_prof), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return 0;
+}

@@ -91,6 +91,42 @@ def test_seam_dense_symmetric_lu_ldiv(gpu, pkg, n, m0):
     assert np.linalg.norm(Cm @ Y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(Y)
 
 
+@pytest.mark.parametrize("n", [33, 100, 129, 300, 700, 1537])
+def test_staged_group_kernels_match_the_round3_kernels(gpu, pkg, wl, n):
+    """Round 5: the kernels of the elimination without interchanges keep what a 128-column group shares -- the finished L11 block rows, the
+    W blocks, the pivots -- in LDS (k_lscale_grp2, default; k_diag_grp2, FEASTHIP_DIAG2=1) instead of reading it from global memory inside
+    their matrix-core chains (k_lscale_grp: FEASTHIP_LSCALE2=0; k_diag_grp).  Same products in the same order -- the solutions agree to a
+    few ulp of the factors (the compiler contracts the scalar epilogues of the two kernels differently: 0 .. 4e-14 relative on these
+    sizes) -- on dense symmetric fronts with ragged last groups and blocks, and on a sparse pencil."""
+    rng = np.random.default_rng(n)
+    S = rng.standard_normal((n, n)); S = S + S.T
+    G = rng.standard_normal((n, n)); Pd = G @ G.T / n + 0.5 * np.eye(n)
+    Cm = (S + 1j * Pd).astype(np.complex128)
+    R = np.asfortranarray(rng.standard_normal((n, 9)) + 1j * rng.standard_normal((n, 9)))
+    modes = [("0", "1"), ("0", "0"), ("1", "0"), ("1", "1")]
+    sols = []
+    for diag2, lscale2 in modes:
+        with env_override(FEASTHIP_DIAG2=diag2, FEASTHIP_LSCALE2=lscale2):
+            F = pkg.lu(Cm)
+            assert F.symmetric == pivot_light_default()
+            Y = np.zeros((n, 9), dtype=np.complex128, order="F")
+            pkg.ldiv(Y, F, R)
+            pkg.finalize(F)
+            sols.append(Y)
+    for y in sols:
+        assert np.abs(y - sols[1]).max() <= 1e-11 * np.abs(sols[1]).max()
+        assert np.linalg.norm(Cm @ y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(y)
+    if n == 300:
+        w = wl.c3_sparse_generalized(16, 19, 32)
+        con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+        qs = []
+        for diag2, lscale2 in modes:
+            with env_override(FEASTHIP_DIAG2=diag2, FEASTHIP_LSCALE2=lscale2):
+                qs.append(_moment(pkg, w, con, True)[0])
+        for q in qs:
+            assert np.abs(q - qs[1]).max() <= 1e-11 * np.abs(qs[1]).max()
+
+
 def test_seam_is_reentrant_across_host_threads(gpu, pkg, wl):
     """The reference calls `factorizer` from Threads.@threads (src/feast.jl:34-37, src/nlfeast.jl:19-26) and
     `left_divider` concurrently in nlfeast! (src/nlfeast.jl:36-55): factor objects created and used from several host
