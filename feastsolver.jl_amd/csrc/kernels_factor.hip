@@ -6,6 +6,7 @@
 #include "kernels.hpp"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace feasthip {
 
@@ -16,6 +17,9 @@ __device__ int g_prof_on;
 __device__ __forceinline__ void prof_stamp(int slot) {
     if (g_prof_on && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_prof[slot] = wall_clock64();
 }
+
+// workgroup barrier that waits for the wave's LDS operations only (__syncthreads() also waits for every global store in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ inline int lower_bound_dev(const int* a, int n, int v) {
     int lo = 0, hi = n;
@@ -523,6 +527,232 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_reg(const FrontD* __restrict
     }
 }
 
+// Round 5: the same panel factorisation with IMPLICIT interchanges.  k_panel_reg's 32 pivot steps cost 3.5 us each whatever the
+// number of rows (111 us for the last, 100-row panels of a dense matrix): two __syncthreads() per step, each of which also waits for
+// the global stores in flight -- the pivot record and the in-memory interchange of the panel's other columns, a dependent load/store
+// pair issued INSIDE the step.  Here no row moves during the panel: a thread keeps its physical rows and, per row, the LOGICAL position
+// the sequence of LAPACK interchanges would have given it by now (the pivot search breaks ties by that position, the pivot record is
+// that position: both exactly as before).  A step touches LDS only -- the pivot row travels through LDS, the barriers wait for LDS
+// alone -- and the rows change places once, at the end: the interchanges are composed into one permutation of at most 2 b rows and
+// every element of the panel that moves is loaded, then stored.  Same arithmetic in the same order as k_panel_reg: same factors.
+
+// RPT rows per thread x SB columns of a sub-panel in registers (RPT SB = 32): a panel of at most 512 rows is factorised entirely in
+// registers (1 x 32), taller ones in 2, 4 or 8 sub-panels whose trailing columns go through memory once per sub-panel
+template <int PANEL_NT, int RPT, int SB>
+__global__ __launch_bounds__(PANEL_NT) void k_panel_imp(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
+                                                         cz* fact, int64_t fs, int* piv, int npiv,
+                                                         const double* __restrict__ tiny, int* nperturb) {
+    constexpr int NW = PANEL_NT / 64;
+    __shared__ double s_val[2][NW];
+    __shared__ int s_lp[2][NW];
+    __shared__ cz s_row[2][SB];         // [parity][sub-panel column]: the pivot row
+    __shared__ cz s_l[SB][SB];
+    __shared__ cz s_u[SB][FACT_NB];
+    __shared__ int s_prow[FACT_NB];            // step -> physical (local) row that became the pivot row
+    __shared__ int s_plp[FACT_NB];             // step -> its logical position then (the LAPACK pivot index, local)
+    __shared__ int s_prow_pos[2 * FACT_NB], s_src[2 * FACT_NB], s_npos;
+    constexpr int MV_COLS = 8;
+    __shared__ cz s_mv[2 * FACT_NB * MV_COLS];      // the elements that change places at the end, eight columns per pass
+    const FrontD f = fr[list[blockIdx.x]];
+    const int k = blockIdx.y;
+    const int p = f.p, ld = f.p + f.u;
+    const int b = min(FACT_NB, p - k0);
+    cz* Lp = fact + (int64_t)k * fs + f.lp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrow = ld - k0, npr = p - k0;       // local row i = r - k0; pivots come from i < npr
+    const double tiny_k = tiny[k];
+    int lpos[RPT];
+    bool done[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) { lpos[q] = tid + PANEL_NT * q; done[q] = false; }
+    for (int sb0 = 0; sb0 < b; sb0 += SB) {
+        const int sbe = min(b, sb0 + SB), sw = sbe - sb0;
+        cz v[RPT][SB];
+        bool mine[RPT];                     // rows whose sub-panel entries this pass owns (not yet pivot rows)
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tid + PANEL_NT * q;
+            mine[q] = !done[q] && i < nrow;
+#pragma unroll
+            for (int c = 0; c < SB; ++c)
+                v[q][c] = (mine[q] && c < sw) ? Lp[(int64_t)(k0 + sb0 + c) * ld + k0 + i] : cz_make(0, 0);
+        }
+#pragma unroll
+        for (int jc = 0; jc < SB; ++jc) {          // (SB <= 8: fully unrolled; wider register panels took the compiler half an hour)
+            if (jc >= sw) break;
+            const int j = sb0 + jc, par = jc & 1;
+            double best = -1.0;
+            int blp = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PANEL_NT * q;
+                const double a = cz_abs1(v[q][jc]);
+                if (!done[q] && i < npr && (a > best || (a == best && lpos[q] < blp))) { best = a; blp = lpos[q]; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int ol = __shfl_xor(blp, off);
+                if (ob > best || (ob == best && ol < blp)) { best = ob; blp = ol; }
+            }
+            if (lane == 0) { s_val[par][wave] = best; s_lp[par][wave] = blp; }
+            lds_barrier();
+            double bb = s_val[par][0];
+            int wl = s_lp[par][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const double ov = s_val[par][w];
+                const int ol = s_lp[par][w];
+                if (ov > bb || (ov == bb && ol < wl)) { bb = ov; wl = ol; }
+            }
+            if (bb < 0) wl = j;                    // no finite candidate: the row in place stays
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const bool was_w = !done[q] && lpos[q] == wl, was_j = !done[q] && lpos[q] == j;
+                if (was_w) {                       // this row is the pivot row of step j
+                    cz pv = v[q][jc];
+                    const double pa = cz_abs1(pv);
+                    if (!(pa >= tiny_k)) {   // static pivot perturbation (also catches NaN)
+                        pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+                        v[q][jc] = pv;
+                        atomicAdd(nperturb + k, 1);
+                    }
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) { s_row[par][c] = v[q][c]; if (c < jc) s_l[jc][c] = v[q][c]; }
+                    s_prow[j] = tid + PANEL_NT * q;
+                    s_plp[j] = wl;
+                    piv[(int64_t)k * npiv + f.c0 + k0 + j] = k0 + wl;
+                    done[q] = true;
+                    lpos[q] = j;
+                } else if (was_j) lpos[q] = wl;     // the row that was in place takes the pivot row's position
+            }
+            lds_barrier();
+            const cz inv = cz_inv(s_row[par][jc]);
+            cz l[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const bool upd = !done[q] && tid + PANEL_NT * q < nrow;
+                l[q] = upd ? cz_mul(v[q][jc], inv) : cz_make(0, 0);      // (pivot rows and rows beyond the front: no update, entries kept)
+                if (upd) v[q][jc] = l[q];
+            }
+#pragma unroll
+            for (int c = jc + 1; c < SB; ++c) {
+                const cz uc = s_row[par][c];           // (one address for the whole wave: a broadcast read)
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) cz_msub(v[q][c], l[q], uc);
+            }
+        }
+        const int nt = b - sbe;                 // trailing panel columns
+        // (a) U rows of the trailing columns: the pivot rows' entries there (last written by the row updates of the previous sub-panel:
+        // long since in memory, the barrier makes it formal), forward substitution with the unit-lower sw x sw block
+        __syncthreads();
+        if (tid < nt) {
+            cz* c2 = Lp + (int64_t)(k0 + sbe + tid) * ld + k0;
+            cz x[SB];
+            int pr[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) pr[i] = s_prow[min(sb0 + i, sbe - 1)];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) x[i] = i < sw ? c2[pr[i]] : cz_make(0, 0);
+#pragma unroll
+            for (int i = 1; i < SB; ++i)
+#pragma unroll
+                for (int q = 0; q < i; ++q) if (i < sw) cz_msub(x[i], s_l[i][q], x[q]);
+#pragma unroll
+            for (int i = 0; i < SB; ++i) if (i < sw) { c2[pr[i]] = x[i]; s_u[i][tid] = x[i]; }
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tid + PANEL_NT * q;
+            if (mine[q]) {
+#pragma unroll
+                for (int c = 0; c < SB; ++c)
+                    if (c < sw) Lp[(int64_t)(k0 + sb0 + c) * ld + k0 + i] = v[q][c];
+            }
+        }
+        if (nt <= 0) break;
+        lds_barrier();
+        // (b) rows that are not pivot rows yet: rank-sw update of the trailing columns with the L values still in registers, the
+        // next column's entries loaded before this one's are stored
+        {
+            bool on[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) on[q] = !done[q] && tid + PANEL_NT * q < nrow;
+            cz* d0 = Lp + (int64_t)(k0 + sbe) * ld + k0 + tid;
+            constexpr bool AHEAD = PANEL_NT <= 512;      // (1024 threads have 128 registers each: no room for the next column's entries)
+            cz t[RPT], tn[AHEAD ? RPT : 1];
+            if (AHEAD) {
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) t[q] = on[q] ? d0[PANEL_NT * q] : cz_make(0, 0);
+            }
+            for (int jj = 0; jj < nt; ++jj) {
+                cz* dj = d0 + (int64_t)jj * ld;
+                if constexpr (AHEAD) {
+                    if (jj + 1 < nt) {
+#pragma unroll
+                        for (int q = 0; q < RPT; ++q) tn[q] = on[q] ? dj[ld + PANEL_NT * q] : cz_make(0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) t[q] = on[q] ? dj[PANEL_NT * q] : cz_make(0, 0);
+                }
+                cz uu[SB];
+#pragma unroll
+                for (int c = 0; c < SB; ++c) uu[c] = s_u[c][jj];
+#pragma unroll
+                for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) if (c < sw) cz_msub(t[q], v[q][c], uu[c]);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q)
+                    if (on[q]) dj[PANEL_NT * q] = t[q];
+                if constexpr (AHEAD) {
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) t[q] = tn[q];
+                }
+            }
+        }
+    }
+    // The rows change places: positions [0, b) are the rows of the diagonal block, then the rows below it that a pivot came from; the b
+    // interchanges (position j <-> the pivot's position) composed by one wave, as in k_swap
+    __syncthreads();
+    if (wave == 0) {
+        for (int q = lane; q < 2 * FACT_NB; q += 64) s_src[q] = q;
+        const int mylp = lane < b ? s_plp[lane] : -1;
+        int low = -1, nlow = 0;                  // lane m: the m-th row below the block that takes part
+        for (int j = 0; j < b; ++j) {
+            const int pr = __builtin_amdgcn_readlane(mylp, j);
+            if (pr == j) continue;
+            int pos;
+            if (pr < b) pos = pr;
+            else {
+                const unsigned long long m = __ballot(low == pr);
+                if (m) pos = b + __builtin_ctzll(m);
+                else { pos = b + nlow; if (lane == nlow) low = pr; ++nlow; }
+            }
+            if (lane == 0) { const int a = s_src[j], c = s_src[pos]; s_src[j] = c; s_src[pos] = a; }
+        }
+        if (lane < b) s_prow_pos[lane] = lane;
+        if (lane < nlow) s_prow_pos[b + lane] = low;
+        if (lane == 0) s_npos = b + nlow;
+    }
+    __syncthreads();
+    {
+        const int npos = s_npos;
+        for (int c0 = 0; c0 < b; c0 += MV_COLS) {
+            for (int idx = tid; idx < npos * MV_COLS; idx += PANEL_NT) {
+                const int pos = idx / MV_COLS, col = c0 + idx % MV_COLS, sp = s_src[pos];
+                if (col < b && sp != pos) s_mv[idx] = Lp[(int64_t)(k0 + col) * ld + k0 + s_prow_pos[sp]];
+            }
+            __syncthreads();                      // every element that moves is loaded before any is stored
+            for (int idx = tid; idx < npos * MV_COLS; idx += PANEL_NT) {
+                const int pos = idx / MV_COLS, col = c0 + idx % MV_COLS;
+                if (col < b && s_src[pos] != pos) Lp[(int64_t)(k0 + col) * ld + k0 + s_prow_pos[pos]] = s_mv[idx];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
                   int* piv, const double* tiny, int* nperturb, int K, bool tall, int max_rows) {
     if (nlist <= 0) return;
@@ -533,6 +763,20 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
     if (!generic && max_rows <= PANEL_RPT * 1024) {
         // few workgroups (every one gets a CU of its own anyway): the widest workgroup has the shortest pivot step
         const int floor_nt = (int64_t)nlist * K <= 256 ? (tall ? (max_rows <= PANEL_RPT * 512 ? 512 : 1024) : 256) : 64;
+        const char* ei = getenv("FEASTHIP_PANEL_IMP");             // 1: implicit interchanges (k_panel_imp), measured no faster: off; read per launch
+        if (ei && atoi(ei) == 1) {
+#define FEASTHIP_PANEL_IMP_CASE(ROWS, NT, R, W) \
+            if (max_rows <= ROWS) { \
+                hipLaunchKernelGGL((k_panel_imp<NT, R, W>), dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
+                return; \
+            }
+            FEASTHIP_PANEL_IMP_CASE(256, 64, 4, 4)
+            FEASTHIP_PANEL_IMP_CASE(512, 128, 4, 4)
+            FEASTHIP_PANEL_IMP_CASE(1024, 256, 4, 4)
+            FEASTHIP_PANEL_IMP_CASE(2048, 512, 4, 8)
+            FEASTHIP_PANEL_IMP_CASE(4096, 1024, 4, 4)
+#undef FEASTHIP_PANEL_IMP_CASE
+        }
 #define FEASTHIP_PANEL_CASE(NT) \
         if (max_rows <= PANEL_RPT * NT && NT >= floor_nt) { \
             hipLaunchKernelGGL(k_panel_reg<NT>, dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
@@ -802,6 +1046,157 @@ __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, con
     }
 }
 
+// Round 5: the same elimination with ONE value per (row, column) slot.  At step j a slot holds the entry of the block for the columns
+// c > j and the entry of inv(L) for c <= j (the multiplier numerator turns into -l at step c: e_ic was zero until then and e_cc = 1), so a
+// thread keeps 2 values instead of 4, the pivot row is published once instead of twice, the update has no branch on the side of the
+// diagonal, and the barriers wait for LDS only.  Same multipliers, pivots and perturbations as lu32_block; the products of the inverse
+// are formed in the same order.
+struct LuShared2 { cz col[2][FACT_NB], row[2][FACT_NB], pinv[2], dinv[FACT_NB]; };
+__device__ __forceinline__ void lu32_block2(cz* __restrict__ D, const int ld, const int b, const double tiny_k, LuShared2& sh, cz* __restrict__ Wc,
+                                            cz* __restrict__ dout, double& lmax, double& dmax, int& npert, cz* Wlds = nullptr, cz* dlds = nullptr) {
+    const int i = threadIdx.x & 31, q = threadIdx.x >> 5, c0 = q, c1 = q + 16;      // 512 threads
+    prof_stamp(40);
+    const bool rok = i < b;
+    cz s0 = (rok && c0 < b) ? D[i + (int64_t)c0 * ld] : cz_make(i == c0 ? 1.0 : 0.0, 0.0);
+    cz s1 = (rok && c1 < b) ? D[i + (int64_t)c1 * ld] : cz_make(i == c1 ? 1.0 : 0.0, 0.0);
+    auto publish = [&](int jn, int nbuf) {
+        if (c0 == jn) sh.col[nbuf][i] = s0;
+        if (c1 == jn) sh.col[nbuf][i] = s1;
+        if (i == jn) {
+            if (c0 == jn || c1 == jn) {
+                cz pv = (c0 == jn) ? s0 : s1;
+                const double pa = fabs(pv.x) + fabs(pv.y);
+                if (jn < b) dmax = fmax(dmax, pa);
+                if (__builtin_expect(!(pa >= tiny_k), 0)) {            // static pivot perturbation (also catches NaN), as in k_panel_reg
+                    pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+                    if (c0 == jn) s0 = pv; else s1 = pv;
+                    if (jn < b) ++npert;
+                }
+                const cz pin = cz_inv_pivot(pv);
+                sh.pinv[nbuf] = pin;
+                sh.dinv[jn] = pin;
+            }
+            sh.row[nbuf][c0] = s0; sh.row[nbuf][c1] = s1;
+        }
+    };
+    publish(0, 0);
+    lds_barrier();
+    prof_stamp(41);
+#pragma unroll 1
+    for (int j = 0; j < FACT_NB; ++j) {
+        const int buf = j & 1;
+        if (i > j) {
+            const cz l = cz_mul(sh.col[buf][i], sh.pinv[buf]);
+            const cz r0 = sh.row[buf][c0], r1 = sh.row[buf][c1];
+            if (c0 == j) { s0 = cz_make(-l.x, -l.y); lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } else cz_msub(s0, l, r0);
+            if (c1 == j) { s1 = cz_make(-l.x, -l.y); lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } else cz_msub(s1, l, r1);
+        }
+        if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
+        lds_barrier();
+    }
+    prof_stamp(42);
+    // slot (i, c): c < i  inv(L)[i][c];  c == i  the pivot d_i;  c > i  U[i][c]
+    const cz dinv = sh.dinv[i];
+    auto finish = [&](int c, cz sv) {
+        if (rok && c > i && c < b) dmax = fmax(dmax, fabs(sv.x) + fabs(sv.y));
+        const cz e = c < i ? sv : cz_make(c == i ? 1.0 : 0.0, 0.0);
+        const cz w = cz_mul(e, dinv);
+        Wc[c * 32 + i] = w;
+        if (Wlds) Wlds[c * 32 + i] = w;
+        if (c == i) { dout[i] = sv; if (dlds) dlds[i] = sv; }
+        if (rok) {
+            if (c < i) D[i + (int64_t)c * ld] = e;              // inv(L)[i][c]           (c < i < b)
+            if (c <= i) D[c + (int64_t)i * ld] = w;             // inv(U)[c][i]
+        }
+    };
+    finish(c0, s0);
+    finish(c1, s1);
+    prof_stamp(43);
+}
+
+// lu32_block2 on 256 threads with four slots each (the other waves of the workgroup only keep the barriers): a step's cost is the issue
+// time of its ~100 instructions per wave -- every wave runs them whatever the number of active lanes --, so one wave per SIMD instead of
+// two takes the step from 0.54 to about 0.3 us
+__device__ __forceinline__ void lu32_block3(cz* __restrict__ D, const int ld, const int b, const double tiny_k, LuShared2& sh, cz* __restrict__ Wc,
+                                            cz* __restrict__ dout, double& lmax, double& dmax, int& npert, cz* Wlds = nullptr, cz* dlds = nullptr) {
+    const bool act = threadIdx.x < 256;
+    const int i = threadIdx.x & 31, q = (threadIdx.x >> 5) & 7;
+    prof_stamp(40);
+    const bool rok = i < b;
+    cz s[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int c = q + 8 * m;
+        s[m] = (act && rok && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);
+    }
+    auto publish = [&](int jn, int nbuf) {
+        const int mj = jn >> 3;                    // slot of column jn in the threads with q == (jn & 7)
+        if (q == (jn & 7)) {
+            cz cv = s[0];
+#pragma unroll
+            for (int m = 1; m < 4; ++m) if (mj == m) cv = s[m];
+            if (i == jn) {
+                const double pa = fabs(cv.x) + fabs(cv.y);
+                if (jn < b) dmax = fmax(dmax, pa);
+                if (__builtin_expect(!(pa >= tiny_k), 0)) {            // static pivot perturbation (also catches NaN), as in k_panel_reg
+                    cv = (pa > 0.0) ? cz_make(cv.x * (tiny_k / pa), cv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) if (mj == m) s[m] = cv;
+                    if (jn < b) ++npert;
+                }
+                const cz pin = cz_inv_pivot(cv);
+                sh.pinv[nbuf] = pin;
+                sh.dinv[jn] = pin;
+            }
+            sh.col[nbuf][i] = cv;
+        }
+        if (i == jn) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sh.row[nbuf][q + 8 * m] = s[m];
+        }
+    };
+    if (act) publish(0, 0);
+    lds_barrier();
+    prof_stamp(41);
+#pragma unroll 1
+    for (int j = 0; j < FACT_NB; ++j) {
+        const int buf = j & 1;
+        if (act) {
+            if (i > j) {
+                const cz l = cz_mul(sh.col[buf][i], sh.pinv[buf]);
+                cz r[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) r[m] = sh.row[buf][q + 8 * m];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (q + 8 * m == j) { s[m] = cz_make(-l.x, -l.y); lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } else cz_msub(s[m], l, r[m]);
+                }
+            }
+            if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
+        }
+        lds_barrier();
+    }
+    prof_stamp(42);
+    if (!act) return;
+    const cz dinv = sh.dinv[i];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int c = q + 8 * m;
+        const cz sv = s[m];
+        if (rok && c > i && c < b) dmax = fmax(dmax, fabs(sv.x) + fabs(sv.y));
+        const cz e = c < i ? sv : cz_make(c == i ? 1.0 : 0.0, 0.0);
+        const cz w = cz_mul(e, dinv);
+        Wc[c * 32 + i] = w;
+        if (Wlds) Wlds[c * 32 + i] = w;
+        if (c == i) { dout[i] = sv; if (dlds) dlds[i] = sv; }
+        if (rok) {
+            if (c < i) D[i + (int64_t)c * ld] = e;              // inv(L)[i][c]           (c < i < b)
+            if (c <= i) D[c + (int64_t)i * ld] = w;             // inv(U)[c][i]
+        }
+    }
+    prof_stamp(43);
+}
+
 // (the substitution's registers and the elimination's are never live together; as a call the two are allocated separately)
 __device__ __attribute__((noinline)) GrowthLU grp_substitute_call(cz* Lp, cz* F12, int ld, int p, int k0, int gw, int ncb, bool upd_only, int rbase, int rend, const cz* Wt) {
     return grp_substitute(Lp, F12, ld, p, k0, gw, ncb, upd_only, rbase, rend, Wt);
@@ -809,10 +1204,12 @@ __device__ __attribute__((noinline)) GrowthLU grp_substitute_call(cz* Lp, cz* F1
 
 constexpr int DIAG_NT = 512;
 
+template <int LUV>
 __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
                                                       cz* fact, int64_t fs, int* piv, int npiv, const double* __restrict__ tiny, int* nperturb,
                                                       unsigned long long* growth, cz* wscr, int64_t wstride) {
     __shared__ LuShared sh;
+    __shared__ LuShared2 sh2;
     __builtin_amdgcn_s_setprio(3);             // the few waves of the dependency chain go first wherever they share a SIMD
     FrontD f = fr[list[blockIdx.x]];
     const int k = blockIdx.y;
@@ -841,7 +1238,9 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
             __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
         }
         prof_stamp(1 + 4 * c + 2);
-        lu32_block(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
+        if constexpr (LUV == 3) lu32_block3(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh2, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
+        else if constexpr (LUV == 2) lu32_block2(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh2, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
+        else lu32_block(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
         if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
         __syncthreads();                       // W_c, L\U of block c: visible to the next block's substitution
         prof_stamp(1 + 4 * c + 3);
@@ -1200,7 +1599,13 @@ void launch_diag_grp(hipStream_t st, const DevSym& S, const int* list, int nlist
         hipLaunchKernelGGL(k_diag_grp2, dim3(nlist, K), dim3(DIAG2_NT), DG2_LDS_BYTES, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
         return;
     }
-    hipLaunchKernelGGL(k_diag_grp, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
+    // FEASTHIP_LU32=1: the round-3 elimination of the 32 x 32 blocks (four values per thread, two published rows); 3: the one-slot form on 256
+    // threads (measured slower in the factorisation: C3 93.5 against 90.5 ms with everything else equal; 2, the default, 91.5 -> 90.5)
+    const char* e3 = getenv("FEASTHIP_LU32");
+    const int luv = e3 ? atoi(e3) : 2;
+    if (luv == 1) hipLaunchKernelGGL(k_diag_grp<1>, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
+    else if (luv == 3) hipLaunchKernelGGL(k_diag_grp<3>, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
+    else hipLaunchKernelGGL(k_diag_grp<2>, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
 }
 
 void launch_lscale_grp(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
@@ -1415,7 +1820,12 @@ __global__ __launch_bounds__(256) void k_swap(const FrontD* __restrict__ fr, con
         int pvr[SWAP_MAXB / 64];
 #pragma unroll
         for (int q = 0; q < SWAP_MAXB / 64; ++q) pvr[q] = (lane + 64 * q < b) ? pv[lane + 64 * q] : -1;
-        for (int q = lane; q < 2 * SWAP_MAXB; q += 64) s_src[q] = q;
+        // position -> source position, entry q in lane q % 64, register q / 64: the b interchanges are b dependent exchanges of two entries,
+        // by lane reads / writes with uniform lane numbers (round 5; through LDS by lane 0 an exchange cost 1 us: 128 us per group of 128
+        // columns in EVERY workgroup of the launch, which was most of the 160 us these launches took on the panel stream)
+        int srcr[2 * SWAP_MAXB / 64];
+#pragma unroll
+        for (int q = 0; q < 2 * SWAP_MAXB / 64; ++q) srcr[q] = lane + 64 * q;
         int low[SWAP_MAXB / 64];              // rows below the diagonal block that are part of the permutation: entry i in lane i % 64, register i / 64
 #pragma unroll
         for (int q = 0; q < SWAP_MAXB / 64; ++q) low[q] = -1;
@@ -1441,8 +1851,20 @@ __global__ __launch_bounds__(256) void k_swap(const FrontD* __restrict__ fr, con
                     ++nlow;
                 }
             }
-            if (lane == 0) { const int a = s_src[j], c = s_src[pos]; s_src[j] = c; s_src[pos] = a; }
+            int a = 0, c = 0;
+#pragma unroll
+            for (int q = 0; q < 2 * SWAP_MAXB / 64; ++q) {
+                if ((j >> 6) == q) a = __builtin_amdgcn_readlane(srcr[q], j & 63);
+                if ((pos >> 6) == q) c = __builtin_amdgcn_readlane(srcr[q], pos & 63);
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * SWAP_MAXB / 64; ++q) {
+                if ((j >> 6) == q && lane == (j & 63)) srcr[q] = c;
+                if ((pos >> 6) == q && lane == (pos & 63)) srcr[q] = a;
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 2 * SWAP_MAXB / 64; ++q) s_src[lane + 64 * q] = srcr[q];
         for (int q = lane; q < b; q += 64) s_row[q] = k0 + q;
 #pragma unroll
         for (int q = 0; q < SWAP_MAXB / 64; ++q) if (lane + 64 * q < nlow) s_row[b + lane + 64 * q] = low[q];

@@ -95,7 +95,8 @@ def test_seam_dense_symmetric_lu_ldiv(gpu, pkg, n, m0):
 def test_staged_group_kernels_match_the_round3_kernels(gpu, pkg, wl, n):
     """Round 5: the kernels of the elimination without interchanges keep what a 128-column group shares -- the finished L11 block rows, the
     W blocks, the pivots -- in LDS (k_lscale_grp2, default; k_diag_grp2, FEASTHIP_DIAG2=1) instead of reading it from global memory inside
-    their matrix-core chains (k_lscale_grp: FEASTHIP_LSCALE2=0; k_diag_grp).  Same products in the same order -- the solutions agree to a
+    their matrix-core chains (k_lscale_grp: FEASTHIP_LSCALE2=0; k_diag_grp), and the 32 x 32 blocks are eliminated with one value per slot
+    (lu32_block2, default; FEASTHIP_LU32=1 the round-3 form, 3 the 256-thread form).  Same products in the same order -- the solutions agree to a
     few ulp of the factors (the compiler contracts the scalar epilogues of the two kernels differently: 0 .. 4e-14 relative on these
     sizes) -- on dense symmetric fronts with ragged last groups and blocks, and on a sparse pencil."""
     rng = np.random.default_rng(n)
@@ -103,10 +104,10 @@ def test_staged_group_kernels_match_the_round3_kernels(gpu, pkg, wl, n):
     G = rng.standard_normal((n, n)); Pd = G @ G.T / n + 0.5 * np.eye(n)
     Cm = (S + 1j * Pd).astype(np.complex128)
     R = np.asfortranarray(rng.standard_normal((n, 9)) + 1j * rng.standard_normal((n, 9)))
-    modes = [("0", "1"), ("0", "0"), ("1", "0"), ("1", "1")]
+    modes = [("0", "1", "2"), ("0", "0", "1"), ("1", "0", "2"), ("1", "1", "2"), ("0", "1", "3"), ("0", "1", "1")]
     sols = []
-    for diag2, lscale2 in modes:
-        with env_override(FEASTHIP_DIAG2=diag2, FEASTHIP_LSCALE2=lscale2):
+    for diag2, lscale2, lu32 in modes:
+        with env_override(FEASTHIP_DIAG2=diag2, FEASTHIP_LSCALE2=lscale2, FEASTHIP_LU32=lu32):
             F = pkg.lu(Cm)
             assert F.symmetric == pivot_light_default()
             Y = np.zeros((n, 9), dtype=np.complex128, order="F")
@@ -120,11 +121,36 @@ def test_staged_group_kernels_match_the_round3_kernels(gpu, pkg, wl, n):
         w = wl.c3_sparse_generalized(16, 19, 32)
         con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
         qs = []
-        for diag2, lscale2 in modes:
-            with env_override(FEASTHIP_DIAG2=diag2, FEASTHIP_LSCALE2=lscale2):
+        for diag2, lscale2, lu32 in modes:
+            with env_override(FEASTHIP_DIAG2=diag2, FEASTHIP_LSCALE2=lscale2, FEASTHIP_LU32=lu32):
                 qs.append(_moment(pkg, w, con, True)[0])
         for q in qs:
             assert np.abs(q - qs[1]).max() <= 1e-11 * np.abs(qs[1]).max()
+
+
+@pytest.mark.parametrize("n", [100, 300, 700, 1537])
+def test_round5_switches_of_the_pivoted_path(gpu, pkg, n):
+    """Round-5 variants that are built but off by default (measured no faster): the panel kernel with implicit interchanges
+    (FEASTHIP_PANEL_IMP=1: rows keep their places during the panel and move once at its end; same pivots -- ties in the pivot search are
+    broken by the LAPACK position) and the solve-ready conversion block column by block column next to the factorisation, the left
+    columns' interchanges on the side stream (FEASTHIP_EARLY_CONVERSION=1).  Same solutions as the default path to rounding."""
+    rng = np.random.default_rng(n)
+    Cm = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex128)
+    if n == 100:
+        Cm = np.round(Cm * 3)            # many exact ties in the pivot search
+    R = np.asfortranarray(rng.standard_normal((n, 5)) + 1j * rng.standard_normal((n, 5)))
+    sols = []
+    for imp, early in [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")]:
+        with env_override(FEASTHIP_PANEL_IMP=imp, FEASTHIP_EARLY_CONVERSION=early):
+            F = pkg.lu(Cm)
+            Y = np.zeros((n, 5), dtype=np.complex128, order="F")
+            pkg.ldiv(Y, F, R)
+            pkg.finalize(F)
+            sols.append(Y)
+    cond = np.linalg.cond(Cm)
+    for y in sols:
+        assert np.linalg.norm(Cm @ y - R) <= 1e-11 * np.linalg.norm(Cm) * np.linalg.norm(y)
+        assert np.abs(y - sols[0]).max() <= 1e-13 * cond * np.abs(sols[0]).max()
 
 
 def test_seam_is_reentrant_across_host_threads(gpu, pkg, wl):
@@ -704,6 +730,54 @@ def test_rr_device_path_matches_host_path(gpu, pkg, wl, golden, case):
     assert out["1"][2]["rr_device_sweeps"] > 0 and out["0"][2]["rr_device_sweeps"] == 0
     assert len(out["1"][0]) == len(out["0"][0]) and match_sets(out["1"][0], out["0"][0]) <= 1e-11 * max(1.0, np.abs(out["0"][0]).max())
     assert abs(out["1"][2]["nit"] - out["0"][2]["nit"]) <= 1
+
+
+@pytest.mark.parametrize("generalized", [False, True])
+def test_rr_device_gate_walk_and_clustered_spectrum(gpu, pkg, generalized):
+    """The device Rayleigh-Ritz path projects on the RAW block (no qr(Q), src/feast.jl:41) when the column-scaled basis is well
+    conditioned (||R^-1||_F / sqrt(m) <= 8) and falls back to CholeskyQR2 + the host eigensolver otherwise.  A block walked ACROSS that gate
+    (basis condition 2 .. 2000), on a spectrum with a cluster of gap 1e-9 inside the subspace: the Ritz values of the two paths agree
+    to 1e-10 on either side of the gate, and both equal the eigenvalues of the pencil restricted to the (exactly invariant) subspace."""
+    rng = np.random.default_rng(5)
+    n, m = 400, 32
+    Qd, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    lam_true = np.sort(rng.uniform(-3.0, 3.0, n))
+    lam_true[10:14] = 0.25 + 1e-9 * np.arange(4)                       # a cluster of four, gap 1e-9
+    lam_true[14] = 0.25 + 1e-5
+    if generalized:
+        Lb = np.linalg.cholesky(np.diag(rng.uniform(0.5, 2.0, n)) + 0.1 * (lambda G: G @ G.conj().T / n)(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))))
+        B = Lb @ Lb.conj().T; B = (B + B.conj().T) / 2
+        Vb = np.linalg.solve(Lb.conj().T, Qd)                          # B-orthonormal eigenvectors of (A, B), A = B Vb diag(lam) Vb^H B
+        A = B @ Vb @ np.diag(lam_true) @ Vb.conj().T @ B; A = (A + A.conj().T) / 2
+        V = Vb[:, 4:4 + m]
+    else:
+        A = Qd @ np.diag(lam_true) @ Qd.conj().T; A = (A + A.conj().T) / 2
+        B = None
+        V = Qd[:, 4:4 + m]
+    exact = lam_true[4:4 + m]
+    taken = []
+    for kappa in (2.0, 8.0, 30.0, 120.0, 500.0, 2000.0):
+        U1, _ = np.linalg.qr(rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
+        U2, _ = np.linalg.qr(rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
+        M = U1 @ np.diag(np.geomspace(1.0, 1.0 / kappa, m)) @ U2.conj().T
+        X = np.asfortranarray(V @ M)
+        out = {}
+        for mode in ("1", "0"):
+            with env_override(FEASTHIP_RR_DEVICE=mode):
+                h = pkg.FeastHandle(0)
+            try:
+                h.set_terms([A, np.eye(n) if B is None else B], [1.0, -1.0])
+                h.set_contour(pkg.circular_contour_trapezoidal(0.0 + 0j, 4.0, 8))
+                h.set_x(X)
+                lam, res, ins = h.rr_step()
+                out[mode] = (np.sort(lam.real), h.stats()["rr_device_sweeps"])
+            finally:
+                h.close()
+        taken.append(out["1"][1] > 0)
+        assert out["0"][1] == 0
+        assert np.abs(out["1"][0] - out["0"][0]).max() <= 1e-10
+        assert np.abs(out["1"][0] - exact).max() <= 1e-10 * max(1.0, kappa / 30.0)      # (the projected pencil loses digits with the basis, on either path)
+    assert taken[0] and not taken[-1]               # both sides of the gate were exercised
 
 
 # ---------------------------------------------------------------------------------------

@@ -18,6 +18,8 @@ out = (C.c_ulonglong * 64)()
 lib.feasthip_debug_prof(0, C.cast(out, C.c_void_p))
 pkg.finalize(F)
 t = np.array(out[:17], dtype=np.float64) * 0.01     # us
+u = np.array(out[40:44], dtype=np.float64) * 0.01
+print(f"  last 32 x 32 block: load + first publish {u[1] - u[0]:.1f}, 32 steps {u[2] - u[1]:.1f}, outputs {u[3] - u[2]:.1f} us")
 print(f"n={n} DIAG2={os.environ.get('FEASTHIP_DIAG2', '1')}: total {t[16] - t[0]:.1f} us")
 print(f"  block 0: lu32 {t[4] - t[0]:.1f}")
 for c in (1, 2, 3):
