@@ -57,9 +57,8 @@ def parse_args():
     ap.add_argument("--no-fold", action="store_true",
                     help="factorise every contour node separately (the conjugate fold of real pencils off): the reference's literal schedule")
     ap.add_argument("--fold", choices=["auto", "on", "off"], default="auto",
-                    help="conjugate fold (one factorisation per node pair, 128-column units).  auto: on with one rank, off with several -- with "
-                         "<= 4 units per rank the steady-state sweep is 4-8 %% faster on single nodes (two 64-column units instead of one of 128: "
-                         "profiles/r04_per_rank_load_single_gpu.txt) at twice the factorisations, and iterations/s is a steady-state metric")
+                    help="conjugate fold (one factorisation per node pair, 128-column units).  auto = on at every rank count: per rank the folded sweep "
+                         "is faster at 2 and 4 units and 2.4 %% slower at one unit (profiles/r04_per_rank_load_single_gpu.txt), for half the factorisations")
     ap.add_argument("--mixed-prec", action="store_true",
                     help="secondary measurement: complex64 shifted solves with complex128 accumulation (feast!'s mixed_prec); not the headline number")
     ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
@@ -249,7 +248,7 @@ def roofline(args, st, st2, prof, detail, levels, world):
     tf = step_flops / t / 1e12
     gbs = step_bytes / t / 1e9
     traffic = tsrc = None
-    for nm in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for nm in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", nm)
         if os.path.exists(tpath) and args.grid == 46 and args.stencil == 19 and world == 1 and not args.mixed_prec and not args.no_fold:
             per_step = json.load(open(tpath)).get("traffic_bytes_per_contour_step")
@@ -358,7 +357,10 @@ def main():
     h.set_terms([w["A"], w["B"]], [1.0, -1.0])
     h.set_contour(con)
     h.set_node_shard(rank, world)
-    fold_on = (not args.no_fold) and (args.fold == "on" or (args.fold == "auto" and world == 1))
+    # auto = on (round 5).  Round 4 turned the fold off for N > 1; measured on one GPU with a rank's share of the units
+    # (profiles/r04_per_rank_load_single_gpu.txt) the fold is FASTER at 2 and 4 units per rank (5.2 / 9.1 against 5.4 / 9.3 ms per contour
+    # step) and costs 2.4 % at one unit per rank (3.34 against 3.26 ms) for half of every rank's factorisations and factor memory
+    fold_on = (not args.no_fold) and args.fold in ("on", "auto")
     if not fold_on:
         h.set_conjugate_fold(False)
     if args.mixed_prec:

@@ -10,13 +10,19 @@
 
 namespace feasthip {
 
-// Development aid (tools/diag_phases.py): wall-clock stamps (100 MHz) of workgroup (0, 0) of the group kernels at their phase boundaries,
-// taken only while g_prof_on is set through feasthip_debug_prof -- one scalar load per stamp otherwise.
+// Development aid (tools/diag_phases.py, tools/diag_phases_insitu.py): wall-clock stamps (100 MHz) of workgroup (0, 0) of the group kernels at
+// their phase boundaries.  Compiled in only with -DFEASTHIP_PROF (make PROF=1): a stamp reads its switch from global memory, a round trip
+// of 1-2 us at every phase boundary -- 16 per k_diag_grp launch -- that the shipped kernels must not pay.
+#ifdef FEASTHIP_PROF
 __device__ unsigned long long g_prof[64];
 __device__ int g_prof_on;
-__device__ __forceinline__ void prof_stamp(int slot) {
-    if (g_prof_on && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_prof[slot] = wall_clock64();
+__device__ int g_prof_k0;      // stamps of the launch with this first column only (-1: every launch, the last one stays)
+__device__ __forceinline__ void prof_stamp(int slot, int k0 = -1) {
+    if (g_prof_on && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (g_prof_k0 < 0 || k0 < 0 || k0 == g_prof_k0)) g_prof[slot] = wall_clock64();
 }
+#else
+__device__ __forceinline__ void prof_stamp(int, int = -1) {}
+#endif
 
 // workgroup barrier that waits for the wave's LDS operations only (__syncthreads() also waits for every global store in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1222,7 +1228,7 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
     const double tiny_k = tiny[k];
     double lmax = 0.0, dmax = 0.0;
     int npert = 0;
-    prof_stamp(0);
+    prof_stamp(0, k0);
     for (int c = 0; c < nb; ++c) {
         const int b = min(FACT_NB, gw - FACT_NB * c);
         if (c > 0) {
@@ -1233,17 +1239,17 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
                 lmax = fmax(lmax, g2.l); dmax = fmax(dmax, g2.u);
             }
             __syncthreads();
-            prof_stamp(1 + 4 * c + 1);
+            prof_stamp(1 + 4 * c + 1, k0);
             if (wave < 2) grp_substitute_call(Lp, F12, ld, p, k0, gw, c, true, k0 + FACT_NB * c + 16 * wave, k0 + FACT_NB * c + b, Wt);
             __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
         }
-        prof_stamp(1 + 4 * c + 2);
+        prof_stamp(1 + 4 * c + 2, k0);
         if constexpr (LUV == 3) lu32_block3(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh2, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
         else if constexpr (LUV == 2) lu32_block2(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh2, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
         else lu32_block(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
         if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
         __syncthreads();                       // W_c, L\U of block c: visible to the next block's substitution
-        prof_stamp(1 + 4 * c + 3);
+        prof_stamp(1 + 4 * c + 3, k0);
     }
     if (npert > 0) atomicAdd(nperturb + k, npert);
     growth_max(growth + gridDim.y + k, dmax);
@@ -1394,7 +1400,7 @@ __global__ __launch_bounds__(DIAG2_NT) void k_diag_grp2(const FrontD* __restrict
                 for (int sidx = 0; sidx < 4; ++sidx) yd[tl][sidx] = ycur[tl][sidx];
         }
         __syncthreads();
-        prof_stamp(1 + 4 * c + 1);
+        prof_stamp(1 + 4 * c + 1, k0);
         if (work) {
             d4 t1[2], t2[2], t3[2];
 #pragma unroll
@@ -1412,19 +1418,19 @@ __global__ __launch_bounds__(DIAG2_NT) void k_diag_grp2(const FrontD* __restrict
         }
         __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
     };
-    prof_stamp(0);
+    prof_stamp(0, k0);
     for (int c = 0; c < nb; ++c) {
         const int b = min(FACT_NB, gw - FACT_NB * c);
         if (c == 1) block_row(std::integral_constant<int, 1>{});
         else if (c == 2) block_row(std::integral_constant<int, 2>{});
         else if (c == 3) block_row(std::integral_constant<int, 3>{});
-        prof_stamp(1 + 4 * c + 2);
+        prof_stamp(1 + 4 * c + 2, k0);
         const int ldl = opaque_uniform(ld);
         lu32_block<DIAG2_NT / 32>(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ldl, ldl, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax,
                                   npert, c < 3 ? Wb + c * 1024 : nullptr, Dsh + FACT_NB * c);
         if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
         __syncthreads();                   // W_c, the pivots and L\U of block c: visible to the next block row
-        prof_stamp(1 + 4 * c + 3);
+        prof_stamp(1 + 4 * c + 3, k0);
     }
     if (npert > 0) atomicAdd(nperturb + k, npert);
     growth_max(growth + gridDim.y + k, dmax);
@@ -2696,9 +2702,17 @@ void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist,
 
 }  // namespace feasthip
 
-// not part of include/feasthip.h: development hook (see g_prof above).  on >= 0 sets the switch; out (64 values) receives the stamps.
+// not part of include/feasthip.h: development hook (see prof_stamp above; -1 when the library was built without FEASTHIP_PROF).
+// on: 0 off, 1 on (every launch), 2 + k0: on for the launches whose first column is k0; out (64 values) receives the stamps.
 extern "C" int feasthip_debug_prof(int on, unsigned long long* out) {
-    if (on >= 0 && hipMemcpyToSymbol(HIP_SYMBOL(feasthip::g_prof_on), &on, sizeof(int)) != hipSuccess) return -1;
+#ifdef FEASTHIP_PROF
+    const int flag = on > 0 ? 1 : 0, k0sel = on >= 2 ? on - 2 : -1;
+    if (on >= 0 && (hipMemcpyToSymbol(HIP_SYMBOL(feasthip::g_prof_on), &flag, sizeof(int)) != hipSuccess ||
+                    hipMemcpyToSymbol(HIP_SYMBOL(feasthip::g_prof_k0), &k0sel, sizeof(int)) != hipSuccess)) return -1;
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(feasthip::g_prof), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
     return 0;
+#else
+    (void)on; (void)out;
+    return -1;
+#endif
 }

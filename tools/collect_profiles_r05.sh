@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-5 measurement set (run on the GPU box through gpurun, on the final build): bench lines, the rocprofv3 kernel-trace summary of
+# the bench command (with the check that the profiled process did not abort at exit: DESIGN.md section 6), the secondary
+# configurations, the per-rank loads of the node-sharded run on one GPU.  Counter passes: tools/collect_pmc_r05.sh.
+set -o pipefail
+O=gpurun_out/${1:-r05final}; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "$R"
+python bench.py > $O/bench_c3_g46.json 2> $O/bench_c3_g46.err || exit 1
+python bench.py --cpu-baseline off --no-fold > $O/bench_c3_g46_no_fold.json 2>> $O/bench.err
+python bench.py --cpu-baseline off --mixed-prec > $O/bench_c3_g46_mixed_prec.json 2>> $O/bench.err
+FEASTHIP_RR_DEVICE=0 python bench.py --cpu-baseline off > $O/bench_c3_g46_host_eigensolver.json 2>> $O/bench.err
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o r05 -- python3 $R/bench.py --cpu-baseline off --cold-solves 0 > $R/$O/bench_c3_g46_under_rocprof.json 2> $R/$O/prof.err)
+if grep -q "Aborted\|Segmentation\|core dumped" $O/prof.err; then echo "ABORT in the profiled bench run"; exit 2; fi
+FEASTHIP_ANALYZE_TRACE=1 python tools/factor_trace.py > $O/factor_trace.out 2> $O/factor_trace_c3_g46.txt
+python tools/bench_c2.py > $O/bench_c2_dense4096.json 2>> $O/bench.err
+python tools/bench_c4c5.py > $O/bench_c4_c5.json 2>> $O/bench.err
+python bench.py --cpu-baseline off --grid 64 > $O/bench_c3_g64_scale_check.json 2>> $O/bench.err
+python tools/few_units_all.py > $O/per_rank_load_single_gpu.txt 2>> $O/bench.err
+python tools/hermitian_c3.py > $O/hermitian_c3.txt 2>> $O/bench.err
+FEASTHIP_ADJ_FOLD=0 python tools/hermitian_c3.py > $O/hermitian_c3_no_adjoint_fold.txt 2>> $O/bench.err
+python tools/other_calls.py > $O/other_calls.txt 2>> $O/bench.err
+python tools/c3_whole_call.py > $O/c3_whole_call.txt 2>> $O/bench.err
+bash tools/collect_factor_traces.sh $(basename $O) "c3 c2 c5" > $O/factor_traces.log 2>&1
+echo collected

@@ -1,4 +1,4 @@
-"""Phase times of the diagonal-block kernel of the elimination without interchanges (workgroup (0, 0) of its LAST launch), dense symmetric
+"""(needs a library built with `make PROF=1` in feastsolver.jl_amd/csrc)  Phase times of the diagonal-block kernel of the elimination without interchanges (workgroup (0, 0) of its LAST launch), dense symmetric
 n x n, one unit, nothing else on the GPU: python tools/diag_phases.py [n]   (FEASTHIP_DIAG2=0: the round-3 kernel)"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
