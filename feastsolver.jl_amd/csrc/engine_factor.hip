@@ -273,7 +273,7 @@ int Engine::factorize() {
         if (skip_conversion) {      // timing probe: how much of the solve-ready conversion a factorisation exposes (the factors are left unusable)
             if (!fuse)
                 launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
-                                  std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
+                                  std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1, nopiv ? 1 : 0);
             continue;
         }
         if (fin != stream_) { HIPCHK(hipEventRecord(ev_fin_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fin_fork_, 0)); fin_used = true; }
@@ -297,7 +297,7 @@ int Engine::factorize() {
         }
         if (!fuse)
             launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
-                              std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1);
+                              std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1, nopiv ? 1 : 0);
     }
     if (fin_used) { HIPCHK(hipEventRecord(ev_fin_, fin_stream_)); HIPCHK(hipStreamWaitEvent(stream_, ev_fin_, 0)); }
     if (ftrace) {

@@ -70,7 +70,8 @@ void launch_group_utrsm(hipStream_t st, const DevSym& S, const Tile* tiles, int 
 void launch_gemm_nn(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int k0, cz* fact, int64_t fs,
                     cz* cb, int64_t cbs, int K, ColSel cs = ColSel(), int bw = FACT_NB, int mrows = 0,
                     const cz* cb_child = nullptr, int64_t cbs_child = 0,     // cb_child: fuse the children's extend-add into the contribution block (kind 2)
-                    int mirror = 0);     // symmetric elimination.  bit 0: kind-2 tiles with b > c also store their transpose (the list holds b >= c only);
+                    int mirror = 0);     // symmetric elimination.  bit 0: symmetric contribution blocks -- the list holds the kind-2 tiles with b >= c only, nothing is mirrored (round 5), and the
+                                         //        children's entries pulled in the epilogue are read from their lower triangles;
                                          // bit 1: kind-1 tiles and kind-0 tiles strictly above the diagonal are skipped (U = D L^T is written by k_lscale_grp);
                                          // bit 2: raised wave priority (products on the dependency chain of the look-ahead schedule)
 // solve-ready form: explicit inverses of the SOLVE_NB diagonal blocks, off-diagonal blocks pre-scaled

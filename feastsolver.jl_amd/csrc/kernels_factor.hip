@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ f
     FrontD f = fr[t.f];
     int p = f.p, u = f.u, ld = p + u;
     int r0 = t.a * 64, q0 = t.b * 64;
-    // symmetric elimination: the U12 panel and the tiles strictly above the diagonal of the pivot block are never read
+    // symmetric elimination: the U12 panel and the tiles strictly above the diagonal of the pivot block are never read; of a contribution
+    // block only the entries on and below its diagonal exist (round 5: the products no longer store the mirror image, every reader
+    // takes entry (i, j) with i < j from (j, i))
     if (sym && phase == 0 && (q0 >= p || r0 + 64 <= q0)) return;
+    if (sym && phase == 1 && q0 > r0) return;
     // phase 0 (before the front is factorised): targets in the L / U12 panels;
     // phase 1 (after the Schur complement has been WRITTEN, CB = -L21 U12): targets in the contribution block
     if (phase == 0 ? (r0 >= p && q0 >= p) : (r0 + 64 <= p || q0 + 64 <= p)) return;
@@ -184,9 +187,10 @@ __global__ __launch_bounds__(256) void k_extend_add(const FrontD* __restrict__ f
             const cz* src = cbc + (int64_t)k * cbsc + g.cb;
             for (int idx = threadIdx.x; idx < nr * nc; idx += 256) {
                 int i = ia + idx % nr, j = ja + idx / nr;
-                cz v = src[i + (int64_t)j * uc];
+                cz v = sym ? src[max(i, j) + (int64_t)min(i, j) * uc] : src[i + (int64_t)j * uc];
                 int r = rc[i], q = rc[j];
                 if ((r >= p && q >= p) != (phase == 1)) continue;
+                if (sym && phase == 1 && r < q) continue;
                 cz* d;
                 if (q < p) d = Lp + r + (int64_t)q * ld;
                 else if (r < p) d = F12 + r + (int64_t)(q - p) * p;
@@ -2269,7 +2273,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (cn[nt][r] >= 0) {
-                        cz v = src[(int64_t)(cn[nt][r] - gcrow) * gu];
+                        // (symmetric contribution blocks hold their lower triangle only: entry (row, col) with row < col is read as (col, row))
+                        const int64_t ri = rm - gcrow, ci = cn[nt][r] - gcrow;
+                        const cz* cbase = cbc + (int64_t)k * cbsc + g->cb;
+                        cz v = ((mirror & 1) && ri < ci) ? cbase[ci + ri * gu] : src[ci * gu];
                         old[nt][r].x += v.x; old[nt][r].y += v.y;
                     }
         }
@@ -2283,9 +2290,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
                 const cz v = cz_make(old[nt][r].x - (t1[nt][r] - t2[nt][r]), old[nt][r].y - (t3[nt][r] - t1[nt][r] - t2[nt][r]));
                 C[mrow + (int64_t)gn * ldc] = v;
                 // symmetric pencil: the contribution block -L21 U12 (+ children) is symmetric; only the tiles on and below the
-                // diagonal are computed, a tile below it also writes its transpose (a lane's 16 values are 4 runs of 4
-                // consecutive elements of one column there: the L2 merges them into whole lines)
-                if ((mirror & 1) && t.a == 2 && t.b != t.c) C[gn + (int64_t)mrow * ldc] = v;
+                // diagonal are computed and (round 5) nothing is mirrored: the parent reads entry (i, j), i < j, as (j, i)
             }
         }
 }
