@@ -261,7 +261,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
-    if (const char* v = getenv("FEASTHIP_RESERVE_CUS")) reserve_cus_ = std::max(0, std::min(4, atoi(v)));
+    if (const char* v = getenv("FEASTHIP_RESERVE_CUS")) reserve_cus_ = std::max(0, std::min(16, atoi(v)));
     if (recycled) return;
     if (nst > 1) {
         (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
@@ -290,7 +290,7 @@ Engine::Engine(int device) : device_(device) {
             uint32_t mask[8];
             for (int x = 0; x < 8; ++x) {
                 mask[x] = 0xffffffffu;
-                for (int m = 0; m < reserve_cus_; ++m) mask[x] &= ~(1u << (8 * m + x));
+                for (int m = 0; m < reserve_cus_; ++m) mask[x] &= ~(1u << ((x + 8 * (m % 4) + 2 * (m / 4)) % 32));      // (distinct bits for up to 16 per XCD; m < 4: 8 m + x)
             }
             if (hipExtStreamCreateWithCUMask(&rest_stream_, 8, mask) != hipSuccess) { rest_stream_ = nullptr; (void)hipGetLastError(); }
             // The solve-ready conversion of the finished levels (long-running workgroups on a low-priority stream) must not sit on the

@@ -322,7 +322,7 @@ private:
     hipStream_t fin_stream_ = nullptr;   // low-priority stream of the solve-ready conversion
     hipEvent_t ev_fin_ = nullptr, ev_fin_fork_ = nullptr;
     hipStream_t rest_stream_ = nullptr;  // trailing updates of the look-ahead levels: a CU mask keeps reserve_cus_ CUs per XCD free for la_stream_
-    int reserve_cus_ = 2;
+    int reserve_cus_ = 4;      // (round 5: 4 per XCD = 32 CUs; C2 96.1 -> 94.6 ms, C5 21.9 -> 21.3, C3 unchanged; 8 and more cost the products more than the chain gains)
     std::vector<hipEvent_t> ev_la_;      // look-ahead events: [0,1] panel done (alternating), [2,3] rest update done, [4] fork, [5] join, [6] rest stream join
     bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true, fuse_extend_ = true;
     int fuse_min_p_ = 1;              // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself (round 3: every level; 128 before, A/B 84.5 -> 82.7 ms)
@@ -332,7 +332,10 @@ private:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)
     bool xcd_balance_ = true;         // FEASTHIP_XCD_BALANCE=0: equal tile counts per XCD in every block-substitution launch (build_plans)
     int short_k_max_p_ = 96;          // levels whose fronts have at most this many pivot columns use 32-row substitution tiles
-    int nb256_min_p_ = 129, nb512_min_p_ = 1024;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks
+    int nb256_min_p_ = 129, nb512_min_p_ = 1 << 30;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks.
+                                      // Round 5: no 512-column blocks by default (they were taken from 1024 pivot columns on).  Coupling 256 -> 512 costs the
+                                      // factorisation 2.1 ms on C3 and 5 ms on C2 (it ends the conversion: nothing hides it) and saves a contour step 0.03 ms
+                                      // (C3) / 0.14 ms (C2): break-even after 70 / 36 iterations of a solver that needs 3 - 10 (FEASTHIP_NB512_MINP=1024 restores it)
                                       // (256 from 129 on, 193 until round 4: a level whose widest front has 132 pivot columns no longer pays an in-block
                                       // step forward and one backward for it: 65 -> 61 launches per sweep pair on C3, contour step -0.2 %, one unit per GPU -1.5 %)
     int nb1024_min_p_ = 1 << 30;      // ... 1024-column ones: built and tested in round 4 (FEASTHIP_NB1024_MINP=2048: the root of C3, p = 3174, gets 4 instead of 7
