@@ -537,58 +537,118 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_reg(const FrontD* __restrict
     }
 }
 
-// Round 5: the same panel factorisation with IMPLICIT interchanges.  k_panel_reg's 32 pivot steps cost 3.5 us each whatever the
-// number of rows (111 us for the last, 100-row panels of a dense matrix): two __syncthreads() per step, each of which also waits for
-// the global stores in flight -- the pivot record and the in-memory interchange of the panel's other columns, a dependent load/store
-// pair issued INSIDE the step.  Here no row moves during the panel: a thread keeps its physical rows and, per row, the LOGICAL position
-// the sequence of LAPACK interchanges would have given it by now (the pivot search breaks ties by that position, the pivot record is
-// that position: both exactly as before).  A step touches LDS only -- the pivot row travels through LDS, the barriers wait for LDS
-// alone -- and the rows change places once, at the end: the interchanges are composed into one permutation of at most 2 b rows and
-// every element of the panel that moves is loaded, then stored.  Same arithmetic in the same order as k_panel_reg: same factors.
-
-// RPT rows per thread x SB columns of a sub-panel in registers (RPT SB = 32): a panel of at most 512 rows is factorised entirely in
-// registers (1 x 32), taller ones in 2, 4 or 8 sub-panels whose trailing columns go through memory once per sub-panel
-template <int PANEL_NT, int RPT, int SB>
-__global__ __launch_bounds__(PANEL_NT) void k_panel_imp(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
-                                                         cz* fact, int64_t fs, int* piv, int npiv,
-                                                         const double* __restrict__ tiny, int* nperturb) {
-    constexpr int NW = PANEL_NT / 64;
+// Round 5: the same panel factorisation LEFT-LOOKING with IMPLICIT interchanges.  k_panel_reg is right-looking in sub-panels of four
+// columns: after every sub-panel a thread reads, updates and writes its rows of every later column of the panel -- 112 column passes per
+// panel, each a round trip of the ONE CU's memory pipe (3 us next to the other stream's product: 490 us for a 4096-row panel, 111 us for
+// a 100-row one) -- and its pivot steps wait for the global stores of the in-memory interchanges.  Here
+//   * no row moves during the panel: a thread keeps its physical rows and, per row, the LOGICAL position the sequence of LAPACK
+//     interchanges would have given it by now (the pivot search breaks ties by that position, the pivot record is that position: exactly
+//     the pivots of k_panel_reg); the rows change places once, at the end (one composed permutation of at most 2 b rows);
+//   * a sub-panel first receives the updates of ALL earlier columns: the U entries of its four columns by a triangular solve with the
+//     pivot rows' multipliers (L11, kept in LDS; one wave, lane reads) and then  a_rc -= sum_k l_rk u_kc  with the L columns streamed
+//     from memory two ahead -- reads only, never a write of a column that is not finished;
+//   * a pivot step touches LDS only, and its barriers wait for LDS only.
+// Same multipliers and pivots as k_panel_reg; the sums of the updates are taken in the same order k = 0, 1, ...
+template <int PANEL_NT, int RPT, int AHEAD>      // AHEAD: L columns in flight beyond the one in use (2; 1 where eight rows per thread fill the registers)
+__global__ __launch_bounds__(PANEL_NT) void k_panel_ll(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
+                                                        cz* fact, int64_t fs, int* piv, int npiv,
+                                                        const double* __restrict__ tiny, int* nperturb) {
+    constexpr int NW = PANEL_NT / 64, SB = 4, MV_COLS = 8;
     __shared__ double s_val[2][NW];
     __shared__ int s_lp[2][NW];
-    __shared__ cz s_row[2][SB];         // [parity][sub-panel column]: the pivot row
-    __shared__ cz s_l[SB][SB];
-    __shared__ cz s_u[SB][FACT_NB];
+    __shared__ cz s_row[2][SB];                // [parity][sub-panel column]: the pivot row
+    __shared__ cz s_U[FACT_NB][SB];            // U entries of the sub-panel's columns in the rows of the earlier pivots
+    __shared__ cz s_L11[FACT_NB][FACT_NB + 1]; // [t][m], m < t: multiplier of the pivot row of step t in column m
     __shared__ int s_prow[FACT_NB];            // step -> physical (local) row that became the pivot row
     __shared__ int s_plp[FACT_NB];             // step -> its logical position then (the LAPACK pivot index, local)
     __shared__ int s_prow_pos[2 * FACT_NB], s_src[2 * FACT_NB], s_npos;
-    constexpr int MV_COLS = 8;
-    __shared__ cz s_mv[2 * FACT_NB * MV_COLS];      // the elements that change places at the end, eight columns per pass
+    __shared__ cz s_mv[2 * FACT_NB * MV_COLS]; // the elements that change places at the end, eight columns per pass
     const FrontD f = fr[list[blockIdx.x]];
     const int k = blockIdx.y;
     const int p = f.p, ld = f.p + f.u;
     const int b = min(FACT_NB, p - k0);
     cz* Lp = fact + (int64_t)k * fs + f.lp;
+    cz* P0 = Lp + (int64_t)k0 * ld + k0;           // element (local row i, panel column c): P0[i + c * ld]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = ld - k0, npr = p - k0;       // local row i = r - k0; pivots come from i < npr
     const double tiny_k = tiny[k];
-    int lpos[RPT];
+    int lpos[RPT], pstep[RPT];
     bool done[RPT];
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) { lpos[q] = tid + PANEL_NT * q; done[q] = false; }
+    for (int q = 0; q < RPT; ++q) { lpos[q] = tid + PANEL_NT * q; done[q] = false; pstep[q] = 0; }
     for (int sb0 = 0; sb0 < b; sb0 += SB) {
         const int sbe = min(b, sb0 + SB), sw = sbe - sb0;
+        // (1) the sub-panel's columns: the thread's rows, and -- into LDS -- the entries of the earlier pivot rows
         cz v[RPT][SB];
-        bool mine[RPT];                     // rows whose sub-panel entries this pass owns (not yet pivot rows)
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int i = tid + PANEL_NT * q;
-            mine[q] = !done[q] && i < nrow;
 #pragma unroll
-            for (int c = 0; c < SB; ++c)
-                v[q][c] = (mine[q] && c < sw) ? Lp[(int64_t)(k0 + sb0 + c) * ld + k0 + i] : cz_make(0, 0);
+            for (int c = 0; c < SB; ++c) v[q][c] = (i < nrow && c < sw) ? P0[i + (int64_t)(sb0 + c) * ld] : cz_make(0, 0);
         }
+        for (int idx = tid; idx < sb0 * SB; idx += PANEL_NT) {
+            const int t = idx / SB, c = idx % SB;
+            s_U[t][c] = c < sw ? P0[s_prow[t] + (int64_t)(sb0 + c) * ld] : cz_make(0, 0);
+        }
+        lds_barrier();
+        // (2) u_t = a_t - sum_{m < t} l_tm u_m, t = 0 .. sb0 - 1 (forward substitution with the unit lower L11), one wave: lane (t, h)
+        // keeps columns 2 h and 2 h + 1 of row t; the finished row t travels by lane reads
+        if (wave == 0 && sb0 > 0) {
+            const int t2 = lane & 31, h = lane >> 5;
+            cz u0 = s_U[t2][2 * h], u1 = s_U[t2][2 * h + 1];
+            for (int t = 0; t + 1 < sb0; ++t) {
+                double r[2][4];
 #pragma unroll
-        for (int jc = 0; jc < SB; ++jc) {          // (SB <= 8: fully unrolled; wider register panels took the compiler half an hour)
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int src = t + 32 * hh;
+                    r[hh][0] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u0.x) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u0.x), src));
+                    r[hh][1] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u0.y) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u0.y), src));
+                    r[hh][2] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u1.x) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u1.x), src));
+                    r[hh][3] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u1.y) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u1.y), src));
+                }
+                if (t2 > t && t2 < sb0) {
+                    const cz l = s_L11[t2][t];
+                    cz_msub(u0, l, cz_make(r[h][0], r[h][1]));
+                    cz_msub(u1, l, cz_make(r[h][2], r[h][3]));
+                }
+            }
+            if (t2 < sb0) {
+                s_U[t2][2 * h] = u0; s_U[t2][2 * h + 1] = u1;
+                // the finished U entries go to their (pivot) rows
+                if (2 * h < sw) P0[s_prow[t2] + (int64_t)(sb0 + 2 * h) * ld] = u0;
+                if (2 * h + 1 < sw) P0[s_prow[t2] + (int64_t)(sb0 + 2 * h + 1) * ld] = u1;
+            }
+        }
+        lds_barrier();
+        // (3) rows that are not pivot rows: a_rc -= sum_{k < sb0} l_rk u_kc, the L columns read two ahead
+        if (sb0 > 0) {
+            bool on[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) on[q] = !done[q] && tid + PANEL_NT * q < nrow;
+            cz l0[RPT], l1[RPT], l2[AHEAD == 2 ? RPT : 1];
+            auto loadl = [&](int kk, auto& dst) {
+                const cz* col = P0 + (int64_t)min(kk, sb0 - 1) * ld + tid;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) dst[q] = on[q] ? col[PANEL_NT * q] : cz_make(0, 0);
+            };
+            loadl(0, l0);
+            if constexpr (AHEAD == 2) loadl(1, l1);
+            for (int kk = 0; kk < sb0; ++kk) {
+                if constexpr (AHEAD == 2) loadl(kk + 2, l2); else loadl(kk + 1, l1);
+                cz uu[SB];
+#pragma unroll
+                for (int c = 0; c < SB; ++c) uu[c] = s_U[kk][c];
+#pragma unroll
+                for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) cz_msub(v[q][c], l0[q], uu[c]);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) { l0[q] = l1[q]; if constexpr (AHEAD == 2) l1[q] = l2[q]; }
+            }
+        }
+        // (4) the four pivot steps of the sub-panel, in registers and LDS
+#pragma unroll
+        for (int jc = 0; jc < SB; ++jc) {
             if (jc >= sw) break;
             const int j = sb0 + jc, par = jc & 1;
             double best = -1.0;
@@ -627,11 +687,12 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_imp(const FrontD* __restrict
                         atomicAdd(nperturb + k, 1);
                     }
 #pragma unroll
-                    for (int c = 0; c < SB; ++c) { s_row[par][c] = v[q][c]; if (c < jc) s_l[jc][c] = v[q][c]; }
+                    for (int c = 0; c < SB; ++c) { s_row[par][c] = v[q][c]; if (c < jc) s_L11[j][sb0 + c] = v[q][c]; }
                     s_prow[j] = tid + PANEL_NT * q;
                     s_plp[j] = wl;
                     piv[(int64_t)k * npiv + f.c0 + k0 + j] = k0 + wl;
                     done[q] = true;
+                    pstep[q] = j;
                     lpos[q] = j;
                 } else if (was_j) lpos[q] = wl;     // the row that was in place takes the pivot row's position
             }
@@ -651,82 +712,27 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_imp(const FrontD* __restrict
                 for (int q = 0; q < RPT; ++q) cz_msub(v[q][c], l[q], uc);
             }
         }
-        const int nt = b - sbe;                 // trailing panel columns
-        // (a) U rows of the trailing columns: the pivot rows' entries there (last written by the row updates of the previous sub-panel:
-        // long since in memory, the barrier makes it formal), forward substitution with the unit-lower sw x sw block
-        __syncthreads();
-        if (tid < nt) {
-            cz* c2 = Lp + (int64_t)(k0 + sbe + tid) * ld + k0;
-            cz x[SB];
-            int pr[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) pr[i] = s_prow[min(sb0 + i, sbe - 1)];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) x[i] = i < sw ? c2[pr[i]] : cz_make(0, 0);
-#pragma unroll
-            for (int i = 1; i < SB; ++i)
-#pragma unroll
-                for (int q = 0; q < i; ++q) if (i < sw) cz_msub(x[i], s_l[i][q], x[q]);
-#pragma unroll
-            for (int i = 0; i < SB; ++i) if (i < sw) { c2[pr[i]] = x[i]; s_u[i][tid] = x[i]; }
-        }
+        // (5) the columns are final: multipliers below, U entries in this sub-panel's pivot rows (the earlier pivot rows were written in (2));
+        // the new pivot rows' multipliers of the EARLIER columns go to L11 for the sub-panels to come
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int i = tid + PANEL_NT * q;
-            if (mine[q]) {
+            const bool older = done[q] && pstep[q] < sb0;
+            if (i < nrow && !older) {
 #pragma unroll
-                for (int c = 0; c < SB; ++c)
-                    if (c < sw) Lp[(int64_t)(k0 + sb0 + c) * ld + k0 + i] = v[q][c];
+                for (int c = 0; c < SB; ++c) if (c < sw) P0[i + (int64_t)(sb0 + c) * ld] = v[q][c];
+            }
+            if (done[q] && pstep[q] >= sb0 && sbe < b) {
+                for (int m = 0; m < sb0; ++m) s_L11[pstep[q]][m] = P0[i + (int64_t)m * ld];
             }
         }
-        if (nt <= 0) break;
         lds_barrier();
-        // (b) rows that are not pivot rows yet: rank-sw update of the trailing columns with the L values still in registers, the
-        // next column's entries loaded before this one's are stored
-        {
-            bool on[RPT];
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) on[q] = !done[q] && tid + PANEL_NT * q < nrow;
-            cz* d0 = Lp + (int64_t)(k0 + sbe) * ld + k0 + tid;
-            constexpr bool AHEAD = PANEL_NT <= 512;      // (1024 threads have 128 registers each: no room for the next column's entries)
-            cz t[RPT], tn[AHEAD ? RPT : 1];
-            if (AHEAD) {
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) t[q] = on[q] ? d0[PANEL_NT * q] : cz_make(0, 0);
-            }
-            for (int jj = 0; jj < nt; ++jj) {
-                cz* dj = d0 + (int64_t)jj * ld;
-                if constexpr (AHEAD) {
-                    if (jj + 1 < nt) {
-#pragma unroll
-                        for (int q = 0; q < RPT; ++q) tn[q] = on[q] ? dj[ld + PANEL_NT * q] : cz_make(0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < RPT; ++q) t[q] = on[q] ? dj[PANEL_NT * q] : cz_make(0, 0);
-                }
-                cz uu[SB];
-#pragma unroll
-                for (int c = 0; c < SB; ++c) uu[c] = s_u[c][jj];
-#pragma unroll
-                for (int q = 0; q < RPT; ++q)
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) if (c < sw) cz_msub(t[q], v[q][c], uu[c]);
-#pragma unroll
-                for (int q = 0; q < RPT; ++q)
-                    if (on[q]) dj[PANEL_NT * q] = t[q];
-                if constexpr (AHEAD) {
-#pragma unroll
-                    for (int q = 0; q < RPT; ++q) t[q] = tn[q];
-                }
-            }
-        }
     }
     // The rows change places: positions [0, b) are the rows of the diagonal block, then the rows below it that a pivot came from; the b
     // interchanges (position j <-> the pivot's position) composed by one wave, as in k_swap
     __syncthreads();
     if (wave == 0) {
-        for (int q = lane; q < 2 * FACT_NB; q += 64) s_src[q] = q;
+        int srcr = lane;                         // position -> source position (at most 2 b = 64 positions: one per lane)
         const int mylp = lane < b ? s_plp[lane] : -1;
         int low = -1, nlow = 0;                  // lane m: the m-th row below the block that takes part
         for (int j = 0; j < b; ++j) {
@@ -739,8 +745,11 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_imp(const FrontD* __restrict
                 if (m) pos = b + __builtin_ctzll(m);
                 else { pos = b + nlow; if (lane == nlow) low = pr; ++nlow; }
             }
-            if (lane == 0) { const int a = s_src[j], c = s_src[pos]; s_src[j] = c; s_src[pos] = a; }
+            const int av = __builtin_amdgcn_readlane(srcr, j), cv = __builtin_amdgcn_readlane(srcr, pos);
+            if (lane == j) srcr = cv;
+            if (lane == pos) srcr = av;
         }
+        s_src[lane] = srcr;
         if (lane < b) s_prow_pos[lane] = lane;
         if (lane < nlow) s_prow_pos[b + lane] = low;
         if (lane == 0) s_npos = b + nlow;
@@ -751,12 +760,12 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_imp(const FrontD* __restrict
         for (int c0 = 0; c0 < b; c0 += MV_COLS) {
             for (int idx = tid; idx < npos * MV_COLS; idx += PANEL_NT) {
                 const int pos = idx / MV_COLS, col = c0 + idx % MV_COLS, sp = s_src[pos];
-                if (col < b && sp != pos) s_mv[idx] = Lp[(int64_t)(k0 + col) * ld + k0 + s_prow_pos[sp]];
+                if (col < b && sp != pos) s_mv[idx] = P0[s_prow_pos[sp] + (int64_t)col * ld];
             }
             __syncthreads();                      // every element that moves is loaded before any is stored
             for (int idx = tid; idx < npos * MV_COLS; idx += PANEL_NT) {
                 const int pos = idx / MV_COLS, col = c0 + idx % MV_COLS;
-                if (col < b && s_src[pos] != pos) Lp[(int64_t)(k0 + col) * ld + k0 + s_prow_pos[pos]] = s_mv[idx];
+                if (col < b && s_src[pos] != pos) P0[s_prow_pos[pos] + (int64_t)col * ld] = s_mv[idx];
             }
             __syncthreads();
         }
@@ -773,19 +782,19 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
     if (!generic && max_rows <= PANEL_RPT * 1024) {
         // few workgroups (every one gets a CU of its own anyway): the widest workgroup has the shortest pivot step
         const int floor_nt = (int64_t)nlist * K <= 256 ? (tall ? (max_rows <= PANEL_RPT * 512 ? 512 : 1024) : 256) : 64;
-        const char* ei = getenv("FEASTHIP_PANEL_IMP");             // 1: implicit interchanges (k_panel_imp), measured no faster: off; read per launch
-        if (ei && atoi(ei) == 1) {
-#define FEASTHIP_PANEL_IMP_CASE(ROWS, NT, R, W) \
+        const char* ei = getenv("FEASTHIP_PANEL_LL");              // 0: the round-1 kernel (right-looking, interchanges in memory); read per launch
+        if (!(ei && atoi(ei) == 0)) {
+#define FEASTHIP_PANEL_LL_CASE(ROWS, NT, R) \
             if (max_rows <= ROWS) { \
-                hipLaunchKernelGGL((k_panel_imp<NT, R, W>), dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
+                hipLaunchKernelGGL((k_panel_ll<NT, R, (R > 4 ? 1 : 2)>), dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
                 return; \
             }
-            FEASTHIP_PANEL_IMP_CASE(256, 64, 4, 4)
-            FEASTHIP_PANEL_IMP_CASE(512, 128, 4, 4)
-            FEASTHIP_PANEL_IMP_CASE(1024, 256, 4, 4)
-            FEASTHIP_PANEL_IMP_CASE(2048, 512, 4, 8)
-            FEASTHIP_PANEL_IMP_CASE(4096, 1024, 4, 4)
-#undef FEASTHIP_PANEL_IMP_CASE
+            FEASTHIP_PANEL_LL_CASE(256, 64, 4)
+            FEASTHIP_PANEL_LL_CASE(512, 128, 4)
+            FEASTHIP_PANEL_LL_CASE(1024, 256, 4)
+            FEASTHIP_PANEL_LL_CASE(2048, 512, 4)
+            FEASTHIP_PANEL_LL_CASE(4096, 512, 8)
+#undef FEASTHIP_PANEL_LL_CASE
         }
 #define FEASTHIP_PANEL_CASE(NT) \
         if (max_rows <= PANEL_RPT * NT && NT >= floor_nt) { \
