@@ -693,29 +693,6 @@ bool Engine::build_plans() {
             for (int a = 0; a < cdiv(ld - k0 - b, 64 * SCALE_ROWTILES); ++a) tiles.push_back({s, t, a, 1});
         }
         F.scale.count = (int)(tiles.size() - F.scale.off);
-        {   // per-group conversion lists (FactorLevel::gscale) for the levels without update rows
-            bool no_update = !lv.empty();
-            for (int s : lv) if (S.u(s) > 0) no_update = false;
-            if (no_update && pmax > SOLVE_NB) {
-                const int ng = cdiv(pmax, SOLVE_NB);
-                F.gbinv.resize(ng); F.gcouple.resize(ng); F.gscale.resize(ng);
-                for (int g = 0; g < ng; ++g) {
-                    F.gbinv[g].off = (int64_t)tiles.size();
-                    for (int s : lv) for (int t = 2 * g; t < std::min(2 * g + 2, cdiv(S.p(s), INV_NB)); ++t) tiles.push_back({s, t, 0, 0});
-                    F.gbinv[g].count = (int)(tiles.size() - F.gbinv[g].off);
-                    F.gcouple[g].off = (int64_t)tiles.size();
-                    for (int s : lv) if (g < cdiv(S.p(s), SOLVE_NB) && S.p(s) - g * SOLVE_NB > INV_NB) tiles.push_back({s, g, 0, 0});
-                    F.gcouple[g].count = (int)(tiles.size() - F.gcouple[g].off);
-                    F.gscale[g].off = (int64_t)tiles.size();
-                    for (int s : lv) if (g < cdiv(S.p(s), SOLVE_NB)) {
-                        int p = S.p(s), ld = p + S.u(s), k0 = g * SOLVE_NB, b = std::min(SOLVE_NB, p - k0);
-                        for (int a = 0; a < cdiv(k0, 64 * SCALE_ROWTILES); ++a) tiles.push_back({s, g, a, 0});
-                        for (int a = 0; a < cdiv(ld - k0 - b, 64 * SCALE_ROWTILES); ++a) tiles.push_back({s, g, a, 1});
-                    }
-                    F.gscale[g].count = (int)(tiles.size() - F.gscale[g].off);
-                }
-            }
-        }
         // coupling into 256- and 512-column super blocks (kernels.hpp: launch_couple_outer / launch_couple_level)
         for (int lvl = 0; lvl < 3; ++lvl) {
             const int half = SOLVE_NB << lvl;

@@ -47,12 +47,9 @@ struct Launch {        // a slice of the tile / list buffers
 struct FactorStep { int k0; Launch panel, swap, trsm, gemm, gemm0, gemm_in, grp;
                     Launch lsg; };     // pivot-light path, first step of a 128-column group: 64-row slices of the rows below the group's diagonal block (k_lscale_grp)
 struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Launch cbgemm;
-                     Launch cbgemm_sym;     // symmetric pencils: the tiles on and below the diagonal of the contribution block only (mirrored on store)
+                     Launch cbgemm_sym;     // symmetric pencils: the tiles on and below the diagonal of the contribution block only (nothing above it is stored or read)
                      Launch fronts; Launch binv, couple, scale;
-                     Launch outer[3], inner[3];
-                     // levels whose fronts have no update rows (dense matrices, the root of a sparse one): the solve-ready conversion of
-                     // block column g (128 columns) on its own, so that it can run while the groups after g are still being factorised
-                     std::vector<Launch> gbinv, gcouple, gscale; };      // coupling of 128 -> 256 ([0]), 256 -> 512 ([1]) and 512 -> 1024 ([2]) super blocks (launch_couple_outer / _level)
+                     Launch outer[3], inner[3]; };      // coupling of 128 -> 256 ([0]), 256 -> 512 ([1]) and 512 -> 1024 ([2]) super blocks (launch_couple_outer / _level)
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     Launch f2red; int f2split = 0;      // forward L21 products split along K (few nodes per GPU): number of parts, reduction tiles
                     Launch b3s;       // B3 tiles of the fronts whose B1 tile is kind 6 (launched only when the apply kernel does not fuse them)

@@ -92,13 +92,12 @@ int Engine::factorize() {
         for (int t = 0; t < nterms; ++t)
             launch_scatter(stream_, d_fact_.p, fs, terms_[t].d_dest.p, terms_[t].d_cscval.p, terms_[t].colptr[n], d_coef_.p, nterms, t, Kloc);
     }
-    bool fin_used = false, early = false;
-    // FEASTHIP_EARLY_CONVERSION=1: block column by block column next to the factorisation (below).  Built, tested and measured SLOWER: the
-    // conversion kernels are latency chains per block column (0.45 + 0.6 + 0.45 ms for a 4096-row column) that only overlap each other when
-    // all columns of a level go in one launch; one column at a time they take 41-54 ms of side-stream time on C2 (13.7 in one batch) and
-    // the 256 / 512-column coupling (7.4 ms) still has to wait for the last column: C2 100 -> 103 ms, C3 79 -> 91 ms.  Off.
-    const char* eec = getenv("FEASTHIP_EARLY_CONVERSION");
-    const bool early_conversion = eec && atoi(eec) == 1;
+    bool fin_used = false;
+    // (Round 5 built the conversion block column by block column NEXT to the factorisation of the fronts without update rows -- dense
+    // matrices, the root --, with the left columns' interchanges on the side stream: commit c55dc22.  Slower: the conversion kernels are
+    // latency chains per block column (0.45 + 0.6 + 0.45 ms for a 4096-row column) that only overlap each other when all columns of a
+    // level go in one launch -- 41-54 ms of side-stream time on C2 instead of 13.7 -- and the coupling of the super blocks still waits
+    // for the last column: C2 100 -> 103 ms, C3 79 -> 91 ms.)
     const bool skip_conversion = getenv("FEASTHIP_PROBE_SKIP_CONVERSION") != nullptr;
     // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
     const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
@@ -150,20 +149,6 @@ int Engine::factorize() {
             // Pivot-light path: the same pipeline with groups of 128 columns; P runs k_diag_grp + k_lscale_grp instead of the panels
             // (no interchanges, no U-row solves: U = D L^T is written with the L columns), the products skip the upper triangle.
             hipStream_t P = la_stream_, R = rest_stream_ ? rest_stream_ : stream_;
-            // Fronts without update rows (dense matrices, the root of a sparse one): nothing reads block column g after group g has been
-            // applied to everything right of it, so its solve-ready conversion -- and, with interchanges, every later group's
-            // interchanges of the columns left of that group, which commute with the conversion (a right multiplication) -- runs on the
-            // side stream one group behind the factorisation instead of after it (round 5: the conversion of a 4096 x 4096 front was
-            // 14 ms at the end of a 100 ms factorisation, the left columns' interchanges 13 ms of the rest stream's 72).
-            hipStream_t finq = (finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_) ? fin_stream_ : nullptr;
-            early = early_conversion && finq && !F.gscale.empty() && R != stream_ && !skip_conversion && (nopiv ? 4 : group_panels_) * FACT_NB == SOLVE_NB;
-            auto convert_group = [&](int g) {
-                if (nopiv) launch_couple32(finq, dsym_, tl + F.gbinv[g].off, F.gbinv[g].count, d_fact_.p, fs, Kloc);
-                else launch_block_inverse(finq, dsym_, tl + F.gbinv[g].off, F.gbinv[g].count, d_fact_.p, fs, Kloc);
-                launch_couple_inverse(finq, dsym_, tl + F.gcouple[g].off, F.gcouple[g].count, d_fact_.p, fs, Kloc);
-                launch_scale_panels(finq, dsym_, tl + F.gscale[g].off, F.gscale[g].count, d_fact_.p, fs, Kloc);
-            };
-            if (early) fin_used = true;
             HIPCHK(hipEventRecord(ev_la_[4], stream_));
             HIPCHK(hipStreamWaitEvent(P, ev_la_[4], 0));
             if (R != stream_) HIPCHK(hipStreamWaitEvent(R, ev_la_[4], 0));
@@ -176,7 +161,7 @@ int Engine::factorize() {
                 const int j0 = g * G, j1 = std::min(ns, j0 + G), k0g = F.steps[j0].k0;
                 auto sel = [&](int origin) {          // column offsets relative to the first column right of `origin`
                     ColSel c;
-                    c.llo = 0; c.lhi = (others && !early) ? k0g : 0;      // (early: the left columns' interchanges run on the side stream)
+                    c.llo = 0; c.lhi = others ? k0g : 0;
                     c.clo = std::max(0, c_lo - origin); c.chi = c_hi >= INF ? INF : std::max(0, c_hi - origin);
                     c.u12 = others ? 1 : 0;
                     return c;
@@ -239,19 +224,6 @@ int Engine::factorize() {
                 HIPCHK(hipStreamWaitEvent(R, ev_la_[g & 1], 0));
                 apply_group(R, g, K0(g + 2), INF, true);
                 HIPCHK(hipEventRecord(ev_la_[2 + (g & 1)], R));
-                if (early && g > 0) {
-                    // group g's pivots are known (and group g - 1 has been applied to group g's columns); the rest stream is done with the L columns of
-                    // group g - 1.  (The events are re-recorded two groups later: the waits are enqueued before that.)
-                    HIPCHK(hipStreamWaitEvent(finq, ev_la_[g & 1], 0));
-                    HIPCHK(hipStreamWaitEvent(finq, ev_la_[2 + ((g - 1) & 1)], 0));
-                    if (!nopiv && !gen) {
-                        ColSel c; c.llo = 0; c.lhi = k0g; c.clo = 0; c.chi = 0; c.u12 = 0;
-                        FactorStep& s0 = F.steps[j0];
-                        const int gw = F.steps[j1 - 1].k0 + FACT_NB - k0g;
-                        launch_swap(finq, dsym_, tl + s0.swap.off, s0.swap.count, k0g, d_fact_.p, fs, d_piv_.p, Kloc, c, gw);
-                    }
-                    convert_group(g - 1);
-                }
             }
             HIPCHK(hipEventRecord(ev_la_[5], P));
             HIPCHK(hipStreamWaitEvent(stream_, ev_la_[5], 0));
@@ -278,19 +250,10 @@ int Engine::factorize() {
         }
         if (fin != stream_) { HIPCHK(hipEventRecord(ev_fin_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fin_fork_, 0)); fin_used = true; }
         launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
-        if (early) {     // every block column but the last has been converted next to the factorisation
-            const int g = (int)F.gscale.size() - 1;
-            if (nopiv) launch_couple32(fin, dsym_, tl + F.gbinv[g].off, F.gbinv[g].count, d_fact_.p, fs, Kloc);
-            else launch_block_inverse(fin, dsym_, tl + F.gbinv[g].off, F.gbinv[g].count, d_fact_.p, fs, Kloc);
-            launch_couple_inverse(fin, dsym_, tl + F.gcouple[g].off, F.gcouple[g].count, d_fact_.p, fs, Kloc);
-            launch_scale_panels(fin, dsym_, tl + F.gscale[g].off, F.gscale[g].count, d_fact_.p, fs, Kloc);
-        } else {
         if (nopiv) launch_couple32(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);      // the 32 x 32 inverses are in place already
         else launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
         launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
-        }
-        early = false;
         for (int lvl = 0; lvl < 3; ++lvl) {       // 256-, 512- and 1024-column super blocks of the fronts with many pivot columns
             launch_couple_outer(fin, dsym_, tl + F.outer[lvl].off, F.outer[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
             launch_couple_level(fin, dsym_, tl + F.inner[lvl].off, F.inner[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);

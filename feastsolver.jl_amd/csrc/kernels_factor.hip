@@ -537,241 +537,10 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel_reg(const FrontD* __restrict
     }
 }
 
-// Round 5: the same panel factorisation LEFT-LOOKING with IMPLICIT interchanges.  k_panel_reg is right-looking in sub-panels of four
-// columns: after every sub-panel a thread reads, updates and writes its rows of every later column of the panel -- 112 column passes per
-// panel, each a round trip of the ONE CU's memory pipe (3 us next to the other stream's product: 490 us for a 4096-row panel, 111 us for
-// a 100-row one) -- and its pivot steps wait for the global stores of the in-memory interchanges.  Here
-//   * no row moves during the panel: a thread keeps its physical rows and, per row, the LOGICAL position the sequence of LAPACK
-//     interchanges would have given it by now (the pivot search breaks ties by that position, the pivot record is that position: exactly
-//     the pivots of k_panel_reg); the rows change places once, at the end (one composed permutation of at most 2 b rows);
-//   * a sub-panel first receives the updates of ALL earlier columns: the U entries of its four columns by a triangular solve with the
-//     pivot rows' multipliers (L11, kept in LDS; one wave, lane reads) and then  a_rc -= sum_k l_rk u_kc  with the L columns streamed
-//     from memory two ahead -- reads only, never a write of a column that is not finished;
-//   * a pivot step touches LDS only, and its barriers wait for LDS only.
-// Same multipliers and pivots as k_panel_reg; the sums of the updates are taken in the same order k = 0, 1, ...
-template <int PANEL_NT, int RPT, int AHEAD>      // AHEAD: L columns in flight beyond the one in use (2; 1 where eight rows per thread fill the registers)
-__global__ __launch_bounds__(PANEL_NT) void k_panel_ll(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
-                                                        cz* fact, int64_t fs, int* piv, int npiv,
-                                                        const double* __restrict__ tiny, int* nperturb) {
-    constexpr int NW = PANEL_NT / 64, SB = 4, MV_COLS = 8;
-    __shared__ double s_val[2][NW];
-    __shared__ int s_lp[2][NW];
-    __shared__ cz s_row[2][SB];                // [parity][sub-panel column]: the pivot row
-    __shared__ cz s_U[FACT_NB][SB];            // U entries of the sub-panel's columns in the rows of the earlier pivots
-    __shared__ cz s_L11[FACT_NB][FACT_NB + 1]; // [t][m], m < t: multiplier of the pivot row of step t in column m
-    __shared__ int s_prow[FACT_NB];            // step -> physical (local) row that became the pivot row
-    __shared__ int s_plp[FACT_NB];             // step -> its logical position then (the LAPACK pivot index, local)
-    __shared__ int s_prow_pos[2 * FACT_NB], s_src[2 * FACT_NB], s_npos;
-    __shared__ cz s_mv[2 * FACT_NB * MV_COLS]; // the elements that change places at the end, eight columns per pass
-    const FrontD f = fr[list[blockIdx.x]];
-    const int k = blockIdx.y;
-    const int p = f.p, ld = f.p + f.u;
-    const int b = min(FACT_NB, p - k0);
-    cz* Lp = fact + (int64_t)k * fs + f.lp;
-    cz* P0 = Lp + (int64_t)k0 * ld + k0;           // element (local row i, panel column c): P0[i + c * ld]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrow = ld - k0, npr = p - k0;       // local row i = r - k0; pivots come from i < npr
-    const double tiny_k = tiny[k];
-    int lpos[RPT], pstep[RPT];
-    bool done[RPT];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) { lpos[q] = tid + PANEL_NT * q; done[q] = false; pstep[q] = 0; }
-    for (int sb0 = 0; sb0 < b; sb0 += SB) {
-        const int sbe = min(b, sb0 + SB), sw = sbe - sb0;
-        // (1) the sub-panel's columns: the thread's rows, and -- into LDS -- the entries of the earlier pivot rows
-        cz v[RPT][SB];
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int i = tid + PANEL_NT * q;
-#pragma unroll
-            for (int c = 0; c < SB; ++c) v[q][c] = (i < nrow && c < sw) ? P0[i + (int64_t)(sb0 + c) * ld] : cz_make(0, 0);
-        }
-        for (int idx = tid; idx < sb0 * SB; idx += PANEL_NT) {
-            const int t = idx / SB, c = idx % SB;
-            s_U[t][c] = c < sw ? P0[s_prow[t] + (int64_t)(sb0 + c) * ld] : cz_make(0, 0);
-        }
-        lds_barrier();
-        // (2) u_t = a_t - sum_{m < t} l_tm u_m, t = 0 .. sb0 - 1 (forward substitution with the unit lower L11), one wave: lane (t, h)
-        // keeps columns 2 h and 2 h + 1 of row t; the finished row t travels by lane reads
-        if (wave == 0 && sb0 > 0) {
-            const int t2 = lane & 31, h = lane >> 5;
-            cz u0 = s_U[t2][2 * h], u1 = s_U[t2][2 * h + 1];
-            for (int t = 0; t + 1 < sb0; ++t) {
-                double r[2][4];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int src = t + 32 * hh;
-                    r[hh][0] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u0.x) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u0.x), src));
-                    r[hh][1] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u0.y) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u0.y), src));
-                    r[hh][2] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u1.x) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u1.x), src));
-                    r[hh][3] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(unsigned long long, u1.y) >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)__builtin_bit_cast(unsigned long long, u1.y), src));
-                }
-                if (t2 > t && t2 < sb0) {
-                    const cz l = s_L11[t2][t];
-                    cz_msub(u0, l, cz_make(r[h][0], r[h][1]));
-                    cz_msub(u1, l, cz_make(r[h][2], r[h][3]));
-                }
-            }
-            if (t2 < sb0) {
-                s_U[t2][2 * h] = u0; s_U[t2][2 * h + 1] = u1;
-                // the finished U entries go to their (pivot) rows
-                if (2 * h < sw) P0[s_prow[t2] + (int64_t)(sb0 + 2 * h) * ld] = u0;
-                if (2 * h + 1 < sw) P0[s_prow[t2] + (int64_t)(sb0 + 2 * h + 1) * ld] = u1;
-            }
-        }
-        lds_barrier();
-        // (3) rows that are not pivot rows: a_rc -= sum_{k < sb0} l_rk u_kc, the L columns read two ahead
-        if (sb0 > 0) {
-            bool on[RPT];
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) on[q] = !done[q] && tid + PANEL_NT * q < nrow;
-            cz l0[RPT], l1[RPT], l2[AHEAD == 2 ? RPT : 1];
-            auto loadl = [&](int kk, auto& dst) {
-                const cz* col = P0 + (int64_t)min(kk, sb0 - 1) * ld + tid;
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) dst[q] = on[q] ? col[PANEL_NT * q] : cz_make(0, 0);
-            };
-            loadl(0, l0);
-            if constexpr (AHEAD == 2) loadl(1, l1);
-            for (int kk = 0; kk < sb0; ++kk) {
-                if constexpr (AHEAD == 2) loadl(kk + 2, l2); else loadl(kk + 1, l1);
-                cz uu[SB];
-#pragma unroll
-                for (int c = 0; c < SB; ++c) uu[c] = s_U[kk][c];
-#pragma unroll
-                for (int q = 0; q < RPT; ++q)
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) cz_msub(v[q][c], l0[q], uu[c]);
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) { l0[q] = l1[q]; if constexpr (AHEAD == 2) l1[q] = l2[q]; }
-            }
-        }
-        // (4) the four pivot steps of the sub-panel, in registers and LDS
-#pragma unroll
-        for (int jc = 0; jc < SB; ++jc) {
-            if (jc >= sw) break;
-            const int j = sb0 + jc, par = jc & 1;
-            double best = -1.0;
-            int blp = 0x7fffffff;
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int i = tid + PANEL_NT * q;
-                const double a = cz_abs1(v[q][jc]);
-                if (!done[q] && i < npr && (a > best || (a == best && lpos[q] < blp))) { best = a; blp = lpos[q]; }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int ol = __shfl_xor(blp, off);
-                if (ob > best || (ob == best && ol < blp)) { best = ob; blp = ol; }
-            }
-            if (lane == 0) { s_val[par][wave] = best; s_lp[par][wave] = blp; }
-            lds_barrier();
-            double bb = s_val[par][0];
-            int wl = s_lp[par][0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const double ov = s_val[par][w];
-                const int ol = s_lp[par][w];
-                if (ov > bb || (ov == bb && ol < wl)) { bb = ov; wl = ol; }
-            }
-            if (bb < 0) wl = j;                    // no finite candidate: the row in place stays
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const bool was_w = !done[q] && lpos[q] == wl, was_j = !done[q] && lpos[q] == j;
-                if (was_w) {                       // this row is the pivot row of step j
-                    cz pv = v[q][jc];
-                    const double pa = cz_abs1(pv);
-                    if (!(pa >= tiny_k)) {   // static pivot perturbation (also catches NaN)
-                        pv = (pa > 0.0) ? cz_make(pv.x * (tiny_k / pa), pv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
-                        v[q][jc] = pv;
-                        atomicAdd(nperturb + k, 1);
-                    }
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) { s_row[par][c] = v[q][c]; if (c < jc) s_L11[j][sb0 + c] = v[q][c]; }
-                    s_prow[j] = tid + PANEL_NT * q;
-                    s_plp[j] = wl;
-                    piv[(int64_t)k * npiv + f.c0 + k0 + j] = k0 + wl;
-                    done[q] = true;
-                    pstep[q] = j;
-                    lpos[q] = j;
-                } else if (was_j) lpos[q] = wl;     // the row that was in place takes the pivot row's position
-            }
-            lds_barrier();
-            const cz inv = cz_inv(s_row[par][jc]);
-            cz l[RPT];
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const bool upd = !done[q] && tid + PANEL_NT * q < nrow;
-                l[q] = upd ? cz_mul(v[q][jc], inv) : cz_make(0, 0);      // (pivot rows and rows beyond the front: no update, entries kept)
-                if (upd) v[q][jc] = l[q];
-            }
-#pragma unroll
-            for (int c = jc + 1; c < SB; ++c) {
-                const cz uc = s_row[par][c];           // (one address for the whole wave: a broadcast read)
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) cz_msub(v[q][c], l[q], uc);
-            }
-        }
-        // (5) the columns are final: multipliers below, U entries in this sub-panel's pivot rows (the earlier pivot rows were written in (2));
-        // the new pivot rows' multipliers of the EARLIER columns go to L11 for the sub-panels to come
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int i = tid + PANEL_NT * q;
-            const bool older = done[q] && pstep[q] < sb0;
-            if (i < nrow && !older) {
-#pragma unroll
-                for (int c = 0; c < SB; ++c) if (c < sw) P0[i + (int64_t)(sb0 + c) * ld] = v[q][c];
-            }
-            if (done[q] && pstep[q] >= sb0 && sbe < b) {
-                for (int m = 0; m < sb0; ++m) s_L11[pstep[q]][m] = P0[i + (int64_t)m * ld];
-            }
-        }
-        lds_barrier();
-    }
-    // The rows change places: positions [0, b) are the rows of the diagonal block, then the rows below it that a pivot came from; the b
-    // interchanges (position j <-> the pivot's position) composed by one wave, as in k_swap
-    __syncthreads();
-    if (wave == 0) {
-        int srcr = lane;                         // position -> source position (at most 2 b = 64 positions: one per lane)
-        const int mylp = lane < b ? s_plp[lane] : -1;
-        int low = -1, nlow = 0;                  // lane m: the m-th row below the block that takes part
-        for (int j = 0; j < b; ++j) {
-            const int pr = __builtin_amdgcn_readlane(mylp, j);
-            if (pr == j) continue;
-            int pos;
-            if (pr < b) pos = pr;
-            else {
-                const unsigned long long m = __ballot(low == pr);
-                if (m) pos = b + __builtin_ctzll(m);
-                else { pos = b + nlow; if (lane == nlow) low = pr; ++nlow; }
-            }
-            const int av = __builtin_amdgcn_readlane(srcr, j), cv = __builtin_amdgcn_readlane(srcr, pos);
-            if (lane == j) srcr = cv;
-            if (lane == pos) srcr = av;
-        }
-        s_src[lane] = srcr;
-        if (lane < b) s_prow_pos[lane] = lane;
-        if (lane < nlow) s_prow_pos[b + lane] = low;
-        if (lane == 0) s_npos = b + nlow;
-    }
-    __syncthreads();
-    {
-        const int npos = s_npos;
-        for (int c0 = 0; c0 < b; c0 += MV_COLS) {
-            for (int idx = tid; idx < npos * MV_COLS; idx += PANEL_NT) {
-                const int pos = idx / MV_COLS, col = c0 + idx % MV_COLS, sp = s_src[pos];
-                if (col < b && sp != pos) s_mv[idx] = P0[s_prow_pos[sp] + (int64_t)col * ld];
-            }
-            __syncthreads();                      // every element that moves is loaded before any is stored
-            for (int idx = tid; idx < npos * MV_COLS; idx += PANEL_NT) {
-                const int pos = idx / MV_COLS, col = c0 + idx % MV_COLS;
-                if (col < b && s_src[pos] != pos) P0[s_prow_pos[pos] + (int64_t)col * ld] = s_mv[idx];
-            }
-            __syncthreads();
-        }
-    }
-}
-
+// (Round 5 built two more panel kernels with IMPLICIT interchanges -- rows keep their places during the panel and move once at its end; the
+// pivot search breaks ties by the LAPACK position --, right-looking (commit c55dc22) and left-looking with the L columns streamed two ahead
+// (commit b61a384).  Both give the pivots of k_panel_reg; neither is faster where it matters: 394 us against 490 for 4096-row panels,
+// 163 against 111 us for short ones, C2 97.9 against 95.8 ms.  A panel on ONE CU is a chain of memory round trips)
 void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs,
                   int* piv, const double* tiny, int* nperturb, int K, bool tall, int max_rows) {
     if (nlist <= 0) return;
@@ -782,20 +551,6 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
     if (!generic && max_rows <= PANEL_RPT * 1024) {
         // few workgroups (every one gets a CU of its own anyway): the widest workgroup has the shortest pivot step
         const int floor_nt = (int64_t)nlist * K <= 256 ? (tall ? (max_rows <= PANEL_RPT * 512 ? 512 : 1024) : 256) : 64;
-        const char* ei = getenv("FEASTHIP_PANEL_LL");              // 0: the round-1 kernel (right-looking, interchanges in memory); read per launch
-        if (!(ei && atoi(ei) == 0)) {
-#define FEASTHIP_PANEL_LL_CASE(ROWS, NT, R) \
-            if (max_rows <= ROWS) { \
-                hipLaunchKernelGGL((k_panel_ll<NT, R, (R > 4 ? 1 : 2)>), dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
-                return; \
-            }
-            FEASTHIP_PANEL_LL_CASE(256, 64, 4)
-            FEASTHIP_PANEL_LL_CASE(512, 128, 4)
-            FEASTHIP_PANEL_LL_CASE(1024, 256, 4)
-            FEASTHIP_PANEL_LL_CASE(2048, 512, 4)
-            FEASTHIP_PANEL_LL_CASE(4096, 512, 8)
-#undef FEASTHIP_PANEL_LL_CASE
-        }
 #define FEASTHIP_PANEL_CASE(NT) \
         if (max_rows <= PANEL_RPT * NT && NT >= floor_nt) { \
             hipLaunchKernelGGL(k_panel_reg<NT>, dim3(nlist, K), dim3(NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb); \
@@ -995,7 +750,7 @@ struct LuShared {
 
 template <int NQ = 16>      // NQ = threads / 32: thread (i, q) keeps the columns q, q + NQ, .. of row i (2 entries with 512 threads, 4 with 256)
 __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, const int b, const double tiny_k, LuShared& sh, cz* __restrict__ Wc,
-                                           cz* __restrict__ dout, double& lmax, double& dmax, int& npert, cz* Wlds = nullptr, cz* dlds = nullptr) {
+                                           cz* __restrict__ dout, double& lmax, double& dmax, int& npert) {
     constexpr int NC = FACT_NB / NQ;
     const int i = threadIdx.x & 31, q = threadIdx.x >> 5;
     const bool rok = i < b;
@@ -1056,8 +811,7 @@ __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, con
         if (rok && cm > i && cm < b) dmax = fmax(dmax, fabs(a[m].x) + fabs(a[m].y));
         const cz w = cz_mul(e[m], dinv);
         Wc[cm * 32 + i] = w;
-        if (Wlds) Wlds[cm * 32 + i] = w;          // (k_diag_grp2 keeps W_c and the pivots in LDS for the blocks to come)
-        if (cm == i) { dout[i] = a[m]; if (dlds) dlds[i] = a[m]; }
+        if (cm == i) dout[i] = a[m];
         if (rok) {
             if (cm < i) D[i + (int64_t)cm * ld] = e[m];            // inv(L)[i][cm]           (cm < i < b)
             if (cm <= i) D[cm + (int64_t)i * ld] = w;              // inv(U)[cm][i]
@@ -1072,7 +826,7 @@ __device__ __forceinline__ void lu32_block(cz* __restrict__ D, const int ld, con
 // are formed in the same order.
 struct LuShared2 { cz col[2][FACT_NB], row[2][FACT_NB], pinv[2], dinv[FACT_NB]; };
 __device__ __forceinline__ void lu32_block2(cz* __restrict__ D, const int ld, const int b, const double tiny_k, LuShared2& sh, cz* __restrict__ Wc,
-                                            cz* __restrict__ dout, double& lmax, double& dmax, int& npert, cz* Wlds = nullptr, cz* dlds = nullptr) {
+                                            cz* __restrict__ dout, double& lmax, double& dmax, int& npert) {
     const int i = threadIdx.x & 31, q = threadIdx.x >> 5, c0 = q, c1 = q + 16;      // 512 threads
     prof_stamp(40);
     const bool rok = i < b;
@@ -1121,8 +875,7 @@ __device__ __forceinline__ void lu32_block2(cz* __restrict__ D, const int ld, co
         const cz e = c < i ? sv : cz_make(c == i ? 1.0 : 0.0, 0.0);
         const cz w = cz_mul(e, dinv);
         Wc[c * 32 + i] = w;
-        if (Wlds) Wlds[c * 32 + i] = w;
-        if (c == i) { dout[i] = sv; if (dlds) dlds[i] = sv; }
+        if (c == i) dout[i] = sv;
         if (rok) {
             if (c < i) D[i + (int64_t)c * ld] = e;              // inv(L)[i][c]           (c < i < b)
             if (c <= i) D[c + (int64_t)i * ld] = w;             // inv(U)[c][i]
@@ -1130,89 +883,6 @@ __device__ __forceinline__ void lu32_block2(cz* __restrict__ D, const int ld, co
     };
     finish(c0, s0);
     finish(c1, s1);
-    prof_stamp(43);
-}
-
-// lu32_block2 on 256 threads with four slots each (the other waves of the workgroup only keep the barriers): a step's cost is the issue
-// time of its ~100 instructions per wave -- every wave runs them whatever the number of active lanes --, so one wave per SIMD instead of
-// two takes the step from 0.54 to about 0.3 us
-__device__ __forceinline__ void lu32_block3(cz* __restrict__ D, const int ld, const int b, const double tiny_k, LuShared2& sh, cz* __restrict__ Wc,
-                                            cz* __restrict__ dout, double& lmax, double& dmax, int& npert, cz* Wlds = nullptr, cz* dlds = nullptr) {
-    const bool act = threadIdx.x < 256;
-    const int i = threadIdx.x & 31, q = (threadIdx.x >> 5) & 7;
-    prof_stamp(40);
-    const bool rok = i < b;
-    cz s[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int c = q + 8 * m;
-        s[m] = (act && rok && c < b) ? D[i + (int64_t)c * ld] : cz_make(i == c ? 1.0 : 0.0, 0.0);
-    }
-    auto publish = [&](int jn, int nbuf) {
-        const int mj = jn >> 3;                    // slot of column jn in the threads with q == (jn & 7)
-        if (q == (jn & 7)) {
-            cz cv = s[0];
-#pragma unroll
-            for (int m = 1; m < 4; ++m) if (mj == m) cv = s[m];
-            if (i == jn) {
-                const double pa = fabs(cv.x) + fabs(cv.y);
-                if (jn < b) dmax = fmax(dmax, pa);
-                if (__builtin_expect(!(pa >= tiny_k), 0)) {            // static pivot perturbation (also catches NaN), as in k_panel_reg
-                    cv = (pa > 0.0) ? cz_make(cv.x * (tiny_k / pa), cv.y * (tiny_k / pa)) : cz_make(tiny_k, 0.0);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) if (mj == m) s[m] = cv;
-                    if (jn < b) ++npert;
-                }
-                const cz pin = cz_inv_pivot(cv);
-                sh.pinv[nbuf] = pin;
-                sh.dinv[jn] = pin;
-            }
-            sh.col[nbuf][i] = cv;
-        }
-        if (i == jn) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sh.row[nbuf][q + 8 * m] = s[m];
-        }
-    };
-    if (act) publish(0, 0);
-    lds_barrier();
-    prof_stamp(41);
-#pragma unroll 1
-    for (int j = 0; j < FACT_NB; ++j) {
-        const int buf = j & 1;
-        if (act) {
-            if (i > j) {
-                const cz l = cz_mul(sh.col[buf][i], sh.pinv[buf]);
-                cz r[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) r[m] = sh.row[buf][q + 8 * m];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (q + 8 * m == j) { s[m] = cz_make(-l.x, -l.y); lmax = fmax(lmax, fabs(l.x) + fabs(l.y)); } else cz_msub(s[m], l, r[m]);
-                }
-            }
-            if (j + 1 < FACT_NB) publish(j + 1, buf ^ 1);
-        }
-        lds_barrier();
-    }
-    prof_stamp(42);
-    if (!act) return;
-    const cz dinv = sh.dinv[i];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int c = q + 8 * m;
-        const cz sv = s[m];
-        if (rok && c > i && c < b) dmax = fmax(dmax, fabs(sv.x) + fabs(sv.y));
-        const cz e = c < i ? sv : cz_make(c == i ? 1.0 : 0.0, 0.0);
-        const cz w = cz_mul(e, dinv);
-        Wc[c * 32 + i] = w;
-        if (Wlds) Wlds[c * 32 + i] = w;
-        if (c == i) { dout[i] = sv; if (dlds) dlds[i] = sv; }
-        if (rok) {
-            if (c < i) D[i + (int64_t)c * ld] = e;              // inv(L)[i][c]           (c < i < b)
-            if (c <= i) D[c + (int64_t)i * ld] = w;             // inv(U)[c][i]
-        }
-    }
     prof_stamp(43);
 }
 
@@ -1257,192 +927,10 @@ __global__ __launch_bounds__(DIAG_NT) void k_diag_grp(const FrontD* __restrict__
             __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
         }
         prof_stamp(1 + 4 * c + 2, k0);
-        if constexpr (LUV == 3) lu32_block3(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh2, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
-        else if constexpr (LUV == 2) lu32_block2(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh2, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
+        if constexpr (LUV == 2) lu32_block2(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh2, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
         else lu32_block(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ld, ld, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax, npert);
         if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
         __syncthreads();                       // W_c, L\U of block c: visible to the next block's substitution
-        prof_stamp(1 + 4 * c + 3, k0);
-    }
-    if (npert > 0) atomicAdd(nperturb + k, npert);
-    growth_max(growth + gridDim.y + k, dmax);
-    growth_max(growth + k, lmax);
-}
-
-// A wave-uniform value the compiler may not look through: address arithmetic that uses it stays behind this point instead of being hoisted to
-// the kernel entry (the unrolled block rows of k_diag_grp2 have some 200 distinct 64-bit addresses: hoisted, they alone spill)
-__device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
-
-// 3M product chain of the staged kernels: acc(16 x 32 of the wave's rows) += Z-or-Y (registers, k-step s = 4 tp + sidx) x A^T with the
-// A operand A[kk][16 tl + li] read from LDS one k-step ahead of its matrix-core instructions; the scheduling barrier keeps the compiler
-// from hoisting every LDS read of the unrolled chain to its top (hundreds of live registers, spilled)
-template <int NS>
-__device__ __forceinline__ void lds_chain(const cz* __restrict__ A, const cz (*zsrc)[4], int li, int lk, d4 (&t1)[2], d4 (&t2)[2], d4 (&t3)[2]) {
-    cz an[2], ac[2];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl) ac[tl] = A[lk * 32 + 16 * tl + li];
-#pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) {
-        if (s2 + 1 < NS) {
-            const int kn = 16 * ((s2 + 1) >> 2) + lk + 4 * ((s2 + 1) & 3);
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) an[tl] = A[kn * 32 + 16 * tl + li];
-        }
-        const cz zb = zsrc[s2 >> 2][s2 & 3];
-        const double zs = zb.x + zb.y;
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            t1[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[tl].x, zb.x, t1[tl], 0, 0, 0);
-            t2[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[tl].y, zb.y, t2[tl], 0, 0, 0);
-            t3[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[tl].x + ac[tl].y, zs, t3[tl], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) ac[tl] = an[tl];
-    }
-}
-
-// k_diag_grp with everything the blocks share kept in LDS (round 5): the L rows of the finished blocks ([kk][jj] per block row, 96 KB
-// for a full group), W_0 .. W_2 (48 KB) and the pivots.  k_diag_grp's substitutions read those from global memory inside their
-// matrix-core chains and its update pass re-reads the L entries it has just written -- a dozen dependent round trips per 32-column
-// block, 190-270 us per group on the big fronts with the trailing product of the other stream next to it.  Here a block row costs
-// one round trip for its own A entries; Z = L D stays in the registers of the wave from the substitution to the update.  Same
-// products in the same order as k_diag_grp: bit-identical factors.
-constexpr int DG2_LROW_OFF[4] = {0, 0, 32 * 32, 32 * 32 + 64 * 32};       // element offsets of the block rows 1, 2, 3 ([kk][32] each, kk < 32 r)
-constexpr int DG2_L_ELEMS = (32 + 64 + 96) * 32, DG2_W_ELEMS = 3 * 1024;
-constexpr size_t DG2_LDS_BYTES = (size_t)(DG2_L_ELEMS + DG2_W_ELEMS + GRP_W) * sizeof(cz) + sizeof(LuShared);
-
-constexpr int DIAG2_NT = 256;      // four waves: the two that work on a block row have 512 registers each
-__global__ __launch_bounds__(DIAG2_NT) void k_diag_grp2(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
-                                                       cz* fact, int64_t fs, int* piv, int npiv, const double* __restrict__ tiny, int* nperturb,
-                                                       unsigned long long* growth, cz* wscr, int64_t wstride) {
-    extern __shared__ cz dg2_lds[];
-    cz* Lrows = dg2_lds;
-    cz* Wb = dg2_lds + DG2_L_ELEMS;
-    cz* Dsh = Wb + DG2_W_ELEMS;
-    LuShared& sh = *reinterpret_cast<LuShared*>(Dsh + GRP_W);
-    __builtin_amdgcn_s_setprio(3);
-    const FrontD f = fr[list[blockIdx.x]];
-    const int k = blockIdx.y;
-    const int p = f.p, ld = f.p + f.u;
-    const int gw = min(GRP_W, p - k0), nb = (gw + FACT_NB - 1) / FACT_NB;
-    cz* Lp = fact + (int64_t)k * fs + f.lp;
-    cz* Wt = wscr + ((int64_t)k * wstride + (int64_t)f.wslot) * WSLOT;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const double tiny_k = tiny[k];
-    double lmax = 0.0, dmax = 0.0;
-    int npert = 0;
-    auto block_row = [&](auto cc_) {
-        constexpr int c = decltype(cc_)::value;
-        // rows 16 wave .. 16 wave + 15 of block c (waves 0 and 1): L entries of the blocks before it, then -- after a barrier: the
-        // operand are the L entries of all 32 rows -- the Schur update of block (c, c).  The other waves only keep the barriers.
-        const int b = min(FACT_NB, gw - FACT_NB * c);
-        const int rloc = 16 * wave + li;                          // row within the block
-        const bool work = wave < 2, rok = work && rloc < b;
-        const int row = k0 + FACT_NB * c + min(rloc, b - 1);
-        cz* Lc = Lrows + DG2_LROW_OFF[c];
-        cz z[2 * c][4];
-        cz yd[2][4];                                              // the rows' entries of block (c, c)
-        auto load_cols = [&](int cc, cz (&out)[2][4], int ldl) {          // the rows' entries of column block cc (zero beyond the rows / columns of a ragged group)
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int col = 32 * cc + 16 * tl + lk + 4 * sidx;
-                    const cz v = Lp[row + (int64_t)(k0 + min(col, gw - 1)) * ldl];
-                    const bool keep = rok && col < gw;
-                    out[tl][sidx] = cz_make(keep ? v.x : 0.0, keep ? v.y : 0.0);
-                }
-        };
-        if (work) {
-            cz ycur[2][4];
-            load_cols(0, ycur, opaque_uniform(ld));
-            auto substage = [&](auto cc_) {
-                constexpr int cc = decltype(cc_)::value;
-                const int ldl = opaque_uniform(ld);
-                cz* ucol = Lp + k0 + (int64_t)row * ldl;         // (rows of the diagonal block are pivot rows: row < p)
-                cz ynext[2][4];
-                load_cols(cc + 1, ynext, ldl);                          // (column block c itself after the last one: the entries the update works on)
-                if constexpr (cc > 0) {
-                    d4 t1[2], t2[2], t3[2];
-#pragma unroll
-                    for (int tl = 0; tl < 2; ++tl) { t1[tl] = (d4){0, 0, 0, 0}; t2[tl] = (d4){0, 0, 0, 0}; t3[tl] = (d4){0, 0, 0, 0}; }
-                    const cz* Lcc = Lrows + DG2_LROW_OFF[cc];
-                    lds_chain<8 * cc>(Lcc, z, li, lk, t1, t2, t3);
-#pragma unroll
-                    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                        for (int sidx = 0; sidx < 4; ++sidx) {
-                            ycur[tl][sidx].x -= t1[tl][sidx] - t2[tl][sidx];
-                            ycur[tl][sidx].y -= t3[tl][sidx] - t1[tl][sidx] - t2[tl][sidx];
-                        }
-                }
-                d4 u1[2], u2[2], u3[2];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl) { u1[tl] = (d4){0, 0, 0, 0}; u2[tl] = (d4){0, 0, 0, 0}; u3[tl] = (d4){0, 0, 0, 0}; }
-                const cz* Wc = Wb + cc * 1024;
-                lds_chain<8>(Wc, ycur, li, lk, u1, u2, u3);
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; ++sidx) {
-                        const int col = 32 * cc + 16 * tl + lk + 4 * sidx;        // (< 32 c <= gw)
-                        const cz x = cz_make(u1[tl][sidx] - u2[tl][sidx], u3[tl][sidx] - u1[tl][sidx] - u2[tl][sidx]);
-                        const cz zz = cz_mul(x, Dsh[col]);
-                        z[2 * cc + tl][sidx] = zz;
-                        Lc[col * 32 + 16 * wave + li] = x;                         // (zero for the rows beyond a ragged last block)
-                        if (rok) {
-                            Lp[row + (int64_t)(k0 + col) * ldl] = x;
-                            ucol[col] = zz;                                        // U[k0 + col][row] = d_col l_(row, col)
-                            lmax = fmax(lmax, fabs(x.x) + fabs(x.y));
-                            dmax = fmax(dmax, fabs(zz.x) + fabs(zz.y));
-                        }
-                    }
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; ++sidx) ycur[tl][sidx] = ynext[tl][sidx];
-            };
-            substage(std::integral_constant<int, 0>{});
-            if constexpr (c > 1) substage(std::integral_constant<int, 1>{});
-            if constexpr (c > 2) substage(std::integral_constant<int, 2>{});
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) yd[tl][sidx] = ycur[tl][sidx];
-        }
-        __syncthreads();
-        prof_stamp(1 + 4 * c + 1, k0);
-        if (work) {
-            d4 t1[2], t2[2], t3[2];
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) { t1[tl] = (d4){0, 0, 0, 0}; t2[tl] = (d4){0, 0, 0, 0}; t3[tl] = (d4){0, 0, 0, 0}; }
-            lds_chain<8 * c>(Lc, z, li, lk, t1, t2, t3);
-            const int ldl = opaque_uniform(ld);
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int col = 32 * c + 16 * tl + lk + 4 * sidx;
-                    const cz v = cz_make(yd[tl][sidx].x - (t1[tl][sidx] - t2[tl][sidx]), yd[tl][sidx].y - (t3[tl][sidx] - t1[tl][sidx] - t2[tl][sidx]));
-                    if (rok && col < gw) Lp[row + (int64_t)(k0 + col) * ldl] = v;
-                }
-        }
-        __syncthreads();                   // the block's entries (global memory, same workgroup) are final for the elimination below
-    };
-    prof_stamp(0, k0);
-    for (int c = 0; c < nb; ++c) {
-        const int b = min(FACT_NB, gw - FACT_NB * c);
-        if (c == 1) block_row(std::integral_constant<int, 1>{});
-        else if (c == 2) block_row(std::integral_constant<int, 2>{});
-        else if (c == 3) block_row(std::integral_constant<int, 3>{});
-        prof_stamp(1 + 4 * c + 2, k0);
-        const int ldl = opaque_uniform(ld);
-        lu32_block<DIAG2_NT / 32>(Lp + (k0 + FACT_NB * c) + (int64_t)(k0 + FACT_NB * c) * ldl, ldl, b, tiny_k, sh, Wt + c * 1024, Wt + 4096 + FACT_NB * c, lmax, dmax,
-                                  npert, c < 3 ? Wb + c * 1024 : nullptr, Dsh + FACT_NB * c);
-        if (threadIdx.x < b) piv[(int64_t)k * npiv + f.c0 + k0 + FACT_NB * c + threadIdx.x] = k0 + FACT_NB * c + threadIdx.x;
-        __syncthreads();                   // W_c, the pivots and L\U of block c: visible to the next block row
         prof_stamp(1 + 4 * c + 3, k0);
     }
     if (npert > 0) atomicAdd(nperturb + k, npert);
@@ -1608,22 +1096,12 @@ __global__ __launch_bounds__(256, 2) void k_lscale_grp2(const FrontD* __restrict
 void launch_diag_grp(hipStream_t st, const DevSym& S, const int* list, int nlist, int k0, cz* fact, int64_t fs, int* piv,
                      const double* tiny, int* nperturb, unsigned long long* growth, cz* wscr, int64_t wstride, int K) {
     if (nlist <= 0) return;
-    // FEASTHIP_DIAG2=1: the LDS-resident variant.  Its substitutions and updates take 33 us per group instead of 57 (and do not slow down
-    // next to the other stream's product), but its 256-thread elimination of the 32 x 32 blocks takes 53 us per block against 20 with 512
-    // threads (tools/diag_phases.py), and with 512 threads the two working waves spill: off until the block elimination is rewritten.
-    const char* e2 = getenv("FEASTHIP_DIAG2");                 // read per launch (tests switch it)
-    if (e2 && atoi(e2) == 1) {
-        static std::atomic<uint64_t> attr_seen{0};
-        if (first_on_this_device(attr_seen)) (void)hipFuncSetAttribute((const void*)k_diag_grp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DG2_LDS_BYTES);
-        hipLaunchKernelGGL(k_diag_grp2, dim3(nlist, K), dim3(DIAG2_NT), DG2_LDS_BYTES, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
-        return;
-    }
-    // FEASTHIP_LU32=1: the round-3 elimination of the 32 x 32 blocks (four values per thread, two published rows); 3: the one-slot form on 256
-    // threads (measured slower in the factorisation: C3 93.5 against 90.5 ms with everything else equal; 2, the default, 91.5 -> 90.5)
+    // FEASTHIP_LU32=1: the round-3 elimination of the 32 x 32 blocks (four values per thread, two published rows).  (A 256-thread form of
+    // the one-slot elimination and a k_diag_grp with the group's L rows, W blocks and pivots resident in LDS -- substitutions 33 us instead
+    // of 57-78 next to the other stream's product, but only 256 threads for the elimination: 53 us per block against 18 -- were built
+    // and measured slower in the factorisation, C3 93.5 / 85.4 against 78.9 ms: commits 3f24d11, c55dc22.)
     const char* e3 = getenv("FEASTHIP_LU32");
-    const int luv = e3 ? atoi(e3) : 2;
-    if (luv == 1) hipLaunchKernelGGL(k_diag_grp<1>, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
-    else if (luv == 3) hipLaunchKernelGGL(k_diag_grp<3>, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
+    if (e3 && atoi(e3) == 1) hipLaunchKernelGGL(k_diag_grp<1>, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
     else hipLaunchKernelGGL(k_diag_grp<2>, dim3(nlist, K), dim3(DIAG_NT), 0, st, S.fr, list, k0, fact, fs, piv, S.n, tiny, nperturb, growth, wscr, wstride);
 }
 

@@ -1,5 +1,5 @@
 """(needs a library built with `make PROF=1` in feastsolver.jl_amd/csrc)  Phase times of the diagonal-block kernel of the elimination without interchanges (workgroup (0, 0) of its LAST launch), dense symmetric
-n x n, one unit, nothing else on the GPU: python tools/diag_phases.py [n]   (FEASTHIP_DIAG2=0: the round-3 kernel)"""
+n x n, one unit, nothing else on the GPU: python tools/diag_phases.py [n]"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,7 +20,7 @@ pkg.finalize(F)
 t = np.array(out[:17], dtype=np.float64) * 0.01     # us
 u = np.array(out[40:44], dtype=np.float64) * 0.01
 print(f"  last 32 x 32 block: load + first publish {u[1] - u[0]:.1f}, 32 steps {u[2] - u[1]:.1f}, outputs {u[3] - u[2]:.1f} us")
-print(f"n={n} DIAG2={os.environ.get('FEASTHIP_DIAG2', '1')}: total {t[16] - t[0]:.1f} us")
+print(f"n={n} LU32={os.environ.get('FEASTHIP_LU32', '2')}: total {t[16] - t[0]:.1f} us")
 print(f"  block 0: lu32 {t[4] - t[0]:.1f}")
 for c in (1, 2, 3):
     b = 1 + 4 * c

@@ -15,7 +15,7 @@ lib.feasthip_debug_prof(2 + k0, None)
 h.factorize()
 out = (C.c_ulonglong * 64)(); lib.feasthip_debug_prof(0, C.cast(out, C.c_void_p))
 t = np.array(out[:17], dtype=np.float64) * 0.01
-print(f"C3 root front, group at column {k0}, DIAG2={os.environ.get('FEASTHIP_DIAG2', '0')} LU32={os.environ.get('FEASTHIP_LU32', '2')}: total {t[16] - t[0]:.1f} us (factor_ms {h.stats()['factor_ms']:.1f})")
+print(f"C3 root front, group at column {k0}, LU32={os.environ.get('FEASTHIP_LU32', '2')}: total {t[16] - t[0]:.1f} us (factor_ms {h.stats()['factor_ms']:.1f})")
 print(f"  block 0: lu32 {t[4] - t[0]:.1f}")
 for c in (1, 2, 3):
     b = 1 + 4 * c
