@@ -10,14 +10,58 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <mutex>
 #include <numeric>
 #include <queue>
 #include <thread>
 
 namespace feasthip {
+
+int host_cpu_budget();      // symbolic.cpp
+
+// ---- host thread pool of the analysis (ordering.hpp: run_parts) ----
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    int nthreads = 0;
+    HostPool() {
+        nthreads = std::max(0, std::min(15, host_cpu_budget() - 1));
+        if (const char* e = getenv("FEASTHIP_HOST_THREADS")) nthreads = std::max(0, std::min(63, atoi(e) - 1));
+        for (int i = 0; i < nthreads; ++i)
+            std::thread([this]() {
+                for (;;) {
+                    std::function<void()> task;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this] { return !q.empty(); });
+                        task = std::move(q.front());
+                        q.pop_front();
+                    }
+                    task();
+                }
+            }).detach();
+    }
+};
+// never destroyed (its threads wait on it until the process ends); a forked child has the object but not the threads: pool_size()
+// then promises helpers that never come, and run_parts' caller does every part itself
+HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }
+}  // namespace
+
+void pool_submit(std::function<void()> task) {
+    HostPool& P = host_pool();
+    { std::lock_guard<std::mutex> lk(P.mu); P.q.push_back(std::move(task)); }
+    P.cv.notify_one();
+}
+int pool_size() { return host_pool().nthreads; }
+
 namespace {
 
 struct XorShift {
@@ -26,56 +70,85 @@ struct XorShift {
     uint32_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
 };
 
+constexpr int NPART = ND_NPART;
+static const int PAR_MIN_N = getenv("FEASTHIP_ND_PARMIN") ? atoi(getenv("FEASTHIP_ND_PARMIN")) : ND_PAR_MIN_N;
+
 // one coarsening step; returns false if the graph hardly shrinks
 bool coarsen(const WGraph& g, WGraph& c, std::vector<int>& cmap, XorShift& rng) {
-    int n = g.n;
+    const int n = g.n;
+    const int nparts = n >= PAR_MIN_N ? NPART : 1;
+    const int* __restrict gx = g.xadj.data(); const int* __restrict ga = g.adj.data(); const int* __restrict ge = g.ewgt.data();
     // Heavy-edge matching.  Vertices are visited in index order (the adjacency arrays stream through the cache; a random visiting
     // order costs a cache miss per vertex on the fine levels) and ties between equally heavy edges are broken at random, which is
-    // what keeps the matching isotropic on stencil graphs whose edges all weigh the same.
-    cmap.assign(n, -1);
-    std::vector<int> mate(n);          // second member of the coarse vertex whose first member is v (or -1), indexed by coarse id
-    int nc = 0;
-    std::vector<int> first(n);
-    for (int v = 0; v < n; ++v) {
-        if (cmap[v] >= 0) continue;
-        int best = -1, bw = -1, ties = 0;
-        for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) {
-            int w = g.adj[t];
-            if (cmap[w] >= 0 || w == v) continue;
-            int e = g.ewgt[t];
-            if (e > bw) { bw = e; best = w; ties = 1; }
-            else if (e == bw && rng.next() % (uint32_t)(++ties) == 0) best = w;
+    // what keeps the matching isotropic on stencil graphs whose edges all weigh the same.  Large graphs: every range of vertices is
+    // matched within itself by its own thread (own random stream, drawn here in range order), then one serial pass over the vertices
+    // still free matches them across the range borders -- on a graph whose numbering has no locality that second pass does all the work.
+    const bool ctrace = n > 90000 && getenv("FEASTHIP_ANALYZE_TRACE");
+    auto ct0 = std::chrono::steady_clock::now();
+    auto clap = [&](const char* nm) { if (!ctrace) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "      [coarsen n=%d] %-14s %.2f ms\n", n, nm, std::chrono::duration<double, std::milli>(t - ct0).count()); ct0 = t; };
+    ivec mt(n);                            // partner of v; v itself for a vertex that stays single
+    std::fill(mt.begin(), mt.end(), -1);
+    int* __restrict mate_of = mt.data();
+    uint64_t seeds[NPART];
+    for (int part = 0; part < nparts; ++part) seeds[part] = ((uint64_t)rng.next() << 32) | rng.next();
+    auto match_range = [&](int lo, int hi, int v0, int v1, XorShift& r, bool final_pass) {
+        for (int v = v0; v < v1; ++v) {
+            if (mate_of[v] >= 0) continue;
+            int best = -1, bw = -1;
+            uint32_t ties = 0;
+            for (int t = gx[v]; t < gx[v + 1]; ++t) {
+                const int w = ga[t];
+                if (w < lo || w >= hi || mate_of[w] >= 0 || w == v) continue;
+                const int e = ge[t];
+                if (e > bw) { bw = e; best = w; ties = 1; }
+                else if (e == bw && (((uint64_t)r.next() * (uint64_t)(++ties)) >> 32) == 0) best = w;      // uniform among the ties (reservoir)
+            }
+            if (best >= 0) { mate_of[v] = best; mate_of[best] = v; }
+            else if (final_pass) mate_of[v] = v;
         }
+    };
+    if (nparts > 1) {
+        run_parts(nparts, [&](int part) {
+            const int v0 = (int)((int64_t)n * part / nparts), v1 = (int)((int64_t)n * (part + 1) / nparts);
+            XorShift r(seeds[part]);
+            match_range(v0, v1, v0, v1, r, false);
+        });
+    }
+    clap("match ranges");
+    { XorShift r(seeds[0] ^ 0x5bd1e995u); match_range(0, n, 0, n, r, true); }
+    clap("match rest");
+    cmap.resize(n);
+    ivec first(n), mate(n);                // members of the coarse vertices (second one or -1), indexed by coarse id
+    int nc = 0;
+    for (int v = 0; v < n; ++v) {
+        const int w = mate_of[v];
+        if (w < v) continue;               // second member: numbered with its partner
         cmap[v] = nc;
-        if (best >= 0) cmap[best] = nc;
-        first[nc] = v; mate[nc] = best;
+        if (w != v) cmap[w] = nc;
+        first[nc] = v; mate[nc] = w != v ? w : -1;
         ++nc;
     }
+    clap("coarse ids");
     if (nc > 0.92 * n) return false;
     c.n = nc;
     c.vwgt.resize(nc);
     c.xadj.resize(nc + 1);
-    // Contraction: coarse vertex cv gets the merged adjacency of its members.  Large graphs are cut into NPART contiguous
-    // ranges of coarse vertices that are built by separate threads into private arrays and concatenated in order, so the result
-    // does not depend on the number of threads or on their timing (NPART is fixed).
-    constexpr int NPART = 8;
-    const int nparts = n >= 16384 ? NPART : 1;
-    std::vector<std::vector<int>> padj(nparts), pew(nparts);
-    std::vector<int> cdeg(nc);
-    const int* __restrict gx = g.xadj.data(); const int* __restrict ga = g.adj.data(); const int* __restrict ge = g.ewgt.data();
+    // Contraction: coarse vertex cv gets the merged adjacency of its members.  The lists are built in place at offsets that leave
+    // room for every member's whole list (large graphs: ranges of coarse vertices on separate threads), then moved down over the gaps.
+    ivec ub(nc + 1);
+    ub[0] = 0;
+    for (int cv = 0; cv < nc; ++cv) ub[cv + 1] = ub[cv] + (gx[first[cv] + 1] - gx[first[cv]]) + (mate[cv] >= 0 ? gx[mate[cv] + 1] - gx[mate[cv]] : 0);
+    c.adj.resize(ub[nc]); c.ewgt.resize(ub[nc]);
+    int* __restrict ca = c.adj.data(); int* __restrict ce = c.ewgt.data();
     const int* __restrict cm = cmap.data();
-    auto build = [&](int part) {
+    run_parts(nparts, [&](int part) {
         const int c0 = (int)((int64_t)nc * part / nparts), c1 = (int)((int64_t)nc * (part + 1) / nparts);
-        int64_t cap = 0;
-        for (int cv = c0; cv < c1; ++cv) { cap += gx[first[cv] + 1] - gx[first[cv]]; if (mate[cv] >= 0) cap += gx[mate[cv] + 1] - gx[mate[cv]]; }
-        std::vector<int>& A = padj[part]; std::vector<int>& E = pew[part];
-        A.resize(cap); E.resize(cap);
-        std::vector<int> pos(nc, -1);
-        int* __restrict ca = A.data(); int* __restrict ce = E.data(); int* __restrict ps = pos.data();
-        int len = 0;
+        std::unique_ptr<int[]> pos(new int[nc]);
+        int* __restrict ps = pos.get();
+        std::fill(ps, ps + nc, -1);
         for (int cv = c0; cv < c1; ++cv) {
-            const int start = len;
-            int vw = 0;
+            const int start = ub[cv];
+            int len = start, vw = 0;
             const int mem[2] = {first[cv], mate[cv]};
             for (int q = 0; q < 2; ++q) {
                 const int v = mem[q];
@@ -90,27 +163,18 @@ bool coarsen(const WGraph& g, WGraph& c, std::vector<int>& cmap, XorShift& rng) 
                 }
             }
             c.vwgt[cv] = vw;
-            cdeg[cv] = len - start;
+            c.xadj[cv + 1] = len - start;           // length for now
         }
-        A.resize(len); E.resize(len);
-    };
-    if (nparts > 1) {
-        std::vector<std::thread> th;
-        for (int part = 1; part < nparts; ++part) th.emplace_back(build, part);
-        build(0);
-        for (auto& t : th) t.join();
-    } else build(0);
+    });
+    clap("contract");
     c.xadj[0] = 0;
-    for (int cv = 0; cv < nc; ++cv) c.xadj[cv + 1] = c.xadj[cv] + cdeg[cv];
-    c.adj.resize(c.xadj[nc]); c.ewgt.resize(c.xadj[nc]);
-    {
-        int64_t off = 0;
-        for (int part = 0; part < nparts; ++part) {
-            std::copy(padj[part].begin(), padj[part].end(), c.adj.begin() + off);
-            std::copy(pew[part].begin(), pew[part].end(), c.ewgt.begin() + off);
-            off += (int64_t)padj[part].size();
-        }
+    for (int cv = 0; cv < nc; ++cv) {
+        const int len = c.xadj[cv + 1], dst = c.xadj[cv], src = ub[cv];
+        if (dst != src) { std::memmove(ca + dst, ca + src, (size_t)len * sizeof(int)); std::memmove(ce + dst, ce + src, (size_t)len * sizeof(int)); }
+        c.xadj[cv + 1] = dst + len;
     }
+    c.adj.resize(c.xadj[nc]); c.ewgt.resize(c.xadj[nc]);
+    clap("compact");
     return true;
 }
 
@@ -121,13 +185,21 @@ struct FM {
     int64_t w[2] = {0, 0}, total = 0, cut = 0;
     FM(const WGraph& g_, std::vector<int>& p) : g(g_), part(p), id(g_.n), ed(g_.n) { recompute(); }
     void recompute() {
+        const int nparts = g.n >= PAR_MIN_N ? NPART : 1;
+        int64_t pw[NPART][2], pc[NPART];
+        run_parts(nparts, [&](int pt) {
+            const int v0 = (int)((int64_t)g.n * pt / nparts), v1 = (int)((int64_t)g.n * (pt + 1) / nparts);
+            int64_t w0 = 0, w1 = 0, cc = 0;
+            for (int v = v0; v < v1; ++v) {
+                (part[v] ? w1 : w0) += g.vwgt[v];
+                int i = 0, e = 0;
+                for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) (part[g.adj[t]] == part[v] ? i : e) += g.ewgt[t];
+                id[v] = i; ed[v] = e; cc += e;
+            }
+            pw[pt][0] = w0; pw[pt][1] = w1; pc[pt] = cc;
+        });
         w[0] = w[1] = 0; cut = 0;
-        for (int v = 0; v < g.n; ++v) {
-            w[part[v]] += g.vwgt[v];
-            int i = 0, e = 0;
-            for (int t = g.xadj[v]; t < g.xadj[v + 1]; ++t) (part[g.adj[t]] == part[v] ? i : e) += g.ewgt[t];
-            id[v] = i; ed[v] = e; cut += e;
-        }
+        for (int pt = 0; pt < nparts; ++pt) { w[0] += pw[pt][0]; w[1] += pw[pt][1]; cut += pc[pt]; }
         cut /= 2;
         total = w[0] + w[1];
     }
@@ -156,8 +228,10 @@ struct FM {
         while (top[side] >= 0 && bhead[side][top[side]] < 0) --top[side];
         return top[side] >= 0 ? bhead[side][top[side]] : -1;
     }
+    double t_init = 0, t_move = 0, t_roll = 0; long long n_moves = 0, n_kept = 0;
     bool pass(double maxfrac) {
         int n = g.n;
+        auto tp0 = std::chrono::steady_clock::now();
         int64_t maxw = (int64_t)(maxfrac * total) + 1;
         if (bnext.empty()) {
             for (int v = 0; v < n; ++v) gmax = std::max(gmax, id[v] + ed[v]);
@@ -171,10 +245,12 @@ struct FM {
         std::vector<char> locked(n, 0);
         for (int v = 0; v < n; ++v) if (ed[v] > 0 || g.xadj[v + 1] == g.xadj[v]) bucket_insert(v, part[v], ed[v] - id[v]);
         std::vector<int> moved;
+        auto tp1 = std::chrono::steady_clock::now();
         int64_t bestcut = cut, curcut = cut;
         int64_t bestimb = std::max(w[0], w[1]);
         int bestidx = 0;
-        int limit = std::max(60, std::min(n / 20, 800));
+        static const int limit_cap = getenv("FEASTHIP_ND_FMLIMIT") ? atoi(getenv("FEASTHIP_ND_FMLIMIT")) : 800;
+        int limit = std::max(std::min(60, limit_cap), std::min(n / 20, limit_cap));
         while (true) {
             int from;
             const int t0 = bucket_top(0), t1 = bucket_top(1);
@@ -223,6 +299,8 @@ struct FM {
             else if ((int)moved.size() - bestidx > limit) break;
         }
         // rollback
+        auto tp2 = std::chrono::steady_clock::now();
+        n_moves += (long long)moved.size(); n_kept += bestidx;
         for (int i = (int)moved.size() - 1; i >= bestidx; --i) {
             int v = moved[i];
             int from = part[v];
@@ -235,6 +313,8 @@ struct FM {
             }
         }
         cut = bestcut;
+        auto tp3 = std::chrono::steady_clock::now();
+        t_init += std::chrono::duration<double, std::milli>(tp1 - tp0).count(); t_move += std::chrono::duration<double, std::milli>(tp2 - tp1).count(); t_roll += std::chrono::duration<double, std::milli>(tp3 - tp2).count();
         return bestidx > 0;
     }
 };
@@ -366,7 +446,9 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
     while (level(nlev - 1).n > 160 && nlev < 40) {
         WGraph c;
         std::vector<int> cmap;
+        auto tc0 = std::chrono::steady_clock::now();
         if (!coarsen(level(nlev - 1), c, cmap, rng)) break;
+        if (trace) fprintf(stderr, "[feasthip nd n=%d]   coarsen level %d: %d -> %d vertices, %zu edges, %.2f ms\n", n, nlev - 1, level(nlev - 1).n, c.n, c.adj.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
         coarse.push_back(std::move(c));
         cmaps.push_back(std::move(cmap));
         ++nlev;
@@ -384,8 +466,13 @@ bool multilevel_separator(const WGraph& g0, std::vector<int>& label, uint64_t se
             for (int v = 0; v < level(l).n; ++v) fine[v] = part[cmaps[l][v]];
             part.swap(fine);
         }
+        auto tf0 = std::chrono::steady_clock::now();
         FM fm(level(l), part);
-        for (int it = 0; it < 8; ++it) if (!fm.pass(0.54)) break;
+        auto tf1 = std::chrono::steady_clock::now();
+        int npass = 0;
+        static const double fm_stop = getenv("FEASTHIP_ND_FMSTOP") ? atof(getenv("FEASTHIP_ND_FMSTOP")) : 0.0;
+        for (int it = 0; it < 8; ++it) { ++npass; const int64_t c0 = fm.cut; const bool imp = fm.pass(0.54); if (!imp || (double)(c0 - fm.cut) < fm_stop * (double)c0) break; }
+        if (trace) fprintf(stderr, "[feasthip nd n=%d]   FM level %d (%d vertices): setup %.2f ms, %d passes %.2f ms (init %.2f moves %.2f rollback %.2f; %lld moves, %lld kept), cut %lld\n", n, l, level(l).n, std::chrono::duration<double, std::milli>(tf1 - tf0).count(), npass, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count(), fm.t_init, fm.t_move, fm.t_roll, fm.n_moves, fm.n_kept, (long long)fm.cut);
     }
     lap("FM refinement");
     std::vector<char> in_sep;

@@ -74,12 +74,7 @@ Graph symmetrize(int n, const int64_t* colptr, const int64_t* rowidx) {
                 cnt[j + 1] = c;
             }
         };
-        {
-            std::vector<std::thread> pool;
-            for (int ti = 1; ti < nth; ++ti) pool.emplace_back(check, ti);
-            check(0);
-            for (auto& th : pool) th.join();
-        }
+        run_parts(nth, check);
         bool sym = true;
         for (char b : bad) if (b) sym = false;
         if (sym) {
@@ -93,10 +88,7 @@ Graph symmetrize(int n, const int64_t* colptr, const int64_t* rowidx) {
                     for (int64_t t = colptr[j]; t < colptr[j + 1]; ++t) if (rowidx[t] != j) g.adj[o++] = (int)rowidx[t];
                 }
             };
-            std::vector<std::thread> pool;
-            for (int ti = 1; ti < nth; ++ti) pool.emplace_back(fill, ti);
-            fill(0);
-            for (auto& th : pool) th.join();
+            run_parts(nth, fill);
             return g;
         }
     }
@@ -139,12 +131,7 @@ Graph symmetrize(int n, const int64_t* colptr, const int64_t* rowidx) {
             g.xadj[j + 1] = (int64_t)(out.size() - start);       // length for now, offsets below
         }
     };
-    {
-        std::vector<std::thread> pool;
-        for (int ti = 1; ti < nth; ++ti) pool.emplace_back(merge_range, ti);
-        merge_range(0);
-        for (auto& th : pool) th.join();
-    }
+    run_parts(nth, merge_range);
     for (int j = 0; j < n; ++j) g.xadj[j + 1] += g.xadj[j];
     g.adj.resize(g.xadj[n]);
     {
@@ -168,11 +155,8 @@ Graph permute_graph(const Graph& g, const std::vector<int>& perm, const std::vec
             std::sort(h.adj.begin() + h.xadj[j], h.adj.begin() + h.xadj[j + 1]);
         }
     };
-    const int nth = g.n >= 20000 ? std::max(1, std::min(8, host_cpu_budget() / 2)) : 1;
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(fill, (int)((int64_t)g.n * t / nth), (int)((int64_t)g.n * (t + 1) / nth));
-    fill(0, (int)((int64_t)g.n / nth));
-    for (auto& th : pool) th.join();
+    const int nth = g.n >= 20000 ? 8 : 1;
+    run_parts(nth, [&](int t) { fill((int)((int64_t)g.n * t / nth), (int)((int64_t)g.n * (t + 1) / nth)); });
     return h;
 }
 
@@ -187,7 +171,13 @@ public:
     std::vector<int> run() {
         std::vector<int> all(g_.n);
         std::iota(all.begin(), all.end(), 0);
+        t_start_ = std::chrono::steady_clock::now();
         dissect(all, 0);
+        if (getenv("FEASTHIP_ANALYZE_TRACE")) {
+            fprintf(stderr, "[feasthip nd] last separator of depth d found at (ms):");
+            for (int d = 0; d < 24 && depth_end_us_[d].load() > 0; ++d) fprintf(stderr, " %d:%.1f", d, depth_end_us_[d].load() * 1e-3);
+            fprintf(stderr, "; all leaves ordered at %.1f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start_).count());
+        }
         return order_;
     }
 
@@ -201,6 +191,8 @@ private:
     int par_depth_ = host_cpu_budget() >= 16 ? 6 : host_cpu_budget() >= 8 ? 5 : host_cpu_budget() >= 4 ? 4 : 3;
     std::vector<int> part_, vis_, lvl_, order_, loc_;
     std::atomic<int> next_id_{0}, stamp_{0};          // sub-problems run on disjoint vertex sets, possibly in parallel
+    std::chrono::steady_clock::time_point t_start_;
+    std::atomic<long long> depth_end_us_[24] = {};    // (trace) when the last separator of each recursion depth was found
     struct Bfs { std::vector<int> queue, lptr; int stamp = 0; };
 
     struct Split {
@@ -216,13 +208,31 @@ private:
         w.xadj.assign(m + 1, 0);
         w.vwgt.assign(m, 1);
         for (int i = 0; i < m; ++i) loc_[verts[i]] = i;
-        for (int i = 0; i < m; ++i) {
-            int v = verts[i];
-            for (int64_t t = g_.xadj[v]; t < g_.xadj[v + 1]; ++t) if (part_[g_.adj[t]] == id) w.adj.push_back(loc_[g_.adj[t]]);
-            w.xadj[i + 1] = (int)w.adj.size();
+        {   // induced subgraph: degrees, offsets, lists -- ranges of vertices on host threads for the large subgraphs at the top
+            const int nparts = m >= ND_PAR_MIN_N ? ND_NPART : 1;
+            run_parts(nparts, [&](int pt) {
+                const int i0 = (int)((int64_t)m * pt / nparts), i1 = (int)((int64_t)m * (pt + 1) / nparts);
+                for (int i = i0; i < i1; ++i) {
+                    const int v = verts[i];
+                    int d = 0;
+                    for (int64_t t = g_.xadj[v]; t < g_.xadj[v + 1]; ++t) d += part_[g_.adj[t]] == id;
+                    w.xadj[i + 1] = d;
+                }
+            });
+            for (int i = 0; i < m; ++i) w.xadj[i + 1] += w.xadj[i];
+            w.adj.resize(w.xadj[m]);
+            w.ewgt.resize(w.xadj[m]);
+            run_parts(nparts, [&](int pt) {
+                const int i0 = (int)((int64_t)m * pt / nparts), i1 = (int)((int64_t)m * (pt + 1) / nparts);
+                for (int i = i0; i < i1; ++i) {
+                    const int v = verts[i];
+                    int o = w.xadj[i];
+                    for (int64_t t = g_.xadj[v]; t < g_.xadj[v + 1]; ++t) if (part_[g_.adj[t]] == id) { w.adj[o] = loc_[g_.adj[t]]; w.ewgt[o] = 1; ++o; }
+                }
+            });
         }
-        w.ewgt.assign(w.adj.size(), 1);
-        int trials = m >= 20000 ? 2 : 1;     // the top separators dominate the fill: try harder there
+        static const int trials2_min = getenv("FEASTHIP_ND_TRIALS2_MIN") ? atoi(getenv("FEASTHIP_ND_TRIALS2_MIN")) : 20000;
+        int trials = m >= trials2_min ? 2 : 1;     // the top separators dominate the fill: try harder there
         // the trials are independent (fixed seeds): run them side by side, then judge them in trial order so that the
         // outcome does not depend on thread timing
         std::vector<std::vector<int>> labels(trials);
@@ -376,6 +386,11 @@ private:
         // their multilevel separator a second time, serially, with the same seed and the same result -- 57 ms of every untraced analysis)
         if (tr_) fprintf(stderr, "[feasthip nd depth %d m=%d] bfs candidates %.1f ms, + wait for multilevel %.1f ms\n", depth, m,
                          std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
+        if (depth < 24) {
+            const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_start_).count();
+            long long cur = depth_end_us_[depth].load();
+            while (us > cur && !depth_end_us_[depth].compare_exchange_weak(cur, us)) {}
+        }
         if (best.s.empty() || best.a.empty() || best.b.empty()) { emit(verts, lo); return; }
         verts.clear(); verts.shrink_to_fit();
         int na = (int)best.a.size(), nb = (int)best.b.size();
