@@ -141,8 +141,7 @@ Graph symmetrize(int n, const int64_t* colptr, const int64_t* rowidx) {
     return g;
 }
 
-Graph permute_graph(const Graph& g, const std::vector<int>& perm, const std::vector<int>& iperm) {
-    Graph h;
+void permute_graph(const Graph& g, const std::vector<int>& perm, const std::vector<int>& iperm, Graph& h) {      // (h's arrays are reused: the analysis permutes three times)
     h.n = g.n;
     h.xadj.assign(g.n + 1, 0);
     h.adj.resize(g.adj.size());
@@ -151,13 +150,11 @@ Graph permute_graph(const Graph& g, const std::vector<int>& perm, const std::vec
     auto fill = [&](int j0, int j1) {
         for (int j = j0; j < j1; ++j) {
             int64_t o = h.xadj[j];
-            for (int64_t t = g.xadj[perm[j]]; t < g.xadj[perm[j] + 1]; ++t) h.adj[o++] = iperm[g.adj[t]];
-            std::sort(h.adj.begin() + h.xadj[j], h.adj.begin() + h.xadj[j + 1]);
+            for (int64_t t = g.xadj[perm[j]]; t < g.xadj[perm[j] + 1]; ++t) h.adj[o++] = iperm[g.adj[t]];      // (unsorted: no reader needs the order, and sorting 97 k short lists was most of the 2.5 ms a call took)
         }
     };
     const int nth = g.n >= 20000 ? 8 : 1;
     run_parts(nth, [&](int t) { fill((int)((int64_t)g.n * t / nth), (int)((int64_t)g.n * (t + 1) / nth)); });
-    return h;
 }
 
 // ---------------------------------------------------------------------------
@@ -342,8 +339,18 @@ private:
         Bfs B;
         std::vector<int>& queue_ = B.queue;
         std::vector<int>& lptr_ = B.lptr;
+        // large subgraphs: the multilevel candidate is computed on its own thread while this one walks the BFS level structures
+        // (disjoint scratch: loc_ vs vis_/lvl_), the first of which also tells whether the subgraph is connected -- if it is not, the
+        // candidate is dropped; merged below in the same order as the serial code
+        Split best, best_ml;
+        const uint64_t ml_seed = (uint64_t)lo * 2654435761ull + (uint64_t)m;      // independent of thread timing
+        std::thread tml;
+        static const int ml_async_min = getenv("FEASTHIP_ND_ASYNC_MIN") ? atoi(getenv("FEASTHIP_ND_ASYNC_MIN")) : 20000;
+        const bool ml_async = m >= ml_async_min;
+        if (ml_async) tml = std::thread([&]() { multilevel_candidate(verts, id, ml_seed, best_ml); });
         bfs(verts[0], id, B);
         if ((int)queue_.size() < m) {   // disconnected: order components independently
+            if (ml_async) tml.join();
             std::vector<int> comp(queue_), rest;
             int st = B.stamp;
             for (int v : verts) if (vis_[v] != st) rest.push_back(v);
@@ -355,13 +362,6 @@ private:
         }
         const bool tr_ = depth <= 2 && getenv("FEASTHIP_ANALYZE_TRACE");
         auto t_a = std::chrono::steady_clock::now();
-        Split best, best_ml;
-        // large subgraphs: the multilevel candidate is computed on its own thread while this one walks the BFS
-        // level structures (disjoint scratch: loc_ vs vis_/lvl_); merged below in the same order as the serial code
-        const uint64_t ml_seed = (uint64_t)lo * 2654435761ull + (uint64_t)m;      // independent of thread timing
-        std::thread tml;
-        const bool ml_async = m >= 20000;
-        if (ml_async) tml = std::thread([&]() { multilevel_candidate(verts, id, ml_seed, best_ml); });
         int height = (int)lptr_.size() - 1;
         candidate(m, best, B);
         for (int it = 0; it < 6; ++it) {
@@ -495,6 +495,7 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         tph = t1;
     };
     phase("A + A^T");
+    auto sub = [&](const char* name) { phase(name); };
     // ---- 1. fill-reducing ordering --------------------------------------
     std::vector<int> perm(n), iperm(n);
     if (opt.ordering == 1) {
@@ -507,19 +508,21 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         if (perm[k] < 0 || perm[k] >= n) return "internal: ordering incomplete";
         iperm[perm[k]] = k;
     }
-    Graph h = permute_graph(g, perm, iperm);
-
     phase("ordering");
+    Graph h;
+    permute_graph(g, perm, iperm, h);
+    sub("  permuted graph");
     // ---- 2. elimination tree (Liu) + postorder ---------------------------
     std::vector<int> parent(n, -1), anc(n, -1);
     for (int j = 0; j < n; ++j)
         for (int64_t t = h.xadj[j]; t < h.xadj[j + 1]; ++t) {
             int i = h.adj[t];
-            if (i >= j) break;
+            if (i >= j) continue;
             int r = i;
             while (anc[r] != -1 && anc[r] != j) { int nx = anc[r]; anc[r] = j; r = nx; }
             if (anc[r] == -1) { anc[r] = j; parent[r] = j; }
         }
+    sub("  etree");
     {   // postorder (iterative DFS, children visited in increasing index)
         std::vector<int> head(n, -1), next(n, -1), post;
         post.reserve(n);
@@ -545,10 +548,11 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         perm.swap(perm2);
         parent.swap(parent2);
         for (int k = 0; k < n; ++k) iperm[perm[k]] = k;
-        h = permute_graph(g, perm, iperm);
+        sub("  postorder");
+        permute_graph(g, perm, iperm, h);
     }
 
-    phase("etree + postorder");
+    phase("  permuted graph 2");
     // ---- 3. column counts (Gilbert, Ng, Peyton: skeleton leaves + least common ancestors, O(nnz(A) alpha)) ----
     // cc[j] = number of off-diagonal entries of column j of L.  The graph is postordered, so post(k) = k.
     std::vector<int> cc(n, 0), nchild(n, 0);
@@ -605,62 +609,74 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
     std::vector<int64_t> P(nf), U(nf);
     std::vector<double> Z(nf, 0.0);
     std::vector<char> dead(nf, 0);
-    std::vector<std::vector<int>> kids(nf), members(nf);
+    // children and members (fundamental supernodes merged into a node) as singly linked lists in flat arrays with tail pointers: a merge
+    // appends the child's lists in O(1) (vectors of vectors cost 60 k small allocations here: 3.7 of the analysis' milliseconds)
+    std::vector<int> kid_head(nf, -1), kid_tail(nf, -1), kid_next(nf, -1), mem_head(nf), mem_tail(nf), mem_next(nf, -1);
     for (int s = 0; s < nf; ++s) {
         P[s] = fstart[s + 1] - fstart[s];
         U[s] = cc[fstart[s + 1] - 1];
-        members[s].push_back(s);
+        mem_head[s] = mem_tail[s] = s;
     }
-    for (int s = 0; s < nf; ++s) if (fparent[s] >= 0) kids[fparent[s]].push_back(s);
+    for (int s = 0; s < nf; ++s) {
+        const int ps = fparent[s];
+        if (ps < 0) continue;
+        if (kid_tail[ps] < 0) kid_head[ps] = s; else kid_next[kid_tail[ps]] = s;
+        kid_tail[ps] = s;
+    }
     for (int s = 0; s < nf; ++s) {   // children have smaller indices (postorder) and are final by now
-        bool changed = true;
-        while (changed) {
-            changed = false;
-            // candidate with the fewest new zeros first
-            int bi = -1;
+        for (;;) {
+            // candidate with the fewest new zeros first (the first of them in list order)
+            int bc = -1, bprev = -1;
             double bz = 1e300;
-            for (size_t q = 0; q < kids[s].size(); ++q) {
-                int c = kids[s][q];
+            for (int c = kid_head[s], prev = -1; c >= 0; prev = c, c = kid_next[c]) {
                 double nz = (double)P[c] * (double)(P[s] + U[s] - U[c]);
-                if (nz < bz) { bz = nz; bi = (int)q; }
+                if (nz < bz) { bz = nz; bc = c; bprev = prev; }
             }
-            if (bi < 0) break;
-            int c = kids[s][bi];
+            if (bc < 0) break;
+            const int c = bc;
             int64_t pn = P[s] + P[c];
             double zn = Z[s] + Z[c] + bz;
             double tot = (double)pn * (pn + 1) / 2.0 + (double)pn * (double)U[s];
             double zf = zn / tot;
             bool ok = pn <= opt.relax_small || (pn <= opt.relax_mid && zf <= opt.zmid) || zf <= opt.zbig;
             if (!ok) break;
-            // merge c into s
+            // merge c into s: c leaves the list of children, its own children and members are appended
             P[s] = pn;
             Z[s] = zn;
             dead[c] = 1;
-            kids[s].erase(kids[s].begin() + bi);
-            kids[s].insert(kids[s].end(), kids[c].begin(), kids[c].end());
-            members[s].insert(members[s].end(), members[c].begin(), members[c].end());
-            kids[c].clear(); members[c].clear();
-            changed = true;
+            if (bprev < 0) kid_head[s] = kid_next[c]; else kid_next[bprev] = kid_next[c];
+            if (kid_tail[s] == c) kid_tail[s] = bprev;
+            kid_next[c] = -1;
+            if (kid_head[c] >= 0) {
+                if (kid_tail[s] < 0) kid_head[s] = kid_head[c]; else kid_next[kid_tail[s]] = kid_head[c];
+                kid_tail[s] = kid_tail[c];
+                kid_head[c] = kid_tail[c] = -1;
+            }
+            mem_next[mem_tail[s]] = mem_head[c];
+            mem_tail[s] = mem_tail[c];
         }
     }
+    sub("  amalgamation merges");
     // final numbering: DFS over the amalgamated tree, children first
+    std::vector<int> sn_parent_new;         // parent of every final supernode (known from the amalgamated tree before any row structure is)
     {
         std::vector<int> newpos;   // newpos[k] = old (postordered) column placed at k
         newpos.reserve(n);
-        std::vector<int> sstart;
-        std::vector<std::pair<int, size_t>> stack;
+        std::vector<int> sstart, newid(nf, -1), cols;
+        std::vector<std::pair<int, int>> stack;      // (node, next child to visit)
         for (int r = 0; r < nf; ++r) {
             if (dead[r] || fparent[r] >= 0) continue;
-            // a live root: note fparent of merged nodes is irrelevant, kids[] holds the tree
-            stack.push_back({r, 0});
+            // a live root: note fparent of merged nodes is irrelevant, the child lists hold the tree
+            stack.push_back({r, kid_head[r]});
             while (!stack.empty()) {
                 auto& top = stack.back();
                 int v = top.first;
-                if (top.second < kids[v].size()) { int c = kids[v][top.second++]; stack.push_back({c, 0}); }
+                if (top.second >= 0) { int c = top.second; top.second = kid_next[c]; stack.push_back({c, kid_head[c]}); }
                 else {
-                    std::vector<int> cols;
-                    for (int f : members[v]) for (int j = fstart[f]; j < fstart[f + 1]; ++j) cols.push_back(j);
+                    cols.clear();
+                    for (int f = mem_head[v]; f >= 0; f = mem_next[f]) for (int j = fstart[f]; j < fstart[f + 1]; ++j) cols.push_back(j);
                     std::sort(cols.begin(), cols.end());
+                    newid[v] = (int)sstart.size();
                     sstart.push_back((int)newpos.size());
                     newpos.insert(newpos.end(), cols.begin(), cols.end());
                     stack.pop_back();
@@ -669,6 +685,9 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         }
         if ((int)newpos.size() != n) return "internal: amalgamation lost columns";
         sstart.push_back(n);
+        sn_parent_new.assign(sstart.size() - 1, -1);
+        for (int v = 0; v < nf; ++v)
+            if (newid[v] >= 0) for (int c = kid_head[v]; c >= 0; c = kid_next[c]) sn_parent_new[newid[c]] = newid[v];
         std::vector<int> perm2(n);
         for (int k = 0; k < n; ++k) perm2[k] = perm[newpos[k]];
         perm.swap(perm2);
@@ -676,40 +695,80 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
         S.sn_start = sstart;
         S.nsuper = (int)sstart.size() - 1;
     }
-    h = permute_graph(g, perm, iperm);
+    sub("  final numbering");
+    permute_graph(g, perm, iperm, h);
     S.perm = perm;
     S.iperm = iperm;
     int ns = S.nsuper;
     S.sn_of.resize(n);
     for (int s = 0; s < ns; ++s) for (int j = S.sn_start[s]; j < S.sn_start[s + 1]; ++j) S.sn_of[j] = s;
 
-    phase("amalgamation");
+    phase("  permuted graph 3");
     // ---- 6. supernode row structures, tree, relative indices ---------------
     S.sn_parent.assign(ns, -1);
     S.struct_ptr.assign(ns + 1, 0);
     std::vector<std::vector<int>> ch(ns);
-    std::vector<int> stamp(n, -1), rows;
     std::vector<std::vector<int>> st(ns);
-    for (int s = 0; s < ns; ++s) {
-        int last = S.sn_start[s + 1] - 1;
+    // The tree is known already (sn_parent_new, from the amalgamation), children before parents, every subtree a contiguous range of
+    // supernodes: disjoint subtrees are independent (a structure depends on the columns' adjacency and on the children's structures
+    // only), so the subtrees below a weight threshold go to the host threads and the few supernodes above them follow serially.
+    for (int s2 = 0; s2 < ns; ++s2) if (sn_parent_new[s2] >= 0) ch[sn_parent_new[s2]].push_back(s2);
+    std::atomic<int> bad_tree{0};
+    auto structure_of = [&](int s2, std::vector<int>& stamp, std::vector<int>& rows) {
+        int last = S.sn_start[s2 + 1] - 1;
         rows.clear();
-        for (int j = S.sn_start[s]; j <= last; ++j)
+        for (int j = S.sn_start[s2]; j <= last; ++j)
             for (int64_t t = h.xadj[j]; t < h.xadj[j + 1]; ++t) {
                 int i = h.adj[t];
-                if (i > last && stamp[i] != s) { stamp[i] = s; rows.push_back(i); }
+                if (i > last && stamp[i] != s2) { stamp[i] = s2; rows.push_back(i); }
             }
-        for (int c : ch[s])
+        for (int c : ch[s2])
             for (int i : st[c])
-                if (i > last && stamp[i] != s) { stamp[i] = s; rows.push_back(i); }
+                if (i > last && stamp[i] != s2) { stamp[i] = s2; rows.push_back(i); }
         std::sort(rows.begin(), rows.end());
-        st[s] = rows;
-        if (!rows.empty()) {
-            int ps = S.sn_of[rows[0]];
-            S.sn_parent[s] = ps;
-            ch[ps].push_back(s);
+        st[s2] = rows;
+        const int ps = rows.empty() ? -1 : S.sn_of[rows[0]];
+        if (ps != sn_parent_new[s2]) bad_tree.store(1);
+        S.sn_parent[s2] = ps;
+    };
+    {
+        std::vector<int64_t> wsub(ns, 0);
+        int64_t wtot = 0;
+        for (int s2 = 0; s2 < ns; ++s2) {
+            wsub[s2] += h.xadj[S.sn_start[s2 + 1]] - h.xadj[S.sn_start[s2]] + 8;
+            wtot += h.xadj[S.sn_start[s2 + 1]] - h.xadj[S.sn_start[s2]] + 8;
+            if (sn_parent_new[s2] >= 0) wsub[sn_parent_new[s2]] += wsub[s2];
         }
-        S.struct_ptr[s + 1] = S.struct_ptr[s] + (int64_t)rows.size();
+        const int64_t wmax = n >= 20000 ? wtot / 48 : wtot + 1;      // small problems: everything "above" the (empty) set of tasks
+        std::vector<int> first_desc(ns);
+        for (int s2 = 0; s2 < ns; ++s2) first_desc[s2] = ch[s2].empty() ? s2 : first_desc[ch[s2][0]];
+        std::vector<std::pair<int, int>> tasks;       // [first, last] supernode ranges of the independent subtrees
+        std::vector<char> above(ns, 0);
+        for (int s2 = 0; s2 < ns; ++s2) {
+            if (wsub[s2] > wmax) { above[s2] = 1; continue; }
+            const int ps = sn_parent_new[s2];
+            if (ps < 0 || wsub[ps] > wmax) tasks.push_back({first_desc[s2], s2});
+        }
+        std::sort(tasks.begin(), tasks.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& b) { return wsub[a.second] != wsub[b.second] ? wsub[a.second] > wsub[b.second] : a.second < b.second; });
+        std::atomic<int> next_task{0};
+        const int ntasks = (int)tasks.size();
+        if (ntasks > 1)
+            run_parts(std::min(ntasks, 16), [&](int) {
+                std::vector<int> stamp, rows;
+                for (;;) {
+                    const int t = next_task.fetch_add(1);
+                    if (t >= ntasks) break;
+                    if (stamp.empty()) stamp.assign(n, -1);
+                    for (int s2 = tasks[t].first; s2 <= tasks[t].second; ++s2) structure_of(s2, stamp, rows);
+                }
+            });
+        std::vector<int> stamp(n, -1), rows;
+        if (ntasks <= 1) { for (int s2 = 0; s2 < ns; ++s2) structure_of(s2, stamp, rows); }
+        else for (int s2 = 0; s2 < ns; ++s2) if (above[s2]) structure_of(s2, stamp, rows);
     }
+    if (bad_tree.load()) return "internal: amalgamated tree and row structures disagree";
+    for (int s2 = 0; s2 < ns; ++s2) S.struct_ptr[s2 + 1] = S.struct_ptr[s2] + (int64_t)st[s2].size();
+    sub("  row structures");
     S.struct_idx.resize(S.struct_ptr[ns]);
     S.rel.resize(S.struct_ptr[ns]);
     S.child_ptr.assign(ns + 1, 0);
@@ -736,7 +795,7 @@ std::string analyze_pattern(int n, const int64_t* colptr, const int64_t* rowidx,
             S.rel[S.struct_ptr[c] + k] = r;
         }
     }
-    phase("structures + relative indices");
+    phase("  relative indices");
     finish_layout(S);
     phase("layout");
     return "";
