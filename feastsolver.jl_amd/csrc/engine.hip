@@ -1,6 +1,7 @@
 // See engine.hpp.  Handle life cycle, inputs, ordering + symbolic analysis and launch plans, the gen_feast driver loop.
 // Reference semantics: src/feast.jl:10-80, 89-156; src/utils.jl:69-77, 104-116, 151-179.
 #include "engine_impl.hpp"
+#include "ordering.hpp"
 #include <memory>
 #include <unistd.h>
 
@@ -574,8 +575,9 @@ void Engine::rebuild_shard() {
 
 // ---------------------------------------------------------------------------
 bool Engine::build_plans() {
-    std::vector<Tile> tiles;
-    std::vector<int> lists;
+    // Every tree level builds its tiles, lists and XCD permutations into arrays of its own (levels are independent: host threads take
+    // them, deepest -- most tiles -- first); the arrays are concatenated afterwards and the levels' offsets shifted accordingly.
+    struct LevelOut { std::vector<Tile> tiles; std::vector<int> lists, xperm; int64_t sk_rows = 0; bool ok = true; };
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
     int nd = S.maxdepth + 1;
     fplan_.assign(nd, FactorLevel());
@@ -583,18 +585,24 @@ bool Engine::build_plans() {
     sk_off_.assign(S.nsuper, -1);
     skf_off_.assign(S.nsuper, -1);
     sk_rows_ = 0;
+    std::vector<LevelOut> outs(nd);
     std::vector<int> nchild(S.nsuper);
     for (int s = 0; s < S.nsuper; ++s) nchild[s] = (int)(S.child_ptr[s + 1] - S.child_ptr[s]);
     std::vector<char> fused_b3(S.nsuper, 0);
-    // product tiles of one front in 8 x 8 super-tiles (64 consecutive tiles share 8 row panels and 8 column panels; k_gemm_nn
-    // hands such runs to one XCD)
-    auto push_supertiles = [&](int s, int kind, int na, int nc) {
-        for (int A = 0; A < na; A += 8)
-            for (int C = 0; C < nc; C += 8)
-                for (int a = A; a < std::min(na, A + 8); ++a)
-                    for (int c = C; c < std::min(nc, C + 8); ++c) tiles.push_back({s, kind, a, c});
-    };
-    for (int d = 0; d < nd; ++d) {
+    const double xcd_c0 = getenv("FEASTHIP_XCD_C0") ? atof(getenv("FEASTHIP_XCD_C0")) : 64.0, xcd_thr = getenv("FEASTHIP_XCD_THR") ? atof(getenv("FEASTHIP_XCD_THR")) : 64.0;
+    auto build_level = [&](int d) {
+        LevelOut& O = outs[d];
+        std::vector<Tile>& tiles = O.tiles;
+        std::vector<int>& lists = O.lists;
+        std::vector<int>& xperm = O.xperm;
+        // product tiles of one front in 8 x 8 super-tiles (64 consecutive tiles share 8 row panels and 8 column panels; k_gemm_nn
+        // hands such runs to one XCD)
+        auto push_supertiles = [&](int s, int kind, int na, int nc) {
+            for (int A = 0; A < na; A += 8)
+                for (int C = 0; C < nc; C += 8)
+                    for (int a = A; a < std::min(na, A + 8); ++a)
+                        for (int c = C; c < std::min(nc, C + 8); ++c) tiles.push_back({s, kind, a, c});
+        };
         const std::vector<int>& lv = S.levels[d];
         FactorLevel& F = fplan_[d];
         SolveLevel& V = splan_[d];
@@ -773,7 +781,7 @@ bool Engine::build_plans() {
         }
         V.f2.count = (int)(tiles.size() - V.f2.off);
         V.f2.sl = sl2;
-        sk_rows_ = std::max(sk_rows_, skf_level);
+        O.sk_rows = std::max(O.sk_rows, skf_level);
         // longest tiles first (LPT): the K loop of a tile is p (kind 1; a part of it when split) or at most the super-block size (kind 2); fronts stay together
         {
             const int nsp = V.f2split;
@@ -816,7 +824,7 @@ bool Engine::build_plans() {
         V.b1.count = (int)(tiles.size() - V.b1.off);
         V.b1.sl = sl3;
         std::stable_sort(tiles.begin() + V.b1.off, tiles.end(), [&](const Tile& a, const Tile& b) { return S.u(a.f) > S.u(b.f); });   // K = u
-        sk_rows_ = std::max(sk_rows_, sk_level);
+        O.sk_rows = std::max(O.sk_rows, sk_level);
         V.b1red.off = (int64_t)tiles.size();
         if (V.b1split) for (int s : lv) if (S.u(s) > 0) for (int a = 0; a < cdiv(S.p(s), 64); ++a) tiles.push_back({s, a, 0, 0});
         V.b1red.count = (int)(tiles.size() - V.b1red.off);
@@ -910,14 +918,12 @@ bool Engine::build_plans() {
             }
             L.count = (int)(tiles.size() - L.off);
         }
-    }
     // ---- split of every block-substitution launch over the 8 XCDs (dev_common.hpp: XcdParts).  A workgroup's XCD is fixed by its index,
     // so the parts are cut here for equal estimated time: a tile costs a start-up plus its K extent times the 16-row slabs a wave
     // walks (host mirror of decode_tile).  Launches of many small fronts are cut contiguously at front boundaries (neighbouring fronts,
     // and a front's tiles in consecutive launches, stay on one XCD's L2); launches with few, long tiles (top of the tree, or the sorted
     // lists of the L21 / U12 products when few nodes are left on this GPU) are dealt longest-first to the least loaded XCD.
     {
-        const double xcd_c0 = getenv("FEASTHIP_XCD_C0") ? atof(getenv("FEASTHIP_XCD_C0")) : 64.0, xcd_thr = getenv("FEASTHIP_XCD_THR") ? atof(getenv("FEASTHIP_XCD_THR")) : 64.0;
         auto tile_cost = [&](const Tile& t) -> double {
             const int kind = t.a & 0xff, slv = (t.a >> 8) & 0xff, th = slv ? 16 * slv : 64, nsplit = t.a >> 16;
             const int p = S.p(t.f), u = S.u(t.f), NB = solve_nb(t.f);
@@ -939,7 +945,7 @@ bool Engine::build_plans() {
             return xcd_c0 + (double)std::max(0, Kd) * ns + (kind == 6 ? 2.0 * p : 0.0);
         };
         std::vector<double> w;
-        std::vector<int> order, bin, xperm;
+        std::vector<int> order, bin;
         bool plans_ok = true;
         auto balance = [&](Launch& L) {
             const int nt = L.count;
@@ -995,14 +1001,50 @@ bool Engine::build_plans() {
             }
             if (!fine) plans_ok = false;
         };
-        for (SolveLevel& V : splan_) {
+        {
             for (Launch& L : V.f1) balance(L);
             for (Launch& L : V.b2) balance(L);
             for (Launch& L : V.afe) balance(L);
             for (Launch& L : V.abe) balance(L);
             balance(V.f2); balance(V.b1); balance(V.b3); balance(V.b3s); balance(V.afd); balance(V.af2); balance(V.ab1);
         }
-        if (!plans_ok) { err = "build_plans: internal, a launch list is not split into disjoint parts"; return false; }
+        O.ok = plans_ok;
+    }
+    };      // build_level
+    {
+        // deepest levels first: they hold most of the tiles
+        std::atomic<int> next_level{nd - 1};
+        run_parts(std::min(nd, 8), [&](int) { for (;;) { const int d = next_level.fetch_sub(1); if (d < 0) break; build_level(d); } });
+    }
+    std::vector<Tile> tiles;
+    std::vector<int> lists, xperm;
+    {
+        size_t nt = 0, nl = 0, nx = 0;
+        for (LevelOut& O : outs) { nt += O.tiles.size(); nl += O.lists.size(); nx += O.xperm.size(); }
+        tiles.reserve(nt + 1); lists.reserve(nl + 1); xperm.reserve(nx + 1);
+        for (int d = 0; d < nd; ++d) {
+            LevelOut& O = outs[d];
+            if (!O.ok) { err = "build_plans: internal, a launch list is not split into disjoint parts"; return false; }
+            sk_rows_ = std::max(sk_rows_, O.sk_rows);
+            const int64_t tb = (int64_t)tiles.size(), lb = (int64_t)lists.size();
+            const int xb = (int)xperm.size();
+            auto shift = [&](Launch& L) { L.off += tb; if (L.xp.perm >= 0) L.xp.perm += xb; };
+            auto shift_list = [&](Launch& L) { L.off += lb; };
+            FactorLevel& F = fplan_[d];
+            SolveLevel& V = splan_[d];
+            shift(F.extend); shift(F.extend1); shift(F.cbgemm); shift(F.cbgemm_sym); shift_list(F.fronts); shift(F.binv); shift(F.couple); shift(F.scale);
+            for (int lvl = 0; lvl < 3; ++lvl) { shift(F.outer[lvl]); shift(F.inner[lvl]); }
+            for (FactorStep& st : F.steps) { shift_list(st.panel); shift(st.swap); shift(st.trsm); shift(st.gemm); shift(st.gemm0); shift(st.gemm_in); shift(st.grp); shift(st.lsg); }
+            shift(V.assemble); shift(V.f2); shift(V.b1); shift(V.b3); shift(V.b1red); shift(V.f2red); shift(V.b3s); shift(V.afd); shift(V.af2); shift(V.ab1);
+            for (Launch& L : V.f1) shift(L);
+            for (Launch& L : V.b2) shift(L);
+            for (Launch& L : V.afe) shift(L);
+            for (Launch& L : V.abe) shift(L);
+            tiles.insert(tiles.end(), O.tiles.begin(), O.tiles.end());
+            lists.insert(lists.end(), O.lists.begin(), O.lists.end());
+            xperm.insert(xperm.end(), O.xperm.begin(), O.xperm.end());
+            O = LevelOut();
+        }
         if (xperm.empty()) xperm.push_back(0);
         if (!d_xperm_.upload(xperm.data(), xperm.size(), stream_)) return false;
         dsym_.xperm = d_xperm_.p;
@@ -1171,7 +1213,42 @@ int Engine::analyze() {
             // union of the terms' patterns (+ the diagonal), column by column, every column sorted and free of duplicates (a symmetric
             // union then is its own transpose: analyze_pattern's fast path), column ranges on host threads
             std::vector<int64_t> cp(n + 1, 0), ri;
+            // The usual pencil: one term carries the whole pattern (ascending columns with their diagonal entries) and the others -- a
+            // diagonal or identity B, a mass matrix on the same mesh -- lie inside it.  Then the union IS that term's pattern: checked
+            // column range by column range on host threads, no sort, no merge (8 -> 1.5 ms of C3's analysis).
+            bool dominant = false;
             {
+                size_t big = 0;
+                for (size_t ti = 1; ti < terms_.size(); ++ti) if (terms_[ti].colptr[n] > terms_[big].colptr[n]) big = ti;
+                const SparseTerm& D = terms_[big];
+                const int nth = n >= 20000 ? 8 : 1;
+                std::vector<char> bad(nth, 0);
+                run_parts(nth, [&](int ti) {
+                    const int j0 = (int)((int64_t)n * ti / nth), j1 = (int)((int64_t)n * (ti + 1) / nth);
+                    for (int j = j0; j < j1 && !bad[ti]; ++j) {
+                        const int* d0 = D.rowval.data() + D.colptr[j]; const int* d1 = D.rowval.data() + D.colptr[j + 1];
+                        bool okc = std::binary_search(d0, d1, j);
+                        for (const int* q = d0; q + 1 < d1 && okc; ++q) okc = q[0] < q[1];
+                        for (size_t t2 = 0; t2 < terms_.size() && okc; ++t2) {
+                            if (t2 == big) continue;
+                            const SparseTerm& T = terms_[t2];
+                            for (int64_t e2 = T.colptr[j]; e2 < T.colptr[j + 1] && okc; ++e2) okc = std::binary_search(d0, d1, T.rowval[e2]);
+                        }
+                        if (!okc) bad[ti] = 1;
+                    }
+                });
+                dominant = true;
+                for (char b : bad) if (b) dominant = false;
+                if (dominant) {
+                    cp.assign(D.colptr.begin(), D.colptr.end());
+                    ri.resize(cp[n]);
+                    run_parts(nth, [&](int ti) {
+                        const int64_t e0 = cp[n] * ti / nth, e1 = cp[n] * (ti + 1) / nth;
+                        for (int64_t e2 = e0; e2 < e1; ++e2) ri[e2] = D.rowval[e2];
+                    });
+                }
+            }
+            if (!dominant) {
                 const int nth = n >= 20000 ? std::max(1, std::min(8, host_cpu_budget() / 2)) : 1;
                 std::vector<std::vector<int64_t>> part(nth);
                 auto build = [&](int ti) {
