@@ -23,45 +23,6 @@
 
 namespace feasthip {
 
-int host_cpu_budget();      // symbolic.cpp
-
-// ---- host thread pool of the analysis (ordering.hpp: run_parts) ----
-namespace {
-struct HostPool {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::function<void()>> q;
-    int nthreads = 0;
-    HostPool() {
-        nthreads = std::max(0, std::min(15, host_cpu_budget() - 1));
-        if (const char* e = getenv("FEASTHIP_HOST_THREADS")) nthreads = std::max(0, std::min(63, atoi(e) - 1));
-        for (int i = 0; i < nthreads; ++i)
-            std::thread([this]() {
-                for (;;) {
-                    std::function<void()> task;
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [this] { return !q.empty(); });
-                        task = std::move(q.front());
-                        q.pop_front();
-                    }
-                    task();
-                }
-            }).detach();
-    }
-};
-// never destroyed (its threads wait on it until the process ends); a forked child has the object but not the threads: pool_size()
-// then promises helpers that never come, and run_parts' caller does every part itself
-HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }
-}  // namespace
-
-void pool_submit(std::function<void()> task) {
-    HostPool& P = host_pool();
-    { std::lock_guard<std::mutex> lk(P.mu); P.q.push_back(std::move(task)); }
-    P.cv.notify_one();
-}
-int pool_size() { return host_pool().nthreads; }
-
 namespace {
 
 struct XorShift {

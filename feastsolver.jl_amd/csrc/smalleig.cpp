@@ -1,4 +1,5 @@
 #include "smalleig.hpp"
+#include "hostpool.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -19,6 +20,14 @@ inline double pythag(double a, double b) {
     if (a == 0.0) return 0.0;
     double r = b / a;
     return a * std::sqrt(1.0 + r * r);
+}
+
+// |z| for the rotation parameters of the QR iteration: libm's hypot (what std::abs calls) guards against overflow and underflow at
+// 15-20 ns a call, three calls per rotation on a chain of 140 ns; the plain formula is safe unless a component is beyond 1e+-140
+inline double fast_abs(zc z) {
+    const double a = std::fabs(z.real()), b = std::fabs(z.imag()), mx = a > b ? a : b;
+    if (mx > 1e-140 && mx < 1e140) return std::sqrt(a * a + b * b);
+    return pythag(a, b);
 }
 
 // Split storage (separate real and imaginary planes, column-major) keeps every inner loop a stride-1 real loop
@@ -107,6 +116,11 @@ inline void rot_cols(int lo, int hi, double c, double sr, double si, double* __r
     }
 }
 
+// (Round 5 handed the rotations of the Schur vectors -- Z <- Z G, which the iteration never reads -- to helper threads of the host pool
+// through a chunked log, every helper owning blocks of 16 rows of Z; bit-identical results.  In the stand-alone probe
+// (tools/probes/smalleig_bench.cpp, calls back to back) m = 128 went from 6.6 to 5.7 ms; inside a FEAST run, where the pool sleeps
+// 10 ms between two Rayleigh-Ritz steps, the helpers arrive late and slow (cold cores): the caller finished 0.7 - 1 ms of their
+// rotations itself and C5's step went from 6.2 to 6.6 ms.  Removed; the eigenvector and B^-1 A column loops below do use the pool.)
 // Single-shift complex QR on an upper Hessenberg matrix; H becomes the Schur form T, Z the Schur vectors.
 // H is kept TRANSPOSED (Ht(j, i) = H(i, j)) so that the row rotations, the longer of the two updates of H, run over
 // contiguous memory like the rotations of Z; only the short column part (rows 0..k+2) is strided.
@@ -159,11 +173,11 @@ int hqr_schur(Planes& H, Planes& Z) {
             for (int q = 0; q < ng; ++q) {
                 const int k = k0 + q;
                 // Givens G = [c sn; -conj(sn) c] with G [x;y] = [r;0]
-                double ax = std::abs(x), ay = std::abs(y), c;
+                double ax = fast_abs(x), ay = fast_abs(y), c;
                 zc sn;
                 if (ay == 0.0) { c = 1.0; sn = 0.0; }
                 else if (ax == 0.0) { c = 0.0; sn = std::conj(y) / ay; }
-                else { double nr = pythag(ax, ay); c = ax / nr; sn = (x / ax) * std::conj(y) / nr; }
+                else { double nr = std::sqrt(ax * ax + ay * ay); c = ax / nr; sn = (x / ax) * std::conj(y) / nr; }
                 gc[q] = c; gsr[q] = sn.real(); gsi[q] = sn.imag();
                 int j0 = std::max(l, k - 1);
                 // rows k, k+1 of H = columns k, k+1 of T:  [h0; h1] <- [c h0 + sn h1; -conj(sn) h0 + c h1]
@@ -242,9 +256,13 @@ int eig_general(int m, zc* A, zc* lam, zc* V) {
     double tn = 0;
     for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) tn = std::max(tn, std::fabs(T.r(j)[i]) + std::fabs(T.i(j)[i]));
     double small = std::max(EPS * tn, 1e-300);
-    std::vector<double> xr(m), xi(m), wr(m), wi(m);
     std::vector<zc> vals(m), vecs((size_t)m * m);
-    for (int k = 0; k < m; ++k) {
+    // the eigenvectors are independent of each other: interleaved column sets on the host pool (column k costs ~ k^2 / 2 + k m); the
+    // caller takes part, so a pool that is slow to wake up only means the caller does more of them
+    const int nvp = (m >= 48 && pool_size() >= 2) ? std::min(8, pool_size() + 1) : 1;
+    run_parts(nvp, [&](int part) {
+    std::vector<double> xr(m), xi(m), wr(m), wi(m);
+    for (int k = part; k < m; k += nvp) {
         // eigenvector of the triangular T for t = T_kk: back substitution in column (axpy) form, x_k = 1
         zc t = T.at(k, k);
         vals[k] = t;
@@ -270,6 +288,7 @@ int eig_general(int m, zc* A, zc* lam, zc* V) {
         nr = 1.0 / std::sqrt(nr);
         for (int i = 0; i < m; ++i) vecs[i + (size_t)k * m] = zc(wr[i] * nr, wi[i] * nr);
     }
+    });
     if (trace) {
         auto msf = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[feasthip eig] m=%d: Hessenberg %.3f, QR iteration %.3f, eigenvectors %.3f ms\n", m, msf(tp0, tp1), msf(tp1, tp2), msf(tp2, std::chrono::steady_clock::now()));
@@ -309,7 +328,9 @@ int eig_generalized(int m, zc* A, zc* B, zc* lam, zc* V) {
         for (int i = k + 1; i < m; ++i) { zc l = zc(bk_r[i], bk_i[i]) * inv; bk_r[i] = l.real(); bk_i[i] = l.imag(); }
         for (int j = k + 1; j < m; ++j) caxpy_sub(k + 1, m, Bp.r(j)[k], Bp.i(j)[k], bk_r, bk_i, Bp.r(j), Bp.i(j));
     }
-    for (int j = 0; j < m; ++j) {
+    const int nsp = (m >= 48 && pool_size() >= 2) ? std::min(8, pool_size() + 1) : 1;      // the columns of A are independent right-hand sides
+    run_parts(nsp, [&](int part) {
+    for (int j = (int)((long long)m * part / nsp); j < (int)((long long)m * (part + 1) / nsp); ++j) {
         double* xr = Ap.r(j);
         double* xi = Ap.i(j);
         for (int k = 0; k < m; ++k) if (piv[k] != k) { std::swap(xr[k], xr[piv[k]]); std::swap(xi[k], xi[piv[k]]); }
@@ -320,6 +341,7 @@ int eig_generalized(int m, zc* A, zc* B, zc* lam, zc* V) {
             caxpy_sub(0, k, x.real(), x.imag(), Bp.r(k), Bp.i(k), xr, xi);
         }
     }
+    });
     Ap.store(A);
     int e = eig_general(m, A, lam, V);
     return e ? e : info;

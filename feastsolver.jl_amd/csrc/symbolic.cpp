@@ -17,27 +17,6 @@
 
 namespace feasthip {
 
-// CPUs this process may actually use: the hardware count capped by the cgroup CPU quota (a container with a 16-CPU quota on
-// a 256-CPU host reports 256 hardware threads; running 32+ busy threads there only gets the process throttled)
-int host_cpu_budget() {
-    static const int budget = [] {
-        int hw = (int)std::thread::hardware_concurrency();
-        if (hw <= 0) hw = 4;
-        long long quota = -1, period = 100000;
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
-            char q[32] = {0};
-            if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm') quota = atoll(q);
-            fclose(f);
-        } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {    // cgroup v1
-            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
-            fclose(f1);
-            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &period) != 1) period = 100000; fclose(f2); }
-        }
-        if (quota > 0 && period > 0) hw = std::min<long long>(hw, std::max<long long>(1, quota / period));
-        return hw;
-    }();
-    return budget;
-}
 namespace {
 
 struct Graph {

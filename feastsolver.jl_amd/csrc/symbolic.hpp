@@ -10,7 +10,7 @@
 
 namespace feasthip {
 
-int host_cpu_budget();      // hardware threads capped by the cgroup CPU quota
+// (host_cpu_budget(): hostpool.hpp)
 
 struct Symbolic {
     int n = 0;

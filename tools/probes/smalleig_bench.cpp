@@ -1,8 +1,10 @@
 // host timing of the reduced general eigensolver (csrc/smalleig.cpp), random and nearly diagonal pencils, m = 64 and 128:
-//   clang++ -O3 <isa flags> -std=c++17 -Ifeastsolver.jl_amd/csrc -o /tmp/se tools/probes/smalleig_bench.cpp feastsolver.jl_amd/csrc/smalleig.cpp
+//   g++ -O3 -mavx2 -mfma -std=c++17 -pthread -Ifeastsolver.jl_amd/csrc -o tools/probes/smalleig_bench tools/probes/smalleig_bench.cpp feastsolver.jl_amd/csrc/smalleig.cpp feastsolver.jl_amd/csrc/hostpool.cpp
+// FEASTHIP_HOST_THREADS=1 runs everything on the calling thread (the result hashes must not change)
 #include "smalleig.hpp"
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <random>
 using namespace feasthip;
 int main() {
@@ -23,6 +25,9 @@ int main() {
             if (info) printf("info %d\n", info);
             best = std::min(best, ms);
         }
-        printf("m=%d %s: eig_generalized %.3f ms\n", m, warm ? "nearly diagonal" : "random", best);
+        unsigned long long hsh = 1469598103934665603ull;      // bit pattern of the last result: the threaded paths must reproduce the serial one exactly
+        for (auto& v : V) { unsigned long long b[2]; double d[2] = {v.real(), v.imag()}; memcpy(b, d, 16); hsh = (hsh ^ b[0]) * 1099511628211ull; hsh = (hsh ^ b[1]) * 1099511628211ull; }
+        for (auto& v : lam) { unsigned long long b[2]; double d[2] = {v.real(), v.imag()}; memcpy(b, d, 16); hsh = (hsh ^ b[0]) * 1099511628211ull; hsh = (hsh ^ b[1]) * 1099511628211ull; }
+        printf("m=%d %s: eig_generalized %.3f ms  result hash %016llx\n", m, warm ? "nearly diagonal" : "random", best, hsh);
     }
 }
