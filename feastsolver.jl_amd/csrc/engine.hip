@@ -1207,6 +1207,10 @@ int Engine::analyze() {
                 ok = ok && hipStreamSynchronize(us) == hipSuccess;      // the handle's own streams read these buffers after the join
                 if (!ok) H.bad = 2;
             });
+        if (getenv("FEASTHIP_PROBE_JOIN_HELPERS")) {      // probe: how much the helper threads (stream warm-up, CSR copies + uploads) slow the ordering beside them
+            if (warm.joinable()) warm.join();
+            for (auto& t2 : csr_pool) if (t2.joinable()) t2.join();
+        }
         if (trace) fprintf(stderr, "[feasthip analyze] + stream sync, CSR threads   %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (sym_entry) S = sym_entry->S;
         else {
