@@ -228,7 +228,9 @@ private:
             if (sp.a.empty() || sp.b.empty() || sp.s.empty()) continue;
             double bal = (double)std::max(sp.a.size(), sp.b.size()) / (double)(m - (int)sp.s.size());
             if (bal > 0.68) continue;
-            sp.cost = (double)sp.s.size();
+            // separator size first; among separators of (nearly) the same size the better balanced one (as for the level-set candidates)
+            // (8 seeds on C3's graph: mean factor flops 4.997e11 with 2 trials, 5.058e11 with 3 or 4 -- a third trial buys balance with fill)
+            sp.cost = (double)sp.s.size() + 1e-3 * std::abs((double)sp.a.size() - (double)sp.b.size());
             if (sp.cost < best.cost) best = std::move(sp);
         }
     }
@@ -322,10 +324,10 @@ private:
         // (disjoint scratch: loc_ vs vis_/lvl_), the first of which also tells whether the subgraph is connected -- if it is not, the
         // candidate is dropped; merged below in the same order as the serial code
         Split best, best_ml;
-        const uint64_t ml_seed = (uint64_t)lo * 2654435761ull + (uint64_t)m;      // independent of thread timing
+        static const uint64_t seed_env = getenv("FEASTHIP_ND_SEED") ? (uint64_t)atoll(getenv("FEASTHIP_ND_SEED")) : 0;      // (experiments: the spread of the ordering quality over seeds)
+        const uint64_t ml_seed = (uint64_t)lo * 2654435761ull + (uint64_t)m + seed_env * 0x9E3779B97F4A7C15ull;      // independent of thread timing
         std::thread tml;
-        static const int ml_async_min = getenv("FEASTHIP_ND_ASYNC_MIN") ? atoi(getenv("FEASTHIP_ND_ASYNC_MIN")) : 20000;
-        const bool ml_async = m >= ml_async_min;
+        const bool ml_async = m >= 20000;      // (down to 1000 measured: no faster)
         if (ml_async) tml = std::thread([&]() { multilevel_candidate(verts, id, ml_seed, best_ml); });
         bfs(verts[0], id, B);
         if ((int)queue_.size() < m) {   // disconnected: order components independently
