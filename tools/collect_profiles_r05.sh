@@ -22,4 +22,10 @@ FEASTHIP_ADJ_FOLD=0 python tools/hermitian_c3.py > $O/hermitian_c3_no_adjoint_fo
 python tools/other_calls.py > $O/other_calls.txt 2>> $O/bench.err
 python tools/c3_whole_call.py > $O/c3_whole_call.txt 2>> $O/bench.err
 bash tools/collect_factor_traces.sh $(basename $O) "c3 c2 c5" > $O/factor_traces.log 2>&1
+python tools/launch_profile.py 46 16 > $O/launch_profile_16_nodes.txt 2>> $O/bench.err
+for c in c3 c2 c5; do FEASTHIP_PROBE_SKIP_CONVERSION=1 python tools/factor_only.py $c 3 2>/dev/null; python tools/factor_only.py $c 3 2>/dev/null; done > $O/conversion_exposure.txt
+FEASTHIP_ANALYZE_TRACE=1 python tools/factor_trace.py 2>&1 | grep "feasthip analyze\|feasthip nd\] last" > $O/analysis_trace_c3_g46.txt
+for i in 1 2 3; do python tools/analysis_time.py 46 5; done > $O/analysis_probe_c3_g46.txt 2>> $O/bench.err
+g++ -O3 -mavx2 -mfma -std=c++17 -pthread -Ifeastsolver.jl_amd/csrc -o /tmp/smalleig_bench tools/probes/smalleig_bench.cpp feastsolver.jl_amd/csrc/smalleig.cpp feastsolver.jl_amd/csrc/hostpool.cpp && { FEASTHIP_EIG_TRACE=1 /tmp/smalleig_bench 2>&1 | tail -8; echo "--- FEASTHIP_HOST_THREADS=1"; FEASTHIP_HOST_THREADS=1 /tmp/smalleig_bench; } > $O/smalleig_bench.txt
+{ python tools/c5_rr_time.py; FEASTHIP_HOST_THREADS=1 python tools/c5_rr_time.py; } > $O/c5_rr_step.txt 2>> $O/bench.err
 echo collected
