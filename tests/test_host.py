@@ -283,3 +283,47 @@ def test_missing_rccl_library_is_a_status_not_a_crash(pkg):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "CODE -8" in out.stdout and "RCCL not found" in out.stdout, out.stdout
+
+
+_THREAD_INDEPENDENCE_CHILD = r"""
+import hashlib, importlib, os, sys
+import numpy as np, scipy.sparse as sp
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as graft
+pkg = graft.load_package(); lib = pkg.load_library()
+wl = importlib.import_module(graft.PKG_NAME + ".workloads")
+h = hashlib.sha256()
+for g, st in ((12, 7), (30, 19)):          # 27,000 vertices: the threaded matching / contraction / row-structure paths
+    A = sp.csc_matrix(wl.laplacian_3d(g, st)); n = A.shape[0]
+    cp = np.ascontiguousarray(A.indptr, dtype=np.int64); ri = np.ascontiguousarray(A.indices, dtype=np.int64)
+    stats = np.zeros(8, dtype=np.int64); perm = np.zeros(n, dtype=np.int32); snof = np.zeros(n, dtype=np.int32); fr = np.zeros(4 * n, dtype=np.int32)
+    assert lib.feasthip_symbolic_probe(n, cp.ctypes.data, ri.ctypes.data, 0, 0, stats.ctypes.data, perm.ctypes.data, snof.ctypes.data, fr.ctypes.data) == 0
+    for a in (stats, perm, snof, fr): h.update(a.tobytes())
+rng = np.random.default_rng(5)
+for m in (64, 128):
+    A = np.asfortranarray(rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m)))
+    B = np.asfortranarray(np.eye(m) + 0.2 * (rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))))
+    lam = np.zeros(m, dtype=np.complex128); V = np.zeros((m, m), dtype=np.complex128, order="F")
+    assert lib.feasthip_small_eig(m, A.ctypes.data, B.ctypes.data, lam.ctypes.data, V.ctypes.data) == 0
+    h.update(lam.tobytes()); h.update(V.tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_results_do_not_depend_on_the_host_thread_count():
+    """The analysis (range-parallel matching, contraction, FM set-up, row structures of independent subtrees, launch plans) and the
+    reduced general eigensolver (eigenvector and right-hand-side loops) run parallel regions on the host pool (csrc/hostpool.cpp).
+    The ranges are fixed, only who executes them varies: one thread, three, or the default must give bit-identical orderings,
+    supernodes, front tables, eigenvalues and eigenvectors."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for nthreads in ("1", "3", None):
+        env = dict(os.environ)
+        env.pop("FEASTHIP_HOST_THREADS", None)
+        if nthreads:
+            env["FEASTHIP_HOST_THREADS"] = nthreads
+        r = subprocess.run([sys.executable, "-c", _THREAD_INDEPENDENCE_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs
