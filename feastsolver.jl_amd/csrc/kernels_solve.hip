@@ -303,7 +303,30 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
 // Measured on random operands (tools/probes/apply2_bench.hip): +21 % on matrix-core-bound tiles (K = 1024: 60.7 -> 73.8 TFLOP/s),
 // +12 % on short-K tiles against the LDS-staged kernel of round 1; bit-identical results (same summation order).
 // ---------------------------------------------------------------------------
-constexpr int A2_DA = 8, A2_DV = 4, A2_DI = 2;
+// Ring depths and occupancy (tools/probes/apply2_variants.sh rebuilds this file with other values and times the bench): until round 5 the
+// factor ring held 8 k-steps everywhere and the 32-row instances ran 3 workgroups per CU.  The counters of round 5 showed the small-front
+// levels latency-bound, not HBM-bound (3.5 TB/s, matrix cores 46 % busy): 4 k-steps in flight leave the contiguous 32-row instance at 128
+// registers = 4 workgroups per CU (the gathered one would spill: it stays at 3), and the shallower ring costs the long-K tiles nothing:
+// C3 contour step 15.07 -> 14.67 ms of k_apply2 (58.7 -> 60.3 iterations/s on the same box).
+#ifndef FEASTHIP_A2_DA4
+#define FEASTHIP_A2_DA4 4
+#endif
+#ifndef FEASTHIP_A2_DA2
+#define FEASTHIP_A2_DA2 4
+#endif
+#ifndef FEASTHIP_A2_OCCN
+#define FEASTHIP_A2_OCCN 4
+#endif
+#ifndef FEASTHIP_A2_OCCG
+#define FEASTHIP_A2_OCCG 3
+#endif
+#ifndef FEASTHIP_A2_DV4
+#define FEASTHIP_A2_DV4 4
+#endif
+#ifndef FEASTHIP_A2_DV2
+#define FEASTHIP_A2_DV2 4
+#endif
+constexpr int A2_DI = 2;
 
 // element type of a sweep: complex128 on the f64 matrix cores, or complex64 (feast!'s mixed_prec) on the f32 ones
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -325,6 +348,8 @@ template <typename T, bool GATHER, int NS>
 __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int ldw, T* Ys = nullptr) {
     typedef typename A2<T>::real real;
     typedef typename A2<T>::acc acc;
+    constexpr int A2_DA = NS >= 4 ? FEASTHIP_A2_DA4 : FEASTHIP_A2_DA2;      // factor ring: k-steps in flight (must divide 8)
+    constexpr int A2_DV = NS >= 4 ? FEASTHIP_A2_DV4 : FEASTHIP_A2_DV2;      // block-vector ring
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wave = tid >> 6;
     const int slab = wave & (NS - 1), ct0 = (wave / NS) * NS;        // column tiles [ct0, ct0 + NS)
@@ -474,8 +499,11 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
 #pragma unroll
             for (int q = 0; q < NS; ++q) t3[q] = A2<T>::mfma(as, vr[j % A2_DV][q].x + vr[j % A2_DV][q].y, t3[q]);
         };
-        // a pass computes steps s0 .. s0 + 7 and prefetches up to step s0 + 7 + DA - 1 (factor) / + DV - 1 + DI (indices): all < nfull
-        for (; s0 + 8 + A2_DA - 1 <= nfull; s0 += 8) {
+        // a pass computes steps s0 .. s0 + 7 and prefetches up to step s0 + 7 + DA - 1 (factor) / + DV - 1 + DI (indices, gathered kinds): all
+        // of them must be < nfull -- with the 8-deep factor ring of rounds 2-4 the factor bound implied the index bound; the 4-deep ring of
+        // round 5 does not (a first build read struct_idx two k-steps past a short gather: memory access fault in the seam test)
+        constexpr int AHEAD = (GATHER && A2_DV - 1 + A2_DI > A2_DA - 1) ? A2_DV - 1 + A2_DI : (A2_DV - 1 > A2_DA - 1 ? A2_DV - 1 : A2_DA - 1);
+        for (; s0 + 8 + AHEAD <= nfull; s0 += 8) {
             fstep(std::integral_constant<int, 0>{}); fstep(std::integral_constant<int, 1>{}); fstep(std::integral_constant<int, 2>{}); fstep(std::integral_constant<int, 3>{});
             fstep(std::integral_constant<int, 4>{}); fstep(std::integral_constant<int, 5>{}); fstep(std::integral_constant<int, 6>{}); fstep(std::integral_constant<int, 7>{});
         }
@@ -620,7 +648,7 @@ __device__ __forceinline__ void apply2_body(const ApplyGeomT<T>& g, int cg, int 
 }
 
 template <typename T, bool GATHER, int NSMAX>
-__global__ __launch_bounds__(256, NSMAX == 4 ? 2 : 3) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
+__global__ __launch_bounds__(256, NSMAX == 4 ? 2 : (GATHER ? FEASTHIP_A2_OCCG : FEASTHIP_A2_OCCN)) void k_apply2(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
                                                 const int* __restrict__ struct_idx, const T* __restrict__ fact, int64_t fs,
                                                 T* W, T* Y, int64_t ws, int ldw, T* crow, int64_t crs, T* skbuf, int64_t sks,
                                                 XcdParts xp, const int* __restrict__ xperm, int lanes, int ncg, const int* __restrict__ cmap, const T* __restrict__ crow_child, int64_t crs_child) {
