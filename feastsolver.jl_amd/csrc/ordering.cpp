@@ -80,27 +80,44 @@ bool coarsen(const WGraph& g, WGraph& c, std::vector<int>& cmap, XorShift& rng) 
     clap("match rest");
     cmap.resize(n);
     ivec first(n), mate(n);                // members of the coarse vertices (second one or -1), indexed by coarse id
-    int nc = 0;
-    for (int v = 0; v < n; ++v) {
-        const int w = mate_of[v];
-        if (w < v) continue;               // second member: numbered with its partner
-        cmap[v] = nc;
-        if (w != v) cmap[w] = nc;
-        first[nc] = v; mate[nc] = w != v ? w : -1;
-        ++nc;
+    // coarse ids in vertex order of the first members (v with partner >= v): counted and assigned by ranges
+    int lead[NPART + 1];
+    lead[0] = 0;
+    run_parts(nparts, [&](int part) {
+        const int v0 = (int)((int64_t)n * part / nparts), v1 = (int)((int64_t)n * (part + 1) / nparts);
+        int cnt = 0;
+        for (int v = v0; v < v1; ++v) cnt += mate_of[v] >= v;
+        lead[part + 1] = cnt;
+    });
+    for (int part = 0; part < nparts; ++part) lead[part + 1] += lead[part];
+    const int nc = lead[nparts];
+    {
+        int* __restrict cmw = cmap.data();
+        run_parts(nparts, [&](int part) {
+            const int v0 = (int)((int64_t)n * part / nparts), v1 = (int)((int64_t)n * (part + 1) / nparts);
+            int id = lead[part];
+            for (int v = v0; v < v1; ++v) {
+                const int w = mate_of[v];
+                if (w < v) continue;               // second member: numbered by its partner (possibly from another range)
+                cmw[v] = id;
+                if (w != v) cmw[w] = id;
+                first[id] = v; mate[id] = w != v ? w : -1;
+                ++id;
+            }
+        });
     }
     clap("coarse ids");
     if (nc > 0.92 * n) return false;
     c.n = nc;
     c.vwgt.resize(nc);
     c.xadj.resize(nc + 1);
-    // Contraction: coarse vertex cv gets the merged adjacency of its members.  The lists are built in place at offsets that leave
-    // room for every member's whole list (large graphs: ranges of coarse vertices on separate threads), then moved down over the gaps.
+    // Contraction: coarse vertex cv gets the merged adjacency of its members.  The lists are built at offsets that leave room for every
+    // member's whole list (large graphs: ranges of coarse vertices on separate threads), then copied, range by range, to their places.
     ivec ub(nc + 1);
     ub[0] = 0;
     for (int cv = 0; cv < nc; ++cv) ub[cv + 1] = ub[cv] + (gx[first[cv] + 1] - gx[first[cv]]) + (mate[cv] >= 0 ? gx[mate[cv] + 1] - gx[mate[cv]] : 0);
-    c.adj.resize(ub[nc]); c.ewgt.resize(ub[nc]);
-    int* __restrict ca = c.adj.data(); int* __restrict ce = c.ewgt.data();
+    ivec sa(ub[nc]), se(ub[nc]);
+    int* __restrict ca = sa.data(); int* __restrict ce = se.data();
     const int* __restrict cm = cmap.data();
     run_parts(nparts, [&](int part) {
         const int c0 = (int)((int64_t)nc * part / nparts), c1 = (int)((int64_t)nc * (part + 1) / nparts);
@@ -129,12 +146,20 @@ bool coarsen(const WGraph& g, WGraph& c, std::vector<int>& cmap, XorShift& rng) 
     });
     clap("contract");
     c.xadj[0] = 0;
-    for (int cv = 0; cv < nc; ++cv) {
-        const int len = c.xadj[cv + 1], dst = c.xadj[cv], src = ub[cv];
-        if (dst != src) { std::memmove(ca + dst, ca + src, (size_t)len * sizeof(int)); std::memmove(ce + dst, ce + src, (size_t)len * sizeof(int)); }
-        c.xadj[cv + 1] = dst + len;
-    }
+    for (int cv = 0; cv < nc; ++cv) c.xadj[cv + 1] += c.xadj[cv];
     c.adj.resize(c.xadj[nc]); c.ewgt.resize(c.xadj[nc]);
+    {
+        int* __restrict da = c.adj.data(); int* __restrict de = c.ewgt.data();
+        const int* __restrict cx = c.xadj.data();
+        run_parts(nparts, [&](int part) {
+            const int c0 = (int)((int64_t)nc * part / nparts), c1 = (int)((int64_t)nc * (part + 1) / nparts);
+            for (int cv = c0; cv < c1; ++cv) {
+                const int len = cx[cv + 1] - cx[cv];
+                std::memcpy(da + cx[cv], ca + ub[cv], (size_t)len * sizeof(int));
+                std::memcpy(de + cx[cv], ce + ub[cv], (size_t)len * sizeof(int));
+            }
+        });
+    }
     clap("compact");
     return true;
 }
