@@ -68,6 +68,7 @@ PROTOTYPES = {
     "feasthip_nlfeast_run": (I, [VP, VP, I64, I, I, D, D, VP, VP, VP, C.POINTER(I)]),
     "feasthip_set_precision": (I, [VP, I]),
     "feasthip_set_conjugate_fold": (I, [VP, I]),
+    "feasthip_set_lazy_conversion": (I, [VP, I]),
     "feasthip_shard_plan": (I, [I, VP, I, I, I, VP, VP, VP, VP]),
     "feasthip_set_coef_functions": (I, [VP, VP, VP]),
     "feasthip_set_node_coefficients": (I, [VP, VP, I, I]),

@@ -204,6 +204,11 @@ class FeastHandle:
         conjugate node pair, the mirror system as m0 more right-hand-side columns (feasthip_set_conjugate_fold)."""
         self._ck(self.lib.feasthip_set_conjugate_fold(self.h, 1 if on else 0))
 
+    def set_lazy_conversion(self, on):
+        """Factorisations that serve one contour step (store=false) keep their update rows raw (feasthip_set_lazy_conversion); the
+        whole-loop calls switch it on by themselves for store=False."""
+        self._ck(self.lib.feasthip_set_lazy_conversion(self.h, 1 if on else 0))
+
     def set_coef_functions(self, funcs):
         """f_t(z) of a split-form NEP (None restores the polynomial default z^t)."""
         if funcs is None:

@@ -131,6 +131,10 @@ int feasthip_set_conjugate_fold(feasthip_handle_t h, int on) {
     GUARD(h) return h->e->set_fold(on); ENDGUARD(h)
 }
 
+int feasthip_set_lazy_conversion(feasthip_handle_t h, int on) {
+    GUARD(h) return h->e->set_lazy_conversion(on); ENDGUARD(h)
+}
+
 int feasthip_set_coef_functions(feasthip_handle_t h, feasthip_coef_fn fn, void* user) {
     GUARD(h) return h->e->set_coef_functions(fn, user); ENDGUARD(h)
 }

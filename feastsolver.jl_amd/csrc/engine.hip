@@ -521,6 +521,13 @@ int Engine::set_fold(int on) {
     return 0;
 }
 
+// Factors that will serve one sweep (the reference's store = false: every iteration factorises again) skip the scaling of their update
+// rows; see engine.hpp.  Takes effect at the next factorisation; the current factors stay what they are (lazy_factors_).
+int Engine::set_lazy_conversion(int on) {
+    lazy_conversion_ = on != 0;
+    return 0;
+}
+
 bool plan_node_shard(const std::vector<zc>& nodes, int first, int stride, bool fold_allowed, std::vector<int>& loc, std::vector<int>& par) {
     const int K = (int)nodes.size();
     loc.clear(); par.clear();
@@ -793,6 +800,15 @@ bool Engine::build_plans() {
         V.f2red.off = (int64_t)tiles.size();
         if (V.f2split) for (int s : lv) if (S.u(s) > 0) for (int a = 0; a < cdiv(S.u(s), 64); ++a) tiles.push_back({s, a, 0, 0});
         V.f2red.count = (int)(tiles.size() - V.f2red.off);
+        // the same tiles as two lists, for the sweeps over lazily converted factors (engine.hpp): first every Y_t = inv(L_tt) w_t
+        // (kind 2), then the contribution rows C_I = .. - L21 Y_J (kind 1, raw L21) -- in the order f2 has them (longest K first)
+        for (int pass = 0; pass < 2; ++pass) {
+            Launch& L = pass == 0 ? V.f2y : V.f2c;
+            L.off = (int64_t)tiles.size(); L.sl = sl2;
+            if (!V.f2split)
+                for (int64_t q = V.f2.off, qe = V.f2.off + V.f2.count; q < qe; ++q) { const Tile tq = tiles[(size_t)q]; if (((tq.a & 0xff) == 2) == (pass == 0)) tiles.push_back(tq); }
+            L.count = (int)(tiles.size() - L.off);
+        }
         V.b1.off = (int64_t)tiles.size();
         int sl3 = pick_slabs([&](auto&& cb) { for (int s : lv) if (S.u(s) > 0) cb(S.p(s)); });
         // 64-row tiles where 32 rows were only chosen for the short K loops of small fronts (the gather's K loop is long): fronts of up
@@ -1007,6 +1023,7 @@ bool Engine::build_plans() {
             for (Launch& L : V.afe) balance(L);
             for (Launch& L : V.abe) balance(L);
             balance(V.f2); balance(V.b1); balance(V.b3); balance(V.b3s); balance(V.afd); balance(V.af2); balance(V.ab1);
+            balance(V.f2y); balance(V.f2c);
         }
         O.ok = plans_ok;
     }
@@ -1036,6 +1053,7 @@ bool Engine::build_plans() {
             for (int lvl = 0; lvl < 3; ++lvl) { shift(F.outer[lvl]); shift(F.inner[lvl]); }
             for (FactorStep& st : F.steps) { shift_list(st.panel); shift(st.swap); shift(st.trsm); shift(st.gemm); shift(st.gemm0); shift(st.gemm_in); shift(st.grp); shift(st.lsg); }
             shift(V.assemble); shift(V.f2); shift(V.b1); shift(V.b3); shift(V.b1red); shift(V.f2red); shift(V.b3s); shift(V.afd); shift(V.af2); shift(V.ab1);
+            shift(V.f2y); shift(V.f2c);
             for (Launch& L : V.f1) shift(L);
             for (Launch& L : V.b2) shift(L);
             for (Launch& L : V.afe) shift(L);
@@ -1594,6 +1612,11 @@ int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int st
     int r = set_x(X, n_, m0_);
     if (r) return r;
     int warn = 0;
+    // store = false (the reference's default, src/feast.jl:5,64-65): every iteration factorises again, so a factorisation serves one
+    // contour step -- the lazy conversion; the handle's setting comes back at the end
+    const bool lazy_before = lazy_conversion_;
+    if (!store) lazy_conversion_ = true;
+    struct RestoreLazy { bool& f; bool v; ~RestoreLazy() { f = v; } } restore_lazy{lazy_conversion_, lazy_before};
     if (store) { r = factorize(); if (r < 0) return r; warn = r; }                 // src/feast.jl:28-38
     int nit = 0;
     for (nit = 0; nit <= iter; ++nit) {                                             // :40

@@ -52,6 +52,7 @@ struct FactorLevel { Launch extend, extend1; std::vector<FactorStep> steps; Laun
                      Launch outer[3], inner[3]; };      // coupling of 128 -> 256 ([0]), 256 -> 512 ([1]) and 512 -> 1024 ([2]) super blocks (launch_couple_outer / _level)
 struct SolveLevel { Launch assemble; std::vector<Launch> f1; Launch f2; Launch b1; std::vector<Launch> b2; Launch b3; Launch b1red; int b1split = 0;
                     Launch f2red; int f2split = 0;      // forward L21 products split along K (few nodes per GPU): number of parts, reduction tiles
+                    Launch f2y, f2c;      // the tiles of f2 apart: diagonal solves (kind 2) / contribution rows (kind 1) -- the two launches of a sweep over lazily converted factors
                     Launch b3s;       // B3 tiles of the fronts whose B1 tile is kind 6 (launched only when the apply kernel does not fuse them)
                     double asm_rows = 0, pull_rows = 0;      // children's contribution rows landing in pivot blocks / in contribution rows of this level
                     // adjoint sweeps (kernels.hpp, tile kinds 8 .. 13): T(z)^H x = r over the same factors
@@ -105,6 +106,7 @@ public:
     // and its mirror image share ONE factorisation; the mirror system rides along as m0 more right-hand-side columns conj(R)
     // (T(conj z)^-1 R = conj(T(z)^-1 conj(R))).  On by default whenever every node of the contour has its mirror node.
     int set_fold(int on);
+    int set_lazy_conversion(int on);
     bool folded() const { return fold_; }
     int solve_width() const { return fold_ ? 2 * ldw : ldw; }    // leading dimension of the per-unit solve blocks
     int set_coef_functions(feasthip_coef_fn fn, void* user);
@@ -324,6 +326,10 @@ private:
     bool look_ahead_ = true, finalize_async_ = true, fused_utrsm_ = true, fuse_extend_ = true;
     int fuse_min_p_ = 1;              // smallest pivot-block width of a level whose Schur product pulls the children's contributions itself (round 3: every level; 128 before, A/B 84.5 -> 82.7 ms)
     int group_panels_ = 4;            // panels per deferred trailing update in the look-ahead factorisation
+    // Lazy conversion (feasthip_set_lazy_conversion; feast_run switches it on for store = false): factors that serve one sweep keep their
+    // update rows L21 raw (k_scale_panels touches the pivot rows only) and the forward sweep computes C_I = .. - L21 Y_J after Y_J in a
+    // second launch per level.  lazy_factors_: what the factors in memory are.  Not with adjoint sweeps or the forward split-K.
+    bool lazy_conversion_ = false, lazy_factors_ = false;
     bool fwd_splitk_ = false;         // FEASTHIP_FWD_SPLITK=1: split the long forward L21 products along K when few nodes are left on this GPU.
                                       // Measured at one unit per GPU (C3): the split launches gain 10-40 us each, their reductions cost 50-80 us:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)

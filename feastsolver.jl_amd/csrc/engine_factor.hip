@@ -99,6 +99,9 @@ int Engine::factorize() {
     // level go in one launch -- 41-54 ms of side-stream time on C2 instead of 13.7 -- and the coupling of the super blocks still waits
     // for the last column: C2 100 -> 103 ms, C3 79 -> 91 ms.)
     const bool skip_conversion = getenv("FEASTHIP_PROBE_SKIP_CONVERSION") != nullptr;
+    // lazy conversion (engine.hpp): only where the primal sweeps alone read these factors, and no level splits its forward products along K
+    bool lazy = lazy_conversion_ && !adj_fold_ && !dual_adj_ && !fwd_splitk_;
+    for (const SolveLevel& V : splan_) if (V.f2split) lazy = false;
     // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
     const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
     std::vector<hipEvent_t> tev;
@@ -253,9 +256,9 @@ int Engine::factorize() {
         if (nopiv) launch_couple32(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);      // the 32 x 32 inverses are in place already
         else launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
-        launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc);
+        launch_scale_panels(fin, dsym_, tl + F.scale.off, F.scale.count, d_fact_.p, fs, Kloc, lazy);
         for (int lvl = 0; lvl < 3; ++lvl) {       // 256-, 512- and 1024-column super blocks of the fronts with many pivot columns
-            launch_couple_outer(fin, dsym_, tl + F.outer[lvl].off, F.outer[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
+            launch_couple_outer(fin, dsym_, tl + F.outer[lvl].off, F.outer[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc, lazy);
             launch_couple_level(fin, dsym_, tl + F.inner[lvl].off, F.inner[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
         }
         if (!fuse)
@@ -342,6 +345,7 @@ int Engine::factorize() {
         }
     }
     factor_ms = ms;
+    lazy_factors_ = lazy;
     factored_ = !skip_conversion;
     return perturbed > 0 ? (int)std::min<int64_t>(perturbed, 0x7fffffff) : 0;
 }

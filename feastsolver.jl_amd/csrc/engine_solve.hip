@@ -64,6 +64,14 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         // contribution rows of the children that pass through to this level's contribution rows are pulled in the
         // epilogue of the F2a tiles (kind 1), so there is no second assembly pass
         const int64_t sksf = std::max<int64_t>(1, sk_rows_) * ldw;
+        if (lazy_factors_) {
+            // lazily converted factors: L21 is raw, so C_I = .. - L21 Y_J needs the solved block first -- the diagonal solves, then
+            // the kind-1 tiles with Y in the place of W (they read their block-vector operand through the W pointer only)
+            launch_apply(st, dsym_, tl + V.f2y.off, V.f2y.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
+                         nullptr, 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2y.sl, &V.f2y.xp);
+            launch_apply(st, dsym_, tl + V.f2c.off, V.f2c.count, Fp, fs, Yp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
+                         nullptr, 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2c.sl, &V.f2c.xp);
+        } else
         launch_apply(st, dsym_, tl + V.f2.off, V.f2.count, Fp, fs, Wp, Yp, ws, ldw, (crowb[par] + (int64_t)kb * crs), crs, kc, false,
                      V.f2split ? skall + (int64_t)kb * sksf : nullptr, V.f2split ? sksf : 0, (crowb[par ^ 1] + (int64_t)kb * crsc), crsc, V.f2.sl, &V.f2.xp);
         if (V.f2.count) { cur_tiles = V.f2.count; end(3, stat_bytes(V.f2, 2.0 * lvl_rows + V.pull_rows), stat_flops(V.f2)); }
@@ -113,6 +121,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
 //   backward  { W_J -= P21^H W[struct] } (+ split-K reduction) -> steps c = S - 2 .. 0 { W_c -= (P_(c,S) c)^H W_(c,S) }
 int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs) {
     if (mixed_) return fail(FEASTHIP_ESTATE, "adjoint sweeps run in complex128 only");
+    if (lazy_factors_) return fail(FEASTHIP_ESTATE, "adjoint sweeps need fully converted factors (feasthip_set_lazy_conversion(h, 0) and factorise again)");
     if (fwd_splitk_) return fail(FEASTHIP_ESTATE, "adjoint sweeps: FEASTHIP_FWD_SPLITK is not supported");
     const int lw = solve_width();
     const int64_t fs = S.fact_size, ws = (int64_t)n * lw;

@@ -80,13 +80,13 @@ void launch_block_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, in
 // (same tiles as launch_block_inverse, which this replaces)
 void launch_couple32(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
 void launch_couple_inverse(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
-void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K);
+void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K, bool pivot_rows_only = false);
 // Coupling of two solve-ready super blocks of `half` columns (a = [k0, k0+half), b = [k0+half, ...)) into one of 2*half, k0 = pair * 2*half:
 //   launch_couple_outer (Tile {front, 3 | pair << 8, m tile, n tile}: rows below the pair, P_a -= P_b Pc;
 //                              {front, 4 | pair << 8, m tile, n tile}: rows above the pair, Q_b -= Q_a Qd)       -- k_gemm_nn
 //   launch_couple_level (Tile {front, pair, side (0 lower / 1 upper), 16-column strip}): Pc <- -inv(L_bb) Pc, Qd <- -inv(U_aa) Qd, in place
 // (inv([L_a 0; C L_b]) = [I_a 0; -I_b C I_a, I_b], and the mirrored identity for the upper factor); run outer first, it reads Pc / Qd.
-void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K);
+void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K, bool pivot_rows_only = false);
 void launch_couple_level(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K);
 void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist, const int* piv, int* rowperm,
                     int* rowinv, int K);

@@ -1656,8 +1656,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const FrontD* __restrict__ f
         // coupling of two solve-ready super blocks of bw columns (launch_couple_outer): pair index in t.a >> 8
         const int half = bw, kp = (t.a >> 8) * 2 * half, bb = min(half, p - kp - half);
         lda = ldb = ldc = ld;
-        if ((t.a & 0xff) == 3) {      // rows below the pair:  P_a -= P_b * Pc
-            A = Lp + (kp + half + bb) + (int64_t)(kp + half) * ld; M = ld - (kp + half + bb); Kd = bb;
+        if ((t.a & 0xff) == 3) {      // rows below the pair:  P_a -= P_b * Pc  (mirror bit 8, lazy conversion: the update rows are raw L21 and stay out of it)
+            A = Lp + (kp + half + bb) + (int64_t)(kp + half) * ld; M = ((mirror & 8) ? p : ld) - (kp + half + bb); Kd = bb;
             B = Lp + (kp + half) + (int64_t)kp * ld; N = half;
             C = Lp + (kp + half + bb) + (int64_t)kp * ld;
         } else {                      // rows above the pair:  Q_b -= Q_a * Qd
@@ -2003,7 +2003,7 @@ constexpr int SCALE_KC = 32;        // k rows of the inverse block staged per st
 // multiplied; in place is still safe because a wave writes its rows only after the last chunk of a pass, and the second pass reads
 // the half of the row the first pass did not write.
 __global__ __launch_bounds__(256, 2) void k_scale_panels(const FrontD* __restrict__ fr, const Tile* __restrict__ tiles,
-                                                         cz* fact, int64_t fs) {
+                                                         cz* fact, int64_t fs, int pivot_rows_only) {
     __shared__ cz Bs[SCALE_KC][65];      // Bs[k][n] = Inv[kfirst + kc + k][ncol0 + n]
     Tile t = tiles[blockIdx.x];
     int k = blockIdx.y;
@@ -2013,7 +2013,10 @@ __global__ __launch_bounds__(256, 2) void k_scale_panels(const FrontD* __restric
     bool below = t.c != 0;
     cz* Lp = fact + (int64_t)k * fs + f.lp;
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int rend = below ? ld : k0;
+    // pivot_rows_only (Engine::lazy_conversion_: factors that serve ONE sweep, the reference's store = false): the update rows L21 stay
+    // raw -- three quarters of this kernel's traffic -- and the forward sweep multiplies them with the solved block Y_J in a launch of
+    // its own instead of P21 = L21 inv(L11) with W_J
+    const int rend = below ? (pivot_rows_only ? f.p : ld) : k0;
     int nhalf = (b > INV_NB) ? 2 : 1;
     for (int pass = 0; pass < nhalf; ++pass) {
         // lower: first the left half (needs both halves of the row), then the right half (needs only itself);
@@ -2083,13 +2086,13 @@ __global__ __launch_bounds__(256, 2) void k_scale_panels(const FrontD* __restric
     }
 }
 
-void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K) {
+void launch_scale_panels(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* fact, int64_t fs, int K, bool pivot_rows_only) {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_scale_panels, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, fact, fs);
+    hipLaunchKernelGGL(k_scale_panels, dim3(ntiles, K), dim3(256), 0, st, S.fr, tiles, fact, fs, pivot_rows_only ? 1 : 0);
 }
 
-void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K) {
-    launch_gemm_nn(st, S, tiles, ntiles, 0, fact, fs, nullptr, 0, K, ColSel(), half, 0, nullptr, 0);
+void launch_couple_outer(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int half, cz* fact, int64_t fs, int K, bool pivot_rows_only) {
+    launch_gemm_nn(st, S, tiles, ntiles, 0, fact, fs, nullptr, 0, K, ColSel(), half, 0, nullptr, 0, pivot_rows_only ? 8 : 0);
 }
 
 // Second half of the coupling of two solve-ready super blocks (kernels.hpp: launch_couple_level): one workgroup owns 16 whole

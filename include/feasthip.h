@@ -182,6 +182,14 @@ int feasthip_set_precision(feasthip_handle_t h, int mixed);
  * (feasthip_set_coef_functions, feasthip_set_node_coefficients, dual_gen_feast).  Node shards (feasthip_set_node_shard) then
  * deal out pairs instead of nodes.  on = 0 factorises every node separately, exactly like the reference. */
 int feasthip_set_conjugate_fold(feasthip_handle_t h, int on);
+/* Lazy solve-ready conversion, for factorisations that serve ONE contour step (the reference's default store = false,
+ * src/feast.jl:5,64-65,84,141-142: every iteration factorises every node again).  The conversion then leaves the update rows L21 of
+ * every front raw (three quarters of its traffic) and the forward sweep takes one more launch per tree level.  feasthip_feast_run
+ * switches it on by itself for store = 0 and restores the handle's setting afterwards; drivers of the phase calls
+ * (feasthip_contour_step(h, refactor = 1)) set it here.  It takes effect at the next factorisation.  Ignored (full conversion) where
+ * the adjoint sweeps read the factors: adjoint fold, dual_gen_feast; feasthip_ldiv_adjoint on lazily converted factors returns
+ * FEASTHIP_ESTATE.  Results agree with the full conversion to rounding. */
+int feasthip_set_lazy_conversion(feasthip_handle_t h, int on);
 
 /* ---- NEPs that are not polynomials (SURVEY 8b "generic-T NLFEAST"; the reference takes any closure z -> matrix,
  * src/nlfeast.jl:2,21, src/utils.jl:107; test/gun2.jl:30-37, test/hadeler.jl:27-59).

@@ -200,6 +200,14 @@ _unstage!(X::AbstractMatrix, Xw::Matrix{ComplexF64}) = (eltype(X) <: Complex && 
 # the fine seam above)
 _default_plugins(factorizer, left_divider) = (factorizer === lu || factorizer === hiplu) && left_divider === ldiv!
 
+"""
+    set_lazy_conversion(h, on::Bool)
+
+Factorisations that serve one contour step (drivers of the phase calls in the `store=false` regime of `src/feast.jl:64-65`) keep the
+update rows of their factors raw (`feasthip_set_lazy_conversion`); the whole-loop calls do this by themselves for `store=false`.
+"""
+set_lazy_conversion(h::Ptr{Cvoid}, on::Bool) = check(h, ccall((:feasthip_set_lazy_conversion, lib), Cint, (Ptr{Cvoid}, Cint), h, on ? 1 : 0))
+
 function _linear_run(X::AbstractMatrix, A::AbstractMatrix, B, contour::Contour, iter, ϵ, store, mixed_prec, device, conjugate_fold)
     N, m₀ = size(X)
     size(A, 1) != size(A, 2) && error("Incorrect dimensions of A, must be square")     # src/feast.jl:13-14, 93-94

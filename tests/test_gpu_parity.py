@@ -2056,3 +2056,83 @@ def test_randomised_differential_runs(gpu, tool, args):
     tail = "\n".join(p.stdout.strip().splitlines()[-6:])
     assert p.returncode == 0, tail + "\n" + p.stderr[-2000:]
     assert " 0 bad" in tail
+
+
+def _moment_lazy(pkg, terms, scales, con, X0, lazy, fold=True, mixed=False):
+    h = pkg.FeastHandle(0)
+    try:
+        h.set_terms(terms, scales)
+        h.set_contour(con)
+        h.set_conjugate_fold(fold)
+        if mixed:
+            h.set_precision(1)
+        h.set_lazy_conversion(lazy)
+        h.factorize()
+        h.set_x(X0)
+        h.rr_step()
+        h.contour_step()
+        Q1 = h.get_block(2).copy()
+        h.rr_step()
+        h.contour_step(True)          # refactorise + sweep: what every iteration of store=false does
+        Q2 = h.get_block(2).copy()
+        st = h.stats()
+    finally:
+        h.close()
+    return Q1, Q2, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sparse_symmetric", "sparse_unsymmetric", "sparse_hermitian", "dense_unsymmetric", "sparse_symmetric_nofold", "sparse_symmetric_mixed"])
+def test_lazy_conversion_gives_the_full_conversion_s_moment(gpu, pkg, wl, case):
+    """feasthip_set_lazy_conversion (factors that serve one sweep: store=false of src/feast.jl:5,64-65): the update rows L21 stay raw and
+    the forward sweep multiplies them with the solved block in a launch of its own.  Same moment as with the full solve-ready conversion,
+    on the symmetric (no interchanges), the pivoted and the dense path, with fronts of one and of several 128- / 256-column blocks, with and
+    without the conjugate fold, in complex64; Hermitian pencils (adjoint sweeps read P21) keep the full conversion whatever the switch says."""
+    rng = np.random.default_rng(77)
+    mixed = case.endswith("mixed")
+    fold = not case.endswith("nofold")
+    if case.startswith("sparse_symmetric"):
+        w = wl.c3_sparse_generalized(16, 19, 24)          # root front of 500+ columns: in-block steps, 256-column super blocks
+        terms, scales, c, r = [w["A"], w["B"]], [1.0, -1.0], w["c"], w["r"]
+        X0 = w["X0"]
+    elif case == "sparse_unsymmetric":
+        w = wl.c3_sparse_generalized(12, 19, 20)
+        A = sp.csc_matrix(w["A"], dtype=np.complex128)
+        A = A + sp.csc_matrix((0.05 * rng.standard_normal(A.nnz), A.indices, A.indptr), shape=A.shape)      # same pattern, unsymmetric values: partial pivoting
+        terms, scales, c, r = [A, w["B"]], [1.0, -1.0], w["c"], w["r"]
+        X0 = w["X0"]
+    elif case == "sparse_hermitian":
+        w = wl.c3_sparse_generalized(10, 19, 16)
+        terms, scales, c, r = [wl.hermitian_phases(w["A"], seed=3), w["B"]], [1.0, -1.0], w["c"], w["r"]
+        X0 = w["X0"]
+    else:
+        n = 700
+        A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        B = np.eye(n) + 0.05 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        terms, scales, c, r = [A, B], [1.0, -1.0], 0.0, 3.0
+        X0 = wl.rand_x0(n, 20, 9)
+    con = pkg.circular_contour_trapezoidal(c, r, 8)
+    qf1, qf2, sf = _moment_lazy(pkg, terms, scales, con, X0, False, fold, mixed)
+    ql1, ql2, sl = _moment_lazy(pkg, terms, scales, con, X0, True, fold, mixed)
+    # (L21 inv(L11)) w against L21 (inv(L11) w): the same to rounding times the growth of the pivoted factors (measured 2e-11 on the
+    # randomly perturbed unsymmetric pencil, 1e-13 on the symmetric one)
+    tol = 2e-5 if mixed else 1e-10 if "unsymmetric" in case else 1e-11
+    for a, b in ((qf1, ql1), (qf2, ql2)):
+        assert np.isfinite(b).all() and np.abs(a - b).max() <= tol * np.abs(a).max()
+
+
+@pytest.mark.gpu
+def test_store_false_runs_on_lazily_converted_factors(gpu, pkg, fo, wl):
+    """gen_feast(...; store=false) -- the reference's default -- factorises before every contour step; the whole-loop call switches the
+    lazy conversion on for it and gives the eigenvalues, residuals and iteration count of store=true, and leaves the handle's own setting
+    alone (a store=true call afterwards converts fully again)."""
+    w = wl.c3_sparse_generalized(12, 19, 64)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    out = {}
+    for store in (True, False, True):
+        info = {}
+        lam, V, res = pkg.gen_feast(w["X0"].copy(), w["A"], w["B"], con, iter=20, eps=1e-10, store=store, info=info)
+        out.setdefault(store, []).append((np.sort(lam.real), res.max(), info["nit"]))
+    lt, rt, nt = out[True][0]
+    for lam, rmax, nit in out[False] + out[True][1:]:
+        assert len(lam) == len(lt) == w["n_inside"] and np.abs(lam - lt).max() < 1e-10 and rmax < 1e-10 and abs(nit - nt) <= 1

@@ -10,7 +10,7 @@ python bench.py > $O/bench_c3_g46.json 2> $O/bench_c3_g46.err || exit 1
 python bench.py --cpu-baseline off --no-fold > $O/bench_c3_g46_no_fold.json 2>> $O/bench.err
 python bench.py --cpu-baseline off --mixed-prec > $O/bench_c3_g46_mixed_prec.json 2>> $O/bench.err
 FEASTHIP_RR_DEVICE=0 python bench.py --cpu-baseline off > $O/bench_c3_g46_host_eigensolver.json 2>> $O/bench.err
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o r05 -- python3 $R/bench.py --cpu-baseline off --cold-solves 0 > $R/$O/bench_c3_g46_under_rocprof.json 2> $R/$O/prof.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o r05 -- python3 $R/bench.py --cpu-baseline off --cold-solves 0 --store-false-steps 0 > $R/$O/bench_c3_g46_under_rocprof.json 2> $R/$O/prof.err)
 if grep -q "Aborted\|Segmentation\|core dumped" $O/prof.err; then echo "ABORT in the profiled bench run"; exit 2; fi
 FEASTHIP_ANALYZE_TRACE=1 python tools/factor_trace.py > $O/factor_trace.out 2> $O/factor_trace_c3_g46.txt
 python tools/bench_c2.py > $O/bench_c2_dense4096.json 2>> $O/bench.err

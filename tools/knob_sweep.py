@@ -2,7 +2,7 @@
 Every variation runs bench.py in a child process (the switches are read at handle creation)."""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-extra = os.environ.get("SWEEP_ARGS", "--cpu-baseline off --cold-solves 0 --steps 10 --warmup 3").split()
+extra = os.environ.get("SWEEP_ARGS", "--cpu-baseline off --cold-solves 0 --store-false-steps 0 --steps 10 --warmup 3").split()
 for spec in sys.argv[1:] or [""]:
     env = dict(os.environ)
     for kv in filter(None, spec.split(",")):
