@@ -444,6 +444,7 @@ def gen_feast(X, A, B, contour=None, *, nodes=8, iter=10, c=0j, r=1.0, debug=Fal
         if debug:
             # same loop, driven from the host so that every iteration can be reported like
             # iter_debug_print (src/utils.jl:2-42): nit, #inside, #inside below 1e-5, max residual inside
+            h.set_lazy_conversion((not store) or iter <= 64)      # what feasthip_feast_run decides for itself: same factors, same bits
             warn = h.factorize() if store else 0
             h.set_x(Xw)
             nit = 0
