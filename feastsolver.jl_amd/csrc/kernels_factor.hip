@@ -334,9 +334,15 @@ __global__ __launch_bounds__(PANEL_NT) void k_panel(const FrontD* __restrict__ f
 // round trip: the pivot search reads registers, the two interchanged rows travel through LDS (the pivot row doubles as the
 // broadcast U row of the rank-1 update), and the columns are written back once per sub-panel.  The generic kernel above
 // updated the sub-panel in global memory, one dependent load/store chain per column and pivot (12 us per pivot at 3000 rows).
-constexpr int PANEL_RPT = 4, PANEL_SBR = 4;
+constexpr int PANEL_RPT_MAX = 4;
+// Sub-panel width PANEL_SBR (columns a thread keeps in registers across their pivot steps) x rows per thread PANEL_RPT: 4 x 4 entries with
+// 1024 threads (128 registers each) and in the narrow workgroups of levels with many fronts (three waves per SIMD); the 512-thread
+// workgroup of a dependency chain (one per matrix, a CU to itself) holds 8 x 4: 48 passes over trailing columns of the panel through
+// L2 instead of 112 -- C5 32 LUs 21.3 -> 19.9 ms, C2 95.0 -> 93.8.  (16 x 2, 16 x 1 and 32 x 1 for short panels: the compiler keeps
+// the column arrays in scratch memory from 16 columns on, 23.1 ms.)
+constexpr int PANEL_SBR_OF(int nt) { return nt == 512 ? 8 : 4; }
 
-template <int PANEL_NT>
+template <int PANEL_NT, int PANEL_SBR = PANEL_SBR_OF(PANEL_NT), int PANEL_RPT = PANEL_RPT_MAX>
 __global__ __launch_bounds__(PANEL_NT) void k_panel_reg(const FrontD* __restrict__ fr, const int* __restrict__ list, int k0,
                                                          cz* fact, int64_t fs, int* piv, int npiv,
                                                          const double* __restrict__ tiny, int* nperturb) {
@@ -548,7 +554,8 @@ void launch_panel(hipStream_t st, const DevSym& S, const int* list, int nlist, i
     // max_rows: tallest panel (ld - k0) of the launch.  The smallest workgroup whose threads hold PANEL_RPT rows each: a
     // 1024-thread workgroup occupies a whole CU, so levels with many mid-sized fronts (81 fronts x 16 nodes of 1000-1500 rows)
     // otherwise run their panels five CU-rounds deep.
-    if (!generic && max_rows <= PANEL_RPT * 1024) {
+    if (!generic && max_rows <= PANEL_RPT_MAX * 1024) {
+        constexpr int PANEL_RPT = PANEL_RPT_MAX;
         // few workgroups (every one gets a CU of its own anyway): the widest workgroup has the shortest pivot step
         const int floor_nt = (int64_t)nlist * K <= 256 ? (tall ? (max_rows <= PANEL_RPT * 512 ? 512 : 1024) : 256) : 64;
 #define FEASTHIP_PANEL_CASE(NT) \
