@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <deque>
 #include <mutex>
+#include <pthread.h>
 
 namespace feasthip {
 
@@ -54,9 +55,13 @@ struct HostPool {
             }).detach();
     }
 };
-// never destroyed (its threads wait on it until the process ends); a forked child has the object but not the threads: pool_size()
-// then promises helpers that never come, and run_parts' caller does every part itself
-HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }
+// never destroyed (its threads wait on it until the process ends).  A forked child has the object but not the threads: the atfork
+// handler makes pool_size() say 0 there, so run_parts hands nothing to a queue nobody drains and its caller does every part itself
+std::atomic<int> g_pool_gone{0};
+HostPool& host_pool() {
+    static HostPool* p = [] { HostPool* q = new HostPool(); (void)pthread_atfork(nullptr, nullptr, [] { g_pool_gone.store(1); }); return q; }();
+    return *p;
+}
 }  // namespace
 
 void pool_submit(std::function<void()> task) {
@@ -64,6 +69,6 @@ void pool_submit(std::function<void()> task) {
     { std::lock_guard<std::mutex> lk(P.mu); P.q.push_back(std::move(task)); }
     P.cv.notify_one();
 }
-int pool_size() { return host_pool().nthreads; }
+int pool_size() { HostPool& P = host_pool(); return g_pool_gone.load(std::memory_order_relaxed) ? 0 : P.nthreads; }
 
 }  // namespace feasthip

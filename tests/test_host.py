@@ -327,3 +327,24 @@ def test_results_do_not_depend_on_the_host_thread_count():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2], outs
+
+
+def test_analysis_in_a_forked_child_has_no_pool_and_the_same_answer(lib, wl):
+    """The host pool's threads do not survive fork(): a child process (multiprocessing's fork start method) runs every parallel
+    region on its calling thread and must get the parent's ordering."""
+    A = wl.laplacian_3d(24, 7)
+    s0, p0, sn0, *_ = _probe(lib, A)          # creates the pool in this process
+    r, w_ = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            s1, p1, sn1, *_ = _probe(lib, A)
+            ok = np.array_equal(s0, s1) and np.array_equal(p0, p1) and np.array_equal(sn0, sn1)
+            os.write(w_, b"1" if ok else b"0")
+        finally:
+            os._exit(0)
+    os.close(w_)
+    out = os.read(r, 1)
+    os.close(r)
+    os.waitpid(pid, 0)
+    assert out == b"1"
