@@ -739,7 +739,7 @@ bool Engine::build_plans() {
             int64_t wgs = 0;
             rows_of([&](int rows) { wgs += cdiv(rows, 64); });
             if (wgs * nodes_local() < 128) return 1;      // latency-bound launch (few nodes left on this GPU): 16-row tiles, four waves share the columns
-            if (pmax <= short_k_max_p_) return 2;         // levels of small fronts (short K loops): 32-row tiles run the k_apply2 instance with three workgroups per CU
+            if (pmax <= short_k_max_p_) return 2;         // levels of small fronts (short K loops): 32-row tiles run the k_apply2 instance with four (gathered: three) workgroups per CU
             return (wgs * nodes_local() >= 1024) ? 4 : 2;
         };
         double rowb = 1.0;   // bytes are scaled by 16*ldw at run time: count block-vector ROWS here
