@@ -255,6 +255,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_FWD_SPLITK")) fwd_splitk_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
+    if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH32")) nopiv_max_growth32_ = atof(v);
     if (const char* v = getenv("FEASTHIP_NOPIV_GEN")) nopiv_gen_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_ADJ_FOLD")) adj_fold_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_RR_DEVICE")) rr_device_ = atoi(v) != 0;
@@ -1617,7 +1618,8 @@ int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int st
     // `iter` sweeps: the lazy conversion saves 6 ms of C3's 76 per round of factorisations and costs 0.08 ms per sweep, so it pays
     // for itself up to ~75 iterations -- taken for iter <= 64 (the reference's default is 10).
     const bool lazy_before = lazy_conversion_;
-    if (!store || iter <= 64) lazy_conversion_ = true;
+    static const bool lazy_auto = [] { const char* e = getenv("FEASTHIP_LAZY"); return e ? atoi(e) != 0 : true; }();      // FEASTHIP_LAZY=0: feast_run never switches it on
+    if (lazy_auto && (!store || iter <= 64)) lazy_conversion_ = true;
     struct RestoreLazy { bool& f; bool v; ~RestoreLazy() { f = v; } } restore_lazy{lazy_conversion_, lazy_before};
     if (store) { r = factorize(); if (r < 0) return r; warn = r; }                 // src/feast.jl:28-38
     int nit = 0;

@@ -205,6 +205,11 @@ private:
     bool terms_symmetric_ = false;         // every coefficient matrix equals its transpose: T(z) = T(z)^T for all z (pivot-light factorisation)
     bool nopiv_enabled_ = true, nopiv_failed_ = false;   // FEASTHIP_NOPIV=0 / a factorisation whose growth check failed: pivoted path from then on
     double nopiv_max_growth_ = 256.0;      // largest max(1, max |l_ij|) * max(1, max |u_ij| / ||T||) an elimination without interchanges is accepted with (FEASTHIP_NOPIV_GROWTH)
+    // ... and with complex64 sweeps over the factors (mixed_prec): the error of a sweep grows with the same product, and at 2^-24 a growth
+    // of 14-37 already put the moment of a dense symmetric 1200 x 1200 pencil off by 1.5e-2 -- the iteration stagnated (tools/fuzz_feast.py,
+    // seed 9002 case 103; with partial pivoting 8e-4 and 3 iterations).  FEASTHIP_NOPIV_GROWTH32.
+    double nopiv_max_growth32_ = 4.0;
+    double nopiv_growth_bound() const { return mixed_ ? std::min(nopiv_max_growth_, nopiv_max_growth32_) : nopiv_max_growth_; }
     bool use_nopiv() const { return terms_symmetric_ && nopiv_enabled_ && !nopiv_failed_; }
     bool use_nopiv_gen() const { return terms_hermitian_ && !terms_symmetric_ && nopiv_enabled_ && nopiv_gen_enabled_ && !nopiv_gen_failed_; }
     void rebuild_shard();                  // local_ / partner_ / fold_ / Kloc from contour, shard, terms and overrides

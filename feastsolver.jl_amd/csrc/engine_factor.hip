@@ -322,7 +322,7 @@ int Engine::factorize() {
     };
     if (gen) {
         for (int kk = 0; kk < Kloc; ++kk) growth = std::max(growth, growth_of(kk));
-        if (!(growth <= nopiv_max_growth_) || perturbed > 0) {
+        if (!(growth <= nopiv_growth_bound()) || perturbed > 0) {
             if (getenv("FEASTHIP_FACTOR_TRACE")) fprintf(stderr, "[feasthip factor] elimination without interchanges rejected (growth %.3g, %lld perturbed pivots): refactorising with partial pivoting\n", growth, (long long)perturbed);
             nopiv_gen_failed_ = true;
             const double t_first = ms;
@@ -335,7 +335,7 @@ int Engine::factorize() {
         for (int kk = 0; kk < Kloc; ++kk) growth = std::max(growth, growth_of(kk));
         // the elimination without interchanges was not harmless (a multiplier beyond the bound, or a pivot that had to be
         // perturbed): this matrix gets partial pivoting, now and on every later factorisation of this handle
-        if (!(growth <= nopiv_max_growth_) || perturbed > 0) {
+        if (!(growth <= nopiv_growth_bound()) || perturbed > 0) {
             if (getenv("FEASTHIP_FACTOR_TRACE")) fprintf(stderr, "[feasthip factor] pivot-light path rejected (max |l| %.3g, %lld perturbed pivots): refactorising with partial pivoting\n", growth, (long long)perturbed);
             nopiv_failed_ = true;
             const double t_first = ms;

@@ -2136,3 +2136,28 @@ def test_store_false_runs_on_lazily_converted_factors(gpu, pkg, fo, wl):
     lt, rt, nt = out[True][0]
     for lam, rmax, nit in out[False] + out[True][1:]:
         assert len(lam) == len(lt) == w["n_inside"] and np.abs(lam - lt).max() < 1e-10 and rmax < 1e-10 and abs(nit - nt) <= 1
+
+
+@pytest.mark.gpu
+def test_mixed_prec_refuses_eliminations_without_interchanges_that_grow(gpu, pkg, wl):
+    """feast!(...; mixed_prec=true) (src/feast.jl:19-25) sweeps in complex64.  Over factors eliminated WITHOUT interchanges the error of a sweep
+    grows with max|l| max|u| / ||T||: at a growth of 23 -- far inside the 256 the complex128 sweeps tolerate -- the moment of this dense
+    symmetric 1200 x 1200 pencil was off by 1e-2 and the iteration stagnated at a residual of 0.6 with two spurious Ritz values inside
+    (found by tools/fuzz_feast.py, seed 9002 case 103; this is the same family with a fixed seed).  With complex64 sweeps the growth
+    bound is 4: such a matrix is factorised with partial pivoting, like the reference's cgetrf, and converges in a handful of iterations;
+    the complex128 run keeps the symmetric path."""
+    n = 1200
+    rng = np.random.default_rng(4)
+    G = rng.standard_normal((n, n))
+    A = (G + G.T) / 2 / np.sqrt(n) + np.diag(np.arange(n) * (2.0 / n))
+    lam_all = np.linalg.eigvalsh(A)
+    c = lam_all[300 + 37 * 4]
+    dist = np.sort(np.abs(lam_all - c))
+    r = 0.5 * (dist[4] + dist[5])
+    con = pkg.circular_contour_trapezoidal(complex(c), float(r), 8)
+    ref = lam_all[np.abs(lam_all - c) <= r]
+    for mixed in (True, False):
+        info = {}
+        lam, V, res = pkg.feast(wl.rand_x0(n, 16, 104).copy(), A, con, iter=40, eps=1e-9, store=True, mixed_prec=mixed, info=info)
+        assert len(lam) == len(ref) == 5 and np.abs(np.sort(lam.real) - ref).max() < 1e-8 and res.max() < 1e-9 and info["nit"] <= 8
+        assert info["symmetric"] == (0 if mixed else 1), (mixed, info["symmetric"], info.get("growth"))

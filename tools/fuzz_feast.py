@@ -57,9 +57,14 @@ for case in range(ncases):
     con = pkg.circular_contour_trapezoidal(complex(c), float(r), K)
     info = {}
     mixed = (not gen) and bool(rng.integers(0, 4) == 0)          # feast!'s mixed_prec: complex64 shifted solves, complex128 accumulation
+    store = bool(rng.integers(0, 2))
+    if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):
+        continue                                    # (replays one case of a run: the random stream is consumed as in the full run)
+    if os.environ.get("FUZZ_DUMP"):                # inputs of the replayed case for a stand-alone reproducer
+        np.savez(os.environ["FUZZ_DUMP"], A=Ad, B=Bd, c=complex(c), r=float(r), K=K, m0=m0, X0=X0, gen=gen, mixed=mixed, store=store, sparse=sparse)
     try:
-        lam, V, res = pkg.gen_feast(X0.copy(), A, B, con, iter=40, eps=1e-9, store=bool(rng.integers(0, 2)), info=info) if gen else \
-                      pkg.feast(X0.copy(), A, con, iter=40, eps=1e-9, store=bool(rng.integers(0, 2)), mixed_prec=mixed, info=info)
+        lam, V, res = pkg.gen_feast(X0.copy(), A, B, con, iter=int(os.environ.get("FUZZ_ITER", "40")), eps=1e-9, store=store, info=info) if gen else \
+                      pkg.feast(X0.copy(), A, con, iter=int(os.environ.get("FUZZ_ITER", "40")), eps=1e-9, store=store, mixed_prec=mixed, info=info)
     except Exception as ex:
         print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} K={K} m0={m0} EXCEPTION {ex}")
         bad += 1
@@ -72,7 +77,7 @@ for case in range(ncases):
     else:
         Rres = float("nan")
     print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} mixed={mixed} K={K} m0={m0} inside {len(ref)} found {len(lam)} nit {info.get('nit')} "
-          f"res {Rres:.1e} symmetric_path {info.get('symmetric')} {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"res {Rres:.1e} symmetric_path {info.get('symmetric')} store {store} {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
 print(f"{ncases} cases, {bad} bad, {time.time() - t_start:.0f} s")
 sys.exit(1 if bad else 0)
