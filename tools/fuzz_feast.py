@@ -54,7 +54,20 @@ for case in range(ncases):
                                                     # all there with few nodes (the CPU oracle shows the same histories), nothing to compare
     m0 = min(n, int(kin * rng.uniform(1.5, 3.0)) + 2)
     X0 = wl.rand_x0(n, m0, int(rng.integers(1 << 30)))
-    con = pkg.circular_contour_trapezoidal(complex(c), float(r), K)
+    # FUZZ_CONTOURS=1: also the reference's other contour constructors (src/contour.jl:33-86), a square of half width r around c for the
+    # rectangular ones (open rectangle: eigenvalues within 10 % of r of an edge: skipped)
+    ckind = "circ_trap"
+    if os.environ.get("FUZZ_CONTOURS"):
+        ckind = str(rng.choice(["circ_trap", "circ_gauss", "rect_trap", "rect_gauss"]))
+        if ckind.startswith("rect"): K = 16
+    if ckind.startswith("rect"):
+        dre, dim = np.abs(lam_all.real - c.real), np.abs(lam_all.imag - c.imag)
+        near = (np.maximum(dre, dim) > 0.9 * r) & (np.maximum(dre, dim) < 1.1 * r)
+        if near.any():
+            continue
+        con = (pkg.rectangular_contour_trapezoidal if ckind == "rect_trap" else pkg.rectangular_contour_gauss)(complex(c) - r * (1 + 1j), complex(c) + r * (1 + 1j), K)
+    else:
+        con = (pkg.circular_contour_gauss if ckind == "circ_gauss" else pkg.circular_contour_trapezoidal)(complex(c), float(r), K)
     info = {}
     mixed = (not gen) and bool(rng.integers(0, 4) == 0)          # feast!'s mixed_prec: complex64 shifted solves, complex128 accumulation
     store = bool(rng.integers(0, 2))
@@ -69,7 +82,7 @@ for case in range(ncases):
         print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} K={K} m0={m0} EXCEPTION {ex}")
         bad += 1
         continue
-    ref = lam_all[np.abs(lam_all - c) <= r]
+    ref = lam_all[(np.maximum(np.abs(lam_all.real - c.real), np.abs(lam_all.imag - c.imag)) < r) if ckind.startswith("rect") else (np.abs(lam_all - c) <= r)]
     ok = len(lam) == len(ref) and (len(ref) == 0 or max(np.abs(lam - x).min() for x in ref) < 1e-6 * max(1.0, abs(c)))
     if len(lam):
         Rres = np.linalg.norm(Ad @ V - (Bd @ V) * lam[None, :], axis=0).max()
@@ -77,7 +90,7 @@ for case in range(ncases):
     else:
         Rres = float("nan")
     print(f"case {case}: n={n} sparse={sparse} sym={sym} cplx={cplx} gen={gen} mixed={mixed} K={K} m0={m0} inside {len(ref)} found {len(lam)} nit {info.get('nit')} "
-          f"res {Rres:.1e} symmetric_path {info.get('symmetric')} store {store} {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"res {Rres:.1e} symmetric_path {info.get('symmetric')} store {store} {ckind} {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
 print(f"{ncases} cases, {bad} bad, {time.time() - t_start:.0f} s")
 sys.exit(1 if bad else 0)
