@@ -21,6 +21,7 @@ python tools/hermitian_c3.py > $O/hermitian_c3.txt 2>> $O/bench.err
 FEASTHIP_ADJ_FOLD=0 python tools/hermitian_c3.py > $O/hermitian_c3_no_adjoint_fold.txt 2>> $O/bench.err
 python tools/other_calls.py > $O/other_calls.txt 2>> $O/bench.err
 python tools/c3_whole_call.py > $O/c3_whole_call.txt 2>> $O/bench.err
+python tools/c1_whole_call.py 2>> $O/bench.err | grep -v amdgpu > $O/c1_whole_call.txt
 bash tools/collect_factor_traces.sh $(basename $O) "c3 c2 c5" > $O/factor_traces.log 2>&1
 python tools/launch_profile.py 46 16 > $O/launch_profile_16_nodes.txt 2>> $O/bench.err
 for c in c3 c2 c5; do FEASTHIP_PROBE_SKIP_CONVERSION=1 python tools/factor_only.py $c 3 2>/dev/null; python tools/factor_only.py $c 3 2>/dev/null; done > $O/conversion_exposure.txt

@@ -3,7 +3,7 @@
 set -e
 O=gpurun_out/${1:-r05final}; P=gpurun_out/${2:-r05pmc}
 for f in bench_c3_g46.json bench_c3_g46_no_fold.json bench_c3_g46_mixed_prec.json bench_c3_g46_host_eigensolver.json bench_c3_g46_under_rocprof.json bench_c3_g64_scale_check.json \
-         bench_c2_dense4096.json bench_c4_c5.json c3_whole_call.txt hermitian_c3.txt hermitian_c3_no_adjoint_fold.txt other_calls.txt per_rank_load_single_gpu.txt \
+         bench_c2_dense4096.json bench_c4_c5.json c3_whole_call.txt c1_whole_call.txt hermitian_c3.txt hermitian_c3_no_adjoint_fold.txt other_calls.txt per_rank_load_single_gpu.txt \
          factor_trace_c3_g46.txt launch_profile_16_nodes.txt conversion_exposure.txt analysis_trace_c3_g46.txt analysis_probe_c3_g46.txt smalleig_bench.txt c5_rr_step.txt; do
   [ -s $O/$f ] && cp $O/$f profiles/r05_$f
 done
