@@ -54,7 +54,17 @@ for case in range(ncases):
     ins = (np.abs(lam - c) <= r) & (res < 1e-7)
     ref = lam_all[np.abs(lam_all - c) <= r]
     ok = ins.sum() == len(ref) and max(np.abs(lam[ins] - x).min() for x in ref) < 1e-6 * max(1.0, abs(c))
-    print(f"case {case}: n={n} deg={deg} sparse={sparse} cplx={cplx} m0={m0} inside {len(ref)} found {int(ins.sum())} nit {info.get('nit')} {'ok' if ok else 'MISMATCH'}", flush=True)
-    bad += 0 if ok else 1
+    okm, fm = True, -1
+    if os.environ.get("FUZZ_MOMENTS"):     # the same problem through nlfeast_moments (src/nlfeast.jl:173-318): a smaller subspace (2 moments), candidates by residual
+        mm = max(2, kin + 1)
+        try:
+            lm, Ym, rm = pkg.nlfeast_moments(T, wl.rand_x0(n, mm, int(rng.integers(1 << 30))), 16, 30, c=complex(c), r=float(r), eps=1e-10, moments=2, spurious=1e-5)
+            im = (np.abs(lm - c) <= r) & (rm < 1e-7)
+            fm = int(im.sum())
+            okm = fm == len(ref) and max(np.abs(lm[im] - x).min() for x in ref) < 1e-6 * max(1.0, abs(c))
+        except Exception as ex:
+            print(f"case {case}: nlfeast_moments EXCEPTION {ex}"); okm = False
+    print(f"case {case}: n={n} deg={deg} sparse={sparse} cplx={cplx} m0={m0} inside {len(ref)} found {int(ins.sum())} nit {info.get('nit')} moments found {fm} {'ok' if ok and okm else 'MISMATCH'}", flush=True)
+    bad += 0 if ok and okm else 1
 print(f"{ncases} cases, {bad} bad, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
