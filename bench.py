@@ -466,9 +466,11 @@ def main():
         sts = h.stats()
         ts = ts[1:]                      # the first one also rebuilds nothing, but it follows a different last kernel: left out like a warm-up step
         store_false = {"iterations_per_s": len(ts) / sum(ts), "ms_per_iteration": 1e3 * sum(ts) / len(ts), "steps": len(ts), "factor_ms": sts["factor_ms"],
-                       "contour_step_ms": sts["solve_ms"], "lazy_conversion": True,
+                       "contour_step_ms": sts["solve_ms"], "lazy_conversion": True, "early_sweep_levels": sts["early_sweep_levels"],
                        "factor_TFLOPs": sts["flops_factor"] * sts["factor_units"] / (sts["factor_ms"] * 1e-3) / 1e12,
-                       "note": "measured: every iteration = Rayleigh-Ritz step + numeric factorisation of every local unit + contour step"}
+                       "note": "measured: every iteration = Rayleigh-Ritz step + numeric factorisation of every local unit + contour step; with early_sweep_levels > 0 "
+                               "the forward sweep of that many tree levels ran under the factorisation (inside factor_ms) and contour_step_ms is the root's "
+                               "forward level + the backward sweep + the accumulation"}
         h.set_lazy_conversion(False)
         h.factorize()
         h.rr_step(); h.contour_step(); lam, res, ins = h.rr_step()

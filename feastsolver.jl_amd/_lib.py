@@ -23,6 +23,7 @@ class Stats(C.Structure):
         ("perturbed_pivots", C.c_int64), ("local_nodes", C.c_int32), ("m0", C.c_int32), ("ldw", C.c_int32),
         ("dense", C.c_int32), ("alloc_seconds", C.c_double),
         ("factor_units", C.c_int32), ("folded", C.c_int32), ("solve_bytes_streamed", C.c_double), ("symmetric", C.c_int32), ("rr_device_sweeps", C.c_int32), ("growth", C.c_double), ("proj_ms", C.c_double),
+        ("early_sweep_levels", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -206,6 +206,8 @@ int feasthip_get_stats(feasthip_handle_t h, feasthip_stats_t* o) {
     o->perturbed_pivots = e->perturbed; o->local_nodes = e->nodes_local(); o->m0 = e->m0; o->ldw = e->ldw; o->dense = e->dense ? 1 : 0;
     o->factor_units = e->Kloc; o->folded = e->folded() ? 1 : e->adj_folded() ? 2 : 0; o->solve_bytes_streamed = e->ldw ? e->solve_bytes_streamed() : 0;
     o->proj_ms = e->proj_ms;
+    o->early_sweep_levels = e->early_levels_;
+    o->reserved0 = 0;
     o->symmetric = e->nopiv_used ? 1 : e->nopiv_gen_used ? 2 : 0; o->growth = e->growth;
     o->rr_device_sweeps = e->rr_device_sweeps;
     return 0;

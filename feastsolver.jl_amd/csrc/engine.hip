@@ -261,6 +261,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_RR_DEVICE")) rr_device_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_RR_COND")) rr_cond_max_ = atof(v);
     if (const char* v = getenv("FEASTHIP_FOLD")) fold_enabled_ = atoi(v) != 0;          // initial state of feasthip_set_conjugate_fold
+    if (const char* v = getenv("FEASTHIP_EARLY_SWEEP")) early_sweep_enabled_ = atoi(v) != 0;
     int nst = 2;
     if (const char* v = getenv("FEASTHIP_STREAMS")) { nst = std::max(1, std::min(8, atoi(v))); streams_forced_ = true; }
     if (const char* v = getenv("FEASTHIP_RESERVE_CUS")) reserve_cus_ = std::max(0, std::min(16, atoi(v)));
@@ -1621,7 +1622,10 @@ int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int st
     static const bool lazy_auto = [] { const char* e = getenv("FEASTHIP_LAZY"); return e ? atoi(e) != 0 : true; }();      // FEASTHIP_LAZY=0: feast_run never switches it on
     if (lazy_auto && (!store || iter <= 64)) lazy_conversion_ = true;
     struct RestoreLazy { bool& f; bool v; ~RestoreLazy() { f = v; } } restore_lazy{lazy_conversion_, lazy_before};
-    if (store) { r = factorize(); if (r < 0) return r; warn = r; }                 // src/feast.jl:28-38
+    // store = true: src/feast.jl:28-38 factorises before the loop.  Nothing of the first Rayleigh-Ritz step reads the factors, so here the
+    // first contour step factorises -- its forward sweep then starts under the factorisation (early forward sweep, engine.hpp); a start
+    // block that already meets the stopping criterion costs no factorisation at all.
+    bool first_step_factorises = store != 0;
     int nit = 0;
     for (nit = 0; nit <= iter; ++nit) {                                             // :40
         r = rr_step(lambda, res, inside);
@@ -1630,7 +1634,7 @@ int Engine::feast_run(void* X, int64_t n_, int m0_, int iter, double eps, int st
         double mx = 0;
         for (int j = 0; j < m0; ++j) if (inside[j]) { any = true; mx = std::max(mx, res[j]); }
         if (any && mx < eps) break;                                                 // :53-56
-        if (nit < iter) { r = contour_step(store ? 0 : 1); if (r < 0) return r; if (r > 0) warn = r; }   // :57-72
+        if (nit < iter) { r = contour_step((!store || first_step_factorises) ? 1 : 0); first_step_factorises = false; if (r < 0) return r; if (r > 0) warn = r; }   // :57-72
     }
     if (nit_out) *nit_out = std::min(nit, iter);
     r = get_block(0, X);

@@ -165,6 +165,7 @@ public:
 
     // stats
     double analyze_seconds = 0, alloc_seconds = 0, factor_ms = 0, solve_ms = 0, rr_ms = 0, proj_ms = 0;
+    int early_levels_ = 0;                 // tree levels of the last factorisation's early forward sweep (feasthip_stats_t::early_sweep_levels)
     int64_t perturbed = 0;
     Symbolic S;
     int n = 0, nterms = 0, K = 0, Kloc = 0, m0 = 0, ldw = 0;
@@ -307,14 +308,14 @@ private:
     int solve_all(const cz* rhs);            // W_k = T(z_k)^-1 rhs for all local nodes
     void inside_test(const zc* lam, uint8_t* inside) const;
     int solve_all_impl(const cz* rhs, ProfileRow* prof);
-    int solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof);
+    int solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, int part = 0, int only_level = -1);
     // Adjoint sweeps T(z_k)^H x = rhs over the factors of the units kb .. kb + kc - 1; the block vectors of the sweep are the instance
     // slots slot0 .. slot0 + kc - 1 of W / Y / the contribution arenas.  The solution: adj_solution() (W, or Y when the fronts interchanged rows)
     int solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs);
     const cz* adj_solution() const { return (nopiv_used || nopiv_gen_used) ? d_W_.p : d_Y_.p; }
     DevBuf<int> d_rowid_;                 // identity "row interchanges" (relative index within the supernode) for the adjoint sweeps' gather / assembly
     template <typename T>
-    int solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall);
+    int solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall, int part, int only_level);
     // mixed precision (feast!'s mixed_prec, src/feast.jl:19-25): complex64 copies of factors and block vectors
     bool mixed_ = false;
     DevBuf<cf> d_fact32_, d_W32_, d_Y32_, d_crow32_[2], d_sk32_;
@@ -335,6 +336,16 @@ private:
     // update rows L21 raw (k_scale_panels touches the pivot rows only) and the forward sweep computes C_I = .. - L21 Y_J after Y_J in a
     // second launch per level.  lazy_factors_: what the factors in memory are.  Not with adjoint sweeps or the forward split-K.
     bool lazy_conversion_ = false, lazy_factors_ = false;
+    // Early forward sweep (store = false: a contour step that factorises first, src/feast.jl:64-65).  The forward sweep of a tree level
+    // needs that level's factors and the levels' below, nothing above: contour_step_begin hands the right-hand side to factorize()
+    // (early_rhs_), which enqueues the gather and the forward sweep of every level below the root on the conversion stream, right behind
+    // that level's conversion -- they run in the gaps of the levels above.  early_done_: the sweep that follows takes up at the root
+    // (solve_range part 2).  Symmetric eliminations without interchanges only (the identity row tables are known before the
+    // factorisation); a rejected factorisation starts over with pivoting and a whole sweep.  Same launches, same order per stream: bitwise
+    // the late sweep's result (test_early_forward_sweep_is_bitwise_the_late_one).
+    bool early_sweep_enabled_ = true;      // FEASTHIP_EARLY_SWEEP=0
+    const cz* early_rhs_ = nullptr;
+    bool early_done_ = false;
     bool fwd_splitk_ = false;         // FEASTHIP_FWD_SPLITK=1: split the long forward L21 products along K when few nodes are left on this GPU.
                                       // Measured at one unit per GPU (C3): the split launches gain 10-40 us each, their reductions cost 50-80 us:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)

@@ -102,6 +102,12 @@ int Engine::factorize() {
     // lazy conversion (engine.hpp): only where the primal sweeps alone read these factors, and no level splits its forward products along K
     bool lazy = lazy_conversion_ && !adj_fold_ && !dual_adj_ && !fwd_splitk_;
     for (const SolveLevel& V : splan_) if (V.f2split) lazy = false;
+    // early forward sweep (engine.hpp): the caller's contour step follows at once and its right-hand sides exist already
+    bool early = early_rhs_ && early_sweep_enabled_ && nopiv && !dense && !mixed_ && !adj_fold_ && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
+                 finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_ && stream_groups() == 1 && have_x_;
+    for (const SolveLevel& V : splan_) if (V.f2split) early = false;
+    early_done_ = false;
+    early_levels_ = 0;
     // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
     const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
     std::vector<hipEvent_t> tev;
@@ -261,10 +267,21 @@ int Engine::factorize() {
             launch_couple_outer(fin, dsym_, tl + F.outer[lvl].off, F.outer[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc, lazy);
             launch_couple_level(fin, dsym_, tl + F.inner[lvl].off, F.inner[lvl].count, SOLVE_NB << lvl, d_fact_.p, fs, Kloc);
         }
+        // ... and, in that stream's order, the forward sweep of this level (the levels below went the same way): it runs at the
+        // conversion's low priority in the gaps of the levels above.  Measured on C3, store=false iterations per second: 11.45 without,
+        // 11.87 so; 11.55 with all early levels enqueued at the end on a stream of their own behind per-level events (normal priority:
+        // the factorisation slows by what the sweep takes), 11.72 on a low-priority stream of their own enqueued level by level (the
+        // chain kernels' reserved CUs get occupied: root chain + 3 ms), 11.67 on a stream with rest_stream_'s CU mask.
+        if (early && d >= 1) {
+            lazy_factors_ = lazy;
+            int r = solve_range(fin, 0, Kloc, early_rhs_, nullptr, 1, d);
+            if (r) return r;
+        }
         if (!fuse)
             launch_extend_add(stream_, dsym_, tl + F.extend1.off, F.extend1.count, d_fact_.p, fs, cbp, cbs, d_cb_[par ^ 1].p,
                               std::max<int64_t>(1, S.cb_size[par ^ 1]), Kloc, 1, nopiv ? 1 : 0);
     }
+    if (early) { early_done_ = true; early_levels_ = S.maxdepth; }      // (the join of the conversion stream below covers the early launches)
     if (fin_used) { HIPCHK(hipEventRecord(ev_fin_, fin_stream_)); HIPCHK(hipStreamWaitEvent(stream_, ev_fin_, 0)); }
     if (ftrace) {
         stamp();
@@ -338,6 +355,7 @@ int Engine::factorize() {
         if (!(growth <= nopiv_growth_bound()) || perturbed > 0) {
             if (getenv("FEASTHIP_FACTOR_TRACE")) fprintf(stderr, "[feasthip factor] pivot-light path rejected (max |l| %.3g, %lld perturbed pivots): refactorising with partial pivoting\n", growth, (long long)perturbed);
             nopiv_failed_ = true;
+            early_done_ = false; early_levels_ = 0;      // (the early forward launches have finished with the stream synchronisation above)
             const double t_first = ms;
             int r = factorize();
             factor_ms += t_first;

@@ -5,13 +5,16 @@ namespace feasthip {
 
 int Engine::solve_all(const cz* rhs) { return solve_all_impl(rhs, nullptr); }
 
-int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof) {
-    if (mixed_) return solve_range_t<cf>(st, kb, kc, rhs, prof, d_fact32_.p, d_W32_.p, d_Y32_.p, d_crow32_[0].p, d_crow32_[1].p, d_sk32_.p);
-    return solve_range_t<cz>(st, kb, kc, rhs, prof, d_fact_.p, d_W_.p, d_Y_.p, d_crow_[0].p, d_crow_[1].p, d_sk_.p);
+// part 0: the whole sweep pair.  part 1: the forward sweep of the one tree level `only_level` >= 1 (with the gather in front of the deepest
+// one): early forward sweep, engine.hpp; identity row tables.  part 2: what is left after all of those -- the root's forward level and the
+// backward sweep.
+int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, int part, int only_level) {
+    if (mixed_) return solve_range_t<cf>(st, kb, kc, rhs, prof, d_fact32_.p, d_W32_.p, d_Y32_.p, d_crow32_[0].p, d_crow32_[1].p, d_sk32_.p, part, only_level);
+    return solve_range_t<cz>(st, kb, kc, rhs, prof, d_fact_.p, d_W_.p, d_Y_.p, d_crow_[0].p, d_crow_[1].p, d_sk_.p, part, only_level);
 }
 
 template <typename T>
-int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall) {
+int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, T* fact, T* Wall, T* Yall, T* crow0, T* crow1, T* skall, int part, int only_level) {
     const int ldw = solve_width();       // from here on the block vectors are the per-unit solve blocks (2 x Engine::ldw columns with the conjugate fold)
     const int ldrhs = this->ldw;
     int64_t fs = S.fact_size, ws = (int64_t)n * ldw;
@@ -19,8 +22,9 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     T* Fp = fact + (int64_t)kb * fs;
     T* Wp = Wall + (int64_t)kb * ws;
     T* Yp = Yall + (int64_t)kb * ws;
-    const int* rperm = d_rowperm_.p + (int64_t)kb * n;
-    const int* rinv = d_rowinv_.p + (int64_t)kb * n;
+    // (part 1 runs before the factorisation has written its row tables: without interchanges they are the identity tables)
+    const int* rperm = (part == 1 ? d_rowid_.p : d_rowperm_.p) + (int64_t)kb * n;
+    const int* rinv = (part == 1 ? d_rowid_.p : d_rowinv_.p) + (int64_t)kb * n;
     const Tile* tl = d_tiles_.p;
     hipEvent_t pa = nullptr, pb = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&pa)); HIPCHK(hipEventCreate(&pb)); }
@@ -37,16 +41,19 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         prof_detail.insert(prof_detail.end(), {(double)row, (double)ms, bytes, flops, (double)cur_tiles, (double)cur_depth});
     };
     double rowb = (double)ldw * sizeof(T);
-    begin();
-    launch_gather_rhs(st, dsym_, rhs, ldrhs, ldw, Wp, ws, rperm, kc);
-    end(0, 2.0 * n * rowb * kc, 0);
+    if (part == 0 || (part == 1 && only_level == S.maxdepth)) {
+        begin();
+        launch_gather_rhs(st, dsym_, rhs, ldrhs, ldw, Wp, ws, rperm, kc);
+        end(0, 2.0 * n * rowb * kc, 0);
+    }
     // Launch::bytes counts factor bytes, Launch::flops complex multiply-adds per block-vector column (one node)
     const double npu = fold_ ? 2.0 : 1.0;      // contour nodes per unit: algorithmic bytes count the factor once per NODE
     auto stat_bytes = [&](const Launch& L, double vec_rows) { return (L.bytes * (sizeof(T) / 16.0) * npu + vec_rows * rowb) * kc; };
     auto stat_flops = [&](const Launch& L) { return L.flops * 8.0 * ldw * kc; };
-    for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep, leaves to root
+    for (int d = (part == 2 ? 0 : S.maxdepth); d >= (part == 1 ? 1 : 0); --d) {          // forward sweep, leaves to root
         SolveLevel& V = splan_[d];
         cur_depth = d;
+        if (part == 1 && d != only_level) continue;          // (one level: in stream order behind that level's conversion)
         int par = d & 1;
         int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * ldw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * ldw;
         begin();
@@ -84,7 +91,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
             cur_tiles = V.f2red.count; end(1, (V.f2split + 1.0) * urows * rowb * kc, 0);
         }
     }
-    for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep, root to leaves
+    for (int d = 0; d <= S.maxdepth && part != 1; ++d) {          // backward sweep, root to leaves
         SolveLevel& V = splan_[d];
         cur_depth = d;
         double lvl_p = 0, lvl_u = 0;
@@ -188,6 +195,10 @@ int Engine::stream_groups() const {
 
 int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
     if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
+    if (early_done_) {      // factorize() has enqueued the gather and the forward levels below the root already (engine.hpp)
+        early_done_ = false;
+        return solve_range(stream_, 0, Kloc, rhs, nullptr, 2);
+    }
     int ns = stream_groups();
     if (adj_fold_) {
         // every unit is solved twice over its one factorisation: T(z_k) y = rhs by the primal sweeps, T(conj z_k) y = T(z_k)^H y = rhs
@@ -261,7 +272,13 @@ int Engine::contour_step_begin(int refactor, int nchunks) {
     if (step_open_) return fail(FEASTHIP_ESTATE, "contour_step_begin: the previous step was not ended");
     HIPCHK(hipSetDevice(device_));
     int warn = 0;
-    if (refactor || !factored_) { int r = factorize(); if (r < 0) return r; warn = r; }
+    if (refactor || !factored_) {
+        early_rhs_ = d_R_.p;      // the right-hand sides exist already: the forward sweep starts under the factorisation (engine.hpp)
+        int r = factorize();
+        early_rhs_ = nullptr;
+        if (r < 0) { early_done_ = false; return r; }
+        warn = r;
+    }
     std::vector<zc> e0 = node_table([&](int k, int j, int) { return weights_[k] / (nodes_[k] - lambda_[j]); });      // src/feast.jl:60,69
     HIPCHK(h2d_async(5, d_e0_.p, e0.data(), e0.size() * sizeof(zc)));
     // the table sits in pinned slot 5, which nothing else uses and which is rewritten only after the synchronisations of the next

@@ -2139,6 +2139,43 @@ def test_store_false_runs_on_lazily_converted_factors(gpu, pkg, fo, wl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lazy", [True, False])
+def test_early_forward_sweep_is_bitwise_the_late_one(gpu, pkg, wl, monkeypatch, lazy):
+    """store=false (src/feast.jl:64-65): feasthip_contour_step(h, 1) factorises and sweeps.  The forward sweep of a tree level only reads the
+    factors of that level and below, so the library enqueues it under the factorisation of the levels above (behind the level's own
+    conversion event) and the step proper takes up at the root.  Same kernels over the same data in the same order per stream: the moment
+    is bit for bit the one of the late sweep (FEASTHIP_EARLY_SWEEP=0), on fully and on lazily converted factors; a factorisation without
+    interchanges that is rejected (growth bound forced to 0.5 here) throws the early launches away and gives the pivoted handle's moment."""
+    w = wl.c3_sparse_generalized(16, 19, 24)
+    terms, scales = [w["A"], w["B"]], [1.0, -1.0]
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    _, q_early, st_early = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy)
+    monkeypatch.setenv("FEASTHIP_EARLY_SWEEP", "0")
+    _, q_late, st_late = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy)
+    monkeypatch.delenv("FEASTHIP_EARLY_SWEEP")
+    assert st_early["early_sweep_levels"] >= 2 and st_late["early_sweep_levels"] == 0 and st_early["symmetric"] == 1
+    assert np.isfinite(q_early).all() and np.array_equal(q_early, q_late)
+
+    def first_step():          # the handle's FIRST factorisation is the one inside the contour step
+        h = pkg.FeastHandle(0)
+        try:
+            h.set_terms(terms, scales); h.set_contour(con); h.set_lazy_conversion(lazy); h.set_x(w["X0"])
+            h.rr_step(); h.contour_step(True)
+            return h.get_block(2).copy(), h.stats()
+        finally:
+            h.close()
+    q_first, st_first = first_step()
+    assert st_first["early_sweep_levels"] >= 2
+    monkeypatch.setenv("FEASTHIP_NOPIV_GROWTH", "0.5")
+    q_rej, st_rej = first_step()
+    monkeypatch.delenv("FEASTHIP_NOPIV_GROWTH")
+    monkeypatch.setenv("FEASTHIP_NOPIV", "0")
+    q_piv, st_piv = first_step()
+    assert st_rej["symmetric"] == 0 and st_rej["early_sweep_levels"] == 0 and st_piv["symmetric"] == 0
+    assert np.array_equal(q_rej, q_piv) and np.abs(q_rej - q_first).max() <= 1e-10 * np.abs(q_first).max()
+
+
+@pytest.mark.gpu
 def test_mixed_prec_refuses_eliminations_without_interchanges_that_grow(gpu, pkg, wl):
     """feast!(...; mixed_prec=true) (src/feast.jl:19-25) sweeps in complex64.  Over factors eliminated WITHOUT interchanges the error of a sweep
     grows with max|l| max|u| / ||T||: at a growth of 23 -- far inside the 256 the complex128 sweeps tolerate -- the moment of this dense
