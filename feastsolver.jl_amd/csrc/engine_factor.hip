@@ -258,7 +258,8 @@ int Engine::factorize() {
             continue;
         }
         if (fin != stream_) { HIPCHK(hipEventRecord(ev_fin_fork_, stream_)); HIPCHK(hipStreamWaitEvent(fin, ev_fin_fork_, 0)); fin_used = true; }
-        launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
+        // (without interchanges the row tables are the identity tables the handle holds anyway, d_rowid_: 2.9 ms of C3's conversion stream, 0.2 of them exposed at the root)
+        if (!nopiv && !gen) launch_rowperm(fin, dsym_, ls + F.fronts.off, F.fronts.count, d_piv_.p, d_rowperm_.p, d_rowinv_.p, Kloc);
         if (nopiv) launch_couple32(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);      // the 32 x 32 inverses are in place already
         else launch_block_inverse(fin, dsym_, tl + F.binv.off, F.binv.count, d_fact_.p, fs, Kloc);
         launch_couple_inverse(fin, dsym_, tl + F.couple.off, F.couple.count, d_fact_.p, fs, Kloc);
@@ -271,7 +272,9 @@ int Engine::factorize() {
         // conversion's low priority in the gaps of the levels above.  Measured on C3, store=false iterations per second: 11.45 without,
         // 11.87 so; 11.55 with all early levels enqueued at the end on a stream of their own behind per-level events (normal priority:
         // the factorisation slows by what the sweep takes), 11.72 on a low-priority stream of their own enqueued level by level (the
-        // chain kernels' reserved CUs get occupied: root chain + 3 ms), 11.67 on a stream with rest_stream_'s CU mask.
+        // chain kernels' reserved CUs get occupied: root chain + 3 ms), 11.67 on a stream with rest_stream_'s CU mask.  (The conversions of
+        // the three top levels on a second low-priority stream, so that the root's does not queue behind the early sweeps: store=false
+        // 11.76 -> 11.5, a factorisation with the full conversion 75.8 -> 84.7 ms; with GPU_MAX_HW_QUEUES=8 11.8 -> 11.9 and 75.8 -> 80.6.)
         if (early && d >= 1) {
             lazy_factors_ = lazy;
             int r = solve_range(fin, 0, Kloc, early_rhs_, nullptr, 1, d);

@@ -22,9 +22,10 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     T* Fp = fact + (int64_t)kb * fs;
     T* Wp = Wall + (int64_t)kb * ws;
     T* Yp = Yall + (int64_t)kb * ws;
-    // (part 1 runs before the factorisation has written its row tables: without interchanges they are the identity tables)
-    const int* rperm = (part == 1 ? d_rowid_.p : d_rowperm_.p) + (int64_t)kb * n;
-    const int* rinv = (part == 1 ? d_rowid_.p : d_rowinv_.p) + (int64_t)kb * n;
+    // factors without interchanges (and part 1, which runs inside such a factorisation) take the identity tables; k_rowperm fills the others
+    const bool idrows = part == 1 || nopiv_used || nopiv_gen_used;
+    const int* rperm = (idrows ? d_rowid_.p : d_rowperm_.p) + (int64_t)kb * n;
+    const int* rinv = (idrows ? d_rowid_.p : d_rowinv_.p) + (int64_t)kb * n;
     const Tile* tl = d_tiles_.p;
     hipEvent_t pa = nullptr, pb = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&pa)); HIPCHK(hipEventCreate(&pb)); }

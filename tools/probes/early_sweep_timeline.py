@@ -20,7 +20,9 @@ for q in qs:
     for r in rq: names[r[2]] = names.get(r[2], 0) + (r[1] - r[0])
     print(f"queue {q}: {len(rq)} launches, first {(rq[0][0] - t0) / 1e6:.2f} last end {(max(r[1] for r in rq) - t0) / 1e6:.2f} ms | " + ", ".join(f"{k} {v / 1e6:.2f}" for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:6]))
 show = ("k_gather_rhs", "k_fwd_assemble", "k_apply2", "k_scale_panels", "k_couple_level", "k_rowperm", "k_splitk_reduce")
+tail_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0      # third argument: every launch of the last so many milliseconds before the root's sweep
 print("start ms   dur us  queue kernel workgroups")
+part2 = next((r[0] for r in R if r[3] == R[0][3] and r[2] in ("k_fwd_assemble", "k_apply2")), R[-1][0])
 for r in R:
-    if r[2] in show and (r[1] - r[0] > 30000 or r[2] in ("k_rowperm", "k_gather_rhs")):
+    if (r[2] in show and (r[1] - r[0] > 30000 or r[2] in ("k_rowperm", "k_gather_rhs"))) or (tail_ms and part2 - tail_ms * 1e6 <= r[0] < part2):
         print(f"{(r[0] - t0) / 1e6:8.3f} {(r[1] - r[0]) / 1e3:8.1f}  {r[3]:>4} {r[2]:18s} {r[4]}")
