@@ -252,6 +252,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* v = getenv("FEASTHIP_NB1024_MINP")) nb1024_min_p_ = std::max(513, atoi(v));
     if (const char* v = getenv("FEASTHIP_XCD_BALANCE")) xcd_balance_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_SHORTK_MAXP")) short_k_max_p_ = atoi(v);
+    if (const char* v = getenv("FEASTHIP_SLAB64_MIN")) slab64_min_wgs_ = atoi(v);
     if (const char* v = getenv("FEASTHIP_FWD_SPLITK")) fwd_splitk_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV")) nopiv_enabled_ = atoi(v) != 0;
     if (const char* v = getenv("FEASTHIP_NOPIV_GROWTH")) nopiv_max_growth_ = atof(v);
@@ -742,7 +743,7 @@ bool Engine::build_plans() {
             rows_of([&](int rows) { wgs += cdiv(rows, 64); });
             if (wgs * nodes_local() < 128) return 1;      // latency-bound launch (few nodes left on this GPU): 16-row tiles, four waves share the columns
             if (pmax <= short_k_max_p_) return 2;         // levels of small fronts (short K loops): 32-row tiles run the k_apply2 instance with four (gathered: three) workgroups per CU
-            return (wgs * nodes_local() >= 1024) ? 4 : 2;
+            return (wgs * nodes_local() >= slab64_min_wgs_) ? 4 : 2;
         };
         double rowb = 1.0;   // bytes are scaled by 16*ldw at run time: count block-vector ROWS here
         (void)rowb;

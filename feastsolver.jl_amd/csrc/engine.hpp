@@ -350,6 +350,7 @@ private:
                                       // Measured at one unit per GPU (C3): the split launches gain 10-40 us each, their reductions cost 50-80 us:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)
     bool xcd_balance_ = true;         // FEASTHIP_XCD_BALANCE=0: equal tile counts per XCD in every block-substitution launch (build_plans)
+    int slab64_min_wgs_ = 1024;       // launches with at least this many 64-row workgroups (over the local nodes) use 64-row tiles, smaller ones 32-row tiles (FEASTHIP_SLAB64_MIN)
     int short_k_max_p_ = 96;          // levels whose fronts have at most this many pivot columns use 32-row substitution tiles
     int nb256_min_p_ = 129, nb512_min_p_ = 1 << 30;   // fronts with at least this many pivot columns get 256- / 512-column solve super blocks.
                                       // Round 5: no 512-column blocks by default (they were taken from 1024 pivot columns on).  Coupling 256 -> 512 costs the
