@@ -340,7 +340,7 @@ private:
     // needs that level's factors and the levels' below, nothing above: contour_step_begin hands the right-hand side to factorize()
     // (early_rhs_), which enqueues the gather and the forward sweep of every level below the root on the conversion stream, right behind
     // that level's conversion -- they run in the gaps of the levels above.  early_done_: the sweep that follows takes up at the root
-    // (solve_range part 2).  Symmetric eliminations without interchanges only (the identity row tables are known before the
+    // (solve_range part 2; in node groups on their own streams where the late sweep would run so).  Symmetric eliminations without interchanges only (the identity row tables are known before the
     // factorisation); a rejected factorisation starts over with pivoting and a whole sweep.  Same launches, same order per stream: bitwise
     // the late sweep's result (test_early_forward_sweep_is_bitwise_the_late_one).
     bool early_sweep_enabled_ = true;      // FEASTHIP_EARLY_SWEEP=0

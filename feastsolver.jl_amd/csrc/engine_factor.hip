@@ -104,7 +104,7 @@ int Engine::factorize() {
     for (const SolveLevel& V : splan_) if (V.f2split) lazy = false;
     // early forward sweep (engine.hpp): the caller's contour step follows at once and its right-hand sides exist already
     bool early = early_rhs_ && early_sweep_enabled_ && nopiv && !dense && !mixed_ && !adj_fold_ && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
-                 finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_ && stream_groups() == 1 && have_x_;
+                 finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_ && have_x_;
     for (const SolveLevel& V : splan_) if (V.f2split) early = false;
     early_done_ = false;
     early_levels_ = 0;

@@ -196,10 +196,8 @@ int Engine::stream_groups() const {
 
 int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
     if (!factored_) return fail(FEASTHIP_ESTATE, "solve: factorize first");
-    if (early_done_) {      // factorize() has enqueued the gather and the forward levels below the root already (engine.hpp)
-        early_done_ = false;
-        return solve_range(stream_, 0, Kloc, rhs, nullptr, 2);
-    }
+    const int part = early_done_ ? 2 : 0;      // 2: factorize() has enqueued the gather and the forward levels below the root already (engine.hpp)
+    early_done_ = false;
     int ns = stream_groups();
     if (adj_fold_) {
         // every unit is solved twice over its one factorisation: T(z_k) y = rhs by the primal sweeps, T(conj z_k) y = T(z_k)^H y = rhs
@@ -219,7 +217,7 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         }
         return 0;
     }
-    if (prof || ns <= 1) return solve_range(stream_, 0, Kloc, rhs, prof);
+    if (prof || ns <= 1) return solve_range(stream_, 0, Kloc, rhs, prof, part);
     // The nodes are independent: split them over a few streams so that the tails and the latency-bound small
     // launches of one group overlap with the large launches of another.
     HIPCHK(hipEventRecord(ev_fork_, stream_));
@@ -228,7 +226,7 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
         int kb = g * per, kc = std::min(per, Kloc - kb);
         if (kc <= 0) break;
         HIPCHK(hipStreamWaitEvent(aux_streams_[g], ev_fork_, 0));
-        int r = solve_range(aux_streams_[g], kb, kc, rhs, nullptr);
+        int r = solve_range(aux_streams_[g], kb, kc, rhs, nullptr, part);
         if (r) return r;
         HIPCHK(hipEventRecord(ev_join_[g], aux_streams_[g]));
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_[g], 0));

@@ -2139,27 +2139,30 @@ def test_store_false_runs_on_lazily_converted_factors(gpu, pkg, fo, wl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lazy", [True, False])
-def test_early_forward_sweep_is_bitwise_the_late_one(gpu, pkg, wl, monkeypatch, lazy):
+@pytest.mark.parametrize("lazy,unfolded16", [(True, False), (False, False), (True, True)])
+def test_early_forward_sweep_is_bitwise_the_late_one(gpu, pkg, wl, monkeypatch, lazy, unfolded16):
     """store=false (src/feast.jl:64-65): feasthip_contour_step(h, 1) factorises and sweeps.  The forward sweep of a tree level only reads the
     factors of that level and below, so the library enqueues it under the factorisation of the levels above (behind the level's own
     conversion event) and the step proper takes up at the root.  Same kernels over the same data in the same order per stream: the moment
     is bit for bit the one of the late sweep (FEASTHIP_EARLY_SWEEP=0), on fully and on lazily converted factors; a factorisation without
-    interchanges that is rejected (growth bound forced to 0.5 here) throws the early launches away and gives the pivoted handle's moment."""
+    interchanges that is rejected (growth bound forced to 0.5 here) throws the early launches away and gives the pivoted handle's moment.
+    unfolded16: 16 units without the conjugate fold -- the rest of the step then runs in two node groups on streams of their own."""
     w = wl.c3_sparse_generalized(16, 19, 24)
     terms, scales = [w["A"], w["B"]], [1.0, -1.0]
-    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
-    _, q_early, st_early = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy)
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 16 if unfolded16 else 8)
+    fold = not unfolded16
+    _, q_early, st_early = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy, fold)
     monkeypatch.setenv("FEASTHIP_EARLY_SWEEP", "0")
-    _, q_late, st_late = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy)
+    _, q_late, st_late = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy, fold)
     monkeypatch.delenv("FEASTHIP_EARLY_SWEEP")
+    assert st_early["factor_units"] == (16 if unfolded16 else 4)
     assert st_early["early_sweep_levels"] >= 2 and st_late["early_sweep_levels"] == 0 and st_early["symmetric"] == 1
     assert np.isfinite(q_early).all() and np.array_equal(q_early, q_late)
 
     def first_step():          # the handle's FIRST factorisation is the one inside the contour step
         h = pkg.FeastHandle(0)
         try:
-            h.set_terms(terms, scales); h.set_contour(con); h.set_lazy_conversion(lazy); h.set_x(w["X0"])
+            h.set_terms(terms, scales); h.set_contour(con); h.set_conjugate_fold(fold); h.set_lazy_conversion(lazy); h.set_x(w["X0"])
             h.rr_step(); h.contour_step(True)
             return h.get_block(2).copy(), h.stats()
         finally:
