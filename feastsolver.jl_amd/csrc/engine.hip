@@ -1426,6 +1426,8 @@ int Engine::analyze() {
     }
     std::vector<int> c0row(n);
     for (int i = 0; i < n; ++i) c0row[i] = S.sn_start[S.sn_of[i]];
+    std::vector<int> drow(n);
+    for (int i = 0; i < n; ++i) drow[i] = S.depth[S.sn_of[i]];
     std::vector<int> rid((size_t)Kloc * n);          // (function scope: the asynchronous upload reads it until the stream is synchronised below)
     for (int k = 0; k < Kloc; ++k) for (int i = 0; i < n; ++i) rid[(size_t)k * n + i] = i - c0row[i];
     if (!d_rowid_.upload(rid.data(), rid.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
@@ -1434,7 +1436,7 @@ int Engine::analyze() {
               d_struct_.upload(S.struct_idx.empty() ? one.data() : S.struct_idx.data(), std::max<size_t>(1, S.struct_idx.size()), stream_) &&
               d_rel_.upload(S.rel.empty() ? one.data() : S.rel.data(), std::max<size_t>(1, S.rel.size()), stream_) &&
               d_child_.upload(S.child_idx.empty() ? one.data() : S.child_idx.data(), std::max<size_t>(1, S.child_idx.size()), stream_) &&
-              d_perm_.upload(S.perm.data(), n, stream_) && d_iperm_.upload(S.iperm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) &&
+              d_perm_.upload(S.perm.data(), n, stream_) && d_iperm_.upload(S.iperm.data(), n, stream_) && d_c0row_.upload(c0row.data(), n, stream_) && d_drow_.upload(drow.data(), n, stream_) &&
               d_cmap_.upload(cmap.data(), cmap.size(), stream_) && d_ebp_.upload(ebp.data(), ebp.size(), stream_) &&
               d_pmap_.upload(pmap.data(), pmap.size(), stream_);
     if (getenv("FEASTHIP_ANALYZE_TRACE")) fprintf(stderr, "[feasthip analyze] + front records, index uploads  %.1f ms (cumulative)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -1444,7 +1446,7 @@ int Engine::analyze() {
     for (int s = 0; s < S.nsuper; ++s) { fr[s].sk_off = sk_off_[s]; fr[s].skf_off = skf_off_[s]; }
     if (!d_fr_.upload(fr.data(), fr.size(), stream_)) return fail(FEASTHIP_EHIP, "analyze: device upload failed");
     dsym_.fr = d_fr_.p; dsym_.struct_idx = d_struct_.p; dsym_.rel = d_rel_.p; dsym_.child_idx = d_child_.p;
-    dsym_.perm = d_perm_.p; dsym_.iperm = d_iperm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.pmap = d_pmap_.p; dsym_.n = n;
+    dsym_.perm = d_perm_.p; dsym_.iperm = d_iperm_.p; dsym_.c0_of_row = d_c0row_.p; dsym_.depth_of_row = d_drow_.p; dsym_.cmap = d_cmap_.p; dsym_.ebp = d_ebp_.p; dsym_.pmap = d_pmap_.p; dsym_.n = n;
     dsym_.asmflag = nullptr;
     {
         // fused right-hand-side gather: the pivot rows that receive contributions of children are written by k_fwd_assemble

@@ -224,7 +224,7 @@ private:
 
     // device symbolic
     DevBuf<FrontD> d_fr_;
-    DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_iperm_, d_c0row_, d_cmap_, d_ebp_;
+    DevBuf<int> d_struct_, d_rel_, d_child_, d_perm_, d_iperm_, d_c0row_, d_drow_, d_cmap_, d_ebp_;
     DevBuf<int> d_asmflag_;     // fused right-hand-side gather (kernels.hpp: DevSym::asmflag; FEASTHIP_FUSE_GATHER=0 turns it off)
     DevBuf<Tile> d_tiles_;
     DevBuf<int> d_lists_;
@@ -337,15 +337,17 @@ private:
     // second launch per level.  lazy_factors_: what the factors in memory are.  Not with adjoint sweeps or the forward split-K.
     bool lazy_conversion_ = false, lazy_factors_ = false;
     // Early forward sweep (store = false: a contour step that factorises first, src/feast.jl:64-65).  The forward sweep of a tree level
-    // needs that level's factors and the levels' below, nothing above: contour_step_begin hands the right-hand side to factorize()
-    // (early_rhs_), which enqueues the gather and the forward sweep of every level below the root on the conversion stream, right behind
-    // that level's conversion -- they run in the gaps of the levels above.  early_done_: the sweep that follows takes up at the root
-    // (solve_range part 2; in node groups on their own streams where the late sweep would run so).  Symmetric eliminations without interchanges only (the identity row tables are known before the
-    // factorisation); a rejected factorisation starts over with pivoting and a whole sweep.  Same launches, same order per stream: bitwise
-    // the late sweep's result (test_early_forward_sweep_is_bitwise_the_late_one).
+    // needs that level's factors and row interchanges and the levels' below, nothing above: contour_step_begin hands the right-hand side to
+    // factorize() (early_rhs_), which enqueues the right-hand-side gather and the forward sweep of every level below the root on the
+    // conversion stream, right behind that level's conversion -- they run in the gaps of the levels above.  early_done_: the sweep that
+    // follows gathers the root's rows and takes up there (solve_range part 2; in node groups on their own streams where the late sweep would
+    // run so).  A rejected elimination without interchanges starts over with pivoting, early sweep included.  The same launches as the late
+    // sweep but for the gather (level by level instead of one pass: a copy), in the same order: bitwise the late sweep's result
+    // (test_early_forward_sweep_is_bitwise_the_late_one).  Not with complex64 sweeps (their factors are converted at the end) or adjoint sweeps.
     bool early_sweep_enabled_ = true;      // FEASTHIP_EARLY_SWEEP=0
     const cz* early_rhs_ = nullptr;
     bool early_done_ = false;
+    bool early_idrows_ = false;            // the factorisation under way runs without interchanges: its early launches read the identity row tables
     bool fwd_splitk_ = false;         // FEASTHIP_FWD_SPLITK=1: split the long forward L21 products along K when few nodes are left on this GPU.
                                       // Measured at one unit per GPU (C3): the split launches gain 10-40 us each, their reductions cost 50-80 us:
                                       // contour step 4.31 instead of 4.11 ms -- off by default (profiles/r03_per_rank_load_single_gpu.txt)

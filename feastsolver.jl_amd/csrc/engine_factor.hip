@@ -103,11 +103,12 @@ int Engine::factorize() {
     bool lazy = lazy_conversion_ && !adj_fold_ && !dual_adj_ && !fwd_splitk_;
     for (const SolveLevel& V : splan_) if (V.f2split) lazy = false;
     // early forward sweep (engine.hpp): the caller's contour step follows at once and its right-hand sides exist already
-    bool early = early_rhs_ && early_sweep_enabled_ && nopiv && !dense && !mixed_ && !adj_fold_ && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
+    bool early = early_rhs_ && early_sweep_enabled_ && !dense && !mixed_ && !adj_fold_ && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
                  finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_ && have_x_;
     for (const SolveLevel& V : splan_) if (V.f2split) early = false;
     early_done_ = false;
     early_levels_ = 0;
+    early_idrows_ = nopiv || gen;
     // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
     const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
     std::vector<hipEvent_t> tev;

@@ -5,9 +5,8 @@ namespace feasthip {
 
 int Engine::solve_all(const cz* rhs) { return solve_all_impl(rhs, nullptr); }
 
-// part 0: the whole sweep pair.  part 1: the forward sweep of the one tree level `only_level` >= 1 (with the gather in front of the deepest
-// one): early forward sweep, engine.hpp; identity row tables.  part 2: what is left after all of those -- the root's forward level and the
-// backward sweep.
+// part 0: the whole sweep pair.  part 1: right-hand-side gather and forward sweep of the one tree level `only_level` >= 1 (early forward
+// sweep, engine.hpp).  part 2: what is left after all of those -- the root's gather and forward level, and the backward sweep.
 int Engine::solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, int part, int only_level) {
     if (mixed_) return solve_range_t<cf>(st, kb, kc, rhs, prof, d_fact32_.p, d_W32_.p, d_Y32_.p, d_crow32_[0].p, d_crow32_[1].p, d_sk32_.p, part, only_level);
     return solve_range_t<cz>(st, kb, kc, rhs, prof, d_fact_.p, d_W_.p, d_Y_.p, d_crow_[0].p, d_crow_[1].p, d_sk_.p, part, only_level);
@@ -22,8 +21,8 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
     T* Fp = fact + (int64_t)kb * fs;
     T* Wp = Wall + (int64_t)kb * ws;
     T* Yp = Yall + (int64_t)kb * ws;
-    // factors without interchanges (and part 1, which runs inside such a factorisation) take the identity tables; k_rowperm fills the others
-    const bool idrows = part == 1 || nopiv_used || nopiv_gen_used;
+    // factors without interchanges take the identity tables, k_rowperm fills the others (part 1 runs inside a factorisation: its kind, not the last one's)
+    const bool idrows = part == 1 ? early_idrows_ : (nopiv_used || nopiv_gen_used);
     const int* rperm = (idrows ? d_rowid_.p : d_rowperm_.p) + (int64_t)kb * n;
     const int* rinv = (idrows ? d_rowid_.p : d_rowinv_.p) + (int64_t)kb * n;
     const Tile* tl = d_tiles_.p;
@@ -42,9 +41,9 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
         prof_detail.insert(prof_detail.end(), {(double)row, (double)ms, bytes, flops, (double)cur_tiles, (double)cur_depth});
     };
     double rowb = (double)ldw * sizeof(T);
-    if (part == 0 || (part == 1 && only_level == S.maxdepth)) {
+    {   // right-hand sides into the fronts' pivot rows: all of them, or the rows of one tree level (part 1: level only_level, part 2: the root's)
         begin();
-        launch_gather_rhs(st, dsym_, rhs, ldrhs, ldw, Wp, ws, rperm, kc);
+        launch_gather_rhs(st, dsym_, rhs, ldrhs, ldw, Wp, ws, rperm, kc, part == 0 ? -1 : part == 1 ? only_level : 0);
         end(0, 2.0 * n * rowb * kc, 0);
     }
     // Launch::bytes counts factor bytes, Launch::flops complex multiply-adds per block-vector column (one node)

@@ -20,6 +20,7 @@ struct DevSym {          // device copies of the symbolic structure
     const int* perm;     // new -> old
     const int* iperm;    // old -> new
     const int* c0_of_row;  // first column of the supernode owning (new) row i
+    const int* depth_of_row;  // tree depth of that supernode (the right-hand-side gather of ONE tree level: early forward sweep)
     const int* cmap;       // per front with children: [contribution row][child slot] -> row in the children's arena, or -1
     const int* ebp;        // extend-add break points, see FrontD::ebp
     const int* pmap;       // per front with children: [pivot row][child slot] -> row in the children's arena, or -1 (k_fwd_assemble)
@@ -93,8 +94,9 @@ void launch_rowperm(hipStream_t st, const DevSym& S, const int* list, int nlist,
 
 // ---- block triangular solves ------------------------------------------------
 // lds = leading dimension of W: ldw, or 2 ldw for the conjugate fold (columns ldw.. receive conj(src))
+// only_depth >= 0: the rows of the fronts of that tree depth only
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cz* W, int64_t ws,
-                       const int* rowperm, int K);
+                       const int* rowperm, int K, int only_depth = -1);
 // (src, ldsrc: the right-hand side the sweep started from, for the rows k_gather_rhs left to the first contribution)
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cz* W, int64_t ws, int ldw,
                          const cz* crow_child, int64_t crs_child, const int* rowinv, int K, const cz* src = nullptr, int ldsrc = 0);
@@ -131,7 +133,7 @@ void launch_apply(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles
                   cf* skbuf = nullptr, int64_t sks = 0, const cf* crow_child = nullptr, int64_t crs_child = 0, int max_slabs = 4,
                   const XcdParts* xp = nullptr);
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cf* W, int64_t ws,
-                       const int* rowperm, int K);
+                       const int* rowperm, int K, int only_depth = -1);
 void launch_fwd_assemble(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, cf* W, int64_t ws, int ldw,
                          const cf* crow_child, int64_t crs_child, const int* rowinv, int K, const cz* src = nullptr, int ldsrc = 0);
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cf* Y, int64_t ws, int ldw,

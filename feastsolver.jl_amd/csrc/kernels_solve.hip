@@ -34,13 +34,13 @@ template <> __device__ inline cf el_make<cf>(double x, double y) { cf r; r.x = (
 template <typename T>
 __global__ __launch_bounds__(256) void k_gather_rhs(const int* __restrict__ perm, const int* __restrict__ c0_of_row, int n,
                                                     const cz* __restrict__ src, int ldw, int lds, T* W, int64_t ws, const int* __restrict__ rowperm,
-                                                    const int* __restrict__ asmflag) {
+                                                    const int* __restrict__ asmflag, const int* __restrict__ depth_of_row, int only_depth) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = (blockIdx.x * 4 + wave) * 64, k = blockIdx.y;
     if (i0 >= n) return;
     const int i = i0 + lane;
     int srow = -1;
-    if (i < n) {
+    if (i < n && (only_depth < 0 || depth_of_row[i] == only_depth)) {      // (one tree level: the early forward sweep gathers level by level)
         const int pre = c0_of_row[i] + rowperm[(int64_t)k * n + i];
         if (!(asmflag && asmflag[pre])) srow = perm[pre];
     }
@@ -68,12 +68,12 @@ __global__ __launch_bounds__(256) void k_gather_rhs(const int* __restrict__ perm
 }
 
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cz* W, int64_t ws,
-                       const int* rowperm, int K) {
-    hipLaunchKernelGGL(k_gather_rhs<cz>, dim3((S.n + 255) / 256, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm, S.asmflag);
+                       const int* rowperm, int K, int only_depth) {
+    hipLaunchKernelGGL(k_gather_rhs<cz>, dim3((S.n + 255) / 256, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm, S.asmflag, S.depth_of_row, only_depth);
 }
 void launch_gather_rhs(hipStream_t st, const DevSym& S, const cz* src, int ldw, int lds, cf* W, int64_t ws,
-                       const int* rowperm, int K) {
-    hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 255) / 256, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm, S.asmflag);
+                       const int* rowperm, int K, int only_depth) {
+    hipLaunchKernelGGL(k_gather_rhs<cf>, dim3((S.n + 255) / 256, K), dim3(256), 0, st, S.perm, S.c0_of_row, S.n, src, ldw, lds, W, ws, rowperm, S.asmflag, S.depth_of_row, only_depth);
 }
 
 // Forward sweep, assembly of the children's contribution rows into the pivot rows of the parent (the rest of a child's rows is pulled

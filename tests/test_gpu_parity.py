@@ -2145,7 +2145,8 @@ def test_early_forward_sweep_is_bitwise_the_late_one(gpu, pkg, wl, monkeypatch, 
     factors of that level and below, so the library enqueues it under the factorisation of the levels above (behind the level's own
     conversion event) and the step proper takes up at the root.  Same kernels over the same data in the same order per stream: the moment
     is bit for bit the one of the late sweep (FEASTHIP_EARLY_SWEEP=0), on fully and on lazily converted factors; a factorisation without
-    interchanges that is rejected (growth bound forced to 0.5 here) throws the early launches away and gives the pivoted handle's moment.
+    interchanges that is rejected (growth bound forced to 0.5 here) starts over with partial pivoting, early sweep included, and gives the
+    pivoted handle's moment -- which is the late pivoted sweep's, bit for bit.
     unfolded16: 16 units without the conjugate fold -- the rest of the step then runs in two node groups on streams of their own."""
     w = wl.c3_sparse_generalized(16, 19, 24)
     terms, scales = [w["A"], w["B"]], [1.0, -1.0]
@@ -2174,8 +2175,36 @@ def test_early_forward_sweep_is_bitwise_the_late_one(gpu, pkg, wl, monkeypatch, 
     monkeypatch.delenv("FEASTHIP_NOPIV_GROWTH")
     monkeypatch.setenv("FEASTHIP_NOPIV", "0")
     q_piv, st_piv = first_step()
-    assert st_rej["symmetric"] == 0 and st_rej["early_sweep_levels"] == 0 and st_piv["symmetric"] == 0
+    monkeypatch.setenv("FEASTHIP_EARLY_SWEEP", "0")
+    q_piv_late, st_piv_late = first_step()
+    assert st_rej["symmetric"] == 0 and st_rej["early_sweep_levels"] >= 2 and st_piv["symmetric"] == 0 and st_piv["early_sweep_levels"] >= 2
+    assert st_piv_late["early_sweep_levels"] == 0 and np.array_equal(q_piv, q_piv_late)
     assert np.array_equal(q_rej, q_piv) and np.abs(q_rej - q_first).max() <= 1e-10 * np.abs(q_first).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["unsymmetric", "unsymmetric_lazy", "hermitian_without_adjoint_fold"])
+def test_early_forward_sweep_with_interchanges(gpu, pkg, wl, monkeypatch, case):
+    """The early forward sweep on factorisations WITH row interchanges inside the fronts (sparse unsymmetric pencil: the look-ahead pivoted
+    schedule), where the right-hand-side gather of a tree level reads that level's interchanges (written by the level's conversion), and on
+    the Hermitian path without interchanges (L and U apart; adjoint fold off, the adjoint sweeps keep the late sweep): bit for bit the late sweep."""
+    rng = np.random.default_rng(5)
+    if case.startswith("unsymmetric"):
+        w = wl.c3_sparse_generalized(14, 19, 24)
+        A = sp.csc_matrix(w["A"], dtype=np.complex128)
+        A = A + sp.csc_matrix((0.05 * rng.standard_normal(A.nnz), A.indices, A.indptr), shape=A.shape)      # same pattern, unsymmetric values
+        terms, want = [A, w["B"]], 0
+    else:
+        w = wl.c3_sparse_generalized(12, 19, 16)
+        terms, want = [wl.hermitian_phases(w["A"], seed=3), w["B"]], 2
+        monkeypatch.setenv("FEASTHIP_ADJ_FOLD", "0")
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    lazy = case.endswith("lazy")
+    q1e, q2e, st_e = _moment_lazy(pkg, terms, [1.0, -1.0], con, w["X0"], lazy)
+    monkeypatch.setenv("FEASTHIP_EARLY_SWEEP", "0")
+    q1l, q2l, st_l = _moment_lazy(pkg, terms, [1.0, -1.0], con, w["X0"], lazy)
+    assert st_e["symmetric"] == want and st_e["early_sweep_levels"] >= 2 and st_l["early_sweep_levels"] == 0
+    assert np.isfinite(q2e).all() and np.array_equal(q1e, q1l) and np.array_equal(q2e, q2l)
 
 
 @pytest.mark.gpu
