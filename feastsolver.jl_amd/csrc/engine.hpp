@@ -343,7 +343,7 @@ private:
     // follows gathers the root's rows and takes up there (solve_range part 2; in node groups on their own streams where the late sweep would
     // run so).  A rejected elimination without interchanges starts over with pivoting, early sweep included.  The same launches as the late
     // sweep but for the gather (level by level instead of one pass: a copy), in the same order: bitwise the late sweep's result
-    // (test_early_forward_sweep_is_bitwise_the_late_one).  Not with complex64 sweeps (their factors are converted at the end) or adjoint sweeps.
+    // (test_early_forward_sweep_is_bitwise_the_late_one).  Not with adjoint sweeps.
     bool early_sweep_enabled_ = true;      // FEASTHIP_EARLY_SWEEP=0
     const cz* early_rhs_ = nullptr;
     bool early_done_ = false;

@@ -103,12 +103,17 @@ int Engine::factorize() {
     bool lazy = lazy_conversion_ && !adj_fold_ && !dual_adj_ && !fwd_splitk_;
     for (const SolveLevel& V : splan_) if (V.f2split) lazy = false;
     // early forward sweep (engine.hpp): the caller's contour step follows at once and its right-hand sides exist already
-    bool early = early_rhs_ && early_sweep_enabled_ && !dense && !mixed_ && !adj_fold_ && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
+    bool early = early_rhs_ && early_sweep_enabled_ && !dense && !adj_fold_ && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
                  finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_ && have_x_;
     for (const SolveLevel& V : splan_) if (V.f2split) early = false;
     early_done_ = false;
     early_levels_ = 0;
     early_idrows_ = nopiv || gen;
+    // complex64 sweeps (mixed_prec): the complex64 copy of a level's solve-ready fronts is made right behind the level's conversion on the
+    // conversion stream (sparse matrices; one pass over the whole arena at the end otherwise: 18.6 GB, 3.5 ms on C3)
+    if (mixed_ && !d_fact32_.alloc((size_t)Kloc * fs)) return fail(FEASTHIP_EHIP, "out of device memory for the complex64 factors");
+    const bool f32_by_level = mixed_ && !dense && !skip_conversion && finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_;
+    if (!f32_by_level && mixed_) early = false;
     // FEASTHIP_FACTOR_TRACE: main-stream time stamps after the extend-add, the panel steps and the Schur product of every level
     const bool ftrace = getenv("FEASTHIP_FACTOR_TRACE") != nullptr;
     std::vector<hipEvent_t> tev;
@@ -276,6 +281,11 @@ int Engine::factorize() {
         // chain kernels' reserved CUs get occupied: root chain + 3 ms), 11.67 on a stream with rest_stream_'s CU mask.  (The conversions of
         // the three top levels on a second low-priority stream, so that the root's does not queue behind the early sweeps: store=false
         // 11.76 -> 11.5, a factorisation with the full conversion 75.8 -> 84.7 ms; with GPU_MAX_HW_QUEUES=8 11.8 -> 11.9 and 75.8 -> 80.6.)
+        if (f32_by_level) {
+            int level_ld2 = 0;
+            for (int s2 : S.levels[d]) level_ld2 = std::max(level_ld2, S.p(s2) + S.u(s2));
+            launch_to_f32_fronts(fin, dsym_, ls + F.fronts.off, F.fronts.count, (int)std::min<int64_t>(1024, ((int64_t)level_ld2 * level_ld2 + 4095) / 4096), d_fact_.p, d_fact32_.p, fs, Kloc);
+        }
         if (early && d >= 1) {
             lazy_factors_ = lazy;
             int r = solve_range(fin, 0, Kloc, early_rhs_, nullptr, 1, d);
@@ -310,10 +320,7 @@ int Engine::factorize() {
         }
         for (hipEvent_t e4 : tev) (void)hipEventDestroy(e4);
     }
-    if (mixed_) {      // complex64 copy of the solve-ready factors for the mixed-precision sweeps
-        if (!d_fact32_.alloc((size_t)Kloc * fs)) return fail(FEASTHIP_EHIP, "out of device memory for the complex64 factors");
-        launch_to_f32(stream_, (int64_t)Kloc * fs, d_fact_.p, d_fact32_.p);
-    }
+    if (mixed_ && !f32_by_level) launch_to_f32(stream_, (int64_t)Kloc * fs, d_fact_.p, d_fact32_.p);      // complex64 copy of the solve-ready factors for the mixed-precision sweeps
     HIPCHK(hipEventRecord(ev1_, stream_));
     std::vector<int> np(Kloc);
     std::vector<int64_t> gr((size_t)3 * Kloc, 0);

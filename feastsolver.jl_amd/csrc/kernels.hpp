@@ -141,6 +141,8 @@ void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, in
 void launch_accumulate(hipStream_t st, const DevSym& S, const cz* X, const cf* W, int64_t ws, int ldw, int lds, int K,
                        const cz* e0, const cz* e1, int mode, cz* Q0, cz* Q1, int row0 = 0, int nrows = -1);
 void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out);
+// the fronts of one tree level (front indices `list`), `chunks` workgroups of 256 entries in flight per front and unit
+void launch_to_f32_fronts(hipStream_t st, const DevSym& S, const int* list, int nlist, int chunks, const cz* in, cf* out, int64_t fs, int K);
 // Kind-3 tiles may be split along K (Tile.a bits 16.. = number of parts, Tile.c = part): each part writes
 // -U12[:, part] * x[part] into its own slab of `skbuf`; launch_splitk_reduce then adds the slabs to Y in a fixed order.
 void launch_splitk_reduce(hipStream_t st, const DevSym& S, const Tile* tiles, int ntiles, int nsplit, cz* Y, int64_t ws, int ldw,

@@ -707,6 +707,26 @@ __global__ void k_to_f32(int64_t total, const cz* __restrict__ in, cf* out) {
     out[e] = r;
 }
 
+// The same for the fronts of one tree level (list of front indices): a front's L panel ((p + u) x p) and its U12 block (p x u).  blockIdx.y
+// walks the front's entries in strides of gridDim.y * 256, blockIdx.z the units.
+__global__ __launch_bounds__(256) void k_to_f32_fronts(const FrontD* __restrict__ fr, const int* __restrict__ list, const cz* __restrict__ in, cf* out, int64_t fs) {
+    const FrontD f = fr[list[blockIdx.x]];
+    const int64_t nl = (int64_t)(f.p + f.u) * f.p, nu = (int64_t)f.p * f.u;
+    const cz* src = in + (int64_t)blockIdx.z * fs;
+    cf* dst = out + (int64_t)blockIdx.z * fs;
+    for (int64_t e = blockIdx.y * 256 + threadIdx.x; e < nl + nu; e += (int64_t)gridDim.y * 256) {
+        const int64_t a = e < nl ? f.lp + e : f.f12 + (e - nl);
+        const cz v = src[a];
+        cf r; r.x = (float)v.x; r.y = (float)v.y;
+        dst[a] = r;
+    }
+}
+
+void launch_to_f32_fronts(hipStream_t st, const DevSym& S, const int* list, int nlist, int chunks, const cz* in, cf* out, int64_t fs, int K) {
+    if (nlist <= 0) return;
+    hipLaunchKernelGGL(k_to_f32_fronts, dim3(nlist, std::max(1, std::min(chunks, 65535)), K), dim3(256), 0, st, S.fr, list, in, out, fs);
+}
+
 void launch_to_f32(hipStream_t st, int64_t total, const cz* in, cf* out) {
     hipLaunchKernelGGL(k_to_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, in, out);
 }

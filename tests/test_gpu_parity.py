@@ -2183,6 +2183,24 @@ def test_early_forward_sweep_is_bitwise_the_late_one(gpu, pkg, wl, monkeypatch, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lazy", [False, True])
+def test_early_forward_sweep_in_complex64(gpu, pkg, wl, monkeypatch, lazy):
+    """mixed_prec (src/feast.jl:19-25) with store=false: the complex64 copy of a tree level's fronts is made right behind the level's
+    conversion, so the complex64 forward sweep of that level can start under the factorisation too.  Bit for bit the late sweep, and the moment
+    of the complex128 sweeps to complex64 accuracy."""
+    w = wl.c3_sparse_generalized(16, 19, 24)
+    terms, scales = [w["A"], w["B"]], [1.0, -1.0]
+    con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
+    q1e, q2e, st_e = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy, True, True)
+    monkeypatch.setenv("FEASTHIP_EARLY_SWEEP", "0")
+    q1l, q2l, st_l = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy, True, True)
+    _, q2d, _ = _moment_lazy(pkg, terms, scales, con, w["X0"], lazy, True, False)
+    assert st_e["early_sweep_levels"] >= 2 and st_l["early_sweep_levels"] == 0
+    assert np.isfinite(q2e).all() and np.array_equal(q1e, q1l) and np.array_equal(q2e, q2l)
+    assert np.abs(q2e - q2d).max() <= 2e-5 * np.abs(q2d).max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["unsymmetric", "unsymmetric_lazy", "hermitian_without_adjoint_fold"])
 def test_early_forward_sweep_with_interchanges(gpu, pkg, wl, monkeypatch, case):
     """The early forward sweep on factorisations WITH row interchanges inside the fronts (sparse unsymmetric pencil: the look-ahead pivoted
