@@ -311,7 +311,7 @@ private:
     int solve_range(hipStream_t st, int kb, int kc, const cz* rhs, ProfileRow* prof, int part = 0, int only_level = -1);
     // Adjoint sweeps T(z_k)^H x = rhs over the factors of the units kb .. kb + kc - 1; the block vectors of the sweep are the instance
     // slots slot0 .. slot0 + kc - 1 of W / Y / the contribution arenas.  The solution: adj_solution() (W, or Y when the fronts interchanged rows)
-    int solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs);
+    int solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs, int part = 0, int only_level = -1);      // part / only_level: as solve_range
     const cz* adj_solution() const { return (nopiv_used || nopiv_gen_used) ? d_W_.p : d_Y_.p; }
     DevBuf<int> d_rowid_;                 // identity "row interchanges" (relative index within the supernode) for the adjoint sweeps' gather / assembly
     template <typename T>
@@ -343,7 +343,7 @@ private:
     // follows gathers the root's rows and takes up there (solve_range part 2; in node groups on their own streams where the late sweep would
     // run so).  A rejected elimination without interchanges starts over with pivoting, early sweep included.  The same launches as the late
     // sweep but for the gather (level by level instead of one pass: a copy), in the same order: bitwise the late sweep's result
-    // (test_early_forward_sweep_is_bitwise_the_late_one).  Not with adjoint sweeps.
+    // (test_early_forward_sweep_is_bitwise_the_late_one).  The adjoint sweeps of the adjoint fold go the same way (their forward sweep, with U^H, climbs the tree too); not dual_gen_feast's.
     bool early_sweep_enabled_ = true;      // FEASTHIP_EARLY_SWEEP=0
     const cz* early_rhs_ = nullptr;
     bool early_done_ = false;

@@ -103,7 +103,7 @@ int Engine::factorize() {
     bool lazy = lazy_conversion_ && !adj_fold_ && !dual_adj_ && !fwd_splitk_;
     for (const SolveLevel& V : splan_) if (V.f2split) lazy = false;
     // early forward sweep (engine.hpp): the caller's contour step follows at once and its right-hand sides exist already
-    bool early = early_rhs_ && early_sweep_enabled_ && !dense && !adj_fold_ && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
+    bool early = early_rhs_ && early_sweep_enabled_ && !dense && !dual_adj_ && !skip_conversion && S.maxdepth >= 2 &&
                  finalize_async_ && fin_stream_ && ev_fin_ && ev_fin_fork_ && have_x_;
     for (const SolveLevel& V : splan_) if (V.f2split) early = false;
     early_done_ = false;
@@ -289,6 +289,7 @@ int Engine::factorize() {
         if (early && d >= 1) {
             lazy_factors_ = lazy;
             int r = solve_range(fin, 0, Kloc, early_rhs_, nullptr, 1, d);
+            if (r == 0 && adj_fold_) r = solve_range_adj(fin, 0, Kloc, Kloc, early_rhs_, ldw, 1, d);      // the mirror nodes' systems T(z_k)^H y = rhs
             if (r) return r;
         }
         if (!fuse)

@@ -126,7 +126,7 @@ int Engine::solve_range_t(hipStream_t st, int kb, int kc, const cz* rhs, Profile
 // the assembly run with identity interchanges (d_rowid_) and k_accumulate undoes them at the end.  Per level:
 //   forward   assemble -> { Y_b = inv(U_bb)^H W_b } -> steps c = 1 .. S - 1 { Y_c -= (PU_[0,c) c)^H Y_[0,c) } -> { C_I = .. - U12^H Y_J ; W_b = inv(L_bb)^H Y_b }
 //   backward  { W_J -= P21^H W[struct] } (+ split-K reduction) -> steps c = S - 2 .. 0 { W_c -= (P_(c,S) c)^H W_(c,S) }
-int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs) {
+int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz* rhs, int ldrhs, int part, int only_level) {
     if (mixed_) return fail(FEASTHIP_ESTATE, "adjoint sweeps run in complex128 only");
     if (lazy_factors_) return fail(FEASTHIP_ESTATE, "adjoint sweeps need fully converted factors (feasthip_set_lazy_conversion(h, 0) and factorise again)");
     if (fwd_splitk_) return fail(FEASTHIP_ESTATE, "adjoint sweeps: FEASTHIP_FWD_SPLITK is not supported");
@@ -138,8 +138,9 @@ int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz*
     cz* Yp = d_Y_.p + (int64_t)slot0 * ws;
     const int* rid = d_rowid_.p;                 // (every unit's copy is the same identity table)
     const Tile* tl = d_tiles_.p;
-    launch_gather_rhs(st, dsym_, rhs, ldrhs, lw, Wp, ws, rid, kc);
-    for (int d = S.maxdepth; d >= 0; --d) {          // forward sweep with U^H, leaves to root
+    launch_gather_rhs(st, dsym_, rhs, ldrhs, lw, Wp, ws, rid, kc, part == 0 ? -1 : part == 1 ? only_level : 0);
+    for (int d = (part == 2 ? 0 : S.maxdepth); d >= (part == 1 ? 1 : 0); --d) {          // forward sweep with U^H, leaves to root
+        if (part == 1 && d != only_level) continue;
         SolveLevel& V = splan_[d];
         const int par = d & 1;
         const int64_t crs = std::max<int64_t>(1, S.crow_size[par]) * lw, crsc = std::max<int64_t>(1, S.crow_size[par ^ 1]) * lw;
@@ -159,7 +160,7 @@ int Engine::solve_range_adj(hipStream_t st, int kb, int kc, int slot0, const cz*
     // their pre-pivot positions in Y (free since the forward sweep ended), which is what the children gather from and what the caller reads.
     const bool unperm = !(nopiv_used || nopiv_gen_used);
     cz* Xs = unperm ? Yp : Wp;
-    for (int d = 0; d <= S.maxdepth; ++d) {          // backward sweep with L^H, root to leaves
+    for (int d = 0; d <= S.maxdepth && part != 1; ++d) {          // backward sweep with L^H, root to leaves
         SolveLevel& V = splan_[d];
         launch_apply(st, dsym_, tl + V.ab1.off, V.ab1.count, Fp, fs, Wp, Xs, ws, lw, nullptr, 0, kc, true, skp, sks, nullptr, 0, V.ab1.sl, &V.ab1.xp);
         if (V.b1split) launch_splitk_reduce(st, dsym_, tl + V.b1red.off, V.b1red.count, V.b1split, Wp, ws, lw, skp, sks, kc);
@@ -207,8 +208,8 @@ int Engine::solve_all_impl(const cz* rhs, ProfileRow* prof) {
             HIPCHK(hipStreamWaitEvent(sa, ev_fork_, 0));
             HIPCHK(hipStreamWaitEvent(sb, ev_fork_, 0));
         }
-        int r = solve_range(sa, 0, Kloc, rhs, prof);
-        if (r == 0) r = solve_range_adj(sb, 0, Kloc, Kloc, rhs, ldw);
+        int r = solve_range(sa, 0, Kloc, rhs, prof, part);
+        if (r == 0) r = solve_range_adj(sb, 0, Kloc, Kloc, rhs, ldw, part);
         if (r) return r;
         if (sa != stream_) {
             HIPCHK(hipEventRecord(ev_join_[0], sa)); HIPCHK(hipStreamWaitEvent(stream_, ev_join_[0], 0));

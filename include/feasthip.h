@@ -301,7 +301,7 @@ typedef struct {
     double growth;              /* max(1, max |l_ij|) * max(1, max |u_ij| / ||T||) of that factorisation (paths 1 and 2; beyond 256 the handle refactorises with pivoting) */
     double proj_ms;             /* last feasthip_rr_step: the projection Aq = Q'(AQ) (src/feast.jl:43,118), 8 n m0^2 flops on the f64 matrix cores */
     int32_t early_sweep_levels; /* last feasthip_contour_step(h, 1) (store = false, src/feast.jl:64-65): tree levels whose forward sweep was enqueued under
-                                 * the factorisation, behind their own level's conversion (0: none -- FEASTHIP_EARLY_SWEEP=0, dense matrices, adjoint sweeps);
+                                 * the factorisation, behind their own level's conversion (0: none -- FEASTHIP_EARLY_SWEEP=0, dense matrices, dual_gen_feast);
                                  * factor_ms then contains those launches and solve_ms only the root's forward level and the backward sweep */
     int32_t reserved0;
 } feasthip_stats_t;

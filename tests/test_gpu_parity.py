@@ -2201,11 +2201,12 @@ def test_early_forward_sweep_in_complex64(gpu, pkg, wl, monkeypatch, lazy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["unsymmetric", "unsymmetric_lazy", "hermitian_without_adjoint_fold"])
+@pytest.mark.parametrize("case", ["unsymmetric", "unsymmetric_lazy", "hermitian_without_adjoint_fold", "hermitian_adjoint_fold"])
 def test_early_forward_sweep_with_interchanges(gpu, pkg, wl, monkeypatch, case):
     """The early forward sweep on factorisations WITH row interchanges inside the fronts (sparse unsymmetric pencil: the look-ahead pivoted
     schedule), where the right-hand-side gather of a tree level reads that level's interchanges (written by the level's conversion), and on
-    the Hermitian path without interchanges (L and U apart; adjoint fold off, the adjoint sweeps keep the late sweep): bit for bit the late sweep."""
+    the Hermitian path without interchanges (L and U apart), without and with the adjoint fold -- there the adjoint sweeps T(z_k)^H y = r of the
+    mirror nodes start under the factorisation as well (their forward sweep, with U^H, climbs the tree too): bit for bit the late sweep."""
     rng = np.random.default_rng(5)
     if case.startswith("unsymmetric"):
         w = wl.c3_sparse_generalized(14, 19, 24)
@@ -2215,13 +2216,15 @@ def test_early_forward_sweep_with_interchanges(gpu, pkg, wl, monkeypatch, case):
     else:
         w = wl.c3_sparse_generalized(12, 19, 16)
         terms, want = [wl.hermitian_phases(w["A"], seed=3), w["B"]], 2
-        monkeypatch.setenv("FEASTHIP_ADJ_FOLD", "0")
+        if case == "hermitian_without_adjoint_fold":
+            monkeypatch.setenv("FEASTHIP_ADJ_FOLD", "0")
     con = pkg.circular_contour_trapezoidal(w["c"], w["r"], 8)
     lazy = case.endswith("lazy")
     q1e, q2e, st_e = _moment_lazy(pkg, terms, [1.0, -1.0], con, w["X0"], lazy)
     monkeypatch.setenv("FEASTHIP_EARLY_SWEEP", "0")
     q1l, q2l, st_l = _moment_lazy(pkg, terms, [1.0, -1.0], con, w["X0"], lazy)
     assert st_e["symmetric"] == want and st_e["early_sweep_levels"] >= 2 and st_l["early_sweep_levels"] == 0
+    assert st_e["folded"] == (2 if case == "hermitian_adjoint_fold" else 1 if case.startswith("unsymmetric") else 0) or case.startswith("unsymmetric")
     assert np.isfinite(q2e).all() and np.array_equal(q1e, q1l) and np.array_equal(q2e, q2l)
 
 
