@@ -17,10 +17,12 @@ bad = 0
 t0 = time.time()
 
 
-def step(terms, scales, con, X0, lazy, fold, first):
+def step(terms, scales, con, X0, lazy, fold, first, mixed=False):
     h = pkg.FeastHandle(0)
     try:
         h.set_terms(terms, scales); h.set_contour(con); h.set_conjugate_fold(fold); h.set_lazy_conversion(lazy)
+        if mixed:
+            h.set_precision(1)
         if not first:
             h.factorize()                      # the step below factorises AGAIN (every iteration of store=false)
         h.set_x(X0); h.rr_step(); h.contour_step(True)
@@ -47,11 +49,22 @@ for case in range(ncases):
     con = pkg.circular_contour_trapezoidal(c, r, K)
     X0 = wl.rand_x0(n, m0, int(rng.integers(1 << 30)))
     lazy, fold, first = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    # FUZZ_KINDS=1: also unsymmetric values on the same pattern (fronts with row interchanges), Hermitian phases (elimination with L and U apart,
+    # adjoint fold) and complex64 sweeps (mixed_prec)
+    kind, mixed = "sym", False
+    if os.environ.get("FUZZ_KINDS"):
+        kind = str(rng.choice(["sym", "unsym", "herm", "sym_mixed"]))
+        if kind == "unsym":
+            A = sp.csc_matrix(A, dtype=np.complex128)
+            A = A + sp.csc_matrix((0.05 * rng.standard_normal(A.nnz), A.indices, A.indptr), shape=A.shape)
+        elif kind == "herm":
+            A = wl.hermitian_phases(A, seed=int(rng.integers(1 << 20)))
+        mixed = kind == "sym_mixed"
     terms, scales = [A, B], [1.0, -1.0]
     try:
-        q_e, R, X, st_e = step(terms, scales, con, X0, lazy, fold, first)
+        q_e, R, X, st_e = step(terms, scales, con, X0, lazy, fold, first, mixed)
         os.environ["FEASTHIP_EARLY_SWEEP"] = "0"
-        q_l, _, _, st_l = step(terms, scales, con, X0, lazy, fold, first)
+        q_l, _, _, st_l = step(terms, scales, con, X0, lazy, fold, first, mixed)
         del os.environ["FEASTHIP_EARLY_SWEEP"]
     except Exception as ex:
         os.environ.pop("FEASTHIP_EARLY_SWEEP", None)
@@ -60,13 +73,13 @@ for case in range(ncases):
     # direct check on the host: Q e_j = sum_k (X e_j - T(z_k)^-1 R e_j) w_k / (z_k - lambda_j) (include/feasthip.h: feasthip_contour_step) lies in the
     # span of X e_j and the K host solutions y_k = T(z_k)^-1 R e_j -- least-squares residual of that (small cases: K sparse host solves)
     err = float("nan")
-    if n <= 12000:
+    if n <= 12000 and not os.environ.get("FUZZ_KINDS"):
         j = int(rng.integers(0, m0))
         Ys = np.stack([spla.spsolve((A - z * B).tocsc().astype(np.complex128), R[:, j]) for z in con.nodes] + [X[:, j]], axis=1)
         coef, *_ = np.linalg.lstsq(Ys, q_e[:, j], rcond=None)
         err = np.linalg.norm(Ys @ coef - q_e[:, j]) / max(np.linalg.norm(q_e[:, j]), 1e-300)
-    ok = same and st_l["early_sweep_levels"] == 0 and (not (err == err) or err < 1e-9)
-    print(f"case {case}: n={n} offsets={offs} extra={extra} gen={gen} K={K} m0={m0} lazy={lazy} fold={fold} first={first} symmetric_path {st_e['symmetric']} "
+    ok = same and st_l["early_sweep_levels"] == 0 and (not (err == err) or err < (1e-4 if mixed else 1e-9))
+    print(f"case {case}: n={n} offsets={offs} extra={extra} gen={gen} kind={kind} K={K} m0={m0} lazy={lazy} fold={fold} first={first} symmetric_path {st_e['symmetric']} "
           f"early levels {st_e['early_sweep_levels']} depth {st_e['depth']} bitwise {same} span residual {err:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
 print(f"{ncases} cases, {bad} bad, {time.time() - t0:.0f} s")
